@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- generate tests/golden/*.json from the reference.
+
+Runs only in the build container: imports the reference in place from
+/root/reference through oracle/ref_shim.py (py2->py3 shim)
+and records inputs + outputs of the hot path as small JSON fixtures.  The
+fixtures are data (inputs and expected outputs); no reference source is
+copied.  Re-run:  python oracle/gen_golden.py
+
+Files written (tests/golden/):
+  readme_example.json   README.rst:143-152 known-answer example, all tables
+  test_base_case.json   tests/asts/test_base.py:13-24 collection/queries, 3 algorithms
+  utils_vectors.json    tests/asts/test_utils.py, tests/test_utils.py vectors + text prep
+  sample_table.json     doc/samples/texts/test.txt x keyphrases/test.txt table + XML/CSV
+  hse_config1.json      BASELINE config 1: 30 HSE sample docs x first 10 HSE keyphrases
+  fuzz_small.json       random small collections: every table + scores (easa == ast_linear)
+  zipf_docs.json        natural-language-like docs scored by ast_linear and easa (config 5 sub-sample)
+"""
+import glob
+import json
+import os
+import random
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+from east import applications, formatting, relevance, utils  # noqa: E402
+from east.asts import base  # noqa: E402
+from east.asts import utils as ast_utils  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+REF = ref_shim.REFERENCE_ROOT
+
+
+def ints(a):
+    return [int(x) for x in a]
+
+
+def ast_dump(strings, queries, algs=("easa", "ast_linear", "ast_naive"), tables=True):
+    ast = base.AST.get_ast(strings, "easa")
+    d = {"strings": strings, "n_strings": len(strings)}
+    if tables:
+        d.update({
+            "string": [ord(c) for c in ast.string],
+            "suftab": ints(ast.suftab), "lcptab": ints(ast.lcptab),
+            "childtab_up": ints(ast.childtab_up), "childtab_down": ints(ast.childtab_down),
+            "childtab_next_l_index": ints(ast.childtab_next_l_index),
+            "anntab": ints(ast.anntab),
+        })
+    others = [base.AST.get_ast(strings, a) for a in algs if a != "easa"]
+    qd = []
+    for q in queries:
+        qq = q.replace(" ", "")
+        if not qq:
+            continue
+        sn, suf_n = ast.score(q, normalized=True, return_suffix_scores=True)
+        sd, suf_d = ast.score(q, normalized=False, return_suffix_scores=True)
+        for o in others:  # the reference's own differential test (tests/asts/test_base.py)
+            assert o.score(q, normalized=True) == sn, (strings, q)
+            assert o.score(q, normalized=False) == sd, (strings, q)
+        qd.append({"query": q, "normalized": float(sn), "denormalized": float(sd),
+                   "suffix_normalized": [float(suf_n[qq[i:]]) for i in range(len(qq))],
+                   "suffix_denormalized": [float(suf_d[qq[i:]]) for i in range(len(qq))]})
+    d["queries"] = qd
+    return d
+
+
+def write(name, obj):
+    path = os.path.join(OUT, name)
+    with open(path, "w", encoding="utf-8") as f:
+        json.dump(obj, f, ensure_ascii=False, indent=None, separators=(",", ":"))
+        f.write("\n")
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def gen_readme():
+    write("readme_example.json", ast_dump(["XABXAC", "HI"], ["ABCI", "NOPE", "XABXAC", "A B", "HI"]))
+
+
+def gen_test_base():
+    write("test_base_case.json",
+          ast_dump(["abcd efg ops", "xyzq", "test"], ["aqcb", "efgp", "mn4", "abcd efg ops", "q t"]))
+
+
+def gen_utils():
+    d = {"match_strings": [], "index": [], "tokenize": [], "text_to_strings_collection": [],
+         "prepare_text": [], "make_unique_endings": []}
+    for a, b in [("abc", "bc"), ("", ""), ("abc", "ac"), ("mnc", "mnd"), ("abc", "abc"), ("abc", "abcd")]:
+        d["match_strings"].append({"a": a, "b": b, "out": ast_utils.match_strings(a, b)})
+    for arr, key in [([0, 2, 4, 6], 0), ([0, 2, 4, 6], 4), ([0, 2, 4, 6], 6),
+                     (["a", "b", "c", "d"], "a"), (["a", "b", "c", "d"], "c"), (["a", "b", "c", "d"], "d")]:
+        d["index"].append({"array": arr, "key": key, "out": ast_utils.index(arr, key)})
+    texts = ["Well, what a sunny day!", "Well, what a sunny day! 123 4567 it's", "", "a bb ccc dddd 12345 x1y2z3",
+             "Дисциплина в университете поддерживается", "one two three four five six seven",
+             "tab\tseparated\nlines and_underscores don't", "   ", "ab cd ef", "4567 89012"]
+    for t in texts:
+        d["tokenize"].append({"text": t, "out": utils.tokenize(t)})
+        d["text_to_strings_collection"].append(
+            {"text_utf8": t, "out": utils.text_to_strings_collection(t.encode("utf-8"))})
+        d["prepare_text"].append({"text_utf8": t, "out": utils.prepare_text(t.encode("utf-8"))})
+    for sc in [["XABXAC", "HI"], ["", "a"], ["abc"]]:
+        d["make_unique_endings"].append(
+            {"strings": sc, "out": [[ord(c) for c in s] for s in ast_utils.make_unique_endings(sc)]})
+    write("utils_vectors.json", d)
+
+
+def read_bytes(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def table_dump(keyphrases_raw, texts, alg="easa"):
+    """texts: ordered {name: bytes}.  Returns table for normalized and denormalized."""
+    out = {}
+    for norm in (True, False):
+        measure = relevance.ASTRelevanceMeasure(alg, norm)
+        table = applications.keyphrases_table(keyphrases_raw, texts, measure)
+        out["normalized" if norm else "denormalized"] = {
+            k: {t: float(v) for t, v in row.items()} for k, row in table.items()}
+    return out
+
+
+def gen_sample_table():
+    text_path = os.path.join(REF, "doc", "samples", "texts", "test.txt")
+    kp_path = os.path.join(REF, "doc", "samples", "keyphrases", "test.txt")
+    lines = read_bytes(text_path).splitlines()           # single file => one text per line (main.py:79-83)
+    texts = {str(i): lines[i] for i in range(len(lines))}
+    keyphrases = read_bytes(kp_path).decode("utf-8").splitlines()
+    d = {"keyphrases": keyphrases, "texts": {k: v.decode("utf-8") for k, v in texts.items()}}
+    tabs = table_dump(keyphrases, texts)
+    d.update(tabs)
+    for mode in ("normalized", "denormalized"):
+        d["xml_" + mode] = formatting.table2xml(tabs[mode])
+        d["csv_" + mode] = formatting.table2csv(tabs[mode])
+    write("sample_table.json", d)
+
+
+def gen_hse():
+    tdir = os.path.join(REF, "doc", "samples", "texts", "HSE rules")
+    files = sorted(glob.glob(os.path.join(tdir, "*.txt")))
+    texts = {os.path.basename(p)[:-4]: read_bytes(p) for p in files}
+    kp = read_bytes(os.path.join(REF, "doc", "samples", "keyphrases", "HSE.txt")).decode("utf-8").splitlines()[:10]
+    d = {"keyphrases": kp, "texts": {k: v.decode("utf-8") for k, v in texts.items()}}
+    easa = table_dump(kp, texts, "easa")
+    lin = table_dump(kp, texts, "ast_linear")
+    assert easa == lin
+    d.update(easa)
+    d["sum_normalized"] = sum(v for row in easa["normalized"].values() for v in row.values())
+    d["sum_denormalized"] = sum(v for row in easa["denormalized"].values() for v in row.values())
+    per_doc = {}
+    for name, raw in texts.items():
+        sc = utils.text_to_strings_collection(raw)
+        ast = base.AST.get_ast(sc, "easa")
+        per_doc[name] = {"m": len(sc), "n": len(ast.string), "max_lcp": int(max(ast.lcptab)),
+                         "suftab_head": ints(ast.suftab[:8]),
+                         "suftab_sum": int(sum(int(x) * (i + 1) for i, x in enumerate(ast.suftab))),
+                         "lcptab_sum": int(sum(ast.lcptab)), "anntab_sum": int(sum(ast.anntab)),
+                         "first_string": sc[0]}
+    d["per_doc"] = per_doc
+    d["xml_normalized"] = formatting.table2xml(easa["normalized"])
+    d["csv_normalized"] = formatting.table2csv(easa["normalized"])
+    write("hse_config1.json", d)
+    print("  sums", d["sum_normalized"], d["sum_denormalized"])
+
+
+def gen_fuzz():
+    rng = random.Random(20240)
+    cases = []
+    alphabets = ["AB", "ABC", "ABCDEFGH", "AB C", "ABCDEFGHIJKLMNOPQRSTUVWXYZ", "АБВГД"]
+    for alpha in alphabets:
+        for _ in range(10):
+            m = rng.randint(1, 6)
+            strings = ["".join(rng.choice(alpha) for _ in range(rng.randint(0, 14))) for _ in range(m)]
+            if sum(len(s) for s in strings) + m < 2:
+                continue
+            queries = ["".join(rng.choice(alpha + "Z") for _ in range(rng.randint(1, 10))) for _ in range(4)]
+            queries.append(strings[0][:5] if strings[0] else alpha[0])
+            cases.append(ast_dump(strings, queries, algs=("easa", "ast_linear")))
+    # degenerate / edge collections the reference handles
+    for strings in [["", "A"], ["A", ""], ["AAAAAAAA"], ["ABABABAB", "ABABABAB"], ["A", "A", "A"],
+                    [" "], ["AB", "", "AB"], ["ZZZZ", "ZZZ", "ZZ", "Z"]]:
+        cases.append(ast_dump(strings, ["A", "AB", "ABAB", "Z", "ZZZ", "AAAA"], algs=("easa", "ast_linear")))
+    write("fuzz_small.json", {"cases": cases})
+
+
+def zipf_text(rng, n_bytes, vocab):
+    words = []
+    size = 0
+    weights = [1.0 / (r + 1) ** 1.1 for r in range(len(vocab))]
+    while size < n_bytes:
+        w = rng.choices(vocab, weights)[0]
+        r = rng.random()
+        if r < 0.08:
+            w = w.capitalize()
+        if r > 0.93:
+            w += rng.choice([",", ".", ";", "!", "?"])
+        if 0.5 < r < 0.52:
+            w = str(rng.randint(0, 99999))
+        words.append(w)
+        size += len(w) + 1
+    return " ".join(words)
+
+
+def gen_zipf():
+    rng = random.Random(20245)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    vocab = []
+    while len(vocab) < 3000:
+        L = min(12, max(2, int(rng.gammavariate(3.0, 1.6))))
+        vocab.append("".join(rng.choice(letters) for _ in range(L)))
+    docs = {("doc%d" % i): zipf_text(rng, 6000, vocab) for i in range(4)}
+    kps = []
+    names = sorted(docs)
+    for i in range(40):
+        if i % 2 == 0:
+            toks = docs[rng.choice(names)].split()
+            st = rng.randrange(len(toks) - 3)
+            kps.append(" ".join(toks[st:st + rng.randint(1, 3)]))
+        else:
+            kps.append(" ".join(rng.choice(vocab) for _ in range(rng.randint(1, 3))))
+    kps = sorted(set(kps))
+    texts = {k: v.encode("utf-8") for k, v in docs.items()}
+    lin = table_dump(kps, texts, "ast_linear")
+    easa = table_dump(kps, texts, "easa")
+    assert lin == easa
+    d = {"keyphrases": kps, "texts": docs, "scored_by": ["ast_linear", "easa"]}
+    d.update(lin)
+    write("zipf_docs.json", d)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_readme()
+    gen_test_base()
+    gen_utils()
+    gen_sample_table()
+    gen_hse()
+    gen_fuzz()
+    gen_zipf()
