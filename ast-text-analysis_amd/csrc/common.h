@@ -1,0 +1,137 @@
+// common.h -- shared host/device helpers for the gfx950 EASA backend.
+//
+// Everything here is written for CDNA4 only: 64-lane wavefronts, 256-thread
+// workgroups (4 waves = one wave per SIMD), 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int64_t i64;
+
+#include "../../include/east_hip.h"
+
+#define WAVE 64
+#define BLOCK 256              // threads per workgroup everywhere
+#define WAVES_PER_BLOCK 4
+
+// ---------------------------------------------------------------- errors ----
+struct EastError {
+    int code;
+    std::string msg;
+};
+
+[[noreturn]] inline void east_throw(int code, const std::string &msg) { throw EastError{code, msg}; }
+
+#define HIP_CHECK(expr)                                                               \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            char _b[512];                                                             \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr,                  \
+                     hipGetErrorString(_e), __FILE__, __LINE__);                      \
+            east_throw(_e == hipErrorOutOfMemory ? EAST_HIP_ERR_OOM : EAST_HIP_ERR_HIP, _b); \
+        }                                                                             \
+    } while (0)
+
+// ----------------------------------------------------------------- arena ----
+// Bump allocator over one device allocation with stack discipline
+// (mark/release).  In dry mode nothing is backed by memory: the same host
+// orchestration code is run to measure the high-water mark before the real
+// arena is allocated, so a build never calls hipMalloc in its timed region.
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0, high = 0;
+    bool dry = false;
+
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+    void *alloc_bytes(size_t bytes)
+    {
+        size_t a = (off + 255) & ~(size_t)255;
+        size_t end = a + bytes;
+        if (!dry && end > cap) east_throw(EAST_HIP_ERR_INTERNAL, "device arena exhausted");
+        off = end;
+        if (off > high) high = off;
+        return dry ? (void *)(uintptr_t)(0x1000 + a) : (void *)(base + a);
+    }
+    template <class T> T *alloc(size_t count) { return (T *)alloc_bytes(count * sizeof(T)); }
+};
+
+struct Stats {
+    i64 levels = 0, radix_passes = 0, radix_elems = 0, radix_elem_bytes = 0;
+};
+
+struct Ctx {
+    hipStream_t stream = nullptr;
+    Arena *arena = nullptr;
+    bool dry = false;
+    Stats *stats = nullptr;
+};
+
+static inline u32 ceil_div_u32(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+static inline int bit_width_u32(u32 x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
+
+#define LAUNCH(ctx, kernel, grid, ...)                                                     \
+    do {                                                                                   \
+        if (!(ctx).dry) {                                                                  \
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, (ctx).stream, __VA_ARGS__); \
+            HIP_CHECK(hipGetLastError());                                                  \
+        }                                                                                  \
+    } while (0)
+
+// ---------------------------------------------------------- device utils ----
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
+
+// Inclusive prefix sum across the 64 lanes of a wavefront.
+__device__ __forceinline__ u32 wave_inclusive_sum(u32 x)
+{
+    const u32 lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        u32 y = __shfl_up(x, off, WAVE);
+        if (lane >= (u32)off) x += y;
+    }
+    return x;
+}
+
+__device__ __forceinline__ u32 wave_min(u32 x)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        u32 y = __shfl_xor(x, off, WAVE);
+        x = y < x ? y : x;
+    }
+    return x;
+}
+
+__device__ __forceinline__ u32 wave_sum(u32 x)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, WAVE);
+    return x;
+}
+
+// Exclusive prefix sum of one value per thread over a 256-thread workgroup.
+// lds4 must hold 4 words; `total` receives the workgroup sum.
+__device__ __forceinline__ u32 block_exclusive_sum(u32 x, u32 *lds4, u32 &total)
+{
+    const u32 inc = wave_inclusive_sum(x);
+    const u32 w = wave_id();
+    if (lane_id() == 63) lds4[w] = inc;
+    __syncthreads();
+    const u32 w0 = lds4[0], w1 = lds4[1], w2 = lds4[2], w3 = lds4[3];
+    u32 base = 0;
+    if (w > 0) base += w0;
+    if (w > 1) base += w1;
+    if (w > 2) base += w2;
+    total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return base + inc - x;
+}

@@ -1,0 +1,645 @@
+// east_hip.hip -- C ABI (include/east_hip.h) + host orchestration of the
+// gfx950 enhanced-annotated-suffix-array build and the score table.
+//
+// Device data layout (all in one arena, one HIP stream per handle):
+//   s        u32[n+3]  dense symbol codes of the concatenated corpus: text code
+//                      points ranked 1..sigma_t in code-point order, the g-th
+//                      terminator of the corpus = sigma_t+1+g, three 0 pads
+//   sa       u32[n]    suffix array, partitioned by document (document d owns
+//                      ranks [doc_off[d], doc_off[d+1])), values = global positions
+//   lcp/ann  u32[n]    per-document LCP and annotation tables, same layout
+//   up/down/next u32[n] child tables, values local to the document
+//   pyramid            64-ary min pyramid over lcp (tables.h)
+//
+// One suffix sort covers the whole shard: terminators are numbered globally
+// (order inside a document preserved, every terminator above every text
+// symbol), so stable-partitioning the global suffix array by document yields
+// each document's own reference suftab bit for bit.
+#include "common.h"
+#include "dc3.h"
+#include "radix_sort.h"
+#include "scan.h"
+#include "score.h"
+#include "tables.h"
+
+#include <algorithm>
+#include <string.h>
+
+#define TEXT_SYMBOLS EAST_HIP_TERMINATOR_START      // 0x0A00 = 2560 possible text code points
+#define PRESENT_WORDS (TEXT_SYMBOLS / 32)           // 80
+
+static thread_local std::string g_last_error;
+
+// ------------------------------------------------------------ prep kernels --
+__global__ __launch_bounds__(BLOCK) void presence_kernel(const u32 *__restrict__ sym, u32 n,
+                                                         u32 *__restrict__ present)
+{
+    __shared__ u32 bits[PRESENT_WORDS];
+    if (threadIdx.x < PRESENT_WORDS) bits[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 stride = gridDim.x * BLOCK;
+    for (u32 i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const u32 c = sym[i];
+        if (c < TEXT_SYMBOLS) atomicOr(&bits[c >> 5], 1u << (c & 31u));
+    }
+    __syncthreads();
+    if (threadIdx.x < PRESENT_WORDS && bits[threadIdx.x]) atomicOr(&present[threadIdx.x], bits[threadIdx.x]);
+}
+
+struct TermIn {                                 // 1 at terminators; defined on [0, n]
+    const u32 *sym;
+    u32 n;
+    __device__ __forceinline__ u32 operator()(u32 i) const
+    {
+        return (i < n && sym[i] >= TEXT_SYMBOLS) ? 1u : 0u;
+    }
+};
+
+// status[0] |= 1: a document does not end in a terminator; |= 2: m_d mismatch
+__global__ __launch_bounds__(BLOCK) void validate_docs_kernel(const u32 *__restrict__ sym,
+                                                              const u32 *__restrict__ term_ex,
+                                                              const u32 *__restrict__ doc_off,
+                                                              const u32 *__restrict__ n_strings,
+                                                              u32 n_docs, u32 *__restrict__ status)
+{
+    const u32 d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d >= n_docs) return;
+    const u32 b = doc_off[d], e = doc_off[d + 1];
+    if (sym[e - 1] < TEXT_SYMBOLS) atomicOr(status, 1u);
+    if (term_ex[e] - term_ex[b] != n_strings[d]) atomicOr(status, 2u);
+}
+
+__global__ __launch_bounds__(BLOCK) void remap_kernel(const u32 *__restrict__ sym,
+                                                      const u32 *__restrict__ term_ex,
+                                                      const u32 *__restrict__ code_map, u32 sigma_t,
+                                                      u32 n, u32 *__restrict__ s)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) {
+        const u32 c = sym[i];
+        s[i] = c < TEXT_SYMBOLS ? code_map[c] : sigma_t + 1u + term_ex[i];
+    } else if (i < n + 3) {
+        s[i] = 0;
+    }
+}
+
+// ------------------------------------------------------------------ index --
+struct east_hip_index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Arena arena;
+    Stats stats;
+    bool built = false;
+    u32 n = 0, n_docs = 0, sigma_t = 0, m_total = 0;
+    int bits0 = 0;
+    std::vector<i64> h_doc_off;
+    std::vector<u32> h_n_strings;
+    // persistent device arrays (inside the arena)
+    u32 *s = nullptr, *sa = nullptr, *lcp = nullptr, *ann = nullptr, *up = nullptr, *down = nullptr,
+        *next = nullptr, *doc_off = nullptr, *n_strings = nullptr, *code_map = nullptr;
+    Pyramid pyr;
+    // keyphrases + score scratch (own allocation, grown on demand)
+    char *q_buf = nullptr;
+    size_t q_cap = 0;
+    u32 n_kp = 0, n_q = 0;
+    u32 *q_raw = nullptr, *q_code = nullptr, *q_end = nullptr, *q_off = nullptr;
+    double *suffix = nullptr, *table = nullptr;
+    float last_build_ms = -1.f, last_score_ms = -1.f;
+};
+
+static void use_device(east_hip_index *h) { HIP_CHECK(hipSetDevice(h->device)); }
+
+// The build proper.  With ctx.dry it only measures the arena high-water mark
+// (worst case: widest keys, recursion to the bottom).
+static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32 n_docs,
+                       const i64 *doc_offsets, const int32_t *n_strings)
+{
+    Arena &ar = *ctx.arena;
+    ar.release(0);
+    // ---- persistent arrays --------------------------------------------------
+    h->s = ar.alloc<u32>((size_t)n + 3);
+    h->sa = ar.alloc<u32>(n);
+    h->lcp = ar.alloc<u32>(n);
+    h->ann = ar.alloc<u32>(n);
+    h->up = ar.alloc<u32>(n);
+    h->down = ar.alloc<u32>(n);
+    h->next = ar.alloc<u32>(n);
+    h->doc_off = ar.alloc<u32>((size_t)n_docs + 1);
+    h->n_strings = ar.alloc<u32>(n_docs);
+    h->code_map = ar.alloc<u32>(TEXT_SYMBOLS);
+    Pyramid pyr;
+    pyr.levels = 1;
+    pyr.ptr[0] = h->lcp;
+    pyr.len[0] = n;
+    while (pyr.len[pyr.levels - 1] > 64) {
+        if (pyr.levels >= PYR_MAX_LEVELS) east_throw(EAST_HIP_ERR_INTERNAL, "pyramid too deep");
+        const u32 len = ceil_div_u32(pyr.len[pyr.levels - 1], 64);
+        pyr.ptr[pyr.levels] = ar.alloc<u32>(len);
+        pyr.len[pyr.levels] = len;
+        pyr.levels++;
+    }
+    h->pyr = pyr;
+
+    // ---- host-side small tables ---------------------------------------------
+    std::vector<u32> off32((size_t)n_docs + 1), m32(n_docs);
+    if (!ctx.dry) {
+        for (u32 d = 0; d <= n_docs; d++) off32[d] = (u32)doc_offsets[d];
+        for (u32 d = 0; d < n_docs; d++) m32[d] = (u32)n_strings[d];
+        HIP_CHECK(hipMemcpyAsync(h->doc_off, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, ctx.stream));
+        HIP_CHECK(hipMemcpyAsync(h->n_strings, m32.data(), m32.size() * 4, hipMemcpyHostToDevice, ctx.stream));
+    }
+
+    const u32 gn = ceil_div_u32(n, BLOCK);
+    u32 sigma_t = TEXT_SYMBOLS - 1, m_total = n;          // dry-run worst case
+    {
+        // ---- alphabet, terminator numbering, validation, dense remap -----------
+        const size_t mark = ar.mark();
+        u32 *present = ar.alloc<u32>(PRESENT_WORDS + 1);  // + status word
+        u32 *term_ex = ar.alloc<u32>((size_t)n + 1);
+        if (!ctx.dry) HIP_CHECK(hipMemsetAsync(present, 0, (PRESENT_WORDS + 1) * 4, ctx.stream));
+        LAUNCH(ctx, presence_kernel, std::min<u32>(gn, 2048), d_sym, n, present);
+        device_scan<TermIn, false>(ctx, TermIn{d_sym, n}, n + 1, term_ex);
+        LAUNCH(ctx, validate_docs_kernel, ceil_div_u32(n_docs, BLOCK), d_sym, (const u32 *)term_ex,
+               (const u32 *)h->doc_off, (const u32 *)h->n_strings, n_docs, present + PRESENT_WORDS);
+        if (!ctx.dry) {
+            u32 hp[PRESENT_WORDS + 1];
+            HIP_CHECK(hipMemcpyAsync(hp, present, sizeof(hp), hipMemcpyDeviceToHost, ctx.stream));
+            HIP_CHECK(hipMemcpyAsync(&m_total, term_ex + n, 4, hipMemcpyDeviceToHost, ctx.stream));
+            HIP_CHECK(hipStreamSynchronize(ctx.stream));
+            if (hp[PRESENT_WORDS] & 1u)
+                east_throw(EAST_HIP_ERR_DOMAIN, "a document does not end in a string terminator (>= U+0A00)");
+            if (hp[PRESENT_WORDS] & 2u)
+                east_throw(EAST_HIP_ERR_DOMAIN, "n_strings does not match the terminators found in a document "
+                                                "(text symbols must be < U+0A00)");
+            std::vector<u32> map(TEXT_SYMBOLS, 0u);
+            sigma_t = 0;
+            for (u32 c = 0; c < TEXT_SYMBOLS; c++)
+                if (hp[c >> 5] & (1u << (c & 31u))) map[c] = ++sigma_t;
+            HIP_CHECK(hipMemcpyAsync(h->code_map, map.data(), TEXT_SYMBOLS * 4, hipMemcpyHostToDevice, ctx.stream));
+            HIP_CHECK(hipStreamSynchronize(ctx.stream));   // `map` is a stack-lifetime source
+        }
+        LAUNCH(ctx, remap_kernel, ceil_div_u32((u64)n + 3, BLOCK), d_sym, (const u32 *)term_ex,
+               (const u32 *)h->code_map, sigma_t, n, h->s);
+        ar.release(mark);
+    }
+    const u32 sigma = sigma_t + m_total;
+    h->sigma_t = sigma_t;
+    h->m_total = m_total;
+    h->bits0 = bit_width_u32(sigma);
+
+    // ---- suffix array of the whole shard, then partition by document -------------
+    if (n_docs == 1) {
+        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa);
+    } else {
+        const size_t mark = ar.mark();
+        SortBufs<u32> sb;
+        for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n); sb.vals[k] = ar.alloc<u32>(n); }
+        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sb.vals[0]);
+        LAUNCH(ctx, doc_keys_kernel, gn, (const u32 *)sb.vals[0], (const u32 *)h->doc_off, n_docs, n, sb.keys[0]);
+        const int r = radix_sort_pairs<u32>(ctx, sb, n, bit_width_u32(n_docs - 1));
+        if (!ctx.dry)
+            HIP_CHECK(hipMemcpyAsync(h->sa, sb.vals[r], (size_t)n * 4, hipMemcpyDeviceToDevice, ctx.stream));
+        ar.release(mark);
+    }
+
+    // ---- LCP, min pyramid, annotation + child tables ------------------------------
+    LAUNCH(ctx, lcp_kernel, gn, (const u32 *)h->s, (const u32 *)h->sa, (const u32 *)h->doc_off, n_docs, n, h->lcp);
+    for (int l = 1; l < pyr.levels; l++)
+        LAUNCH(ctx, pyramid_level_kernel, ceil_div_u32(pyr.len[l - 1], BLOCK), pyr.ptr[l - 1], pyr.len[l - 1],
+               (u32 *)pyr.ptr[l]);
+    LAUNCH(ctx, ann_child_kernel, gn, pyr, (const u32 *)h->doc_off, (const u32 *)h->n_strings, n_docs, n, h->ann,
+           h->up, h->down, h->next);
+}
+
+static size_t plan_arena_bytes(u32 n, u32 n_docs)
+{
+    east_hip_index tmp;
+    Arena dry;
+    dry.dry = true;
+    Stats st;
+    Ctx ctx;
+    ctx.arena = &dry;
+    ctx.dry = true;
+    ctx.stats = &st;
+    build_impl(&tmp, ctx, nullptr, n, n_docs, nullptr, nullptr);
+    return dry.high + (1u << 20);
+}
+
+static void ensure_arena(east_hip_index *h, size_t bytes)
+{
+    if (h->arena.cap >= bytes) return;
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->arena.base) HIP_CHECK(hipFree(h->arena.base));
+    h->arena.base = nullptr;
+    h->arena.cap = 0;
+    h->built = false;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        char b[160];
+        snprintf(b, sizeof(b), "hipMalloc of the %.2f GiB build arena failed: %s", bytes / 1073741824.0,
+                 hipGetErrorString(e));
+        east_throw(EAST_HIP_ERR_OOM, b);
+    }
+    h->arena.base = (char *)p;
+    h->arena.cap = bytes;
+}
+
+static void check_build_args(i64 n_total, const i64 *doc_offsets, const int32_t *n_strings, int32_t n_docs)
+{
+    if (n_docs < 1 || !doc_offsets || !n_strings) east_throw(EAST_HIP_ERR_INVALID, "n_docs < 1 or null offsets");
+    if (n_total < 1 || n_total >= (i64)0x7FFFFFF0) east_throw(EAST_HIP_ERR_INVALID, "n_total must be in [1, 2^31-16)");
+    if (doc_offsets[0] != 0 || doc_offsets[n_docs] != n_total)
+        east_throw(EAST_HIP_ERR_INVALID, "doc_offsets must start at 0 and end at n_total");
+    for (int32_t d = 0; d < n_docs; d++) {
+        if (doc_offsets[d + 1] <= doc_offsets[d]) east_throw(EAST_HIP_ERR_INVALID, "empty document (the reference raises EmptyStringsCollectionException)");
+        if (n_strings[d] < 1 || n_strings[d] > doc_offsets[d + 1] - doc_offsets[d])
+            east_throw(EAST_HIP_ERR_INVALID, "n_strings[d] must be in [1, n_d]");
+    }
+}
+
+static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i64 n_total, const i64 *doc_offsets,
+                         const int32_t *n_strings, int32_t n_docs)
+{
+    if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
+    if (!sym) east_throw(EAST_HIP_ERR_INVALID, "null symbols");
+    check_build_args(n_total, doc_offsets, n_strings, n_docs);
+    use_device(h);
+    h->built = false;
+    const u32 n = (u32)n_total;
+    size_t need = plan_arena_bytes(n, (u32)n_docs);
+    u32 *staging = nullptr;
+    if (sym_on_host) need += ((size_t)n * 4 + 255) & ~(size_t)255;
+    ensure_arena(h, need);
+    if (sym_on_host) {   // raw symbols are staged at the top of the arena
+        staging = (u32 *)(h->arena.base + (h->arena.cap - (((size_t)n * 4 + 255) & ~(size_t)255)));
+        HIP_CHECK(hipMemcpyAsync(staging, sym, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        sym = staging;
+    }
+    h->stats = Stats();
+    h->arena.high = 0;
+    Ctx ctx;
+    ctx.stream = h->stream;
+    ctx.arena = &h->arena;
+    ctx.stats = &h->stats;
+    HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings);
+    HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(hipEventElapsedTime(&h->last_build_ms, h->ev0, h->ev1));
+    h->n = n;
+    h->n_docs = (u32)n_docs;
+    h->h_doc_off.assign(doc_offsets, doc_offsets + n_docs + 1);
+    h->h_n_strings.assign(n_strings, n_strings + n_docs);
+    h->built = true;
+}
+
+// ------------------------------------------------------------------ score --
+static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q_offsets, int32_t n_kp)
+{
+    if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
+    if (!h->built) east_throw(EAST_HIP_ERR_NOT_BUILT, "no index has been built on this handle");
+    if (n_kp < 1 || !q_symbols || !q_offsets) east_throw(EAST_HIP_ERR_INVALID, "no keyphrases");
+    if (q_offsets[0] != 0) east_throw(EAST_HIP_ERR_INVALID, "q_offsets[0] must be 0");
+    for (int32_t k = 0; k < n_kp; k++)
+        if (q_offsets[k + 1] <= q_offsets[k])
+            east_throw(EAST_HIP_ERR_INVALID, "empty keyphrase (the reference raises ZeroDivisionError, easa.py:134)");
+    const i64 S = q_offsets[n_kp];
+    if (S >= (i64)0x7FFFFFF0 || (i64)n_kp * h->n_docs >= ((i64)1 << 40))
+        east_throw(EAST_HIP_ERR_INVALID, "keyphrase set too large");
+    use_device(h);
+    const u32 n_q = (u32)S;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t bytes = al((size_t)n_q * 4) * 3 + al(((size_t)n_kp + 1) * 4) +
+                         al((size_t)n_q * h->n_docs * 8) + al((size_t)n_kp * h->n_docs * 8);
+    if (bytes > h->q_cap) {
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->q_buf) HIP_CHECK(hipFree(h->q_buf));
+        h->q_buf = nullptr;
+        h->q_cap = 0;
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) east_throw(EAST_HIP_ERR_OOM, "hipMalloc of the score scratch failed");
+        h->q_buf = (char *)p;
+        h->q_cap = bytes;
+    }
+    char *p = h->q_buf;
+    h->q_raw = (u32 *)p;  p += al((size_t)n_q * 4);
+    h->q_code = (u32 *)p; p += al((size_t)n_q * 4);
+    h->q_end = (u32 *)p;  p += al((size_t)n_q * 4);
+    h->q_off = (u32 *)p;  p += al(((size_t)n_kp + 1) * 4);
+    h->suffix = (double *)p; p += al((size_t)n_q * h->n_docs * 8);
+    h->table = (double *)p;
+    std::vector<u32> end(n_q), off((size_t)n_kp + 1);
+    for (int32_t k = 0; k < n_kp; k++) {
+        off[k] = (u32)q_offsets[k];
+        for (i64 i = q_offsets[k]; i < q_offsets[k + 1]; i++) end[i] = (u32)q_offsets[k + 1];
+    }
+    off[n_kp] = n_q;
+    HIP_CHECK(hipMemcpyAsync(h->q_raw, q_symbols, (size_t)n_q * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(h->q_end, end.data(), (size_t)n_q * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(h->q_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->n_kp = (u32)n_kp;
+    h->n_q = n_q;
+}
+
+// queues the three score kernels; result in h->table (K x D) / h->suffix (D x S)
+static void score_resident(east_hip_index *h, int normalized)
+{
+    if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
+    if (!h->built) east_throw(EAST_HIP_ERR_NOT_BUILT, "no index has been built on this handle");
+    if (!h->n_kp) east_throw(EAST_HIP_ERR_INVALID, "no keyphrases set");
+    use_device(h);
+    Ctx ctx;
+    ctx.stream = h->stream;
+    HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    LAUNCH(ctx, query_map_kernel, ceil_div_u32(h->n_q, BLOCK), (const u32 *)h->q_raw, h->n_q,
+           (const u32 *)h->code_map, h->q_code);
+    LAUNCH(ctx, score_walk_kernel, ceil_div_u32((u64)h->n_q * h->n_docs, BLOCK), (const u32 *)h->s,
+           (const u32 *)h->sa, (const u32 *)h->doc_off, (const u32 *)h->n_strings, h->n_docs,
+           (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, h->suffix);
+    LAUNCH(ctx, score_reduce_kernel, ceil_div_u32((u64)h->n_kp * h->n_docs, BLOCK), (const double *)h->suffix,
+           (const u32 *)h->q_off, h->n_kp, h->n_docs, h->n_q, h->table);
+    HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+}
+
+// ------------------------------------------------------------------ C ABI --
+template <class F> static int guarded(F f)
+{
+    try {
+        f();
+        return EAST_HIP_OK;
+    } catch (const EastError &e) {
+        g_last_error = e.msg;
+        return e.code;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return EAST_HIP_ERR_INTERNAL;
+    }
+}
+
+extern "C" {
+
+const char *east_hip_version(void) { return "east-hip 0.1 (gfx950)"; }
+const char *east_hip_last_error(void) { return g_last_error.c_str(); }
+
+int east_hip_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) {
+        g_last_error = "no HIP device available (this library has no CPU fallback)";
+        return EAST_HIP_ERR_NO_DEVICE;
+    }
+    return c;
+}
+
+int east_hip_create(int device, int64_t reserve_symbols, east_hip_handle_t *out)
+{
+    if (out) *out = nullptr;
+    return guarded([&] {
+        if (!out) east_throw(EAST_HIP_ERR_INVALID, "null out pointer");
+        int c = 0;
+        if (hipGetDeviceCount(&c) != hipSuccess || c <= 0)
+            east_throw(EAST_HIP_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+        if (device < 0 || device >= c) east_throw(EAST_HIP_ERR_NO_DEVICE, "device ordinal out of range");
+        if (reserve_symbols < 0 || reserve_symbols >= (i64)0x7FFFFFF0)
+            east_throw(EAST_HIP_ERR_INVALID, "reserve_symbols out of range");
+        east_hip_index *h = new east_hip_index();
+        h->device = device;
+        try {
+            HIP_CHECK(hipSetDevice(device));
+            HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreate(&h->ev0));
+            HIP_CHECK(hipEventCreate(&h->ev1));
+            if (reserve_symbols > 0)
+                ensure_arena(h, plan_arena_bytes((u32)reserve_symbols, 1) + (((size_t)reserve_symbols * 4 + 255) & ~(size_t)255));
+        } catch (...) {
+            east_hip_destroy(h);
+            throw;
+        }
+        *out = h;
+    });
+}
+
+void east_hip_destroy(east_hip_handle_t h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->arena.base) (void)hipFree(h->arena.base);
+    if (h->q_buf) (void)hipFree(h->q_buf);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int east_hip_build(east_hip_handle_t h, const uint32_t *symbols, int64_t n_total, const int64_t *doc_offsets,
+                   const int32_t *n_strings, int32_t n_docs)
+{
+    return guarded([&] { build_common(h, symbols, true, n_total, doc_offsets, n_strings, n_docs); });
+}
+
+int east_hip_build_device(east_hip_handle_t h, const uint32_t *d_symbols, int64_t n_total,
+                          const int64_t *doc_offsets, const int32_t *n_strings, int32_t n_docs)
+{
+    return guarded([&] { build_common(h, d_symbols, false, n_total, doc_offsets, n_strings, n_docs); });
+}
+
+int east_hip_get_tables(east_hip_handle_t h, int32_t doc, int32_t *suftab, int32_t *lcptab, int32_t *anntab,
+                        int32_t *childtab_up, int32_t *childtab_down, int32_t *childtab_next_l_index)
+{
+    return guarded([&] {
+        if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
+        if (!h->built) east_throw(EAST_HIP_ERR_NOT_BUILT, "no index has been built on this handle");
+        if (doc < 0 || (u32)doc >= h->n_docs) east_throw(EAST_HIP_ERR_INVALID, "document index out of range");
+        use_device(h);
+        const size_t b = (size_t)h->h_doc_off[doc], nd = (size_t)(h->h_doc_off[doc + 1] - h->h_doc_off[doc]);
+        struct { int32_t *dst; const u32 *src; } jobs[6] = {
+            {suftab, h->sa}, {lcptab, h->lcp}, {anntab, h->ann},
+            {childtab_up, h->up}, {childtab_down, h->down}, {childtab_next_l_index, h->next}};
+        for (auto &j : jobs)
+            if (j.dst) HIP_CHECK(hipMemcpyAsync(j.dst, j.src + b, nd * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (suftab)
+            for (size_t i = 0; i < nd; i++) suftab[i] -= (int32_t)b;      // global -> document-local positions
+    });
+}
+
+int east_hip_set_keyphrases(east_hip_handle_t h, const uint32_t *q_symbols, const int64_t *q_offsets,
+                            int32_t n_keyphrases)
+{
+    return guarded([&] { set_keyphrases(h, q_symbols, q_offsets, n_keyphrases); });
+}
+
+int east_hip_score_resident(east_hip_handle_t h, int normalized, double *d_out)
+{
+    return guarded([&] {
+        score_resident(h, normalized);
+        if (d_out)
+            HIP_CHECK(hipMemcpyAsync(d_out, h->table, (size_t)h->n_kp * h->n_docs * 8, hipMemcpyDeviceToDevice,
+                                     h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        HIP_CHECK(hipEventElapsedTime(&h->last_score_ms, h->ev0, h->ev1));
+    });
+}
+
+int east_hip_score_resident_async(east_hip_handle_t h, int normalized)
+{
+    return guarded([&] { score_resident(h, normalized); });
+}
+
+int east_hip_score_table(east_hip_handle_t h, const uint32_t *q_symbols, const int64_t *q_offsets,
+                         int32_t n_keyphrases, int normalized, double *out, double *suffix_out)
+{
+    return guarded([&] {
+        if (!out) east_throw(EAST_HIP_ERR_INVALID, "null output table");
+        set_keyphrases(h, q_symbols, q_offsets, n_keyphrases);
+        score_resident(h, normalized);
+        HIP_CHECK(hipMemcpyAsync(out, h->table, (size_t)h->n_kp * h->n_docs * 8, hipMemcpyDeviceToHost, h->stream));
+        if (suffix_out)
+            HIP_CHECK(hipMemcpyAsync(suffix_out, h->suffix, (size_t)h->n_q * h->n_docs * 8, hipMemcpyDeviceToHost,
+                                     h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        HIP_CHECK(hipEventElapsedTime(&h->last_score_ms, h->ev0, h->ev1));
+    });
+}
+
+int east_hip_synchronize(east_hip_handle_t h)
+{
+    return guarded([&] {
+        if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
+        use_device(h);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    });
+}
+
+void *east_hip_stream(east_hip_handle_t h) { return h ? (void *)h->stream : nullptr; }
+
+int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap)
+{
+    if (!h || !out) return EAST_HIP_ERR_INVALID;
+    const int64_t v[11] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
+                           (int64_t)h->arena.cap, (int64_t)h->arena.high, h->stats.radix_passes,
+                           h->stats.radix_elems, h->stats.radix_elem_bytes};
+    for (int i = 0; i < 11 && i < cap; i++) out[i] = v[i];
+    return 11;
+}
+
+int64_t east_hip_plan_arena_bytes(int64_t n_total, int32_t n_docs)
+{
+    if (n_total < 1 || n_total >= (i64)0x7FFFFFF0 || n_docs < 1) return EAST_HIP_ERR_INVALID;
+    int64_t r = EAST_HIP_ERR_INTERNAL;
+    guarded([&] { r = (int64_t)plan_arena_bytes((u32)n_total, (u32)n_docs); });
+    return r;
+}
+
+double east_hip_last_build_ms(east_hip_handle_t h) { return h ? (double)h->last_build_ms : -1.0; }
+double east_hip_last_score_ms(east_hip_handle_t h) { return h ? (double)h->last_score_ms : -1.0; }
+
+}  // extern "C"
+
+// ---- kernel-level test entry points --------------------------------------------
+struct DebugScope {
+    hipStream_t stream = nullptr;
+    Arena arena;
+    Stats stats;
+    Ctx ctx;
+    DebugScope(int device, size_t bytes)
+    {
+        int c = 0;
+        if (hipGetDeviceCount(&c) != hipSuccess || c <= 0)
+            east_throw(EAST_HIP_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+        if (device < 0 || device >= c) east_throw(EAST_HIP_ERR_NO_DEVICE, "device ordinal out of range");
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        void *p = nullptr;
+        HIP_CHECK(hipMalloc(&p, bytes));
+        arena.base = (char *)p;
+        arena.cap = bytes;
+        ctx.stream = stream;
+        ctx.arena = &arena;
+        ctx.stats = &stats;
+    }
+    ~DebugScope()
+    {
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (arena.base) (void)hipFree(arena.base);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+template <class K> static void debug_sort(int device, K *keys, u32 *vals, i64 n, int bits)
+{
+    if (n < 0 || n >= (i64)0x7FFFFFF0 || !keys || !vals || bits < 1 || bits > (int)sizeof(K) * 8)
+        east_throw(EAST_HIP_ERR_INVALID, "bad radix sort arguments");
+    if (n == 0) return;
+    DebugScope sc(device, (size_t)n * (sizeof(K) + 4) * 2 + (size_t)ceil_div_u32(n, RS_TILE) * 1200 + (8u << 20));
+    SortBufs<K> sb;
+    for (int k = 0; k < 2; k++) { sb.keys[k] = sc.arena.alloc<K>(n); sb.vals[k] = sc.arena.alloc<u32>(n); }
+    HIP_CHECK(hipMemcpyAsync(sb.keys[0], keys, (size_t)n * sizeof(K), hipMemcpyHostToDevice, sc.stream));
+    HIP_CHECK(hipMemcpyAsync(sb.vals[0], vals, (size_t)n * 4, hipMemcpyHostToDevice, sc.stream));
+    const int r = radix_sort_pairs<K>(sc.ctx, sb, (u32)n, bits);
+    HIP_CHECK(hipMemcpyAsync(keys, sb.keys[r], (size_t)n * sizeof(K), hipMemcpyDeviceToHost, sc.stream));
+    HIP_CHECK(hipMemcpyAsync(vals, sb.vals[r], (size_t)n * 4, hipMemcpyDeviceToHost, sc.stream));
+    HIP_CHECK(hipStreamSynchronize(sc.stream));
+}
+
+extern "C" {
+
+int east_hip_debug_radix_sort_u64(int device, uint64_t *keys, uint32_t *vals, int64_t n, int bits)
+{
+    return guarded([&] { debug_sort<u64>(device, keys, vals, n, bits); });
+}
+
+int east_hip_debug_radix_sort_u32(int device, uint32_t *keys, uint32_t *vals, int64_t n, int bits)
+{
+    return guarded([&] { debug_sort<u32>(device, keys, vals, n, bits); });
+}
+
+int east_hip_debug_exclusive_scan(int device, const uint32_t *in, uint32_t *out, int64_t n)
+{
+    return guarded([&] {
+        if (n < 0 || n >= (i64)0x7FFFFFF0 || !in || !out) east_throw(EAST_HIP_ERR_INVALID, "bad scan arguments");
+        if (n == 0) return;
+        DebugScope sc(device, (size_t)n * 8 + (size_t)ceil_div_u32(n, SCAN_TILE) * 16 + (8u << 20));
+        u32 *d_in = sc.arena.alloc<u32>(n), *d_out = sc.arena.alloc<u32>(n);
+        HIP_CHECK(hipMemcpyAsync(d_in, in, (size_t)n * 4, hipMemcpyHostToDevice, sc.stream));
+        device_scan<ArrIn, false>(sc.ctx, ArrIn{d_in}, (u32)n, d_out);
+        HIP_CHECK(hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, sc.stream));
+        HIP_CHECK(hipStreamSynchronize(sc.stream));
+    });
+}
+
+int east_hip_debug_suffix_array(int device, const uint32_t *symbols, int64_t n, uint32_t sigma, int32_t *sa_out,
+                                int32_t *levels_out)
+{
+    return guarded([&] {
+        if (n < 1 || n >= (i64)0x7FFFFFF0 || !symbols || !sa_out || sigma < 1)
+            east_throw(EAST_HIP_ERR_INVALID, "bad suffix array arguments");
+        for (i64 i = 0; i < n; i++)
+            if (symbols[i] < 1 || symbols[i] > sigma) east_throw(EAST_HIP_ERR_INVALID, "symbol outside [1, sigma]");
+        // measure the arena with the same code path, then run it
+        Arena dry;
+        dry.dry = true;
+        Stats st;
+        Ctx dctx;
+        dctx.arena = &dry;
+        dctx.dry = true;
+        dctx.stats = &st;
+        (void)dry.alloc<u32>((size_t)n + 3);
+        (void)dry.alloc<u32>(n);
+        dc3_suffix_array(dctx, nullptr, (u32)n, (u32)std::max<i64>(n, sigma), nullptr);
+        DebugScope sc(device, dry.high + (8u << 20));
+        u32 *s = sc.arena.alloc<u32>((size_t)n + 3), *sa = sc.arena.alloc<u32>(n);
+        HIP_CHECK(hipMemsetAsync(s + n, 0, 12, sc.stream));
+        HIP_CHECK(hipMemcpyAsync(s, symbols, (size_t)n * 4, hipMemcpyHostToDevice, sc.stream));
+        const int levels = dc3_suffix_array(sc.ctx, s, (u32)n, sigma, sa);
+        HIP_CHECK(hipMemcpyAsync(sa_out, sa, (size_t)n * 4, hipMemcpyDeviceToHost, sc.stream));
+        HIP_CHECK(hipStreamSynchronize(sc.stream));
+        if (levels_out) *levels_out = levels;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+# -*- coding: utf-8 -*-
+"""AST helpers (reference east/asts/utils.py:6-40)."""
+import numpy as np
+
+from east import consts
+from east import exceptions
+
+
+def index(array, key, start=0):
+    """Linear scan without boundary check (asts/utils.py:6-11)."""
+    i = start
+    while array[i] != key:
+        i += 1
+    return i
+
+
+def match_strings(str1, str2):
+    """Largest i such that str1[:i] == str2[:i] (asts/utils.py:14-22)."""
+    i = 0
+    min_len = len(str1) if len(str1) < len(str2) else len(str2)
+    while i < min_len and str1[i] == str2[i]:
+        i += 1
+    return i
+
+
+def make_unique_endings(strings_collection):
+    """String i gets the terminator chr(0x0A00 + i) appended (asts/utils.py:25-40)."""
+    start = consts.String.UNICODE_SPECIAL_SYMBOLS_START
+    return [s + chr(start + i) for i, s in enumerate(strings_collection)]
+
+
+def strings_to_symbols(strings_collection):
+    """The code points of "".join(make_unique_endings(strings)) as uint32 -- the
+    input layout of east_hip_build (include/east_hip.h).  Terminators are written
+    numerically, so collections beyond the reference's 1 111 552-string limit
+    (0x0A00+i > 0x10FFFF) are fine.  Text code points >= 0x0A00 are rejected."""
+    start = consts.String.UNICODE_SPECIAL_SYMBOLS_START
+    m = len(strings_collection)
+    text = "".join(strings_collection)
+    lens = np.fromiter((len(s) for s in strings_collection), dtype=np.int64, count=m)
+    cps = np.frombuffer(text.encode("utf-32-le", errors="surrogatepass"), dtype="<u4")
+    if cps.size and int(cps.max()) >= start:
+        raise exceptions.SymbolOutOfDomainException(code=int(cps[cps >= start][0]))
+    out = np.empty(cps.size + m, dtype=np.uint32)
+    term_pos = np.cumsum(lens) + np.arange(m)
+    mask = np.ones(out.size, dtype=bool)
+    mask[term_pos] = False
+    out[mask] = cps
+    out[term_pos] = np.arange(m, dtype=np.uint32) + np.uint32(start)
+    return out
+
+
+def query_to_symbols(query):
+    """score() removes U+0020 only (easa.py:36)."""
+    q = query.replace(" ", "")
+    return np.frombuffer(q.encode("utf-32-le", errors="surrogatepass"), dtype="<u4").astype(np.uint32)

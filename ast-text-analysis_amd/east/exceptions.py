@@ -1,0 +1,44 @@
+# -*- coding: utf-8 -*-
+"""Exceptions of the EAST surface (reference east/exceptions.py:6-64)."""
+
+
+class EastException(Exception):
+    """Base EAST exception: `msg_fmt` is %-formatted with the constructor kwargs."""
+    msg_fmt = "An unknown exception occurred."
+
+    def __init__(self, message=None, **kwargs):
+        self.kwargs = kwargs
+        if not message:
+            try:
+                message = self.msg_fmt % kwargs
+            except KeyError:
+                message = self.msg_fmt
+        super(EastException, self).__init__(message)
+
+    def format_message(self):
+        return str(self)
+
+
+class NotFoundException(EastException):
+    msg_fmt = "Not found."
+
+
+class NoSuchASTAlgorithm(NotFoundException):
+    msg_fmt = "There is no AST construction algorithm with name `%(name)s`."
+
+
+class EmptyStringsCollectionException(EastException):
+    msg_fmt = "The input strings collection is empty."
+
+
+class SymbolOutOfDomainException(EastException):
+    """New: the reference is only defined for text code points below U+0A00
+    (its string terminators start there, east/asts/utils.py:25-40); it crashes or
+    gives algorithm-dependent scores beyond.  The HIP backend rejects such input."""
+    msg_fmt = ("Text contains the code point U+%(code)04X >= U+0A00, which collides with the "
+               "string terminators of the annotated suffix tree (outside the method's domain).")
+
+
+class HipBackendError(EastException):
+    """New: the MI355X backend is unavailable or failed.  There is no CPU fallback."""
+    msg_fmt = "HIP backend error: %(reason)s"

@@ -1,0 +1,198 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of the C ABI in include/east_hip.h (libeast_hip.so).
+
+Thin by design: numpy arrays in, numpy arrays out, every error code turned
+into HipBackendError.  There is no CPU fallback -- if the library or a HIP
+device is missing, every compute call raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from east import exceptions
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("EAST_HIP_LIBRARY", os.path.join(_HERE, "_lib", "libeast_hip.so"))
+
+_c_i64p = ctypes.POINTER(ctypes.c_int64)
+_c_i32p = ctypes.POINTER(ctypes.c_int32)
+_c_u32p = ctypes.POINTER(ctypes.c_uint32)
+_c_u64p = ctypes.POINTER(ctypes.c_uint64)
+_c_dblp = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); mirrors include/east_hip.h one to one
+SIGNATURES = {
+    "east_hip_version": (ctypes.c_char_p, []),
+    "east_hip_last_error": (ctypes.c_char_p, []),
+    "east_hip_device_count": (ctypes.c_int, []),
+    "east_hip_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
+    "east_hip_destroy": (None, [ctypes.c_void_p]),
+    "east_hip_build": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, ctypes.c_int64, _c_i64p, _c_i32p, ctypes.c_int32]),
+    "east_hip_build_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _c_i64p, _c_i32p,
+                                             ctypes.c_int32]),
+    "east_hip_get_tables": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [_c_i32p] * 6),
+    "east_hip_score_table": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, _c_i64p, ctypes.c_int32, ctypes.c_int,
+                                            _c_dblp, _c_dblp]),
+    "east_hip_set_keyphrases": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, _c_i64p, ctypes.c_int32]),
+    "east_hip_score_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "east_hip_score_resident_async": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "east_hip_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "east_hip_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "east_hip_build_info": (ctypes.c_int, [ctypes.c_void_p, _c_i64p, ctypes.c_int32]),
+    "east_hip_last_build_ms": (ctypes.c_double, [ctypes.c_void_p]),
+    "east_hip_last_score_ms": (ctypes.c_double, [ctypes.c_void_p]),
+    "east_hip_debug_radix_sort_u64": (ctypes.c_int, [ctypes.c_int, _c_u64p, _c_u32p, ctypes.c_int64, ctypes.c_int]),
+    "east_hip_debug_radix_sort_u32": (ctypes.c_int, [ctypes.c_int, _c_u32p, _c_u32p, ctypes.c_int64, ctypes.c_int]),
+    "east_hip_debug_exclusive_scan": (ctypes.c_int, [ctypes.c_int, _c_u32p, _c_u32p, ctypes.c_int64]),
+    "east_hip_debug_suffix_array": (ctypes.c_int, [ctypes.c_int, _c_u32p, ctypes.c_int64, ctypes.c_uint32, _c_i32p,
+                                                   _c_i32p]),
+    "east_hip_plan_arena_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32]),
+}
+
+BUILD_INFO_FIELDS = ("n_total", "n_docs", "n_strings", "sigma_text", "bits_level0", "dc3_levels", "arena_bytes",
+                     "arena_high_water", "radix_passes", "radix_elements", "radix_element_bytes")
+
+_lib = None
+
+
+def load():
+    """Load libeast_hip.so (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise exceptions.HipBackendError(
+                reason="%s not found -- build it with `make -C ast-text-analysis_amd/csrc` "
+                       "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise exceptions.HipBackendError(reason="cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load().east_hip_last_error()
+        raise exceptions.HipBackendError(reason="%s (code %d)" % (msg.decode("utf-8", "replace") if msg else "?", rc))
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def device_count():
+    c = load().east_hip_device_count()
+    return c if c > 0 else 0
+
+
+def default_device():
+    for var in ("EAST_HIP_DEVICE", "LOCAL_RANK"):
+        if os.environ.get(var, "") != "":
+            return int(os.environ[var])
+    return 0
+
+
+class HipIndex(object):
+    """One device-resident batch of annotated suffix arrays (an AST shard)."""
+
+    def __init__(self, device=None, reserve_symbols=0):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        self.device = default_device() if device is None else int(device)
+        _check(self._lib.east_hip_create(self.device, int(reserve_symbols), ctypes.byref(self._h)))
+        self.n_docs = 0
+        self.doc_offsets = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.east_hip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    # -- build ---------------------------------------------------------------
+    def build(self, symbols, doc_offsets, n_strings):
+        symbols = np.ascontiguousarray(symbols, dtype=np.uint32)
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.int64)
+        n_strings = np.ascontiguousarray(n_strings, dtype=np.int32)
+        _check(self._lib.east_hip_build(self._h, _ptr(symbols, _c_u32p), symbols.size, _ptr(doc_offsets, _c_i64p),
+                                        _ptr(n_strings, _c_i32p), n_strings.size))
+        self.n_docs = int(n_strings.size)
+        self.doc_offsets = doc_offsets.copy()
+
+    def build_device(self, d_symbols_ptr, n_total, doc_offsets, n_strings):
+        """d_symbols_ptr: integer address of a uint32 device buffer (e.g. tensor.data_ptr())."""
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.int64)
+        n_strings = np.ascontiguousarray(n_strings, dtype=np.int32)
+        _check(self._lib.east_hip_build_device(self._h, ctypes.c_void_p(int(d_symbols_ptr)), int(n_total),
+                                               _ptr(doc_offsets, _c_i64p), _ptr(n_strings, _c_i32p), n_strings.size))
+        self.n_docs = int(n_strings.size)
+        self.doc_offsets = doc_offsets.copy()
+
+    def tables(self, doc=0, names=("suftab", "lcptab", "anntab", "childtab_up", "childtab_down",
+                                   "childtab_next_l_index")):
+        order = ("suftab", "lcptab", "anntab", "childtab_up", "childtab_down", "childtab_next_l_index")
+        nd = int(self.doc_offsets[doc + 1] - self.doc_offsets[doc])
+        bufs = {k: np.empty(nd, dtype=np.int32) for k in names}
+        args = [_ptr(bufs[k], _c_i32p) if k in bufs else None for k in order]
+        _check(self._lib.east_hip_get_tables(self._h, int(doc), *args))
+        return {k: v.astype(np.int64) for k, v in bufs.items()}    # the reference's np.int dtype
+
+    # -- score ---------------------------------------------------------------
+    def score_table(self, q_symbols, q_offsets, normalized=True, want_suffix=False):
+        q_symbols = np.ascontiguousarray(q_symbols, dtype=np.uint32)
+        q_offsets = np.ascontiguousarray(q_offsets, dtype=np.int64)
+        K = q_offsets.size - 1
+        out = np.empty((K, self.n_docs), dtype=np.float64)
+        suf = np.empty((self.n_docs, int(q_offsets[-1])), dtype=np.float64) if want_suffix else None
+        _check(self._lib.east_hip_score_table(self._h, _ptr(q_symbols, _c_u32p), _ptr(q_offsets, _c_i64p), K,
+                                              int(bool(normalized)), _ptr(out, _c_dblp),
+                                              _ptr(suf, _c_dblp) if want_suffix else None))
+        return (out, suf) if want_suffix else out
+
+    def set_keyphrases(self, q_symbols, q_offsets):
+        q_symbols = np.ascontiguousarray(q_symbols, dtype=np.uint32)
+        q_offsets = np.ascontiguousarray(q_offsets, dtype=np.int64)
+        _check(self._lib.east_hip_set_keyphrases(self._h, _ptr(q_symbols, _c_u32p), _ptr(q_offsets, _c_i64p),
+                                                 q_offsets.size - 1))
+
+    def score_resident(self, normalized=True, d_out_ptr=None):
+        _check(self._lib.east_hip_score_resident(self._h, int(bool(normalized)),
+                                                 ctypes.c_void_p(int(d_out_ptr)) if d_out_ptr else None))
+
+    def synchronize(self):
+        _check(self._lib.east_hip_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return self._lib.east_hip_stream(self._h)
+
+    def info(self):
+        buf = np.zeros(len(BUILD_INFO_FIELDS), dtype=np.int64)
+        self._lib.east_hip_build_info(self._h, _ptr(buf, _c_i64p), buf.size)
+        return dict(zip(BUILD_INFO_FIELDS, (int(x) for x in buf)))
+
+    @property
+    def last_build_ms(self):
+        return float(self._lib.east_hip_last_build_ms(self._h))
+
+    @property
+    def last_score_ms(self):
+        return float(self._lib.east_hip_last_score_ms(self._h))
+
+
+def pack_queries(queries):
+    """[unicode query with spaces already removed] -> (q_symbols uint32, q_offsets int64)."""
+    from east.asts import utils as ast_utils
+    parts = [ast_utils.query_to_symbols(q) for q in queries]
+    offsets = np.zeros(len(parts) + 1, dtype=np.int64)
+    for i, p in enumerate(parts):
+        offsets[i + 1] = offsets[i] + p.size
+    symbols = np.concatenate(parts) if parts else np.zeros(0, np.uint32)
+    return symbols.astype(np.uint32), offsets

@@ -1,0 +1,95 @@
+# -*- coding: utf-8 -*-
+"""Relevance measures (reference east/relevance.py:16-53, AST half).
+
+ASTRelevanceMeasure keeps the reference surface (set_text_collection /
+relevance) and adds the batched path the GPU needs: ONE build call for the whole
+text collection (the documents become one device-resident shard of annotated
+suffix arrays) and `relevance_table`, ONE score call for all keyphrases.
+CosineRelevanceMeasure is a different method and out of scope.
+"""
+import numpy as np
+
+from east import consts
+from east import hip_backend
+from east import utils
+from east.asts import utils as ast_utils
+
+
+class RelevanceMeasure(object):
+
+    def set_text_collection(self, texts, language=consts.Language.ENGLISH):
+        raise NotImplementedError()
+
+    def relevance(self, keyphrase, text, synonimizer=None):
+        # text is the index of the text to measure the relevance to
+        raise NotImplementedError()
+
+
+class _DocumentAST(object):
+    """What `measure.asts[i]` is in the reference: something with .score()."""
+
+    def __init__(self, measure, doc):
+        self._measure, self._doc = measure, doc
+
+    def score(self, query, normalized=True, synonimizer=None, return_suffix_scores=False):
+        if synonimizer or return_suffix_scores:
+            raise NotImplementedError("use east.asts.base.AST.get_ast(...) for synonym / per-suffix scoring")
+        return self._measure._row(query, normalized)[self._doc]
+
+
+class ASTRelevanceMeasure(RelevanceMeasure):
+
+    def __init__(self, ast_algorithm=consts.ASTAlgorithm.EASA, normalized=True, device=None):
+        super(ASTRelevanceMeasure, self).__init__()
+        if ast_algorithm not in list(consts.ASTAlgorithm):
+            from east import exceptions
+            raise exceptions.NoSuchASTAlgorithm(name=ast_algorithm)
+        self.ast_algorithm = ast_algorithm
+        self.normalized = normalized
+        self.device = device
+        self.index = None
+        self._row_cache = (None, None, None)
+
+    # HOT LOOP A (relevance.py:34-49) as one batched build
+    def set_text_collection(self, texts, language=consts.Language.ENGLISH):
+        self.texts = texts
+        self.language = language
+        collections = [utils.text_to_strings_collection(text) for text in texts]   # relevance.py:44-45
+        self.set_strings_collections(collections)
+
+    def set_strings_collections(self, collections):
+        """collections[d] = the strings collection of document d (one AST each)."""
+        parts = [ast_utils.strings_to_symbols(sc) for sc in collections]
+        doc_offsets = np.zeros(len(parts) + 1, dtype=np.int64)
+        np.cumsum([p.size for p in parts], out=doc_offsets[1:])
+        n_strings = np.array([len(sc) for sc in collections], dtype=np.int32)
+        symbols = np.concatenate(parts) if parts else np.zeros(0, np.uint32)
+        if self.index is None:
+            self.index = hip_backend.HipIndex(self.device)
+        self.index.build(symbols, doc_offsets, n_strings)
+        self.asts = [_DocumentAST(self, d) for d in range(len(parts))]
+        self._row_cache = (None, None, None)
+
+    def _row(self, query, normalized):
+        q = query.replace(" ", "")
+        if self._row_cache[0] != q or self._row_cache[1] != bool(normalized):
+            if not q:
+                raise ZeroDivisionError("float division by zero")              # easa.py:134
+            qs, qo = hip_backend.pack_queries([q])
+            self._row_cache = (q, bool(normalized), self.index.score_table(qs, qo, normalized)[0])
+        return self._row_cache[2]
+
+    def relevance(self, keyphrase, text, synonimizer=None):
+        """relevance.py:51-53: the score of a prepared keyphrase in text number `text`."""
+        if synonimizer:
+            raise NotImplementedError("synonym-expanded scoring is not part of the HIP hot path")
+        return float(self._row(keyphrase, self.normalized)[text])
+
+    # HOT LOOP B (applications.py:43-52) as one batched call
+    def relevance_table(self, prepared_keyphrases):
+        """K prepared keyphrases -> K x D float64 array of scores."""
+        queries = [kp.replace(" ", "") for kp in prepared_keyphrases]
+        if not all(queries):
+            raise ZeroDivisionError("float division by zero")
+        qs, qo = hip_backend.pack_queries(queries)
+        return self.index.score_table(qs, qo, self.normalized)

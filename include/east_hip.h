@@ -1,0 +1,169 @@
+/*
+ * east_hip.h -- C ABI of the MI355X (gfx950) annotated-suffix-array backend.
+ *
+ * This is the drop-in boundary for the one hot path of EAST
+ * (mikhaildubov/AST-text-analysis): building the enhanced annotated suffix
+ * array of every document and filling the keyphrase x document score table.
+ * The reference has no FFI on this path -- it is a Python class plugin
+ * (east/asts/base.py:10-46: subclass AST, set __algorithm__, implement
+ * score()).  The entry points below are what that plugin binds through
+ * ctypes; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative EAST_HIP_ERR_* code;
+ *     east_hip_last_error() returns a thread-local message for the last failure
+ *   - plain pointers and sizes only; the caller owns every host buffer
+ *     (C-contiguous), the library owns device memory behind the opaque handle
+ *   - calls are blocking unless the name ends in _async; a handle is not
+ *     thread-safe, distinct handles are; one HIP stream per handle
+ *   - indices are int32 on the device (n_total < 2^31 - 8); the Python side
+ *     widens to int64 to match the reference's np.int tables
+ *   - symbols are Unicode code points; a symbol >= 0x0A00 is a string
+ *     terminator (east/consts.py:23-24, east/asts/utils.py:25-40); text symbols
+ *     must be < 0x0A00 (the reference's defined input domain)
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     fails with EAST_HIP_ERR_NO_DEVICE
+ */
+#ifndef EAST_HIP_H
+#define EAST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EAST_HIP_OK                 0
+#define EAST_HIP_ERR_NO_DEVICE     -1  /* no HIP device / bad device ordinal            */
+#define EAST_HIP_ERR_INVALID       -2  /* bad argument (null pointer, size, offsets)    */
+#define EAST_HIP_ERR_OOM           -3  /* device allocation failed                      */
+#define EAST_HIP_ERR_HIP           -4  /* a HIP runtime call or kernel launch failed    */
+#define EAST_HIP_ERR_DOMAIN        -5  /* input outside the reference's domain          */
+#define EAST_HIP_ERR_NOT_BUILT     -6  /* score/get_tables before a successful build    */
+#define EAST_HIP_ERR_INTERNAL      -7  /* self-check failed (a bug)                     */
+
+#define EAST_HIP_TERMINATOR_START 0x0A00u /* east/consts.py:23-24 */
+
+typedef struct east_hip_index *east_hip_handle_t;
+
+/* Library / device discovery. */
+const char *east_hip_version(void);
+const char *east_hip_last_error(void);
+int east_hip_device_count(void);       /* >= 0, or EAST_HIP_ERR_NO_DEVICE */
+
+/*
+ * Create / destroy an index object bound to one device.  reserve_symbols > 0
+ * pre-allocates the device arena for builds of up to that many symbols so
+ * that later builds do not allocate (0 = allocate lazily at build time).
+ */
+int east_hip_create(int device, int64_t reserve_symbols, east_hip_handle_t *out);
+void east_hip_destroy(east_hip_handle_t h);
+
+/*
+ * Batched EASA build: replaces EnhancedAnnotatedSuffixArray.__init__
+ * (east/asts/easa.py:16-24: make_unique_endings + _compute_suftab /
+ * _compute_lcptab / _compute_childtab* / _compute_anntab) for D documents
+ * at once -- i.e. HOT LOOP A of ASTRelevanceMeasure.set_text_collection
+ * (east/relevance.py:34-49).
+ *
+ *   symbols       concatenation of every document's EASA string: for document
+ *                 d, its strings in order, string i followed by the terminator
+ *                 0x0A00+i (i local to the document) -- exactly the code points
+ *                 of the reference's `self.string`
+ *   n_total       number of symbols (sum of n_d)
+ *   doc_offsets   D+1 offsets into symbols, doc_offsets[0]=0, [D]=n_total
+ *   n_strings     D values m_d (strings per document = terminators per document)
+ *
+ * On success the suffix array, LCP table, child tables and annotation table of
+ * every document are resident on the device.  east_hip_build_device takes a
+ * DEVICE pointer for `symbols` (doc_offsets / n_strings stay host pointers);
+ * the buffer is only read.
+ */
+int east_hip_build(east_hip_handle_t h, const uint32_t *symbols, int64_t n_total,
+                   const int64_t *doc_offsets, const int32_t *n_strings, int32_t n_docs);
+int east_hip_build_device(east_hip_handle_t h, const uint32_t *d_symbols, int64_t n_total,
+                          const int64_t *doc_offsets, const int32_t *n_strings, int32_t n_docs);
+
+/*
+ * Copy one document's tables to the host (each pointer nullable, n_d int32
+ * values each, positions local to the document): the reference attributes
+ * suftab, lcptab, anntab (easa.py:20-24) and childtab_up / childtab_down /
+ * childtab_next_l_index (easa.py:268-304).
+ */
+int east_hip_get_tables(east_hip_handle_t h, int32_t doc, int32_t *suftab, int32_t *lcptab,
+                        int32_t *anntab, int32_t *childtab_up, int32_t *childtab_down,
+                        int32_t *childtab_next_l_index);
+
+/*
+ * Keyphrase x document score table: replaces HOT LOOP B
+ * (east/applications.py:43-52 -> relevance.py:51-53 -> easa.py:26-36,91-139).
+ *
+ *   q_symbols   concatenated code points of the K prepared keyphrases with
+ *               U+0020 already removed (easa.py:36)
+ *   q_offsets   K+1 offsets into q_symbols; every keyphrase must be non-empty
+ *               (the reference raises ZeroDivisionError, easa.py:134)
+ *   normalized  non-zero = divide each suffix score by its matched length
+ *               (easa.py:128-129), zero = the CLI's -d
+ *   out         K x D doubles, row-major (out[k*D + d])
+ *   suffix_out  nullable; D x S doubles (S = q_offsets[K]), suffix_out[d*S + s]
+ *               = the per-suffix result of the suffix starting at q_symbols[s]
+ *               (the values of return_suffix_scores=True, easa.py:132-137)
+ */
+int east_hip_score_table(east_hip_handle_t h, const uint32_t *q_symbols,
+                         const int64_t *q_offsets, int32_t n_keyphrases, int normalized,
+                         double *out, double *suffix_out);
+
+/*
+ * The same in two steps, for callers that score one keyphrase set repeatedly
+ * or want the table to stay in HBM: east_hip_set_keyphrases uploads the
+ * keyphrases (host pointers, as above) and keeps them resident;
+ * east_hip_score_resident runs the score kernels on the resident index and
+ * keyphrases.  d_out (nullable) is a DEVICE pointer receiving the K x D table;
+ * without it the table stays in the handle's own buffer.  The _async form only
+ * queues the kernels on the handle's stream (pair with east_hip_synchronize).
+ */
+int east_hip_set_keyphrases(east_hip_handle_t h, const uint32_t *q_symbols,
+                            const int64_t *q_offsets, int32_t n_keyphrases);
+int east_hip_score_resident(east_hip_handle_t h, int normalized, double *d_out);
+int east_hip_score_resident_async(east_hip_handle_t h, int normalized);
+
+/* Block until everything queued on the handle's stream has finished. */
+int east_hip_synchronize(east_hip_handle_t h);
+/* The handle's hipStream_t (as void*) so callers can record events on it. */
+void *east_hip_stream(east_hip_handle_t h);
+
+/*
+ * Build facts for reports: fills up to `cap` int64 values and returns how many
+ * exist: [0] n_total, [1] n_docs, [2] total strings, [3] text alphabet size,
+ * [4] bits per symbol at level 0, [5] DC3 recursion levels, [6] arena bytes,
+ * [7] arena high-water bytes, [8] radix passes executed, [9] radix elements
+ * moved (sum over passes), [10] bytes of one radix element (key+value) at the
+ * widest level.
+ */
+int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap);
+
+/* Device-time of the last build / score call in milliseconds (HIP events on
+ * the handle's stream around the whole call), or a negative error code. */
+double east_hip_last_build_ms(east_hip_handle_t h);
+double east_hip_last_score_ms(east_hip_handle_t h);
+
+/*
+ * Kernel-level entry points used by the parity tests (host buffers in/out).
+ * They exercise exactly the kernels the build uses.
+ *   radix sort: stable LSD sort of (key, value) pairs on key bits [0, bits)
+ *   scan:       exclusive prefix sum of uint32
+ *   suffix_array: DC3 over a dense alphabet: symbols in [1, sigma], n >= 1
+ */
+int east_hip_debug_radix_sort_u64(int device, uint64_t *keys, uint32_t *vals, int64_t n, int bits);
+int east_hip_debug_radix_sort_u32(int device, uint32_t *keys, uint32_t *vals, int64_t n, int bits);
+int east_hip_debug_exclusive_scan(int device, const uint32_t *in, uint32_t *out, int64_t n);
+int east_hip_debug_suffix_array(int device, const uint32_t *symbols, int64_t n, uint32_t sigma,
+                                int32_t *sa_out, int32_t *levels_out);
+/* Host-only: bytes of device arena a build of n_total symbols / n_docs documents
+ * reserves (worst case over inputs).  Needs no device. */
+int64_t east_hip_plan_arena_bytes(int64_t n_total, int32_t n_docs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAST_HIP_H */

@@ -1,0 +1,214 @@
+"""gpu tier: the parity tests proper.  Everything goes through the C ABI
+(east.hip_backend -> libeast_hip.so); the checker is the committed golden
+fixtures (generated from the imported reference) and the CPU oracle.
+
+Bar: suffix array, LCP, annotation and child tables bit-exact; scores are
+compared with == (bit-equal) where the fixtures hold them and the required
+tolerance 1e-6 is asserted as well.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, word_stream
+
+pytestmark = pytest.mark.gpu
+
+TABLES = ("suftab", "lcptab", "anntab", "childtab_up", "childtab_down", "childtab_next_l_index")
+TOL = 1e-6
+
+
+def _check_case(base, case):
+    ast = base.AST.get_ast(case["strings"])
+    assert [ord(c) for c in ast.string] == case["string"]
+    for name in TABLES:
+        got = getattr(ast, name)
+        assert got.dtype == np.int64
+        assert got.tolist() == case[name], (name, case["strings"])
+    for q in case["queries"]:
+        for mode, norm in (("normalized", True), ("denormalized", False)):
+            total, suffixes = ast.score(q["query"], normalized=norm, return_suffix_scores=True)
+            assert abs(total - q[mode]) <= TOL
+            assert total == q[mode], (case["strings"], q["query"], mode, total, q[mode])
+            assert ast.score(q["query"], normalized=norm) == q[mode]
+            qq = q["query"].replace(" ", "")
+            want = q["suffix_" + mode]
+            # the reference returns a dict keyed by suffix text: repeated suffixes collapse to the last
+            expect = {qq[i:]: want[i] for i in range(len(qq))}
+            assert suffixes == expect
+
+
+def test_readme_example(hip):
+    from east.asts import base
+    case = load_golden("readme_example.json")
+    _check_case(base, case)
+    ast = base.AST.get_ast(["XABXAC", "HI"])
+    assert ast.score("ABCI") == 0.1875          # README.rst:151
+    assert ast.score("NOPE") == 0               # README.rst:152
+
+
+def test_reference_unit_test_case(hip):
+    """tests/asts/test_base.py:13-24: every algorithm name gives identical scores."""
+    from east.asts import base
+    case = load_golden("test_base_case.json")
+    _check_case(base, case)
+    for alg in ("easa", "easa_hip", "ast_linear", "ast_naive"):
+        ast = base.AST.get_ast(case["strings"], alg)
+        for q in case["queries"]:
+            assert ast.score(q["query"], normalized=True) == q["normalized"]
+            assert ast.score(q["query"], normalized=False) == q["denormalized"]
+
+
+def test_fuzz_fixtures(hip):
+    from east.asts import base
+    for case in load_golden("fuzz_small.json")["cases"]:
+        _check_case(base, case)
+
+
+def test_factory_errors(hip):
+    from east import exceptions
+    from east.asts import base
+    with pytest.raises(exceptions.EmptyStringsCollectionException):
+        base.AST.get_ast([])
+    with pytest.raises(exceptions.NoSuchASTAlgorithm):
+        base.AST.get_ast(["A"], "no_such")
+    with pytest.raises(exceptions.SymbolOutOfDomainException):
+        base.AST.get_ast(["中文AB"])
+    with pytest.raises(ZeroDivisionError):
+        base.AST.get_ast(["AB"]).score(" ")
+
+
+def _table_equal(got, want):
+    assert set(got) == set(want)
+    for kp in want:
+        assert set(got[kp]) == set(want[kp])
+        for t in want[kp]:
+            assert abs(got[kp][t] - want[kp][t]) <= TOL
+            assert got[kp][t] == want[kp][t], (kp, t, got[kp][t], want[kp][t])
+
+
+@pytest.mark.parametrize("fixture", ["sample_table.json", "hse_config1.json", "zipf_docs.json"])
+def test_keyphrases_table_fixtures(hip, fixture):
+    """BASELINE config 1 (30 HSE docs x 10 keyphrases), the XABXAC sample and the
+    natural-language-like docs scored by ast_linear: the batched build + batched score."""
+    from east import applications, relevance
+    g = load_golden(fixture)
+    texts = {k: v.encode("utf-8") for k, v in g["texts"].items()}
+    for mode, norm in (("normalized", True), ("denormalized", False)):
+        measure = relevance.ASTRelevanceMeasure("easa", norm)
+        table = applications.keyphrases_table(g["keyphrases"], texts, measure)
+        _table_equal(table, g[mode])
+        if "sum_" + mode in g:
+            assert abs(sum(v for row in table.values() for v in row.values()) - g["sum_" + mode]) < 1e-9
+        # per-pair surface (relevance.py:51-53) agrees with the batched table
+        from east import utils
+        names = list(texts.keys())
+        for kp in g["keyphrases"][:3]:
+            for j in (0, len(names) - 1):
+                assert measure.relevance(utils.prepare_text(kp), j) == g[mode][kp][names[j]]
+
+
+def test_hse_per_doc_tables(hip):
+    """Per-document tables out of ONE batched build equal the reference's per-document ASTs."""
+    from east import relevance
+    g = load_golden("hse_config1.json")
+    names = list(g["texts"].keys())
+    measure = relevance.ASTRelevanceMeasure()
+    measure.set_text_collection([g["texts"][k].encode("utf-8") for k in names])
+    for d, name in enumerate(names):
+        want = g["per_doc"][name]
+        t = measure.index.tables(d)
+        assert len(t["suftab"]) == want["n"]
+        assert t["suftab"][:8].tolist() == want["suftab_head"]
+        assert int(sum(int(x) * (i + 1) for i, x in enumerate(t["suftab"]))) == want["suftab_sum"]
+        assert int(t["lcptab"].sum()) == want["lcptab_sum"] and int(t["lcptab"].max()) == want["max_lcp"]
+        assert int(t["anntab"].sum()) == want["anntab_sum"]
+
+
+def _random_collections(rng, n_docs, alphabet, max_strings=8, max_len=14):
+    docs = []
+    for _ in range(n_docs):
+        m = int(rng.integers(1, max_strings + 1))
+        sc = ["".join(rng.choice(list(alphabet), size=int(rng.integers(0, max_len + 1)))) for _ in range(m)]
+        if sum(map(len, sc)) == 0:
+            sc[0] = alphabet[0]
+        docs.append(sc)
+    return docs
+
+
+@pytest.mark.parametrize("alphabet", ["AB", "ABC", "ABCDEFGH", "AB C", "АБВГДЕЖЗ"])
+def test_fuzz_multidoc_vs_oracle(hip, oracle, alphabet):
+    """Random small corpora: every table of every document and the K x D scores vs the oracle's
+    faithful port (sibling-chain walk), normalized and denormalized."""
+    from east import relevance
+    rng = np.random.default_rng(abs(hash(alphabet)) % 1000)
+    for it in range(6):
+        docs = _random_collections(rng, int(rng.integers(1, 9)), alphabet)
+        measure = relevance.ASTRelevanceMeasure()
+        measure.set_strings_collections(docs)
+        oracles = [oracle.OracleEASA(sc) for sc in docs]
+        for d, o in enumerate(oracles):
+            t = measure.index.tables(d)
+            for name in TABLES:
+                assert np.array_equal(t[name], getattr(o, name)), (name, docs[d])
+        queries = ["".join(rng.choice(list(alphabet + "Z"), size=int(rng.integers(1, 12)))) for _ in range(12)]
+        queries = [q for q in queries if q.replace(" ", "")]
+        for norm in (True, False):
+            measure.normalized = norm
+            table = measure.relevance_table(queries)
+            for k, q in enumerate(queries):
+                for d, o in enumerate(oracles):
+                    assert table[k, d] == o.score(q, normalized=norm), (docs[d], q, norm)
+
+
+def test_medium_docs_vs_oracle(hip, oracle):
+    """8 word-stream docs of 64 KiB in text mode (3-word strings): bit-exact tables and scores
+    against the oracle (fast walk, itself pinned to the faithful walk in the CPU tier)."""
+    from east import relevance, utils
+    rng = np.random.default_rng(20243)
+    texts = [word_stream(rng, 64 << 10) for _ in range(8)]
+    measure = relevance.ASTRelevanceMeasure()
+    measure.set_text_collection(texts)
+    collections = [utils.text_to_strings_collection(t) for t in texts]
+    oracles = [oracle.OracleEASA(sc) for sc in collections]
+    for d, o in enumerate(oracles):
+        t = measure.index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+    kps = []
+    for i in range(200):
+        if i % 2 == 0:
+            toks = texts[i % 8].decode().split()
+            st = int(rng.integers(0, len(toks) - 3))
+            kps.append(" ".join(toks[st:st + int(rng.integers(1, 4))]))
+        else:
+            kps.append(word_stream(rng, int(rng.integers(4, 24))).decode().strip())
+    kps = [k for k in kps if k.replace(" ", "")]
+    for norm in (True, False):
+        measure.normalized = norm
+        table = measure.relevance_table([utils.prepare_text(k) for k in kps])
+        for k, kp in enumerate(kps):
+            for d, o in enumerate(oracles):
+                assert table[k, d] == o.score(utils.prepare_text(kp), normalized=norm, fast=True)
+
+
+def test_score_invariant_to_sharding(hip):
+    """Shard-emulation (SURVEY.md section 4 tier 5): the K x D table does not depend on how the
+    documents are split into device shards or on document order."""
+    from east import relevance, utils
+    rng = np.random.default_rng(7)
+    texts = [word_stream(rng, 8 << 10) for _ in range(12)]
+    kps = [utils.prepare_text(word_stream(rng, 12).decode()) for _ in range(40)]
+    full = relevance.ASTRelevanceMeasure()
+    full.set_text_collection(texts)
+    want = full.relevance_table(kps)
+    for shards in (2, 3, 4):
+        cols = []
+        for r in range(shards):
+            part = texts[r::shards]
+            m = relevance.ASTRelevanceMeasure()
+            m.set_text_collection(part)
+            cols.append((list(range(len(texts)))[r::shards], m.relevance_table(kps)))
+        got = np.empty_like(want)
+        for idx, block in cols:
+            got[:, idx] = block
+        assert np.array_equal(got, want)
