@@ -65,6 +65,54 @@ struct Arena {
 
 struct Stats {
     i64 levels = 0, radix_passes = 0, radix_elems = 0, radix_elem_bytes = 0;
+    i64 radix_elems_u32 = 0, radix_elems_u64 = 0, radix_passes_u32 = 0, radix_passes_u64 = 0;
+};
+
+// Optional per-kernel timing with HIP events on the handle's own stream (the
+// stream the kernels are launched on); off unless east_hip_profile_enable().
+struct Profiler {
+    struct Rec { const char *name; hipEvent_t e0, e1; };
+    struct Sum { std::string name; i64 count; double ms; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    std::vector<Sum> sums;
+    bool enabled = false;
+
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) east_throw(EAST_HIP_ERR_HIP, "hipEventCreate failed");
+        return e;
+    }
+    void begin(const char *name, hipStream_t st)
+    {
+        Rec r{name, get(), get()};
+        (void)hipEventRecord(r.e0, st);
+        recs.push_back(r);
+    }
+    void end(hipStream_t st) { (void)hipEventRecord(recs.back().e1, st); }
+    // call after the stream has been synchronised
+    void collect()
+    {
+        for (auto &r : recs) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+            bool found = false;
+            for (auto &s : sums)
+                if (s.name == r.name) { s.count++; s.ms += ms; found = true; break; }
+            if (!found) sums.push_back(Sum{r.name, 1, ms});
+            pool.push_back(r.e0);
+            pool.push_back(r.e1);
+        }
+        recs.clear();
+    }
+    void reset() { collect(); sums.clear(); }
+    ~Profiler()
+    {
+        for (auto &r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
 };
 
 struct Ctx {
@@ -72,16 +120,22 @@ struct Ctx {
     Arena *arena = nullptr;
     bool dry = false;
     Stats *stats = nullptr;
+    Profiler *prof = nullptr;
 };
 
 static inline u32 ceil_div_u32(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 static inline int bit_width_u32(u32 x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
 
-#define LAUNCH(ctx, kernel, grid, ...)                                                     \
+#define LAUNCH(ctx, kernel, grid, ...) LAUNCH_NAMED(ctx, #kernel, kernel, grid, __VA_ARGS__)
+
+#define LAUNCH_NAMED(ctx, name, kernel, grid, ...)                                         \
     do {                                                                                   \
         if (!(ctx).dry) {                                                                  \
+            const bool _p = (ctx).prof && (ctx).prof->enabled;                             \
+            if (_p) (ctx).prof->begin(name, (ctx).stream);                                 \
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, (ctx).stream, __VA_ARGS__); \
             HIP_CHECK(hipGetLastError());                                                  \
+            if (_p) (ctx).prof->end((ctx).stream);                                         \
         }                                                                                  \
     } while (0)
 

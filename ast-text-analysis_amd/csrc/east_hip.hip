@@ -90,6 +90,7 @@ struct east_hip_index {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Arena arena;
     Stats stats;
+    Profiler prof;
     bool built = false;
     u32 n = 0, n_docs = 0, sigma_t = 0, m_total = 0;
     int bits0 = 0;
@@ -283,12 +284,15 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     ctx.stream = h->stream;
     ctx.arena = &h->arena;
     ctx.stats = &h->stats;
+    ctx.prof = &h->prof;
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));
     build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings);
     HIP_CHECK(hipEventRecord(h->ev1, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->prof.collect();
     HIP_CHECK(hipEventElapsedTime(&h->last_build_ms, h->ev0, h->ev1));
     h->n = n;
+    if (h->n_docs != (u32)n_docs) h->n_kp = 0;       // resident keyphrase scratch is sized per n_docs
     h->n_docs = (u32)n_docs;
     h->h_doc_off.assign(doc_offsets, doc_offsets + n_docs + 1);
     h->h_n_strings.assign(n_strings, n_strings + n_docs);
@@ -353,6 +357,7 @@ static void score_resident(east_hip_index *h, int normalized)
     use_device(h);
     Ctx ctx;
     ctx.stream = h->stream;
+    ctx.prof = &h->prof;
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));
     LAUNCH(ctx, query_map_kernel, ceil_div_u32(h->n_q, BLOCK), (const u32 *)h->q_raw, h->n_q,
            (const u32 *)h->code_map, h->q_code);
@@ -520,11 +525,41 @@ void *east_hip_stream(east_hip_handle_t h) { return h ? (void *)h->stream : null
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap)
 {
     if (!h || !out) return EAST_HIP_ERR_INVALID;
-    const int64_t v[11] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
+    const int64_t v[15] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
                            (int64_t)h->arena.cap, (int64_t)h->arena.high, h->stats.radix_passes,
-                           h->stats.radix_elems, h->stats.radix_elem_bytes};
-    for (int i = 0; i < 11 && i < cap; i++) out[i] = v[i];
-    return 11;
+                           h->stats.radix_elems, h->stats.radix_elem_bytes, h->stats.radix_passes_u32,
+                           h->stats.radix_elems_u32, h->stats.radix_passes_u64, h->stats.radix_elems_u64};
+    for (int i = 0; i < 15 && i < cap; i++) out[i] = v[i];
+    return 15;
+}
+
+int east_hip_profile_enable(east_hip_handle_t h, int on)
+{
+    if (!h) return EAST_HIP_ERR_INVALID;
+    return guarded([&] {
+        use_device(h);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->prof.reset();
+        h->prof.enabled = on != 0;
+    });
+}
+
+int64_t east_hip_profile_report(east_hip_handle_t h, char *buf, int64_t cap)
+{
+    if (!h || !buf || cap < 1) return EAST_HIP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    h->prof.collect();
+    std::string out;
+    for (auto &s : h->prof.sums) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s\t%lld\t%.6f\n", s.name.c_str(), (long long)s.count, s.ms);
+        out += line;
+    }
+    const int64_t nb = (int64_t)out.size() < cap - 1 ? (int64_t)out.size() : cap - 1;
+    memcpy(buf, out.data(), (size_t)nb);
+    buf[nb] = 0;
+    return (int64_t)out.size();
 }
 
 int64_t east_hip_plan_arena_bytes(int64_t n_total, int32_t n_docs)

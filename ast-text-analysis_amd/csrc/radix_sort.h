@@ -145,15 +145,19 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits)
     u32 *hist = ctx.arena->alloc<u32>((size_t)RS_BINS * n_tiles);
     int cur = 0;
     for (int shift = 0; shift < bits; shift += 8) {
-        LAUNCH(ctx, (radix_hist_kernel<K>), n_tiles, (const K *)b.keys[cur], n, shift, hist, n_tiles);
+        LAUNCH_NAMED(ctx, sizeof(K) == 8 ? "radix_hist_kernel<u64>" : "radix_hist_kernel<u32>",
+                     (radix_hist_kernel<K>), n_tiles, (const K *)b.keys[cur], n, shift, hist, n_tiles);
         device_scan<ArrIn, false>(ctx, ArrIn{hist}, RS_BINS * n_tiles, hist);
-        LAUNCH(ctx, (radix_scatter_kernel<K>), n_tiles, (const K *)b.keys[cur],
+        LAUNCH_NAMED(ctx, sizeof(K) == 8 ? "radix_scatter_kernel<u64>" : "radix_scatter_kernel<u32>",
+                     (radix_scatter_kernel<K>), n_tiles, (const K *)b.keys[cur],
                (const u32 *)b.vals[cur], b.keys[cur ^ 1], b.vals[cur ^ 1], n, shift,
                (const u32 *)hist, n_tiles);
         cur ^= 1;
         if (ctx.stats) {
             ctx.stats->radix_passes++;
             ctx.stats->radix_elems += n;
+            if (sizeof(K) == 8) { ctx.stats->radix_elems_u64 += n; ctx.stats->radix_passes_u64++; }
+            else { ctx.stats->radix_elems_u32 += n; ctx.stats->radix_passes_u32++; }
             if ((i64)(sizeof(K) + 4) > ctx.stats->radix_elem_bytes)
                 ctx.stats->radix_elem_bytes = sizeof(K) + 4;
         }

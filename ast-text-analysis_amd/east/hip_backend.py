@@ -48,10 +48,13 @@ SIGNATURES = {
     "east_hip_debug_suffix_array": (ctypes.c_int, [ctypes.c_int, _c_u32p, ctypes.c_int64, ctypes.c_uint32, _c_i32p,
                                                    _c_i32p]),
     "east_hip_plan_arena_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32]),
+    "east_hip_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "east_hip_profile_report": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
 }
 
 BUILD_INFO_FIELDS = ("n_total", "n_docs", "n_strings", "sigma_text", "bits_level0", "dc3_levels", "arena_bytes",
-                     "arena_high_water", "radix_passes", "radix_elements", "radix_element_bytes")
+                     "arena_high_water", "radix_passes", "radix_elements", "radix_element_bytes",
+                     "radix_passes_u32", "radix_elements_u32", "radix_passes_u64", "radix_elements_u64")
 
 _lib = None
 
@@ -177,6 +180,19 @@ class HipIndex(object):
         buf = np.zeros(len(BUILD_INFO_FIELDS), dtype=np.int64)
         self._lib.east_hip_build_info(self._h, _ptr(buf, _c_i64p), buf.size)
         return dict(zip(BUILD_INFO_FIELDS, (int(x) for x in buf)))
+
+    def profile_enable(self, on=True):
+        _check(self._lib.east_hip_profile_enable(self._h, int(bool(on))))
+
+    def profile_report(self):
+        """{kernel name: (launches, total_ms)} accumulated since profile_enable()."""
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._lib.east_hip_profile_report(self._h, buf, len(buf))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, count, ms = line.split("\t")
+            out[name.strip("()")] = (int(count), float(ms))
+        return out
 
     @property
     def last_build_ms(self):

@@ -1,0 +1,88 @@
+# -*- coding: utf-8 -*-
+"""BASELINE synthetic corpora: uniform A-Z word streams.
+
+`word_stream_document` returns the text AND the EASA symbol array the product's
+own text preparation would produce for it (utils.text_to_strings_collection +
+asts.utils.strings_to_symbols), built with numpy so that 64 MiB documents do
+not go through Python's regex tokenizer.  tests/test_host_logic.py checks the
+two routes give identical symbols.
+"""
+import numpy as np
+
+TERMINATOR_START = 0x0A00
+
+
+def _words(rng, n_bytes, lo=3, hi=10):
+    n_words = int(n_bytes // ((lo + hi) / 2.0 + 1.0) * 1.1) + 16
+    lens = rng.integers(lo, hi + 1, size=n_words).astype(np.int64)
+    while int(lens.sum() + n_words) < n_bytes + hi + 1:
+        lens = np.concatenate([lens, rng.integers(lo, hi + 1, size=n_words).astype(np.int64)])
+    starts = np.cumsum(lens + 1) - (lens + 1)              # word w occupies [start, start+len), then a space
+    keep = starts < n_bytes
+    lens, starts = lens[keep], starts[keep]
+    lens[-1] = min(int(lens[-1]), n_bytes - int(starts[-1]))   # the byte budget may cut the last word
+    return lens, starts
+
+
+def word_stream_document(rng, n_bytes, want_text=True):
+    """One document: words of length U{3..10} over A-Z joined by single spaces, cut at n_bytes.
+
+    Returns (text bytes or None, symbols uint32, n_strings): symbols is the
+    document's EASA string -- groups of three words (tokens of length <= 2 are
+    dropped, utils.py:63) each followed by its terminator 0x0A00+i."""
+    lens, starts = _words(rng, n_bytes)
+    letters = rng.integers(65, 91, size=int(lens.sum()), dtype=np.uint8)
+    text = None
+    if want_text:
+        buf = np.full(n_bytes, 32, dtype=np.uint8)
+        pos = np.repeat(starts - (np.cumsum(lens) - lens), lens) + np.arange(letters.size)
+        buf[pos] = letters
+        text = buf.tobytes()
+    tok = lens > 2                                          # only the cut last word can fail this
+    if not tok.all():
+        letter_keep = np.repeat(tok, lens)
+        letters, lens = letters[letter_keep], lens[tok]
+    k = lens.size
+    if k == 0:                                              # utils.py:76-77: [" "]
+        return text, np.array([32, TERMINATOR_START], dtype=np.uint32), 1
+    m = (k + 2) // 3
+    tok_idx = np.arange(k, dtype=np.int64)
+    out_start = (np.cumsum(lens) - lens) + tok_idx // 3
+    is_last = (tok_idx % 3 == 2) | (tok_idx == k - 1)
+    term_pos = (out_start + lens)[is_last]
+    out = np.empty(int(lens.sum()) + m, dtype=np.uint32)
+    mask = np.ones(out.size, dtype=bool)
+    mask[term_pos] = False
+    out[mask] = letters
+    out[term_pos] = np.arange(m, dtype=np.uint32) + np.uint32(TERMINATOR_START)
+    return text, out, int(m)
+
+
+def direct_document(rng, n_symbols):
+    """`get_ast([one long string])` mode: n_symbols-1 letters A-Z + the single terminator."""
+    out = rng.integers(65, 91, size=n_symbols, dtype=np.uint32)
+    out[-1] = TERMINATOR_START
+    return out, 1
+
+
+def keyphrases(rng, doc_symbols, n_keyphrases, doc_offsets=None):
+    """1-3 'words': half copied from random corpus positions (deep matches), half fresh random.
+
+    Returns (q_symbols uint32, q_offsets int64) with spaces already removed --
+    the layout of east_hip_score_table."""
+    parts = []
+    n = doc_symbols.size
+    for i in range(n_keyphrases):
+        length = int(rng.integers(3, 11, size=int(rng.integers(1, 4))).sum())
+        if i % 2 == 0 and n > length + 1:
+            st = int(rng.integers(0, n - length))
+            q = doc_symbols[st:st + length]
+            q = q[q < TERMINATOR_START]
+            if q.size == 0:
+                q = rng.integers(65, 91, size=length, dtype=np.uint32)
+        else:
+            q = rng.integers(65, 91, size=length, dtype=np.uint32)
+        parts.append(q.astype(np.uint32))
+    offsets = np.zeros(n_keyphrases + 1, dtype=np.int64)
+    np.cumsum([p.size for p in parts], out=offsets[1:])
+    return np.concatenate(parts), offsets

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- the EAST hot path on N MI355X GPUs (one process per GPU).
+
+Workload (BASELINE.json configs[1], one copy per GPU = weak scaling):
+  one synthetic 64 MiB random-ASCII word-stream document per GPU, turned into
+  3-word strings exactly as `east keyphrases table` does (text mode), and 1 000
+  keyphrases.  The corpus shards at document granularity: rank r owns one AST
+  shard; the K x N score table is assembled with one RCCL all-gather.
+
+A "step" is one pass of the whole hot path over that batch, with the symbol
+stream already resident in HBM:
+    EASA build (dense remap, DC3 suffix array, LCP, annotation + child tables)
+    + score table (K keyphrases x local documents) [+ all-gather of the blocks]
+value = input document bytes of all ranks / step time.
+
+The JSON line also carries
+  roofline      -- the dominant kernel of the timed region (by summed HIP-event
+                   time on the library's own stream): algorithmic bytes / time
+  cpu_baseline  -- the CPU oracle (C port of the reference's easa.py) timed on
+                   this box's host cores on a bounded sample (rank 0, N=1 only)
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ast-text-analysis_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--doc-mib", type=float, default=64.0, help="document size per GPU in MiB")
+    ap.add_argument("--keyphrases", type=int, default=1000)
+    ap.add_argument("--mode", choices=["text", "direct"], default="text",
+                    help="text: 3-word strings as the CLI does; direct: get_ast([one string])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=float, default=8.0)
+    return ap.parse_args()
+
+
+def kernel_bytes(name, info, n, n_q, n_docs):
+    """Algorithmic HBM bytes of ALL launches of one kernel in one step."""
+    e32, e64 = info["radix_elements_u32"], info["radix_elements_u64"]
+    table = {
+        # read key+value, write key+value
+        "radix_scatter_kernel<u64>": e64 * 24, "radix_scatter_kernel<u32>": e32 * 16,
+        # read keys once
+        "radix_hist_kernel<u64>": e64 * 8, "radix_hist_kernel<u32>": e32 * 4,
+    }
+    return table.get(name)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from east import hip_backend, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- synthetic inputs (seed = 20240 + config# + rank), outside the timed region ----
+    n_bytes = int(args.doc_mib * (1 << 20))
+    rng = np.random.default_rng(20240 + 2 + 1000 * rank)
+    if args.mode == "text":
+        _, symbols, m = synthetic.word_stream_document(rng, n_bytes, want_text=False)
+    else:
+        symbols, m = synthetic.direct_document(rng, n_bytes + 1)
+    n = int(symbols.size)
+    K = args.keyphrases
+    # keyphrases: every rank contributes K/world sampled from its own document, the set is replicated
+    share = [K // world + (1 if r < K % world else 0) for r in range(world)]
+    q_local = synthetic.keyphrases(rng, symbols, share[rank])
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (q_local[0], q_local[1]))
+    else:
+        gathered = [q_local]
+    q_parts, q_off = [], [0]
+    for qs, qo in gathered:
+        q_parts.append(qs)
+        q_off.extend((qo[1:] + q_off[-1]).tolist())
+    q_symbols, q_offsets = np.concatenate(q_parts), np.array(q_off, dtype=np.int64)
+
+    d_symbols = torch.from_numpy(symbols.view(np.int32)).to(dev)          # resident in HBM
+    doc_offsets = np.array([0, n], dtype=np.int64)
+    n_strings = np.array([m], dtype=np.int32)
+    local_block = torch.empty((K, 1), dtype=torch.float64, device=dev)    # K x D_local
+    full_table = torch.empty((world, K, 1), dtype=torch.float64, device=dev) if world > 1 else None
+
+    index = hip_backend.HipIndex(local_rank, reserve_symbols=n)
+    index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)    # also sizes the score scratch
+    index.set_keyphrases(q_symbols, q_offsets)
+
+    def step():
+        index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)
+        index.score_resident(True, local_block.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(full_table, local_block)           # RCCL over xGMI
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    index.profile_enable(True)
+    build_ms, score_ms = [], []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        build_ms.append(index.last_build_ms)
+        score_ms.append(index.last_score_ms)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = index.profile_report()
+    index.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    info = index.info()
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = world * n_bytes / (elapsed / args.steps)
+        # ---- roofline of the dominant kernel (HIP events on the library's stream) ----
+        total_kernel_ms = sum(ms for _, ms in prof.values())
+        dom = max(prof.items(), key=lambda kv: kv[1][1])
+        dom_name, (dom_launches, dom_ms) = dom
+        bytes_per_step = kernel_bytes(dom_name, info, n, int(q_offsets[-1]), 1)
+        roofline = {"kernel": dom_name, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "launches_per_step": dom_launches // args.steps,
+                    "avg_launch_ms": dom_ms / dom_launches,
+                    "share_of_kernel_time": dom_ms / total_kernel_ms, "traffic": None}
+        if bytes_per_step is not None:
+            achieved = bytes_per_step * args.steps / (dom_ms * 1e-3) / 1e9
+            roofline.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": bytes_per_step / (dom_launches // args.steps)})
+        else:
+            roofline.update({"achieved": None, "frac": None})
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):
+            with open(traffic_file) as f:
+                roofline["traffic"] = json.load(f).get(dom_name)
+        out = {
+            "metric": "corpus chars/sec (SA+annotation build + keyphrase score table)",
+            "value": value, "unit": "chars/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 (symbols/indices) + f64 (scores)", "data": "synthetic",
+            "config": {"workload": "1 synthetic %g MiB random-ASCII word-stream doc per GPU (%s mode), "
+                                   "%d keyphrases, easa-HIP" % (args.doc_mib, args.mode, K),
+                       "symbols_per_gpu": n, "strings_per_gpu": m, "parallelism": "doc-shard x%d" % world},
+            "build_ms": float(np.mean(build_ms)), "score_ms": float(np.mean(score_ms)),
+            "build_symbols_per_s": n / (float(np.mean(build_ms)) * 1e-3),
+            "build_chars_per_s": n_bytes / (float(np.mean(build_ms)) * 1e-3),
+            "keyphrase_scores_per_s": K / (float(np.mean(score_ms)) * 1e-3),
+            "build_algorithmic_GBps": 16.0 * n / (float(np.mean(build_ms)) * 1e-3) / 1e9,
+            "dc3_levels": info["dc3_levels"], "radix_passes": info["radix_passes"],
+            "roofline": roofline,
+            "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in
+                                    sorted(prof.items(), key=lambda kv: -kv[1][1])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, synthetic)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, synthetic):
+    """The oracle (C port of the reference algorithm, single thread) on a bounded sample."""
+    from oracle import easa_oracle
+    easa_oracle.build()
+    n_bytes = int(args.cpu_sample_mib * (1 << 20))
+    rng = np.random.default_rng(20240 + 2)
+    if args.mode == "text":
+        _, symbols, m = synthetic.word_stream_document(rng, n_bytes, want_text=False)
+    else:
+        symbols, m = synthetic.direct_document(rng, n_bytes + 1)
+    t0 = time.perf_counter()
+    orc = easa_oracle.OracleEASA(symbols=symbols, n_strings=m)
+    t_build = time.perf_counter() - t0
+    qs, qo = synthetic.keyphrases(rng, symbols, 200)
+    t0 = time.perf_counter()
+    for k in range(200):
+        orc.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=False)
+    t_score = time.perf_counter() - t0
+    return {"value": n_bytes / t_build, "unit": "chars/s", "cores": 1, "kind": "port",
+            "sample": "oracle/easa_oracle.c full EASA build (DC3+Kasai+childtab+anntab) of one %g MiB "
+                      "word-stream doc (%d symbols, %d strings), %.1f s; host has %d cores"
+                      % (args.cpu_sample_mib, symbols.size, m, t_build, os.cpu_count()),
+            "build_symbols_per_s": symbols.size / t_build,
+            "keyphrase_scores_per_s": 200 / t_score}
+
+
+if __name__ == "__main__":
+    main()

@@ -138,7 +138,8 @@ void *east_hip_stream(east_hip_handle_t h);
  * [4] bits per symbol at level 0, [5] DC3 recursion levels, [6] arena bytes,
  * [7] arena high-water bytes, [8] radix passes executed, [9] radix elements
  * moved (sum over passes), [10] bytes of one radix element (key+value) at the
- * widest level.
+ * widest level, [11] passes and [12] elements with 32-bit keys, [13] passes and
+ * [14] elements with 64-bit keys.
  */
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap);
 
@@ -146,6 +147,15 @@ int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap);
  * the handle's stream around the whole call), or a negative error code. */
 double east_hip_last_build_ms(east_hip_handle_t h);
 double east_hip_last_score_ms(east_hip_handle_t h);
+
+/*
+ * Per-kernel timing for bench.py's roofline leg: when enabled, every kernel the
+ * handle launches is bracketed by HIP events on the handle's stream.  The
+ * report is text, one line per kernel: "name<TAB>launches<TAB>total_ms".
+ * Enabling resets the accumulated sums.  Returns the report length.
+ */
+int east_hip_profile_enable(east_hip_handle_t h, int on);
+int64_t east_hip_profile_report(east_hip_handle_t h, char *buf, int64_t cap);
 
 /*
  * Kernel-level entry points used by the parity tests (host buffers in/out).
