@@ -1,0 +1,98 @@
+# -*- coding: utf-8 -*-
+"""Multi-GPU sharding of the hot path: one process per GPU, one AST shard per GPU.
+
+Every document is an independent annotated suffix tree (reference
+east/relevance.py:41-46) and every (keyphrase, document) score is independent
+(east/applications.py:43-52), so the corpus shards at document granularity with
+no collective on the build path.  The only exchange step is assembling the
+K x D score table: one all-gather of each rank's K x D_local block
+(`torch.distributed`, backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
+in the CPU tests).  A single document's suffix sort does not shard.
+"""
+import numpy as np
+
+from east import consts
+from east import relevance
+from east import utils
+
+
+def shard_documents(sizes, world_size):
+    """Contiguous blocks of documents balanced by size (symbols or bytes).
+
+    Returns world_size (start, end) pairs covering range(len(sizes)); blocks may
+    be empty when there are fewer documents than ranks."""
+    sizes = np.asarray(sizes, dtype=np.float64)
+    n = len(sizes)
+    csum = np.cumsum(sizes)
+    total = float(csum[-1]) if n else 0.0
+    bounds = [0]
+    for r in range(1, world_size):
+        # first document count whose cumulative size reaches r/world of the total
+        cut = int(np.searchsorted(csum, total * r / world_size, side="left")) + 1 if n else 0
+        bounds.append(min(max(cut, bounds[-1]), n))
+    bounds.append(n)
+    return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
+
+
+def all_gather_table(local_block, counts, group=None):
+    """Assemble the K x D table from per-rank K x D_local blocks.
+
+    local_block: torch tensor (K, D_local) float64 on the rank's device (cuda for
+    RCCL, cpu for gloo); counts[r] = D_local of rank r.  Blocks are padded to the
+    largest D_local so that a single all_gather_into_tensor moves everything."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    K = local_block.shape[0]
+    width = max(max(counts), 1)
+    padded = torch.zeros((K, width), dtype=local_block.dtype, device=local_block.device)
+    padded[:, :local_block.shape[1]] = local_block
+    gathered = torch.empty((world * K, width), dtype=local_block.dtype, device=local_block.device)
+    dist.all_gather_into_tensor(gathered, padded.contiguous(), group=group)     # rank-major concatenation
+    gathered = gathered.view(world, K, width)
+    return torch.cat([gathered[r, :, :counts[r]] for r in range(world)], dim=1)
+
+
+class DistributedASTRelevanceMeasure(relevance.ASTRelevanceMeasure):
+    """ASTRelevanceMeasure whose text collection is sharded over the ranks of a
+    torch.distributed process group.  Every rank calls the same methods with the
+    same arguments; relevance_table returns the full K x D table on every rank."""
+
+    def __init__(self, ast_algorithm=consts.ASTAlgorithm.EASA, normalized=True, device=None, group=None,
+                 measure_factory=None):
+        super(DistributedASTRelevanceMeasure, self).__init__(ast_algorithm, normalized, device)
+        self.group = group
+        # the local shard's measure; the factory hook exists so that the collective
+        # logic can be exercised on CPU (gloo) with a stand-in scorer
+        self._factory = measure_factory or (lambda: relevance.ASTRelevanceMeasure(ast_algorithm, normalized, device))
+
+    def set_text_collection(self, texts, language=consts.Language.ENGLISH):
+        import torch.distributed as dist
+        self.texts = texts
+        self.language = language
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        self.shards = shard_documents([len(t) for t in texts], world)
+        self.counts = [e - b for b, e in self.shards]
+        b, e = self.shards[rank]
+        self.local = self._factory()
+        self.local.normalized = self.normalized
+        if e > b:
+            self.local.set_text_collection(list(texts[b:e]), language)
+
+    def relevance_table(self, prepared_keyphrases):
+        import torch
+        import torch.distributed as dist
+        rank = dist.get_rank(self.group)
+        K = len(prepared_keyphrases)
+        self.local.normalized = self.normalized
+        if self.counts[rank]:
+            block = np.asarray(self.local.relevance_table(prepared_keyphrases), dtype=np.float64)
+        else:
+            block = np.zeros((K, 0), dtype=np.float64)
+        backend = dist.get_backend(self.group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        table = all_gather_table(torch.from_numpy(block).to(dev), self.counts, self.group)
+        return table.cpu().numpy()
+
+    def relevance(self, keyphrase, text, synonimizer=None):
+        return float(self.relevance_table([keyphrase])[0, text])

@@ -109,7 +109,7 @@ def main():
     doc_offsets = np.array([0, n], dtype=np.int64)
     n_strings = np.array([m], dtype=np.int32)
     local_block = torch.empty((K, 1), dtype=torch.float64, device=dev)    # K x D_local
-    full_table = torch.empty((world, K, 1), dtype=torch.float64, device=dev) if world > 1 else None
+    full_table = torch.empty((world * K, 1), dtype=torch.float64, device=dev) if world > 1 else None
 
     index = hip_backend.HipIndex(local_rank, reserve_symbols=n)
     index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)    # also sizes the score scratch

@@ -115,6 +115,7 @@ static void kark_sort(const i64 *s, i64 *SA, i64 n, i64 K)
 int easa_suftab(const uint32_t *sym, i64 n, i64 *suftab)
 {
     if (n <= 0) return -1;
+    if (n == 1) { suftab[0] = 0; return 0; }   /* the reference raises IndexError here */
     i64 *s = (i64 *)malloc(((size_t)n + 3) * sizeof(i64));
     i64 K = 1;
     for (i64 i = 0; i < n; i++) { s[i] = (i64)sym[i]; if (s[i] > K) K = s[i]; }
