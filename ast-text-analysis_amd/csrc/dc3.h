@@ -41,6 +41,45 @@ __global__ __launch_bounds__(BLOCK) void dc3_triple_keys_kernel(const u32 *__res
     vals[t] = t;
 }
 
+// Level 0 of an EASA build: every symbol >= term_first is a unique string
+// terminator, ordered by its position in the corpus.  All terminators share the
+// code term_first in the key and the symbols behind the first terminator of a
+// triple are dropped; triples are enumerated in text order, so the STABLE sort
+// leaves equal keys in position order = terminator order.  Triples holding a
+// terminator are unique and get their own name (KeyNeqTermIn).  This keeps the
+// level-0 keys at 3*bits(sigma_text+1) instead of 3*bits(sigma_text+n_strings).
+template <class K>
+__global__ __launch_bounds__(BLOCK) void dc3_triple_keys_term_kernel(const u32 *__restrict__ s, u32 n0,
+                                                                     u32 n02, int b, u32 term_first,
+                                                                     K *__restrict__ keys,
+                                                                     u32 *__restrict__ vals)
+{
+    const u32 u = blockIdx.x * BLOCK + threadIdx.x;
+    if (u >= n02) return;
+    const u32 q = u >> 1, r = u & 1u;
+    const u32 p = 3u * q + 1u + r;                  // sample positions in text order: 1,2,4,5,7,8,...
+    u32 c0 = s[p], c1 = s[p + 1], c2 = s[p + 2];
+    c0 = c0 < term_first ? c0 : term_first;
+    c1 = c0 == term_first ? 0u : (c1 < term_first ? c1 : term_first);
+    c2 = (c0 == term_first || c1 == term_first) ? 0u : (c2 < term_first ? c2 : term_first);
+    keys[u] = ((K)c0 << (2 * b)) | ((K)c1 << b) | (K)c2;
+    vals[u] = r ? n0 + q : q;
+}
+
+template <class K> struct KeyNeqTermIn {
+    const K *keys;
+    int b;
+    u32 term_first;
+    __device__ __forceinline__ u32 operator()(u32 i) const
+    {
+        const K k = keys[i];
+        const u32 mask = (1u << b) - 1u;
+        const bool has_term = ((u32)(k >> (2 * b)) & mask) == term_first ||
+                              ((u32)(k >> b) & mask) == term_first || ((u32)k & mask) == term_first;
+        return (i == 0 || has_term || k != keys[i - 1]) ? 1u : 0u;
+    }
+};
+
 // wide alphabets (3b > 64): stage A sorts by the third symbol ...
 __global__ __launch_bounds__(BLOCK) void dc3_third_keys_kernel(const u32 *__restrict__ s, u32 n0,
                                                                u32 n02, u32 *__restrict__ keys,
@@ -102,12 +141,23 @@ __global__ __launch_bounds__(BLOCK) void dc3_scatter_names_kernel(const u32 *__r
     if (i < 3) s12[n02 + i] = 0;
 }
 
-// ---- step 3: ranks from the recursive suffix array --------------------------
-__global__ __launch_bounds__(BLOCK) void dc3_rank_kernel(const u32 *__restrict__ sa12, u32 n02,
-                                                         u32 *__restrict__ s12)
+// ---- step 3: ranks by text position, interleaved with the symbols -------------
+// SR[p] = (s[p], R[p]): R[p] = rank of the sample suffix at p among all sample
+// suffixes (1-based), 0 for p mod 3 == 0 and for p past the end.  One 24-byte
+// window SR[p..p+2] then holds everything the merge comparator needs for the
+// suffix at p: (s[p], s[p+1], R[p+1], R[p+2]).
+__global__ __launch_bounds__(BLOCK) void dc3_sr_init_kernel(const u32 *__restrict__ s, u32 n_pad,
+                                                            uint2 *__restrict__ sr)
+{
+    const u32 p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p < n_pad) sr[p] = make_uint2(s[p], 0u);
+}
+
+__global__ __launch_bounds__(BLOCK) void dc3_rank_kernel(const u32 *__restrict__ sa12, u32 n0, u32 n02,
+                                                         uint2 *__restrict__ sr)
 {
     const u32 i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n02) s12[sa12[i]] = i + 1;
+    if (i < n02) sr[dc3_sample_pos(sa12[i], n0)].y = i + 1;
 }
 
 // ---- step 4: non-sample suffixes --------------------------------------------
@@ -134,63 +184,153 @@ __global__ __launch_bounds__(BLOCK) void dc3_compact_s0_kernel(const u32 *__rest
 }
 
 // ---- step 5: merge -----------------------------------------------------------
-// true iff the sample suffix (index t in s12 space) sorts before the non-sample
-// suffix at text position j (j mod 3 == 0).            [easa.py:202-207]
-__device__ __forceinline__ bool dc3_sample_leq(const u32 *__restrict__ s,
-                                               const u32 *__restrict__ s12, u32 n0, u32 t, u32 j)
+// Merge-path merge of A = SA12 (sample suffixes, minus the dummy) and B = SA0.
+// The DC3 comparator [easa.py:202-207] on self-contained tuples:
+//   sample at p, p mod 3 == 1:  (s[p], R[p+1])          vs (s[j], R[j+1])
+//   sample at p, p mod 3 == 2:  (s[p], s[p+1], R[p+2])  vs (s[j], s[j+1], R[j+2])
+struct MergeTup {
+    u32 w0, w1, r1, r2;
+};
+
+__device__ __forceinline__ MergeTup dc3_load_tup(const uint2 *__restrict__ sr, u32 p)
 {
-    if (t < n0) {
-        const u32 i = 3u * t + 1u;
-        const u32 a = s[i], c = s[j];
-        if (a != c) return a < c;
-        return s12[t + n0] <= s12[j / 3u];
-    }
-    const u32 i = 3u * (t - n0) + 2u;
-    u32 a = s[i], c = s[j];
-    if (a != c) return a < c;
-    a = s[i + 1];
-    c = s[j + 1];
-    if (a != c) return a < c;
-    return s12[t - n0 + 1u] <= s12[j / 3u + n0];
+    const uint2 x0 = sr[p], x1 = sr[p + 1], x2 = sr[p + 2];
+    MergeTup t;
+    t.w0 = x0.x; t.w1 = x1.x; t.r1 = x1.y; t.r2 = x2.y;
+    return t;
 }
 
-#define MERGE_IPT 8     // outputs per thread
-
-__global__ __launch_bounds__(BLOCK) void dc3_merge_kernel(const u32 *__restrict__ s,
-                                                          const u32 *__restrict__ s12,
-                                                          const u32 *__restrict__ sa12,   // n02
-                                                          const u32 *__restrict__ sa0,    // n0
-                                                          u32 n, u32 n0, u32 n02, u32 skip,
-                                                          u32 *__restrict__ sa_out)
+__device__ __forceinline__ bool dc3_a_leq_b(const MergeTup &a, bool a_mod1, const MergeTup &b)
 {
-    const u32 k0 = (blockIdx.x * BLOCK + threadIdx.x) * MERGE_IPT;
-    if (k0 >= n) return;
-    const u32 *A = sa12 + skip;
-    const u32 nA = n02 - skip, nB = n0;
-    // merge-path split of diagonal k0
-    u32 lo = k0 > nB ? k0 - nB : 0u;
-    u32 hi = k0 < nA ? k0 : nA;
+    if (a.w0 != b.w0) return a.w0 < b.w0;
+    if (a_mod1) return a.r1 <= b.r1;
+    if (a.w1 != b.w1) return a.w1 < b.w1;
+    return a.r2 <= b.r2;
+}
+
+#define MERGE_IPT 8
+#define MERGE_TILE (BLOCK * MERGE_IPT)     // 2048 outputs per workgroup
+
+// splits[i] = number of A elements among the first i*MERGE_TILE outputs
+__global__ __launch_bounds__(BLOCK) void dc3_merge_partition_kernel(const uint2 *__restrict__ sr,
+                                                                    const u32 *__restrict__ A, u32 nA,
+                                                                    const u32 *__restrict__ B, u32 nB,
+                                                                    u32 n0, u32 n_tiles,
+                                                                    u32 *__restrict__ splits)
+{
+    const u32 tile = blockIdx.x * BLOCK + threadIdx.x;
+    if (tile > n_tiles) return;
+    const u64 kk = (u64)tile * MERGE_TILE;
+    const u32 k = kk < (u64)nA + nB ? (u32)kk : nA + nB;
+    u32 lo = k > nB ? k - nB : 0u;
+    u32 hi = k < nA ? k : nA;
     while (lo < hi) {
         const u32 mid = (lo + hi) >> 1;
-        if (dc3_sample_leq(s, s12, n0, A[mid], sa0[k0 - 1u - mid])) lo = mid + 1u;
-        else hi = mid;
+        const u32 t = A[mid];
+        const MergeTup a = dc3_load_tup(sr, dc3_sample_pos(t, n0));
+        const MergeTup b = dc3_load_tup(sr, B[k - 1u - mid]);
+        if (dc3_a_leq_b(a, t < n0, b)) lo = mid + 1u; else hi = mid;
     }
-    u32 a = lo, bq = k0 - lo;
-#pragma unroll 1
-    for (u32 i = 0; i < MERGE_IPT && k0 + i < n; i++) {
-        bool take_a;
-        if (bq >= nB) take_a = true;
-        else if (a >= nA) take_a = false;
-        else take_a = dc3_sample_leq(s, s12, n0, A[a], sa0[bq]);
-        if (take_a) { sa_out[k0 + i] = dc3_sample_pos(A[a], n0); a++; }
-        else { sa_out[k0 + i] = sa0[bq]; bq++; }
+    splits[tile] = lo;
+}
+
+__global__ __launch_bounds__(BLOCK) void dc3_merge_tile_kernel(const uint2 *__restrict__ sr,
+                                                               const u32 *__restrict__ A, u32 nA,
+                                                               const u32 *__restrict__ B, u32 nB, u32 n0,
+                                                               const u32 *__restrict__ splits,
+                                                               u32 *__restrict__ sa_out)
+{
+    __shared__ u32 l_w0[MERGE_TILE], l_w1[MERGE_TILE], l_r1[MERGE_TILE], l_r2[MERGE_TILE];
+    __shared__ u32 l_pos[MERGE_TILE];       // text position; bit 31 = "sample with p mod 3 == 1"
+    __shared__ u32 l_out[MERGE_TILE];
+    const u32 tid = threadIdx.x;
+    const u32 n = nA + nB;
+    const u32 k0 = blockIdx.x * MERGE_TILE;
+    const u32 count = n - k0 < (u32)MERGE_TILE ? n - k0 : (u32)MERGE_TILE;
+    const u32 a0 = splits[blockIdx.x], a1 = splits[blockIdx.x + 1];
+    const u32 na = a1 - a0, b0 = k0 - a0;
+    const u32 nb = count - na;
+
+    // stage the tile: coalesced reads of the two sorted lists, one 24-byte gather per suffix
+#pragma unroll
+    for (int j = 0; j < MERGE_IPT; j++) {
+        const u32 idx = j * BLOCK + tid;
+        if (idx < count) {
+            u32 p, flag = 0;
+            if (idx < na) {
+                const u32 t = A[a0 + idx];
+                p = dc3_sample_pos(t, n0);
+                flag = t < n0 ? 0x80000000u : 0u;
+            } else {
+                p = B[b0 + (idx - na)];
+            }
+            const MergeTup tp = dc3_load_tup(sr, p);
+            l_w0[idx] = tp.w0; l_w1[idx] = tp.w1; l_r1[idx] = tp.r1; l_r2[idx] = tp.r2;
+            l_pos[idx] = p | flag;
+        }
+    }
+    __syncthreads();
+
+    // per-thread merge path inside the tile
+    const u32 d0 = tid * MERGE_IPT;
+    if (d0 < count) {
+        u32 lo = d0 > nb ? d0 - nb : 0u;
+        u32 hi = d0 < na ? d0 : na;
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            const u32 y = na + (d0 - 1u - mid);
+            const MergeTup a = {l_w0[mid], l_w1[mid], l_r1[mid], l_r2[mid]};
+            const MergeTup b = {l_w0[y], l_w1[y], l_r1[y], l_r2[y]};
+            if (dc3_a_leq_b(a, (l_pos[mid] >> 31) != 0, b)) lo = mid + 1u; else hi = mid;
+        }
+        u32 x = lo, y = d0 - lo;               // heads: A[x], B[y]
+        MergeTup ta = {0, 0, 0, 0}, tb = {0, 0, 0, 0};
+        u32 pa = 0, pb = 0;
+        if (x < na) { ta = MergeTup{l_w0[x], l_w1[x], l_r1[x], l_r2[x]}; pa = l_pos[x]; }
+        if (y < nb) { const u32 q = na + y; tb = MergeTup{l_w0[q], l_w1[q], l_r1[q], l_r2[q]}; pb = l_pos[q]; }
+#pragma unroll
+        for (int i = 0; i < MERGE_IPT; i++) {
+            if (d0 + i < count) {
+                bool take_a;
+                if (y >= nb) take_a = true;
+                else if (x >= na) take_a = false;
+                else take_a = dc3_a_leq_b(ta, (pa >> 31) != 0, tb);
+                if (take_a) {
+                    l_out[d0 + i] = pa & 0x7FFFFFFFu;
+                    x++;
+                    if (x < na) { ta = MergeTup{l_w0[x], l_w1[x], l_r1[x], l_r2[x]}; pa = l_pos[x]; }
+                } else {
+                    l_out[d0 + i] = pb;
+                    y++;
+                    if (y < nb) { const u32 q = na + y; tb = MergeTup{l_w0[q], l_w1[q], l_r1[q], l_r2[q]}; pb = l_pos[q]; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MERGE_IPT; j++) {
+        const u32 idx = j * BLOCK + tid;
+        if (idx < count) sa_out[k0 + idx] = l_out[idx];
     }
 }
 
 // ---- host driver ----------------------------------------------------------------
 // s: n+3 symbols (three zero pads), values in [1, sigma].  sa_out: n words.
+// term_first > 0 (level 0 of an EASA build only): symbols >= term_first are
+// unique terminators in increasing order of position.
 // Returns the number of levels executed.
-static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_out, int depth = 0)
+template <class K, class Flag>
+static const u32 *dc3_sort_and_name(Ctx &ctx, SortBufs<K> &sb, u32 n02, int bits, u32 *names, Flag make_flag)
+{
+    const int r = radix_sort_pairs<K>(ctx, sb, n02, bits);
+    auto flag = make_flag(sb.keys[r]);
+    device_scan<decltype(flag), true>(ctx, flag, n02, names);
+    return sb.vals[r];
+}
+
+static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_out, int depth = 0,
+                            u32 term_first = 0)
 {
     const u32 n0 = (n + 2) / 3, n1 = (n + 1) / 3, n2 = n / 3, n02 = n0 + n2;
     const int b = bit_width_u32(sigma);
@@ -198,8 +338,9 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
     int levels = 1;
     Arena &ar = *ctx.arena;
     const size_t mark_level = ar.mark();
-    u32 *s12 = ar.alloc<u32>((size_t)n02 + 3);
     u32 *sa12 = ar.alloc<u32>(n02);
+    const size_t mark_s12 = ar.mark();
+    u32 *s12 = ar.alloc<u32>((size_t)n02 + 3);
 
     // -- sort the sample triples, name them --------------------------------
     u32 n_names = 0;
@@ -207,20 +348,31 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         const size_t mark = ar.mark();
         u32 *names = ar.alloc<u32>(n02);
         const u32 *sorted_vals = nullptr;
-        if (3 * b <= 32) {
+        const int bt = bit_width_u32(term_first);          // bits of the compressed level-0 alphabet
+        if (term_first > 0 && 3 * bt <= 32) {
+            SortBufs<u32> sb;
+            for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
+            LAUNCH(ctx, (dc3_triple_keys_term_kernel<u32>), g02, s, n0, n02, bt, term_first, sb.keys[0], sb.vals[0]);
+            sorted_vals = dc3_sort_and_name<u32>(ctx, sb, n02, 3 * bt, names, [&](const u32 *k) {
+                return KeyNeqTermIn<u32>{k, bt, term_first}; });
+        } else if (term_first > 0) {                       // bt <= 12 always, so 3*bt <= 36 fits 64 bits
+            SortBufs<u64> sb;
+            for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u64>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
+            LAUNCH(ctx, (dc3_triple_keys_term_kernel<u64>), g02, s, n0, n02, bt, term_first, sb.keys[0], sb.vals[0]);
+            sorted_vals = dc3_sort_and_name<u64>(ctx, sb, n02, 3 * bt, names, [&](const u64 *k) {
+                return KeyNeqTermIn<u64>{k, bt, term_first}; });
+        } else if (3 * b <= 32) {
             SortBufs<u32> sb;
             for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
             LAUNCH(ctx, (dc3_triple_keys_kernel<u32>), g02, s, n0, n02, b, sb.keys[0], sb.vals[0]);
-            const int r = radix_sort_pairs<u32>(ctx, sb, n02, 3 * b);
-            device_scan<KeyNeqIn<u32>, true>(ctx, KeyNeqIn<u32>{sb.keys[r]}, n02, names);
-            sorted_vals = sb.vals[r];
+            sorted_vals = dc3_sort_and_name<u32>(ctx, sb, n02, 3 * b, names, [&](const u32 *k) {
+                return KeyNeqIn<u32>{k}; });
         } else if (3 * b <= 64) {
             SortBufs<u64> sb;
             for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u64>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
             LAUNCH(ctx, (dc3_triple_keys_kernel<u64>), g02, s, n0, n02, b, sb.keys[0], sb.vals[0]);
-            const int r = radix_sort_pairs<u64>(ctx, sb, n02, 3 * b);
-            device_scan<KeyNeqIn<u64>, true>(ctx, KeyNeqIn<u64>{sb.keys[r]}, n02, names);
-            sorted_vals = sb.vals[r];
+            sorted_vals = dc3_sort_and_name<u64>(ctx, sb, n02, 3 * b, names, [&](const u64 *k) {
+                return KeyNeqIn<u64>{k}; });
         } else {
             SortBufs<u32> sa;
             for (int k = 0; k < 2; k++) { sa.keys[k] = ar.alloc<u32>(n02); sa.vals[k] = ar.alloc<u32>(n02); }
@@ -256,13 +408,15 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
     }
 
     // -- recurse on the name string ----------------------------------------
-    if (n_names < n02) {
-        levels += dc3_suffix_array(ctx, s12, n02, n_names, sa12, depth + 1);
-        LAUNCH(ctx, dc3_rank_kernel, g02, (const u32 *)sa12, n02, s12);
-    }
+    if (n_names < n02) levels += dc3_suffix_array(ctx, s12, n02, n_names, sa12, depth + 1);
+    ar.release(mark_s12);                              // the name string is dead from here on
 
-    // -- non-sample suffixes + merge ------------------------------------------
+    // -- ranks in text order, non-sample suffixes, merge --------------------------
     {
+        // (unique names: sa12 is the sorted order itself, so rank = index + 1 either way)
+        uint2 *sr = ar.alloc<uint2>((size_t)n + 3);
+        LAUNCH(ctx, dc3_sr_init_kernel, ceil_div_u32((u64)n + 3, BLOCK), s, n + 3, sr);
+        LAUNCH(ctx, dc3_rank_kernel, g02, (const u32 *)sa12, n0, n02, sr);
         u32 *slot = ar.alloc<u32>(n02);
         device_scan<LtIn, false>(ctx, LtIn{sa12, n0}, n02, slot);
         SortBufs<u32> s0;
@@ -270,9 +424,13 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         LAUNCH(ctx, dc3_compact_s0_kernel, g02, s, (const u32 *)sa12, (const u32 *)slot, n0, n02,
                s0.keys[0], s0.vals[0]);
         const int r0 = radix_sort_pairs<u32>(ctx, s0, n0, b);
-        LAUNCH(ctx, dc3_merge_kernel, ceil_div_u32(ceil_div_u32(n, MERGE_IPT), BLOCK), s,
-               (const u32 *)s12, (const u32 *)sa12, (const u32 *)s0.vals[r0], n, n0, n02, n0 - n1,
-               sa_out);
+        const u32 skip = n0 - n1, nA = n02 - skip;
+        const u32 n_tiles = ceil_div_u32(n, MERGE_TILE);
+        u32 *splits = ar.alloc<u32>((size_t)n_tiles + 1);
+        LAUNCH(ctx, dc3_merge_partition_kernel, ceil_div_u32((u64)n_tiles + 1, BLOCK), (const uint2 *)sr,
+               (const u32 *)sa12 + skip, nA, (const u32 *)s0.vals[r0], n0, n0, n_tiles, splits);
+        LAUNCH(ctx, dc3_merge_tile_kernel, n_tiles, (const uint2 *)sr, (const u32 *)sa12 + skip, nA,
+               (const u32 *)s0.vals[r0], n0, n0, (const u32 *)splits, sa_out);
     }
     ar.release(mark_level);
     return levels;

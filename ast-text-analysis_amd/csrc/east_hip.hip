@@ -91,7 +91,7 @@ struct east_hip_index {
     Arena arena;
     Stats stats;
     Profiler prof;
-    bool built = false;
+    bool built = false, child_built = false;
     u32 n = 0, n_docs = 0, sigma_t = 0, m_total = 0;
     int bits0 = 0;
     std::vector<i64> h_doc_off;
@@ -191,12 +191,12 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
 
     // ---- suffix array of the whole shard, then partition by document -------------
     if (n_docs == 1) {
-        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa);
+        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa, 0, sigma_t + 1);
     } else {
         const size_t mark = ar.mark();
         SortBufs<u32> sb;
         for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n); sb.vals[k] = ar.alloc<u32>(n); }
-        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sb.vals[0]);
+        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sb.vals[0], 0, sigma_t + 1);
         LAUNCH(ctx, doc_keys_kernel, gn, (const u32 *)sb.vals[0], (const u32 *)h->doc_off, n_docs, n, sb.keys[0]);
         const int r = radix_sort_pairs<u32>(ctx, sb, n, bit_width_u32(n_docs - 1));
         if (!ctx.dry)
@@ -209,8 +209,8 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     for (int l = 1; l < pyr.levels; l++)
         LAUNCH(ctx, pyramid_level_kernel, ceil_div_u32(pyr.len[l - 1], BLOCK), pyr.ptr[l - 1], pyr.len[l - 1],
                (u32 *)pyr.ptr[l]);
-    LAUNCH(ctx, ann_child_kernel, gn, pyr, (const u32 *)h->doc_off, (const u32 *)h->n_strings, n_docs, n, h->ann,
-           h->up, h->down, h->next);
+    LAUNCH(ctx, ann_kernel, gn, pyr, (const u32 *)h->doc_off, (const u32 *)h->n_strings, n_docs, n, h->ann);
+    h->child_built = false;      // childtab_up / down / next_l_index: built on first east_hip_get_tables request
 }
 
 static size_t plan_arena_bytes(u32 n, u32 n_docs)
@@ -460,6 +460,14 @@ int east_hip_get_tables(east_hip_handle_t h, int32_t doc, int32_t *suftab, int32
         if (!h->built) east_throw(EAST_HIP_ERR_NOT_BUILT, "no index has been built on this handle");
         if (doc < 0 || (u32)doc >= h->n_docs) east_throw(EAST_HIP_ERR_INVALID, "document index out of range");
         use_device(h);
+        if ((childtab_up || childtab_down || childtab_next_l_index) && !h->child_built) {
+            Ctx ctx;
+            ctx.stream = h->stream;
+            ctx.prof = &h->prof;
+            LAUNCH(ctx, child_kernel, ceil_div_u32(h->n, BLOCK), h->pyr, (const u32 *)h->doc_off, h->n_docs, h->n,
+                   h->up, h->down, h->next);
+            h->child_built = true;
+        }
         const size_t b = (size_t)h->h_doc_off[doc], nd = (size_t)(h->h_doc_off[doc + 1] - h->h_doc_off[doc]);
         struct { int32_t *dst; const u32 *src; } jobs[6] = {
             {suftab, h->sa}, {lcptab, h->lcp}, {anntab, h->ann},

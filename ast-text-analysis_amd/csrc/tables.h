@@ -182,21 +182,46 @@ __device__ __forceinline__ u32 pyr_leftmost_argmin(const Pyramid &P, u32 a, u32 
     return pyr_find_right<false>(P, lo, best);
 }
 
-// anntab + the three child tables of one rank.  doc segment starts carry
-// lcp == 0, which bounds every search inside the document.
-__global__ __launch_bounds__(BLOCK) void ann_child_kernel(Pyramid P, const u32 *__restrict__ doc_off,
-                                                          const u32 *__restrict__ n_strings,
-                                                          u32 n_docs, u32 n, u32 *__restrict__ ann,
-                                                          u32 *__restrict__ up, u32 *__restrict__ down,
-                                                          u32 *__restrict__ next)
+// anntab of one rank (easa.py:306-331).  doc segment starts carry lcp == 0,
+// which bounds every search inside the document.
+__global__ __launch_bounds__(BLOCK) void ann_kernel(Pyramid P, const u32 *__restrict__ doc_off,
+                                                    const u32 *__restrict__ n_strings, u32 n_docs, u32 n,
+                                                    u32 *__restrict__ ann)
 {
     const u32 k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n) return;
     const u32 *lcp = P.ptr[0];
     const u32 v = lcp[k];
-    u32 d = 0, seg = 0, seg_end = n;
+    u32 a = 0;
+    if (v == 0) {
+        // only a document's first rank carries an annotation here: the root, n_d - m_d
+        const u32 d = n_docs > 1 ? doc_of(doc_off, n_docs, k) : 0u;
+        if (doc_off[d] == k) a = (doc_off[d + 1] - k) - n_strings[d];
+    } else {
+        // first l-index of its interval <=> the previous value <= v is strictly smaller
+        const u32 pse = pyr_find_left<false>(P, k, v);          // exists: the segment start holds 0
+        if (lcp[pse] < v) {
+            u32 nsv = pyr_find_right<true>(P, k, v);            // stops at the next segment start
+            if (nsv == NONE_U32) nsv = n;
+            a = nsv - pse;                                      // pse == PSV here
+        }
+    }
+    ann[k] = a;
+}
+
+// The three child tables of one rank, positions local to the document, 0 = none
+// (easa.py:268-304).  Not needed by the score walk: computed on first request.
+__global__ __launch_bounds__(BLOCK) void child_kernel(Pyramid P, const u32 *__restrict__ doc_off, u32 n_docs,
+                                                      u32 n, u32 *__restrict__ up, u32 *__restrict__ down,
+                                                      u32 *__restrict__ next)
+{
+    const u32 k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const u32 *lcp = P.ptr[0];
+    const u32 v = lcp[k];
+    u32 seg = 0, seg_end = n;
     if (n_docs > 1) {
-        d = doc_of(doc_off, n_docs, k);
+        const u32 d = doc_of(doc_off, n_docs, k);
         seg = doc_off[d];
         seg_end = doc_off[d + 1];
     }
@@ -208,19 +233,6 @@ __global__ __launch_bounds__(BLOCK) void ann_child_kernel(Pyramid P, const u32 *
     }
     nse = pyr_find_right<false>(P, k, v);
     if (nse != NONE_U32 && nse >= seg_end) nse = NONE_U32;
-
-    // annotation (easa.py:306-331)
-    u32 a = 0;
-    if (k == seg) {
-        a = (seg_end - seg) - n_strings[d];
-    } else if (v > 0 && pse != NONE_U32 && lcp[pse] < v) {
-        u32 nsv = pyr_find_right<true>(P, k, v);
-        if (nsv == NONE_U32 || nsv > seg_end) nsv = seg_end;
-        a = nsv - pse;                                  // pse == PSV here
-    }
-    ann[k] = a;
-
-    // child tables, positions local to the document (0 = none)  (easa.py:268-304)
     next[k] = (nse != NONE_U32 && lcp[nse] == v) ? nse - seg : 0u;
     u32 u = 0, dn = 0;
     if (pse != NONE_U32 && k - pse > 1) u = pyr_leftmost_argmin(P, pse, k) - seg;

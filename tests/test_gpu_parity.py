@@ -212,3 +212,39 @@ def test_score_invariant_to_sharding(hip):
         for idx, block in cols:
             got[:, idx] = block
         assert np.array_equal(got, want)
+
+
+def test_wide_text_alphabet_vs_oracle(hip, oracle):
+    """~2500 distinct text code points: level-0 keys need the 64-bit compressed-terminator path."""
+    from east import relevance
+    rng = np.random.default_rng(5)
+    docs = []
+    for _ in range(3):
+        docs.append(["".join(chr(int(c)) for c in rng.integers(2, 0x0A00, size=int(rng.integers(1, 40))))
+                     for _ in range(int(rng.integers(50, 200)))])
+    measure = relevance.ASTRelevanceMeasure()
+    measure.set_strings_collections(docs)
+    assert measure.index.info()["sigma_text"] > 1024
+    for d, sc in enumerate(docs):
+        o = oracle.OracleEASA(sc)
+        t = measure.index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+        queries = [sc[i][:12] for i in range(0, len(sc), 17) if sc[i]]
+        table = measure.relevance_table(queries)
+        for k, q in enumerate(queries):
+            assert table[k, d] == o.score(q, fast=True)
+
+
+def test_many_strings_terminator_order(hip, oracle):
+    """Many short and duplicate strings: suffixes that differ only in their terminator must come
+    out in terminator (= position) order -- the stable level-0 sort with shared terminator code."""
+    from east.asts import base
+    rng = np.random.default_rng(9)
+    strings = ["".join(rng.choice(list("AB"), size=int(rng.integers(0, 4)))) for _ in range(3000)]
+    ast = base.AST.get_ast(strings)
+    o = oracle.OracleEASA(strings)
+    for name in TABLES:
+        assert np.array_equal(getattr(ast, name), getattr(o, name)), name
+    for q in ["A", "AB", "ABA", "BBB", "ABAB"]:
+        assert ast.score(q) == o.score(q) and ast.score(q, normalized=False) == o.score(q, normalized=False)
