@@ -7,18 +7,15 @@
 //                         the tile, tile re-ordered by digit in LDS, then
 //                         written out as contiguous per-digit runs.
 //
-// Tile = 4096 pairs per 256-thread workgroup: wave w owns the contiguous 1024
-// pairs [w*1024, (w+1)*1024) and walks them in 16 rows of 64 (coalesced 64-lane
-// loads), so the order (wave, row, lane) is the input order and the sort is
-// stable.  LDS: 4096 * (sizeof(K)+4) bytes of staged pairs + 5 KiB of counters
-// (u64 keys: 53 KiB -> 2-3 workgroups per CU out of the 160 KiB).
+// Tile = 4096 pairs per workgroup (see radix_scatter_kernel for the geometry).
 #pragma once
 #include "common.h"
 #include "scan.h"
 
-#define RS_IPT 16
-#define RS_TILE (BLOCK * RS_IPT)       // 4096
-#define RS_WAVE_ITEMS (RS_TILE / WAVES_PER_BLOCK)   // 1024
+#ifndef RS_THREADS
+#define RS_THREADS 1024                // threads per scatter workgroup (16 waves)
+#endif
+#define RS_TILE 4096                   // pairs per workgroup, both kernels
 #define RS_BINS 256
 
 template <class K>
@@ -31,7 +28,7 @@ __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const K *__restrict__
     __syncthreads();
     const u32 base = blockIdx.x * RS_TILE;
 #pragma unroll 4
-    for (int j = 0; j < RS_IPT; j++) {
+    for (int j = 0; j < RS_TILE / BLOCK; j++) {
         const u32 i = base + j * BLOCK + threadIdx.x;
         if (i < n) atomicAdd(&bins[(u32)(keys[i] >> shift) & 255u], 1u);
     }
@@ -39,34 +36,43 @@ __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const K *__restrict__
     hist[threadIdx.x * n_tiles + blockIdx.x] = bins[threadIdx.x];
 }
 
-template <class K>
-__global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(
+// THREADS = 64*WAVES threads move one 4096-pair tile.  Wave w owns the contiguous
+// 4096/WAVES pairs [w*64*IPT, (w+1)*64*IPT) and walks them in IPT rows of 64
+// (coalesced), so (wave, row, lane) is the input order and the pass is stable.
+// Keys and values are staged through the SAME LDS buffer one after the other
+// (the per-pair destination is kept in registers), which keeps the workgroup at
+// 4096*sizeof(K) + 4*WAVES*256 + 2 KiB of LDS: two 16-wave workgroups (32 waves,
+// the hardware maximum) fit a CU.
+template <class K, int THREADS>
+__global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     const K *__restrict__ keys_in, const u32 *__restrict__ vals_in, K *__restrict__ keys_out,
     u32 *__restrict__ vals_out, u32 n, int shift, const u32 *__restrict__ scanned_hist, u32 n_tiles)
 {
+    constexpr int WAVES = THREADS / WAVE;
+    constexpr int IPT = RS_TILE / THREADS;
+    constexpr int WAVE_ITEMS = WAVE * IPT;
+    static_assert(THREADS >= RS_BINS && RS_TILE % THREADS == 0, "bad scatter geometry");
     __shared__ K s_keys[RS_TILE];
-    __shared__ u32 s_vals[RS_TILE];
-    __shared__ u32 wave_cnt[WAVES_PER_BLOCK][RS_BINS];  // per-wave digit counts, then wave bases
+    __shared__ u32 wave_cnt[WAVES][RS_BINS];            // per-wave digit counts, then wave bases
     __shared__ u32 digit_start[RS_BINS];                // first slot of the digit inside the tile
     __shared__ u32 global_base[RS_BINS];                // output index of slot 0 of the digit
-    __shared__ u32 lds4[WAVES_PER_BLOCK];
+    __shared__ u32 lds4[4];
+    u32 *s_vals = reinterpret_cast<u32 *>(s_keys);
 
     const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const u32 tile_base = blockIdx.x * RS_TILE;
     const u32 tile_count = (n - tile_base) < (u32)RS_TILE ? (n - tile_base) : (u32)RS_TILE;
 
-#pragma unroll
-    for (int k = 0; k < WAVES_PER_BLOCK; k++) wave_cnt[k][tid] = 0;
+    for (u32 i = tid; i < WAVES * RS_BINS; i += THREADS) (&wave_cnt[0][0])[i] = 0;
     __syncthreads();
 
-    K key[RS_IPT];
-    u32 val[RS_IPT];
-    u32 rank[RS_IPT];          // (rank among equal digits inside this wave's 1024 pairs)
-    const u64 lt_mask = (1ull << lane) - 1ull;
+    K key[IPT];
+    u32 val[IPT];
+    u32 slot[IPT];             // rank among equal digits inside this wave's pairs, later the tile slot
 
 #pragma unroll
-    for (int j = 0; j < RS_IPT; j++) {
-        const u32 local = w * RS_WAVE_ITEMS + j * WAVE + lane;
+    for (int j = 0; j < IPT; j++) {
+        const u32 local = w * WAVE_ITEMS + j * WAVE + lane;
         const bool valid = local < tile_count;
         key[j] = valid ? keys_in[tile_base + local] : (K)0;
         val[j] = valid ? vals_in[tile_base + local] : 0u;
@@ -81,51 +87,74 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(
         }
         if (!valid) mask = 1ull << lane;
         const u32 cnt = (u32)__popcll(mask);
-        const u32 before = (u32)__popcll(mask & lt_mask);
+        // set bits of `mask` below this lane (v_mbcnt_lo/hi take a per-lane mask)
+        const u32 before = __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
         const int leader = __ffsll((unsigned long long)mask) - 1;
         u32 prior = 0;
-        if (valid && (int)lane == leader) prior = atomicAdd(&wave_cnt[w][digit], cnt);
+        if (valid && before == 0) prior = atomicAdd(&wave_cnt[w][digit], cnt);
         prior = __shfl(prior, leader, WAVE);
-        rank[j] = prior + before;
+        slot[j] = prior + before;
     }
     __syncthreads();
 
-    // thread d owns digit d: wave bases, then the exclusive scan over digits inside the tile
-    {
-        const u32 c0 = wave_cnt[0][tid], c1 = wave_cnt[1][tid], c2 = wave_cnt[2][tid],
-                  c3 = wave_cnt[3][tid];
-        wave_cnt[0][tid] = 0;
-        wave_cnt[1][tid] = c0;
-        wave_cnt[2][tid] = c0 + c1;
-        wave_cnt[3][tid] = c0 + c1 + c2;
-        u32 total;
-        const u32 start = block_exclusive_sum(c0 + c1 + c2 + c3, lds4, total);
+    // thread d (< 256) owns digit d: wave bases, then the exclusive scan over digits inside the tile
+    u32 total_d = 0, inc = 0;
+    if (tid < RS_BINS) {
+        u32 run = 0;
+#pragma unroll
+        for (int k = 0; k < WAVES; k++) {
+            const u32 c = wave_cnt[k][tid];
+            wave_cnt[k][tid] = run;
+            run += c;
+        }
+        total_d = run;
+        inc = wave_inclusive_sum(total_d);
+        if (lane == 63) lds4[w] = inc;
+    }
+    __syncthreads();
+    if (tid < RS_BINS) {
+        u32 start = inc - total_d;
+        if (w > 0) start += lds4[0];
+        if (w > 1) start += lds4[1];
+        if (w > 2) start += lds4[2];
         digit_start[tid] = start;
         global_base[tid] = scanned_hist[tid * n_tiles + blockIdx.x] - start;
     }
     __syncthreads();
 
+    // keys: scatter into tile order, then stream out as contiguous per-digit runs
 #pragma unroll
-    for (int j = 0; j < RS_IPT; j++) {
-        const u32 local = w * RS_WAVE_ITEMS + j * WAVE + lane;
+    for (int j = 0; j < IPT; j++) {
+        const u32 local = w * WAVE_ITEMS + j * WAVE + lane;
         if (local < tile_count) {
             const u32 digit = (u32)(key[j] >> shift) & 255u;
-            const u32 slot = digit_start[digit] + wave_cnt[w][digit] + rank[j];
-            s_keys[slot] = key[j];
-            s_vals[slot] = val[j];
+            slot[j] = digit_start[digit] + wave_cnt[w][digit] + slot[j];
+            s_keys[slot[j]] = key[j];
         }
     }
     __syncthreads();
-
-#pragma unroll 4
-    for (int j = 0; j < RS_IPT; j++) {
-        const u32 slot = j * BLOCK + tid;
-        if (slot < tile_count) {
-            const K k = s_keys[slot];
-            const u32 dst = global_base[(u32)(k >> shift) & 255u] + slot;
-            keys_out[dst] = k;
-            vals_out[dst] = s_vals[slot];
+    u32 dst[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const u32 pos = j * THREADS + tid;
+        if (pos < tile_count) {
+            const K k = s_keys[pos];
+            dst[j] = global_base[(u32)(k >> shift) & 255u] + pos;
+            keys_out[dst[j]] = k;
         }
+    }
+    __syncthreads();
+    // values: same slots, same destinations, through the same LDS buffer
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const u32 local = w * WAVE_ITEMS + j * WAVE + lane;
+        if (local < tile_count) s_vals[slot[j]] = val[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const u32 pos = j * THREADS + tid;
+        if (pos < tile_count) vals_out[dst[j]] = s_vals[pos];
     }
 }
 
@@ -148,10 +177,15 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits)
         LAUNCH_NAMED(ctx, sizeof(K) == 8 ? "radix_hist_kernel<u64>" : "radix_hist_kernel<u32>",
                      (radix_hist_kernel<K>), n_tiles, (const K *)b.keys[cur], n, shift, hist, n_tiles);
         device_scan<ArrIn, false>(ctx, ArrIn{hist}, RS_BINS * n_tiles, hist);
-        LAUNCH_NAMED(ctx, sizeof(K) == 8 ? "radix_scatter_kernel<u64>" : "radix_scatter_kernel<u32>",
-                     (radix_scatter_kernel<K>), n_tiles, (const K *)b.keys[cur],
-               (const u32 *)b.vals[cur], b.keys[cur ^ 1], b.vals[cur ^ 1], n, shift,
-               (const u32 *)hist, n_tiles);
+        if (!ctx.dry) {
+            const bool prof = ctx.prof && ctx.prof->enabled;
+            if (prof) ctx.prof->begin(sizeof(K) == 8 ? "radix_scatter_kernel<u64>" : "radix_scatter_kernel<u32>", ctx.stream);
+            hipLaunchKernelGGL((radix_scatter_kernel<K, RS_THREADS>), dim3(n_tiles), dim3(RS_THREADS), 0, ctx.stream,
+                               (const K *)b.keys[cur], (const u32 *)b.vals[cur], b.keys[cur ^ 1], b.vals[cur ^ 1], n,
+                               shift, (const u32 *)hist, n_tiles);
+            HIP_CHECK(hipGetLastError());
+            if (prof) ctx.prof->end(ctx.stream);
+        }
         cur ^= 1;
         if (ctx.stats) {
             ctx.stats->radix_passes++;

@@ -34,31 +34,71 @@ __global__ __launch_bounds__(BLOCK) void scan_reduce_kernel(In in, u32 n, u32 *b
     if (threadIdx.x == 0) block_sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
 }
 
+// four consecutive inputs starting at i (i is a multiple of 4); zeros past n
+template <class In>
+__device__ __forceinline__ void scan_load4(const In &in, u32 i, u32 n, u32 x[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = (i + k < n) ? in(i + k) : 0u;
+}
+
+__device__ __forceinline__ void scan_load4(const ArrIn &in, u32 i, u32 n, u32 x[4])
+{
+    if (i + 3 < n) {        // arrays come from the 256-byte aligned arena: 16-byte vector load
+        const uint4 v = *reinterpret_cast<const uint4 *>(in.p + i);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = (i + k < n) ? in.p[i + k] : 0u;
+    }
+}
+
 // out[i] = (exclusive or inclusive) prefix of in over [0, i], plus the scanned
 // sum of all earlier tiles.  block_offsets == nullptr means a single tile.
+// Wave w owns 1024 contiguous inputs as 4 rows of 64 lanes x 4 inputs: every
+// load and store is a coalesced 1 KiB (16 B per lane) wavefront access.
 template <class In, bool INCLUSIVE>
 __global__ __launch_bounds__(BLOCK) void scan_apply_kernel(In in, u32 n, const u32 *block_offsets,
                                                            u32 *out)
 {
     __shared__ u32 lds[WAVES_PER_BLOCK];
-    const u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_IPT;   // blocked
-    u32 v[SCAN_IPT];
-    u32 sum = 0;
+    const u32 lane = lane_id(), w = wave_id();
+    const u32 wave_base = blockIdx.x * SCAN_TILE + w * (SCAN_TILE / WAVES_PER_BLOCK);
+    u32 v[4][4];
+    u32 carry = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_IPT; j++) {
-        const u32 i = base + j;
-        v[j] = i < n ? in(i) : 0u;
-        sum += v[j];
+    for (int r = 0; r < 4; r++) {
+        const u32 i = wave_base + r * 256 + lane * 4;
+        u32 x[4];
+        scan_load4(in, i, n, x);
+        const u32 t = x[0] + x[1] + x[2] + x[3];
+        const u32 inc = wave_inclusive_sum(t);
+        u32 run = carry + inc - t;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (INCLUSIVE) run += x[k];
+            v[r][k] = run;
+            if (!INCLUSIVE) run += x[k];
+        }
+        carry += __shfl(inc, 63, WAVE);
     }
-    u32 total;
-    u32 run = block_exclusive_sum(sum, lds, total);
-    if (block_offsets) run += block_offsets[blockIdx.x];
+    if (lane == 0) lds[w] = carry;
+    __syncthreads();
+    u32 base = block_offsets ? block_offsets[blockIdx.x] : 0u;
+    if (w > 0) base += lds[0];
+    if (w > 1) base += lds[1];
+    if (w > 2) base += lds[2];
 #pragma unroll
-    for (int j = 0; j < SCAN_IPT; j++) {
-        const u32 i = base + j;
-        if (INCLUSIVE) run += v[j];
-        if (i < n) out[i] = run;
-        if (!INCLUSIVE) run += v[j];
+    for (int r = 0; r < 4; r++) {
+        const u32 i = wave_base + r * 256 + lane * 4;
+        if (i + 3 < n) {
+            *reinterpret_cast<uint4 *>(out + i) =
+                make_uint4(v[r][0] + base, v[r][1] + base, v[r][2] + base, v[r][3] + base);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (i + k < n) out[i + k] = v[r][k] + base;
+        }
     }
 }
 
