@@ -64,7 +64,7 @@ struct Arena {
 };
 
 struct Stats {
-    i64 levels = 0, radix_passes = 0, radix_elems = 0, radix_elem_bytes = 0;
+    i64 levels = 0, levels_resolved = 0, merge_elems = 0, radix_passes = 0, radix_elems = 0, radix_elem_bytes = 0;
     i64 radix_elems_u32 = 0, radix_elems_u64 = 0, radix_passes_u32 = 0, radix_passes_u64 = 0;
 };
 

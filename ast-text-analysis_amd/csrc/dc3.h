@@ -141,6 +141,47 @@ __global__ __launch_bounds__(BLOCK) void dc3_scatter_names_kernel(const u32 *__r
     if (i < 3) s12[n02 + i] = 0;
 }
 
+// ---- step 2b: almost-unique names: order the few tied samples directly ---------
+// When only a few names are shared, the recursion (a full DC3 over 2n/3 names) is
+// replaced by ranking each tied sample inside its group of equal names: the
+// suffixes of the name string are compared name by name from offset 1 on (the
+// three zero pads end every comparison).  Groups larger than RESOLVE_MAX_GROUP or
+// comparisons longer than RESOLVE_MAX_LEN raise `fail` and the caller recurses.
+#define RESOLVE_MAX_GROUP 32
+#define RESOLVE_MAX_LEN 2048
+
+__global__ __launch_bounds__(BLOCK) void dc3_resolve_ties_kernel(const u32 *__restrict__ sorted_vals,
+                                                                 const u32 *__restrict__ names,
+                                                                 const u32 *__restrict__ s12, u32 n02,
+                                                                 u32 *__restrict__ sa12, u32 *__restrict__ fail)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n02) return;
+    const u32 nm = names[i];
+    const u32 t = sorted_vals[i];
+    const bool left_same = i > 0 && names[i - 1] == nm;
+    const bool right_same = i + 1 < n02 && names[i + 1] == nm;
+    if (!left_same && !right_same) { sa12[i] = t; return; }
+    u32 a = i, b = i + 1;
+    while (a > 0 && names[a - 1] == nm && i - a <= RESOLVE_MAX_GROUP) a--;
+    while (b < n02 && names[b] == nm && b - i <= RESOLVE_MAX_GROUP) b++;
+    if (b - a > RESOLVE_MAX_GROUP) { atomicOr(fail, 1u); return; }
+    u32 r = 0;
+    for (u32 x = a; x < b; x++) {
+        if (x == i) continue;
+        const u32 t2 = sorted_vals[x];
+        u32 h = 1, c1, c2;
+        do {
+            c1 = s12[t + h];
+            c2 = s12[t2 + h];
+            h++;
+        } while (c1 == c2 && h <= RESOLVE_MAX_LEN);
+        if (c1 == c2) { atomicOr(fail, 1u); return; }
+        if (c2 < c1) r++;
+    }
+    sa12[a + r] = t;
+}
+
 // ---- step 3: ranks by text position, interleaved with the symbols -------------
 // SR[p] = (s[p], R[p]): R[p] = rank of the sample suffix at p among all sample
 // suffixes (1-based), 0 for p mod 3 == 0 and for p past the end.  One 24-byte
@@ -401,9 +442,23 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
             if (n_names == 0 || n_names > n02)
                 east_throw(EAST_HIP_ERR_INTERNAL, "dc3: impossible name count");
         }
-        if (n_names == n02 && !ctx.dry)   // unique names: the sorted order is SA12 already
+        if (n_names == n02 && !ctx.dry) {  // unique names: the sorted order is SA12 already
             HIP_CHECK(hipMemcpyAsync(sa12, sorted_vals, (size_t)n02 * sizeof(u32),
                                      hipMemcpyDeviceToDevice, ctx.stream));
+        } else if (!ctx.dry && n02 - n_names <= n02 / 16) {
+            // few ties: order them in place instead of recursing (names[] doubles as the fail word's home)
+            u32 *fail = ar.alloc<u32>(1);
+            u32 h_fail = 0;
+            HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
+            LAUNCH(ctx, dc3_resolve_ties_kernel, g02, sorted_vals, (const u32 *)names, (const u32 *)s12, n02, sa12,
+                   fail);
+            HIP_CHECK(hipMemcpyAsync(&h_fail, fail, sizeof(u32), hipMemcpyDeviceToHost, ctx.stream));
+            HIP_CHECK(hipStreamSynchronize(ctx.stream));
+            if (!h_fail) {
+                n_names = n02;             // SA12 is final
+                if (ctx.stats) ctx.stats->levels_resolved++;
+            }
+        }
         ar.release(mark);
     }
 
@@ -429,6 +484,7 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         u32 *splits = ar.alloc<u32>((size_t)n_tiles + 1);
         LAUNCH(ctx, dc3_merge_partition_kernel, ceil_div_u32((u64)n_tiles + 1, BLOCK), (const uint2 *)sr,
                (const u32 *)sa12 + skip, nA, (const u32 *)s0.vals[r0], n0, n0, n_tiles, splits);
+        if (ctx.stats) ctx.stats->merge_elems += n;
         LAUNCH(ctx, dc3_merge_tile_kernel, n_tiles, (const uint2 *)sr, (const u32 *)sa12 + skip, nA,
                (const u32 *)s0.vals[r0], n0, n0, (const u32 *)splits, sa_out);
     }

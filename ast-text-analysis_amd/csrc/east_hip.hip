@@ -533,12 +533,13 @@ void *east_hip_stream(east_hip_handle_t h) { return h ? (void *)h->stream : null
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap)
 {
     if (!h || !out) return EAST_HIP_ERR_INVALID;
-    const int64_t v[15] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
+    const int64_t v[17] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
                            (int64_t)h->arena.cap, (int64_t)h->arena.high, h->stats.radix_passes,
                            h->stats.radix_elems, h->stats.radix_elem_bytes, h->stats.radix_passes_u32,
-                           h->stats.radix_elems_u32, h->stats.radix_passes_u64, h->stats.radix_elems_u64};
-    for (int i = 0; i < 15 && i < cap; i++) out[i] = v[i];
-    return 15;
+                           h->stats.radix_elems_u32, h->stats.radix_passes_u64, h->stats.radix_elems_u64,
+                           h->stats.levels_resolved, h->stats.merge_elems};
+    for (int i = 0; i < 17 && i < cap; i++) out[i] = v[i];
+    return 17;
 }
 
 int east_hip_profile_enable(east_hip_handle_t h, int on)

@@ -59,6 +59,12 @@ def kernel_bytes(name, info, n, n_q, n_docs):
         "radix_scatter_kernel<u64>": e64 * 24, "radix_scatter_kernel<u32>": e32 * 16,
         # read keys once
         "radix_hist_kernel<u64>": e64 * 8, "radix_hist_kernel<u32>": e32 * 4,
+        # per merged suffix: 4 B sorted-list read + 24 B (symbol, rank) window gather + 4 B write
+        "dc3_merge_tile_kernel": info["merge_elements"] * 32,
+        # 4 B SA read, 2 x 16 B symbol windows, 4 B LCP write per rank (first comparison step)
+        "lcp_kernel": n * 40,
+        # 4 B LCP read + 4 B annotation write per rank
+        "ann_kernel": n * 8,
     }
     return table.get(name)
 
@@ -182,7 +188,8 @@ def main():
             "build_chars_per_s": n_bytes / (float(np.mean(build_ms)) * 1e-3),
             "keyphrase_scores_per_s": K / (float(np.mean(score_ms)) * 1e-3),
             "build_algorithmic_GBps": 16.0 * n / (float(np.mean(build_ms)) * 1e-3) / 1e9,
-            "dc3_levels": info["dc3_levels"], "radix_passes": info["radix_passes"],
+            "dc3_levels": info["dc3_levels"], "dc3_levels_resolved": info["dc3_levels_resolved"],
+            "radix_passes": info["radix_passes"],
             "roofline": roofline,
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in
                                     sorted(prof.items(), key=lambda kv: -kv[1][1])},

@@ -139,7 +139,8 @@ void *east_hip_stream(east_hip_handle_t h);
  * [7] arena high-water bytes, [8] radix passes executed, [9] radix elements
  * moved (sum over passes), [10] bytes of one radix element (key+value) at the
  * widest level, [11] passes and [12] elements with 32-bit keys, [13] passes and
- * [14] elements with 64-bit keys.
+ * [14] elements with 64-bit keys, [15] DC3 levels whose few tied names were
+ * ordered directly instead of recursing, [16] suffixes merged (sum over levels).
  */
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap);
 
