@@ -9,7 +9,8 @@
 //                      ranks [doc_off[d], doc_off[d+1])), values = global positions
 //   lcp/ann  u32[n]    per-document LCP and annotation tables, same layout
 //   up/down/next u32[n] child tables, values local to the document
-//   pyramid            64-ary min pyramid over lcp (tables.h)
+//   s8       u8[n+16]  the same stream, one byte per symbol (0xFF = terminator), when sigma_t <= 254
+//   pyramid            16-ary min pyramid over lcp (tables.h)
 //
 // One suffix sort covers the whole shard: terminators are numbered globally
 // (order inside a document preserved, every terminator above every text
@@ -72,14 +73,18 @@ __global__ __launch_bounds__(BLOCK) void validate_docs_kernel(const u32 *__restr
 __global__ __launch_bounds__(BLOCK) void remap_kernel(const u32 *__restrict__ sym,
                                                       const u32 *__restrict__ term_ex,
                                                       const u32 *__restrict__ code_map, u32 sigma_t,
-                                                      u32 n, u32 *__restrict__ s)
+                                                      u32 n, u32 *__restrict__ s, uint8_t *__restrict__ s8)
 {
     const u32 i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < n) {
         const u32 c = sym[i];
-        s[i] = c < TEXT_SYMBOLS ? code_map[c] : sigma_t + 1u + term_ex[i];
-    } else if (i < n + 3) {
-        s[i] = 0;
+        const bool text = c < TEXT_SYMBOLS;
+        const u32 code = text ? code_map[c] : sigma_t + 1u + term_ex[i];
+        s[i] = code;
+        if (s8) s8[i] = text ? (uint8_t)code : (uint8_t)0xFF;
+    } else {
+        if (i < n + 3) s[i] = 0;
+        if (s8 && i < n + 16) s8[i] = 0;
     }
 }
 
@@ -97,6 +102,8 @@ struct east_hip_index {
     std::vector<i64> h_doc_off;
     std::vector<u32> h_n_strings;
     // persistent device arrays (inside the arena)
+    uint8_t *s8 = nullptr;
+    bool use_s8 = false;
     u32 *s = nullptr, *sa = nullptr, *lcp = nullptr, *ann = nullptr, *up = nullptr, *down = nullptr,
         *next = nullptr, *doc_off = nullptr, *n_strings = nullptr, *code_map = nullptr;
     Pyramid pyr;
@@ -120,8 +127,9 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     ar.release(0);
     // ---- persistent arrays --------------------------------------------------
     h->s = ar.alloc<u32>((size_t)n + 3);
+    h->s8 = ar.alloc<uint8_t>((size_t)n + 16);
     h->sa = ar.alloc<u32>(n);
-    h->lcp = ar.alloc<u32>(n);
+    h->lcp = ar.alloc<u32>(pyr_padded(n));
     h->ann = ar.alloc<u32>(n);
     h->up = ar.alloc<u32>(n);
     h->down = ar.alloc<u32>(n);
@@ -133,10 +141,10 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     pyr.levels = 1;
     pyr.ptr[0] = h->lcp;
     pyr.len[0] = n;
-    while (pyr.len[pyr.levels - 1] > 64) {
+    while (pyr.len[pyr.levels - 1] > PYR_FAN) {
         if (pyr.levels >= PYR_MAX_LEVELS) east_throw(EAST_HIP_ERR_INTERNAL, "pyramid too deep");
-        const u32 len = ceil_div_u32(pyr.len[pyr.levels - 1], 64);
-        pyr.ptr[pyr.levels] = ar.alloc<u32>(len);
+        const u32 len = ceil_div_u32(pyr.len[pyr.levels - 1], PYR_FAN);
+        pyr.ptr[pyr.levels] = ar.alloc<u32>(pyr_padded(len));
         pyr.len[pyr.levels] = len;
         pyr.levels++;
     }
@@ -180,8 +188,9 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
             HIP_CHECK(hipMemcpyAsync(h->code_map, map.data(), TEXT_SYMBOLS * 4, hipMemcpyHostToDevice, ctx.stream));
             HIP_CHECK(hipStreamSynchronize(ctx.stream));   // `map` is a stack-lifetime source
         }
-        LAUNCH(ctx, remap_kernel, ceil_div_u32((u64)n + 3, BLOCK), d_sym, (const u32 *)term_ex,
-               (const u32 *)h->code_map, sigma_t, n, h->s);
+        h->use_s8 = sigma_t <= 254;
+        LAUNCH(ctx, remap_kernel, ceil_div_u32((u64)n + 16, BLOCK), d_sym, (const u32 *)term_ex,
+               (const u32 *)h->code_map, sigma_t, n, h->s, h->use_s8 ? h->s8 : (uint8_t *)nullptr);
         ar.release(mark);
     }
     const u32 sigma = sigma_t + m_total;
@@ -205,10 +214,15 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     }
 
     // ---- LCP, min pyramid, annotation + child tables ------------------------------
-    LAUNCH(ctx, lcp_kernel, gn, (const u32 *)h->s, (const u32 *)h->sa, (const u32 *)h->doc_off, n_docs, n, h->lcp);
+    if (h->use_s8)
+        LAUNCH(ctx, lcp8_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const uint8_t *)h->s8, (const u32 *)h->sa,
+               (const u32 *)h->doc_off, n_docs, n, h->lcp);
+    else
+        LAUNCH(ctx, lcp_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const u32 *)h->s, (const u32 *)h->sa,
+               (const u32 *)h->doc_off, n_docs, n, h->lcp);
     for (int l = 1; l < pyr.levels; l++)
-        LAUNCH(ctx, pyramid_level_kernel, ceil_div_u32(pyr.len[l - 1], BLOCK), pyr.ptr[l - 1], pyr.len[l - 1],
-               (u32 *)pyr.ptr[l]);
+        LAUNCH(ctx, pyramid_level_kernel, ceil_div_u32(pyr_padded(pyr.len[l]), BLOCK), pyr.ptr[l - 1], pyr.len[l],
+               pyr_padded(pyr.len[l]), (u32 *)pyr.ptr[l]);
     LAUNCH(ctx, ann_kernel, gn, pyr, (const u32 *)h->doc_off, (const u32 *)h->n_strings, n_docs, n, h->ann);
     h->child_built = false;      // childtab_up / down / next_l_index: built on first east_hip_get_tables request
 }

@@ -10,22 +10,28 @@
 //   childtab_next_l_index / up / down (easa.py:268-304) -> closed forms over
 //           PSE / NSE and leftmost range minima
 //
-// Nearest-smaller-value and range-minimum queries run on a 64-ary min pyramid
-// over lcptab (level i+1 = min of 64 entries of level i, one wavefront
-// reduction per entry), so every query is O(64 * log64 n) worst case and a
-// handful of L2-resident loads in the common case; the sequential stacks of
-// the reference disappear.
+// Nearest-smaller-value and range-minimum queries run on a 16-ary min pyramid
+// over lcptab (level i+1 = min of 16 entries = one 64-byte line of level i), so
+// every query costs one group fetch (four independent 16-byte loads) per level,
+// O(log16 n) worst case and one or two L2-resident groups in the common case;
+// the sequential stacks of the reference disappear.
 #pragma once
 #include "common.h"
 
-#define PYR_MAX_LEVELS 7
+#define PYR_SHIFT 4
+#define PYR_FAN 16u                 // one group = 16 words = one 64-byte line = 4 x 16-byte loads
+#define PYR_MAX_LEVELS 9            // 16^8 > 2^31
 #define NONE_U32 0xFFFFFFFFu
 
+// Every level is padded to a multiple of 16 words with NONE_U32, so a whole
+// group can always be fetched with four aligned 16-byte loads.
 struct Pyramid {
     const u32 *ptr[PYR_MAX_LEVELS];
     u32 len[PYR_MAX_LEVELS];
     int levels;
 };
+
+static inline u32 pyr_padded(u32 len) { return (len + PYR_FAN - 1u) & ~(PYR_FAN - 1u); }
 
 // document of a rank / position: last d with doc_off[d] <= x
 __device__ __forceinline__ u32 doc_of(const u32 *__restrict__ doc_off, u32 n_docs, u32 x)
@@ -46,14 +52,16 @@ __global__ __launch_bounds__(BLOCK) void doc_keys_kernel(const u32 *__restrict__
     if (i < n) keys[i] = doc_of(doc_off, n_docs, sa[i]);
 }
 
-// seg_start[r] = 1 iff rank r is the first rank of a document segment
 __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
                                                     const u32 *__restrict__ sa,
                                                     const u32 *__restrict__ doc_off, u32 n_docs,
                                                     u32 n, u32 *__restrict__ lcp)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= n) return;
+    if (r >= n) {
+        if (r < ((n + PYR_FAN - 1u) & ~(PYR_FAN - 1u))) lcp[r] = NONE_U32;     // pyramid padding
+        return;
+    }
     if (r == 0) { lcp[0] = 0; return; }
     const u32 i = sa[r - 1], j = sa[r];
     u32 h = 0;
@@ -79,47 +87,104 @@ __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
     lcp[r] = h;
 }
 
-__global__ __launch_bounds__(BLOCK) void pyramid_level_kernel(const u32 *__restrict__ in, u32 len_in,
-                                                              u32 *__restrict__ out)
+// out[i] = min of in[16i .. 16i+15]; the padding of out becomes NONE_U32
+// LCP for small text alphabets (sigma_text <= 254): the symbol stream is also
+// kept as one byte per symbol (text code, 0xFF = "a terminator"), a quarter of
+// the footprint, so the two random windows per rank mostly come out of the
+// Infinity Cache.  Eight symbols per step: first differing byte by xor + ctz;
+// equal 0xFF bytes are two DIFFERENT terminators, so a 0xFF byte also ends the
+// common prefix.  The stream is padded with 16 zero bytes.
+__device__ __forceinline__ u64 load_u64_unaligned(const uint8_t *p)
 {
-    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
-    const u32 v = wave_min(i < len_in ? in[i] : NONE_U32);
-    if (lane_id() == 0 && i < len_in) out[i >> 6] = v;
+    u64 x;
+    __builtin_memcpy(&x, p, 8);
+    return x;
 }
 
-// largest p < k with level0[p] < v (STRICT) or <= v; NONE_U32 if none
+__global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__ s8,
+                                                     const u32 *__restrict__ sa,
+                                                     const u32 *__restrict__ doc_off, u32 n_docs, u32 n,
+                                                     u32 *__restrict__ lcp)
+{
+    const u32 r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) {
+        if (r < ((n + PYR_FAN - 1u) & ~(PYR_FAN - 1u))) lcp[r] = NONE_U32;     // pyramid padding
+        return;
+    }
+    if (r == 0) { lcp[0] = 0; return; }
+    const u32 i = sa[r - 1], j = sa[r];
+    u32 h = 0;
+    while (true) {
+        const u64 a = load_u64_unaligned(s8 + i + h), b = load_u64_unaligned(s8 + j + h);
+        const u64 x = a ^ b;
+        const u64 z = ~a;                                            // zero byte <=> 0xFF in a
+        const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+        const u32 mism = x ? (u32)__builtin_ctzll(x) >> 3 : 8u;
+        const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
+        const u32 step = mism < term ? mism : term;
+        h += step;
+        if (step < 8u) break;
+    }
+    if (n_docs > 1 && h > 0) {
+        const u32 d = doc_of(doc_off, n_docs, r);
+        if (doc_off[d] == r) h = 0;
+    }
+    lcp[r] = h;
+}
+
+__global__ __launch_bounds__(BLOCK) void pyramid_level_kernel(const u32 *__restrict__ in, u32 len_out,
+                                                              u32 len_out_padded, u32 *__restrict__ out)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= len_out_padded) return;
+    u32 v = NONE_U32;
+    if (i < len_out) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(in + ((size_t)i << PYR_SHIFT));
+        const uint4 a = g[0], b = g[1], c = g[2], d = g[3];
+        const u32 m0 = min(min(a.x, a.y), min(a.z, a.w)), m1 = min(min(b.x, b.y), min(b.z, b.w));
+        const u32 m2 = min(min(c.x, c.y), min(c.z, c.w)), m3 = min(min(d.x, d.y), min(d.z, d.w));
+        v = min(min(m0, m1), min(m2, m3));
+    }
+    out[i] = v;
+}
+
+// bit i set iff M[start + i] < v (STRICT) or <= v, for the 16-word group at `start`
+template <bool STRICT>
+__device__ __forceinline__ u32 pyr_group_mask(const u32 *__restrict__ M, u32 start, u32 v)
+{
+    const uint4 *g = reinterpret_cast<const uint4 *>(M + start);
+    const uint4 a = g[0], b = g[1], c = g[2], d = g[3];
+    const u32 x[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    u32 m = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) m |= (STRICT ? x[i] < v : x[i] <= v) ? (1u << i) : 0u;
+    return m;
+}
+
+// largest p < k with level0[p] < v (STRICT) or <= v; NONE_U32 if none.
+// One group (four independent 16-byte loads) per level on the way up and down.
 template <bool STRICT>
 __device__ __forceinline__ u32 pyr_find_left(const Pyramid &P, u32 k, u32 v)
 {
     u32 pos = k;
     int lvl = 0;
     while (true) {
-        const u32 *M = P.ptr[lvl];
-        const u32 start = pos & ~63u;
-        u32 q = pos;
-        bool found = false;
-        while (q > start) {
-            q--;
-            const u32 x = M[q];
-            if (STRICT ? x < v : x <= v) { found = true; break; }
-        }
-        if (found) {
-            while (lvl > 0) {
-                lvl--;
-                const u32 *C = P.ptr[lvl];
-                const u32 base = q << 6;
-                u32 c = base + 64u < P.len[lvl] ? base + 64u : P.len[lvl];
-                while (c > base) {
-                    c--;
-                    const u32 x = C[c];
-                    if (STRICT ? x < v : x <= v) break;
+        const u32 start = pos & ~(PYR_FAN - 1u);
+        if (pos > start) {
+            const u32 m = pyr_group_mask<STRICT>(P.ptr[lvl], start, v) & ((1u << (pos - start)) - 1u);
+            if (m) {
+                u32 q = start + 31u - (u32)__clz((int)m);
+                while (lvl > 0) {
+                    lvl--;
+                    const u32 base = q << PYR_SHIFT;
+                    const u32 mm = pyr_group_mask<STRICT>(P.ptr[lvl], base, v);
+                    q = base + 31u - (u32)__clz((int)mm);
                 }
-                q = c;
+                return q;
             }
-            return q;
         }
         if (start == 0 || lvl + 1 >= P.levels) return NONE_U32;
-        pos = start >> 6;
+        pos = start >> PYR_SHIFT;
         lvl++;
     }
 }
@@ -131,63 +196,51 @@ __device__ __forceinline__ u32 pyr_find_right(const Pyramid &P, u32 k, u32 v)
     u32 pos = k + 1;
     int lvl = 0;
     while (true) {
-        const u32 *M = P.ptr[lvl];
         const u32 len = P.len[lvl];
-        u32 end = (pos + 63u) & ~63u;
-        if (end > len) end = len;
-        u32 q = pos;
-        bool found = false;
-        while (q < end) {
-            const u32 x = M[q];
-            if (STRICT ? x < v : x <= v) { found = true; break; }
-            q++;
-        }
-        if (found) {
+        if (pos >= len) return NONE_U32;
+        const u32 start = pos & ~(PYR_FAN - 1u);
+        const u32 m = pyr_group_mask<STRICT>(P.ptr[lvl], start, v) & ~((1u << (pos - start)) - 1u);
+        if (m) {
+            u32 q = start + (u32)__ffs((int)m) - 1u;
             while (lvl > 0) {
                 lvl--;
-                const u32 *C = P.ptr[lvl];
-                const u32 base = q << 6;
-                const u32 lim = base + 64u < P.len[lvl] ? base + 64u : P.len[lvl];
-                u32 c = base;
-                while (c < lim) {
-                    const u32 x = C[c];
-                    if (STRICT ? x < v : x <= v) break;
-                    c++;
-                }
-                q = c;
+                const u32 base = q << PYR_SHIFT;
+                const u32 mm = pyr_group_mask<STRICT>(P.ptr[lvl], base, v);
+                q = base + (u32)__ffs((int)mm) - 1u;
             }
             return q;
         }
-        if (end >= len || lvl + 1 >= P.levels) return NONE_U32;
-        pos = end >> 6;
+        const u32 next = start + PYR_FAN;
+        if (next >= len || lvl + 1 >= P.levels) return NONE_U32;
+        pos = next >> PYR_SHIFT;
         lvl++;
     }
 }
 
 // leftmost position of the minimum of level0 over the open interval (a, b),
-// a + 1 < b.  Walks whole 64-groups through the pyramid.
+// a + 1 < b.  Walks whole groups through the pyramid.
 __device__ __forceinline__ u32 pyr_leftmost_argmin(const Pyramid &P, u32 a, u32 b)
 {
     // 1. minimum value over (a, b)
-    u32 lo = a + 1, hi = b;           // [lo, hi)
+    const u32 lo = a + 1;
     u32 best = NONE_U32;
     {
-        u32 l = lo, h = hi;
+        u32 l = lo, h = b;            // [l, h)
         int lvl = 0;
         while (l < h) {
             const u32 *M = P.ptr[lvl];
             // peel unaligned heads/tails at this level, then go up
-            while (l < h && (l & 63u)) { const u32 x = M[l]; best = x < best ? x : best; l++; }
-            while (l < h && (h & 63u)) { h--; const u32 x = M[h]; best = x < best ? x : best; }
+            while (l < h && (l & (PYR_FAN - 1u))) { const u32 x = M[l]; best = x < best ? x : best; l++; }
+            while (l < h && (h & (PYR_FAN - 1u))) { h--; const u32 x = M[h]; best = x < best ? x : best; }
             if (l >= h) break;
             if (lvl + 1 >= P.levels) {
                 for (u32 q = l; q < h; q++) { const u32 x = M[q]; best = x < best ? x : best; }
                 break;
             }
-            l >>= 6; h >>= 6; lvl++;
+            l >>= PYR_SHIFT; h >>= PYR_SHIFT; lvl++;
         }
     }
-    // 2. first position >= lo holding a value <= best (it is == best and < hi)
+    // 2. first position >= lo holding a value <= best (it is == best and < b)
     if (P.ptr[0][lo] == best) return lo;
     return pyr_find_right<false>(P, lo, best);
 }
