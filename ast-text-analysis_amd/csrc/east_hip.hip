@@ -113,6 +113,12 @@ struct east_hip_index {
     u32 n_kp = 0, n_q = 0;
     u32 *q_raw = nullptr, *q_code = nullptr, *q_end = nullptr, *q_off = nullptr;
     double *suffix = nullptr, *table = nullptr;
+    // k-gram bucket tables for the score walk (own allocation, rebuilt after every build)
+    u32 *kg = nullptr;
+    size_t kg_cap = 0;
+    int kg_k = 0;
+    u32 kg_A = 0, kg_bins = 0;
+    bool kg_built = false;
     float last_build_ms = -1.f, last_score_ms = -1.f;
 };
 
@@ -224,6 +230,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         LAUNCH(ctx, pyramid_level_kernel, ceil_div_u32(pyr_padded(pyr.len[l]), BLOCK), pyr.ptr[l - 1], pyr.len[l],
                pyr_padded(pyr.len[l]), (u32 *)pyr.ptr[l]);
     LAUNCH(ctx, ann_kernel, gn, pyr, (const u32 *)h->doc_off, (const u32 *)h->n_strings, n_docs, n, h->ann);
+    h->kg_built = false;
     h->child_built = false;      // childtab_up / down / next_l_index: built on first east_hip_get_tables request
 }
 
@@ -362,7 +369,45 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
     h->n_q = n_q;
 }
 
-// queues the three score kernels; result in h->table (K x D) / h->suffix (D x S)
+// k-gram bucket tables of the current index (score.h); k = 0 when the alphabet is too wide
+static void ensure_kgram(east_hip_index *h, Ctx &ctx)
+{
+    if (h->kg_built) return;
+    h->kg_k = 0;
+    h->kg_built = true;
+    if (!h->use_s8 || h->n_docs > 65535) return;
+    const u32 A = h->sigma_t + 2;
+    int k = 0;
+    u64 bins = 1;
+    while (k < KGRAM_MAX_K && bins * A <= KGRAM_MAX_BINS && bins * A * 16 <= h->n / h->n_docs + 4096 &&
+           (bins * A + 1) * h->n_docs * 4 <= ((u64)1 << 30)) {
+        bins *= A;
+        k++;
+    }
+    if (k == 0) return;
+    const size_t bytes = (size_t)(bins + 1) * h->n_docs * 4;
+    if (bytes > h->kg_cap) {
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->kg) HIP_CHECK(hipFree(h->kg));
+        h->kg = nullptr;
+        h->kg_cap = 0;
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return;          // no table: plain binary search
+        h->kg = (u32 *)p;
+        h->kg_cap = bytes;
+    }
+    HIP_CHECK(hipMemsetAsync(h->kg, 0xFF, bytes, h->stream));
+    i64 longest = 0;
+    for (u32 d = 0; d < h->n_docs; d++) longest = std::max(longest, h->h_doc_off[d + 1] - h->h_doc_off[d]);
+    LAUNCH(ctx, kgram_mark_kernel, dim3(ceil_div_u32((u64)longest, BLOCK), h->n_docs), (const u32 *)h->lcp, (const u32 *)h->sa,
+           (const uint8_t *)h->s8, (const u32 *)h->doc_off, h->n_docs, h->n, k, A, (u32)bins, h->kg);
+    LAUNCH(ctx, kgram_fill_kernel, h->n_docs, (const u32 *)h->doc_off, (u32)bins, h->kg);
+    h->kg_k = k;
+    h->kg_A = A;
+    h->kg_bins = (u32)bins;
+}
+
+// queues the score kernels; result in h->table (K x D) / h->suffix (D x S)
 static void score_resident(east_hip_index *h, int normalized)
 {
     if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
@@ -373,11 +418,13 @@ static void score_resident(east_hip_index *h, int normalized)
     ctx.stream = h->stream;
     ctx.prof = &h->prof;
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    ensure_kgram(h, ctx);
     LAUNCH(ctx, query_map_kernel, ceil_div_u32(h->n_q, BLOCK), (const u32 *)h->q_raw, h->n_q,
            (const u32 *)h->code_map, h->q_code);
     LAUNCH(ctx, score_walk_kernel, ceil_div_u32((u64)h->n_q * h->n_docs, BLOCK), (const u32 *)h->s,
            (const u32 *)h->sa, (const u32 *)h->doc_off, (const u32 *)h->n_strings, h->n_docs,
-           (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, h->suffix);
+           (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, (const u32 *)h->kg, h->kg_k, h->kg_A,
+           h->kg_bins, h->suffix);
     LAUNCH(ctx, score_reduce_kernel, ceil_div_u32((u64)h->n_kp * h->n_docs, BLOCK), (const double *)h->suffix,
            (const u32 *)h->q_off, h->n_kp, h->n_docs, h->n_q, h->table);
     HIP_CHECK(hipEventRecord(h->ev1, h->stream));
@@ -448,6 +495,7 @@ void east_hip_destroy(east_hip_handle_t h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->arena.base) (void)hipFree(h->arena.base);
     if (h->q_buf) (void)hipFree(h->q_buf);
+    if (h->kg) (void)hipFree(h->kg);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -17,6 +17,74 @@
 #include "common.h"
 
 #define Q_NOMATCH 0xFFFFFFFFu
+#define KGRAM_MAX_K 3
+#define KGRAM_MAX_BINS 65536u
+
+// ---- k-gram bucket tables ---------------------------------------------------------
+// Most walks end within the first few symbols, where the
+// SA intervals are widest and a binary search costs the most probes.  For small
+// text alphabets every document therefore gets a table over all k-grams
+// (k <= 3, A = sigma_text + 2 codes: 0 = pad, 1..sigma_text, A-1 = "terminator"):
+//   kg[d][g] = first rank of document d whose suffix has a k-gram >= g,  kg[d][A^k] = n_d
+// so the interval of a text prefix c_0..c_j (j < k) is
+//   [ kg[code * A^(k-1-j)], kg[(code+1) * A^(k-1-j)] )   with code = sum c_i A^(j-i).
+// The table is read off the finished arrays: rank r starts a bucket iff lcp[r] < k.
+// k-gram code of the suffix at p; symbols behind the first terminator are dropped,
+// so all suffixes that agree up to (and including) a terminator class share one code
+__device__ __forceinline__ u32 kgram_code(const uint8_t *__restrict__ s8, u32 p, int k, u32 A)
+{
+    u32 g = 0;
+    bool ended = false;
+    for (int i = 0; i < k; i++) {
+        const u32 b = ended ? 0u : (u32)s8[p + i];
+        const u32 c = b == 0xFFu ? A - 1u : (b < A ? b : A - 1u);
+        ended = ended || b == 0xFFu;
+        g = g * A + c;
+    }
+    return g;
+}
+
+__global__ __launch_bounds__(BLOCK) void kgram_mark_kernel(const u32 *__restrict__ lcp, const u32 *__restrict__ sa,
+                                                           const uint8_t *__restrict__ s8,
+                                                           const u32 *__restrict__ doc_off, u32 n_docs, u32 n,
+                                                           int k, u32 A, u32 bins, u32 *__restrict__ kg)
+{
+    const u32 lo = blockIdx.y;                    // grid: (ranks of the longest document / BLOCK, documents)
+    const u32 r = doc_off[lo] + blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= doc_off[lo + 1]) return;
+    const u32 L = lcp[r];
+    if (L >= (u32)k) return;                      // same k-gram as the rank before
+    const u32 p = sa[r];
+    // two suffixes that part at two different terminators still share their (class) k-gram:
+    // only the first of them opens the bucket
+    if (r != doc_off[lo] && s8[p + L] == 0xFFu && s8[sa[r - 1] + L] == 0xFFu) return;
+    kg[(size_t)lo * (bins + 1) + kgram_code(s8, p, k, A)] = r - doc_off[lo];
+}
+
+// one workgroup per document: kg[d][g] = min over g' >= g (suffix minimum), kg[d][bins] = n_d
+__global__ __launch_bounds__(BLOCK) void kgram_fill_kernel(const u32 *__restrict__ doc_off, u32 bins,
+                                                           u32 *__restrict__ kg)
+{
+    __shared__ u32 part[BLOCK];
+    const u32 d = blockIdx.x, tid = threadIdx.x;
+    u32 *row = kg + (size_t)d * (bins + 1);
+    const u32 nd = doc_off[d + 1] - doc_off[d];
+    const u32 per = (bins + BLOCK - 1) / BLOCK;
+    const u32 b = tid * per, e = (b + per < bins) ? b + per : bins;
+    u32 m = 0xFFFFFFFFu;
+    for (u32 g = e; g > b; g--) { const u32 x = row[g - 1]; m = x < m ? x : m; }
+    part[tid] = m;
+    __syncthreads();
+    u32 after = nd;                               // minimum over all later chunks
+    for (u32 t = tid + 1; t < BLOCK; t++) { const u32 x = part[t]; after = x < after ? x : after; }
+    m = after;
+    for (u32 g = e; g > b; g--) {
+        const u32 x = row[g - 1];
+        m = x < m ? x : m;
+        row[g - 1] = m;
+    }
+    if (tid == 0) row[bins] = nd;
+}
 
 // raw query code points -> dense codes of the corpus alphabet
 __global__ __launch_bounds__(BLOCK) void query_map_kernel(const u32 *__restrict__ q_raw, u32 n_q,
@@ -37,7 +105,8 @@ __global__ __launch_bounds__(BLOCK) void query_map_kernel(const u32 *__restrict_
 __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
     const u32 *__restrict__ s, const u32 *__restrict__ sa, const u32 *__restrict__ doc_off,
     const u32 *__restrict__ n_strings, u32 n_docs, const u32 *__restrict__ q_code,
-    const u32 *__restrict__ q_end, u32 n_q, int normalized, double *__restrict__ suffix_out)
+    const u32 *__restrict__ q_end, u32 n_q, int normalized, const u32 *__restrict__ kg, int kg_k, u32 kg_A,
+    u32 kg_bins, double *__restrict__ suffix_out)
 {
     const u64 gid = (u64)blockIdx.x * BLOCK + threadIdx.x;
     if (gid >= (u64)n_docs * n_q) return;
@@ -51,7 +120,29 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
 
     u32 lo = 0, hi = nd - 1, depth = 0, nodes = 0;
     double acc = 0.0;
-    for (u32 t = si; t < end; t++) {
+    u32 t = si;
+    if (kg_k > 0) {
+        // the first kg_k symbols: two table reads per symbol instead of two binary searches
+        const u32 *row = kg + (size_t)d * (kg_bins + 1);
+        u32 code = 0, stride = kg_bins;
+        for (; t < end && depth < (u32)kg_k; t++) {
+            const u32 c = q_code[t];
+            if (c == Q_NOMATCH) break;
+            stride /= kg_A;
+            code = code * kg_A + c;
+            const u32 a = row[code * stride], b1 = row[(code + 1u) * stride];
+            if (b1 <= a) break;                           // no suffix continues with c
+            const u32 b = b1 - 1u;
+            if (b - a < hi - lo) {
+                const u32 parent = depth == 0 ? root_ann : hi - lo + 1;
+                acc += (double)(b - a + 1) / (double)parent;
+                nodes++;
+            }
+            lo = a; hi = b; depth++;
+        }
+        if (depth < (u32)kg_k) t = end;                   // the walk ended inside the table levels
+    }
+    for (; t < end; t++) {
         const u32 c = q_code[t];
         if (c == Q_NOMATCH) break;
         u32 a, b;

@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--doc-mib", type=float, default=64.0, help="document size per GPU in MiB")
+    ap.add_argument("--doc-mib", type=float, default=64.0, help="size of one document in MiB")
+    ap.add_argument("--docs", type=int, default=1, help="documents per GPU (BASELINE configs[2]: 256 x 1 MiB)")
     ap.add_argument("--keyphrases", type=int, default=1000)
     ap.add_argument("--mode", choices=["text", "direct"], default="text",
                     help="text: 3-word strings as the CLI does; direct: get_ast([one string])")
@@ -89,13 +90,21 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- synthetic inputs (seed = 20240 + config# + rank), outside the timed region ----
-    n_bytes = int(args.doc_mib * (1 << 20))
+    doc_bytes = int(args.doc_mib * (1 << 20))
+    n_bytes = doc_bytes * args.docs                       # input bytes per GPU
     rng = np.random.default_rng(20240 + 2 + 1000 * rank)
-    if args.mode == "text":
-        _, symbols, m = synthetic.word_stream_document(rng, n_bytes, want_text=False)
-    else:
-        symbols, m = synthetic.direct_document(rng, n_bytes + 1)
+    parts, ms = [], []
+    for _ in range(args.docs):
+        if args.mode == "text":
+            _, sym_d, m_d = synthetic.word_stream_document(rng, doc_bytes, want_text=False)
+        else:
+            sym_d, m_d = synthetic.direct_document(rng, doc_bytes + 1)
+        parts.append(sym_d)
+        ms.append(m_d)
+    symbols = np.concatenate(parts) if len(parts) > 1 else parts[0]
+    m = int(sum(ms))
     n = int(symbols.size)
+    D = args.docs
     K = args.keyphrases
     # keyphrases: every rank contributes K/world sampled from its own document, the set is replicated
     share = [K // world + (1 if r < K % world else 0) for r in range(world)]
@@ -112,10 +121,10 @@ def main():
     q_symbols, q_offsets = np.concatenate(q_parts), np.array(q_off, dtype=np.int64)
 
     d_symbols = torch.from_numpy(symbols.view(np.int32)).to(dev)          # resident in HBM
-    doc_offsets = np.array([0, n], dtype=np.int64)
-    n_strings = np.array([m], dtype=np.int32)
-    local_block = torch.empty((K, 1), dtype=torch.float64, device=dev)    # K x D_local
-    full_table = torch.empty((world * K, 1), dtype=torch.float64, device=dev) if world > 1 else None
+    doc_offsets = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.int64)
+    n_strings = np.array(ms, dtype=np.int32)
+    local_block = torch.empty((K, D), dtype=torch.float64, device=dev)    # K x D_local
+    full_table = torch.empty((world * K, D), dtype=torch.float64, device=dev) if world > 1 else None
 
     index = hip_backend.HipIndex(local_rank, reserve_symbols=n)
     index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)    # also sizes the score scratch
@@ -160,7 +169,7 @@ def main():
         total_kernel_ms = sum(ms for _, ms in prof.values())
         dom = max(prof.items(), key=lambda kv: kv[1][1])
         dom_name, (dom_launches, dom_ms) = dom
-        bytes_per_step = kernel_bytes(dom_name, info, n, int(q_offsets[-1]), 1)
+        bytes_per_step = kernel_bytes(dom_name, info, n, int(q_offsets[-1]), D)
         roofline = {"kernel": dom_name, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "launches_per_step": dom_launches // args.steps,
                     "avg_launch_ms": dom_ms / dom_launches,
@@ -180,13 +189,13 @@ def main():
             "value": value, "unit": "chars/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (symbols/indices) + f64 (scores)", "data": "synthetic",
-            "config": {"workload": "1 synthetic %g MiB random-ASCII word-stream doc per GPU (%s mode), "
-                                   "%d keyphrases, easa-HIP" % (args.doc_mib, args.mode, K),
+            "config": {"workload": "%d synthetic %g MiB random-ASCII word-stream doc(s) per GPU (%s mode), "
+                                   "%d keyphrases, easa-HIP" % (D, args.doc_mib, args.mode, K),
                        "symbols_per_gpu": n, "strings_per_gpu": m, "parallelism": "doc-shard x%d" % world},
             "build_ms": float(np.mean(build_ms)), "score_ms": float(np.mean(score_ms)),
             "build_symbols_per_s": n / (float(np.mean(build_ms)) * 1e-3),
             "build_chars_per_s": n_bytes / (float(np.mean(build_ms)) * 1e-3),
-            "keyphrase_scores_per_s": K / (float(np.mean(score_ms)) * 1e-3),
+            "keyphrase_scores_per_s": K * D / (float(np.mean(score_ms)) * 1e-3),
             "build_algorithmic_GBps": 16.0 * n / (float(np.mean(build_ms)) * 1e-3) / 1e9,
             "dc3_levels": info["dc3_levels"], "dc3_levels_resolved": info["dc3_levels_resolved"],
             "radix_passes": info["radix_passes"],
