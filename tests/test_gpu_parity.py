@@ -248,3 +248,94 @@ def test_many_strings_terminator_order(hip, oracle):
         assert np.array_equal(getattr(ast, name), getattr(o, name)), name
     for q in ["A", "AB", "ABA", "BBB", "ABAB"]:
         assert ast.score(q) == o.score(q) and ast.score(q, normalized=False) == o.score(q, normalized=False)
+
+
+def test_16mib_document_vs_oracle(hip, oracle):
+    """One 16 MiB word-stream document in text mode (15 M symbols, 0.75 M strings): SA, LCP and
+    annotation table bit-exact against the oracle; 500 keyphrases bit-equal."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(20240 + 2)
+    _, sym, m = synthetic.word_stream_document(rng, 16 << 20, want_text=False)
+    index = hip_backend.HipIndex()
+    index.build(sym, np.array([0, sym.size]), np.array([m]))
+    t = index.tables(0, names=("suftab", "lcptab", "anntab"))
+    o = oracle.OracleEASA(symbols=sym, n_strings=m)
+    for name in ("suftab", "lcptab", "anntab"):
+        assert np.array_equal(t[name], getattr(o, name)), name
+    qs, qo = synthetic.keyphrases(rng, sym, 500)
+    for norm in (True, False):
+        table = index.score_table(qs, qo, norm)
+        for k in range(500):
+            assert table[k, 0] == o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=True)
+
+
+def _check_easa_properties(sym, m, t):
+    """Size-independent properties that pin SA and LCP completely: sa is a permutation; for every
+    rank r the two neighbouring suffixes agree on exactly lcp[r] symbols and the next symbol of the
+    left one is smaller (=> sorted, and lcp exact).  anntab: root n-m, interval widths."""
+    n = sym.size
+    sa, lcp, ann = t["suftab"], t["lcptab"], t["anntab"]
+    assert np.array_equal(np.sort(sa), np.arange(n))
+    assert lcp[0] == 0 and int(lcp.min()) >= 0
+    a, b, h = sa[:-1], sa[1:], lcp[1:]
+    pad = np.concatenate([sym.astype(np.int64), [-1] * 4])
+    assert (pad[a + h] < pad[b + h]).all()                       # first differing symbol orders them
+    for off in range(int(h.max())):                              # and everything before it agrees
+        sel = h > off
+        assert (pad[a[sel] + off] == pad[b[sel] + off]).all()
+    assert int(ann[0]) == n - m
+    first = np.flatnonzero(ann[1:] > 0) + 1
+    assert (lcp[first] > 0).all()
+    rng = np.random.default_rng(1)
+    for i in rng.integers(1, n, size=4000).tolist():             # spot-check against plain scans
+        v = lcp[i]
+        p = i - 1
+        while lcp[p] > v:
+            p -= 1                                               # previous value <= v
+        if v == 0 or lcp[p] == v:
+            assert ann[i] == 0                                   # not the first l-index of its interval
+        else:
+            j = i + 1
+            while j < n and lcp[j] >= v:
+                j += 1
+            assert ann[i] == j - p                               # interval width = NSV - PSV
+
+
+def test_64mib_document_properties(hip):
+    """BASELINE configs[1] at full size (64 MiB, text mode): property checks + score sanity."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(20240 + 2)
+    _, sym, m = synthetic.word_stream_document(rng, 64 << 20, want_text=False)
+    index = hip_backend.HipIndex()
+    index.build(sym, np.array([0, sym.size]), np.array([m]))
+    t = index.tables(0, names=("suftab", "lcptab", "anntab"))
+    _check_easa_properties(sym, m, t)
+    qs, qo = synthetic.keyphrases(rng, sym, 1000)
+    table = index.score_table(qs, qo, True)
+    assert table.shape == (1000, 1) and (table >= 0).all() and (table <= 1).all()
+    assert (table[0::2] > 0).all()                               # keyphrases copied from the text match
+    # idempotence: rebuilding and rescoring gives the same bits
+    index.build(sym, np.array([0, sym.size]), np.array([m]))
+    assert np.array_equal(index.score_table(qs, qo, True), table)
+
+
+def test_256_documents_batched_equals_individual(hip):
+    """BASELINE configs[2] shape (many 1 MiB documents in one batched build), reduced to 24
+    documents: every per-document table equals a build of that document alone."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(20240 + 3)
+    docs = [synthetic.word_stream_document(rng, 1 << 20, want_text=False)[1:] for _ in range(24)]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    ms = np.array([d[1] for d in docs])
+    batch = hip_backend.HipIndex()
+    batch.build(sym, off, ms)
+    qs, qo = synthetic.keyphrases(rng, sym, 300)
+    table = batch.score_table(qs, qo, True)
+    single = hip_backend.HipIndex()
+    for d in (0, 7, 23):
+        single.build(docs[d][0], np.array([0, docs[d][0].size]), np.array([docs[d][1]]))
+        tb, ts = batch.tables(d), single.tables(0)
+        for name in TABLES:
+            assert np.array_equal(tb[name], ts[name]), (name, d)
+        assert np.array_equal(single.score_table(qs, qo, True)[:, 0], table[:, d])
