@@ -4,6 +4,7 @@ README.rst:27-63; the shipped reference main crashes with a NameError, SURVEY.md
 
     east [-s ast] [-a easa|easa_hip|ast_linear|ast_naive] [-d] [-f xml|csv] \\
          keyphrases table <keyphrases file> <directory with .txt files | single file>
+    east [-c confidence] [-r relevance] [-p support] [-f edges|gml] keyphrases graph <keyphrases file> <texts>
 """
 import getopt
 import os
@@ -85,9 +86,19 @@ def main(argv=None):
             print(e)
             return 1
         return 0
-    elif subcommand == "graph":
-        print("Subcommand 'graph' is not part of the MI355X hot path yet.")
-        return 1
+    elif subcommand == "graph":                                                                 # main.py:124-143
+        opts.setdefault("-c", "0.6")    # referral confidence
+        opts.setdefault("-r", "0.25")   # relevance threshold of the matching score
+        opts.setdefault("-p", "1")      # support threshold for graph nodes
+        graph = applications.keyphrases_graph(keyphrases, texts, float(opts["-c"]), float(opts["-r"]),
+                                              float(opts["-p"]), similarity_measure, None, opts["-l"])
+        graph_format = opts.get("-f", "edges").lower()
+        try:
+            print(formatting.format_graph(graph, graph_format))
+        except Exception as e:
+            print(e)
+            return 1
+        return 0
     print("Invalid subcommand: '%s'. Please use one of: 'table', 'graph'." % subcommand)
     return 1
 

@@ -339,3 +339,50 @@ def test_256_documents_batched_equals_individual(hip):
         for name in TABLES:
             assert np.array_equal(tb[name], ts[name]), (name, d)
         assert np.array_equal(single.score_table(qs, qo, True)[:, 0], table[:, d])
+
+
+def test_keyphrases_graph_fixture(hip):
+    """applications.keyphrases_graph + graph2gml / graph2edges on the HSE corpus (17 keyphrases)."""
+    from east import applications, formatting, relevance
+    g = load_golden("hse_graph.json")
+    texts = {k: v.encode("utf-8") for k, v in load_golden(g["texts_from"])["texts"].items()}
+    for case in g["cases"]:
+        graph = applications.keyphrases_graph(g["keyphrases"], texts, case["referral_confidence"],
+                                              case["relevance_threshold"], case["support_threshold"],
+                                              relevance.ASTRelevanceMeasure("easa", True))
+        assert graph == case["graph"]
+        assert formatting.graph2gml(graph) == case["gml"]
+        if case["edges"] is not None:
+            assert formatting.graph2edges(graph) == case["edges"]
+
+
+def test_cli_table_and_graph(hip, tmp_path, capsys):
+    """`east keyphrases table|graph` end to end (README.rst:27-63): directory mode, single-file mode,
+    -d, -f csv / xml / gml."""
+    from east import main
+    g = load_golden("hse_config1.json")
+    tdir = tmp_path / "texts"
+    tdir.mkdir()
+    for name, text in g["texts"].items():
+        (tdir / (name + ".txt")).write_bytes(text.encode("utf-8"))
+    (tdir / "ignored.dat").write_text("not a text")
+    kp = tmp_path / "kp.txt"
+    kp.write_bytes(("\n".join(g["keyphrases"]) + "\n\n").encode("utf-8"))     # trailing empty lines are skipped
+    assert main.main(["keyphrases", "table", str(kp), str(tdir)]) == 0
+    assert capsys.readouterr().out == g["xml_normalized"] + "\n"
+    assert main.main(["-f", "csv", "-a", "ast_linear", "keyphrases", "table", str(kp), str(tdir)]) == 0
+    assert capsys.readouterr().out == g["csv_normalized"] + "\n"
+    s = load_golden("sample_table.json")
+    one = tmp_path / "test.txt"
+    one.write_bytes("\n".join(s["texts"][k] for k in sorted(s["texts"], key=int)).encode("utf-8"))
+    kp2 = tmp_path / "kp2.txt"
+    kp2.write_text("\n".join(s["keyphrases"]))
+    assert main.main(["-d", "keyphrases", "table", str(kp2), str(one)]) == 0
+    assert capsys.readouterr().out == s["xml_denormalized"] + "\n"
+    gg = load_golden("hse_graph.json")
+    kp3 = tmp_path / "kp3.txt"
+    kp3.write_bytes("\n".join(gg["keyphrases"]).encode("utf-8"))
+    case = gg["cases"][1]
+    assert main.main(["-f", "gml", "-c", str(case["referral_confidence"]), "-r", str(case["relevance_threshold"]),
+                      "-p", str(case["support_threshold"]), "keyphrases", "graph", str(kp3), str(tdir)]) == 0
+    assert capsys.readouterr().out == case["gml"] + "\n"

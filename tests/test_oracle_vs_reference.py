@@ -87,6 +87,6 @@ def test_golden_fixtures_are_reproducible(tmp_path):
     r = subprocess.run([sys.executable, str(gen / "gen_golden.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     for name in ["readme_example.json", "test_base_case.json", "utils_vectors.json", "sample_table.json",
-                 "hse_config1.json", "fuzz_small.json", "zipf_docs.json"]:
+                 "hse_config1.json", "hse_graph.json", "fuzz_small.json", "zipf_docs.json"]:
         assert filecmp.cmp(str(tmp_path / "tests" / "golden" / name), os.path.join(ROOT, "tests", "golden", name),
                            shallow=False), name
