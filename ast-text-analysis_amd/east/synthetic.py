@@ -86,3 +86,37 @@ def keyphrases(rng, doc_symbols, n_keyphrases, doc_offsets=None):
     offsets = np.zeros(n_keyphrases + 1, dtype=np.int64)
     np.cumsum([p.size for p in parts], out=offsets[1:])
     return np.concatenate(parts), offsets
+
+
+def zipf_vocabulary(rng, size=50000, exponent=1.1):
+    """Natural-language stand-in for BASELINE config 5 (enwik8 is not available offline): a
+    vocabulary of `size` random upper-case words of length 3..12 with Zipf(exponent) frequencies."""
+    lens = np.clip(rng.geometric(0.28, size=size) + 2, 3, 12).astype(np.int64)
+    letters = rng.integers(65, 91, size=int(lens.sum()), dtype=np.uint8)
+    starts = np.cumsum(lens) - lens
+    prob = 1.0 / np.arange(1, size + 1, dtype=np.float64) ** exponent
+    return {"lens": lens, "starts": starts, "letters": letters, "cdf": np.cumsum(prob / prob.sum())}
+
+
+def zipf_document(rng, n_bytes, vocab):
+    """One document of about n_bytes: Zipf-distributed words joined by single spaces, as the EASA
+    symbol array of its 3-word strings (every word has >= 3 letters, so none is filtered).
+    Returns (symbols uint32, n_strings)."""
+    mean_len = float((vocab["lens"] * np.diff(np.concatenate([[0.0], vocab["cdf"]]))).sum())
+    n_words = max(1, int(n_bytes / (mean_len + 1.0)))
+    ids = np.searchsorted(vocab["cdf"], rng.random(n_words), side="left").clip(0, vocab["lens"].size - 1)
+    lens = vocab["lens"][ids]
+    src = np.repeat(vocab["starts"][ids] - (np.cumsum(lens) - lens), lens) + np.arange(int(lens.sum()))
+    letters = vocab["letters"][src]
+    k = n_words
+    m = (k + 2) // 3
+    tok_idx = np.arange(k, dtype=np.int64)
+    out_start = (np.cumsum(lens) - lens) + tok_idx // 3
+    is_last = (tok_idx % 3 == 2) | (tok_idx == k - 1)
+    term_pos = (out_start + lens)[is_last]
+    out = np.empty(int(lens.sum()) + m, dtype=np.uint32)
+    mask = np.ones(out.size, dtype=bool)
+    mask[term_pos] = False
+    out[mask] = letters
+    out[term_pos] = np.arange(m, dtype=np.uint32) + np.uint32(TERMINATOR_START)
+    return out, int(m)

@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--keyphrases", type=int, default=1000)
     ap.add_argument("--mode", choices=["text", "direct"], default="text",
                     help="text: 3-word strings as the CLI does; direct: get_ast([one string])")
+    ap.add_argument("--corpus", choices=["words", "zipf"], default="words",
+                    help="words: uniform A-Z word stream (configs 1-3); zipf: natural-language-like (config 5)")
+    ap.add_argument("--denormalized", action="store_true", help="the CLI's -d")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=float, default=8.0)
     return ap.parse_args()
@@ -94,8 +97,11 @@ def main():
     n_bytes = doc_bytes * args.docs                       # input bytes per GPU
     rng = np.random.default_rng(20240 + 2 + 1000 * rank)
     parts, ms = [], []
+    vocab = synthetic.zipf_vocabulary(np.random.default_rng(20245)) if args.corpus == "zipf" else None
     for _ in range(args.docs):
-        if args.mode == "text":
+        if vocab is not None:
+            sym_d, m_d = synthetic.zipf_document(rng, doc_bytes, vocab)
+        elif args.mode == "text":
             _, sym_d, m_d = synthetic.word_stream_document(rng, doc_bytes, want_text=False)
         else:
             sym_d, m_d = synthetic.direct_document(rng, doc_bytes + 1)
@@ -132,7 +138,7 @@ def main():
 
     def step():
         index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)
-        index.score_resident(True, local_block.data_ptr())
+        index.score_resident(not args.denormalized, local_block.data_ptr())
         if world > 1:
             dist.all_gather_into_tensor(full_table, local_block)           # RCCL over xGMI
 
@@ -189,8 +195,11 @@ def main():
             "value": value, "unit": "chars/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (symbols/indices) + f64 (scores)", "data": "synthetic",
-            "config": {"workload": "%d synthetic %g MiB random-ASCII word-stream doc(s) per GPU (%s mode), "
-                                   "%d keyphrases, easa-HIP" % (D, args.doc_mib, args.mode, K),
+            "config": {"workload": "%d synthetic %g MiB %s doc(s) per GPU (%s mode), "
+                                   "%d keyphrases, %s scores, easa-HIP"
+                                   % (D, args.doc_mib, "random-ASCII word-stream" if vocab is None else
+                                      "Zipf natural-language-like", args.mode, K,
+                                      "denormalized" if args.denormalized else "normalized"),
                        "symbols_per_gpu": n, "strings_per_gpu": m, "parallelism": "doc-shard x%d" % world},
             "build_ms": float(np.mean(build_ms)), "score_ms": float(np.mean(score_ms)),
             "build_symbols_per_s": n / (float(np.mean(build_ms)) * 1e-3),

@@ -386,3 +386,28 @@ def test_cli_table_and_graph(hip, tmp_path, capsys):
     assert main.main(["-f", "gml", "-c", str(case["referral_confidence"]), "-r", str(case["relevance_threshold"]),
                       "-p", str(case["support_threshold"]), "keyphrases", "graph", str(kp3), str(tdir)]) == 0
     assert capsys.readouterr().out == case["gml"] + "\n"
+
+
+def test_natural_language_like_16mib_vs_oracle(hip, oracle):
+    """BASELINE config 5 stand-in (Zipf word stream: repeated strings, LCP up to a whole string,
+    deeper DC3 recursion, tie groups too large for the in-place resolve): 16 documents of 1 MiB,
+    tables bit-exact and normalized + denormalized scores bit-equal against the oracle."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(20245)
+    vocab = synthetic.zipf_vocabulary(rng)
+    docs = [synthetic.zipf_document(rng, 1 << 20, vocab) for _ in range(16)]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    index = hip_backend.HipIndex()
+    index.build(sym, off, np.array([d[1] for d in docs]))
+    qs, qo = synthetic.keyphrases(rng, sym, 200)
+    tables = {norm: index.score_table(qs, qo, norm) for norm in (True, False)}
+    for d in (0, 5, 15):
+        o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+        for norm in (True, False):
+            for k in range(200):
+                assert tables[norm][k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=True)
+    assert float(tables[False].max()) > 1.0          # denormalized scores exceed 1 on deep matches
