@@ -235,6 +235,42 @@ __global__ __launch_bounds__(BLOCK) void dc3_compact_s0_kernel(const u32 *__rest
     }
 }
 
+// Level 0 with the byte stream: the non-sample suffixes are sorted on the one-byte
+// class code (0xFF = terminator) in a single radix pass.  Suffixes that START with a
+// terminator all carry 0xFF and end up as one block at the end of SA0; their true
+// order is terminator order = position order, so that block is simply rewritten
+// with the terminator-holding mod-0 positions in increasing order (a compaction).
+__global__ __launch_bounds__(BLOCK) void dc3_compact_s0_bytes_kernel(const uint8_t *__restrict__ s8,
+                                                                     const u32 *__restrict__ sa12,
+                                                                     const u32 *__restrict__ slot, u32 n0,
+                                                                     u32 n02, u32 *__restrict__ keys,
+                                                                     u32 *__restrict__ vals)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n02) return;
+    const u32 t = sa12[i];
+    if (t < n0) {
+        const u32 p0 = 3u * t;
+        keys[slot[i]] = s8[p0];
+        vals[slot[i]] = p0;
+    }
+}
+
+struct TermAtMod0In {                           // 1 iff mod-0 position 3q holds a terminator; defined on [0, n0]
+    const uint8_t *s8;
+    u32 n0;
+    __device__ __forceinline__ u32 operator()(u32 q) const { return (q < n0 && s8[3u * q] == 0xFFu) ? 1u : 0u; }
+};
+
+__global__ __launch_bounds__(BLOCK) void dc3_term_block_kernel(const uint8_t *__restrict__ s8,
+                                                               const u32 *__restrict__ ex, u32 n0,
+                                                               u32 *__restrict__ sa0)
+{
+    const u32 q = blockIdx.x * BLOCK + threadIdx.x;
+    if (q >= n0 || s8[3u * q] != 0xFFu) return;
+    sa0[n0 - ex[n0] + ex[q]] = 3u * q;          // ex[n0] = number of terminator-first non-sample suffixes
+}
+
 // ---- step 5: merge -----------------------------------------------------------
 // Merge-path merge of A = SA12 (sample suffixes, minus the dummy) and B = SA0.
 // The DC3 comparator [easa.py:202-207] on self-contained tuples:
@@ -382,7 +418,7 @@ static const u32 *dc3_sort_and_name(Ctx &ctx, SortBufs<K> &sb, u32 n02, int bits
 }
 
 static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_out, int depth = 0,
-                            u32 term_first = 0)
+                            u32 term_first = 0, const uint8_t *s8 = nullptr)
 {
     const u32 n0 = (n + 2) / 3, n1 = (n + 1) / 3, n2 = n / 3, n02 = n0 + n2;
     const int b = bit_width_u32(sigma);
@@ -489,9 +525,20 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         device_scan<LtIn, false>(ctx, LtIn{sa12, n0}, n02, slot);
         SortBufs<u32> s0;
         for (int k = 0; k < 2; k++) { s0.keys[k] = ar.alloc<u32>(n0); s0.vals[k] = ar.alloc<u32>(n0); }
-        LAUNCH(ctx, dc3_compact_s0_kernel, g02, s, (const u32 *)sa12, (const u32 *)slot, n0, n02,
-               s0.keys[0], s0.vals[0]);
-        const int r0 = radix_sort_pairs<u32>(ctx, s0, n0, b);
+        int r0;
+        if (ctx.dry && term_first) (void)ar.alloc<u32>((size_t)n0 + 1);   // the byte path's extra scan buffer
+        if (s8) {
+            LAUNCH(ctx, dc3_compact_s0_bytes_kernel, g02, s8, (const u32 *)sa12, (const u32 *)slot, n0, n02,
+                   s0.keys[0], s0.vals[0]);
+            r0 = radix_sort_pairs<u32>(ctx, s0, n0, 8);
+            u32 *ex = ar.alloc<u32>((size_t)n0 + 1);
+            device_scan<TermAtMod0In, false>(ctx, TermAtMod0In{s8, n0}, n0 + 1, ex);
+            LAUNCH(ctx, dc3_term_block_kernel, ceil_div_u32(n0, BLOCK), s8, (const u32 *)ex, n0, s0.vals[r0]);
+        } else {
+            LAUNCH(ctx, dc3_compact_s0_kernel, g02, s, (const u32 *)sa12, (const u32 *)slot, n0, n02,
+                   s0.keys[0], s0.vals[0]);
+            r0 = radix_sort_pairs<u32>(ctx, s0, n0, b);
+        }
         const u32 skip = n0 - n1, nA = n02 - skip;
         const u32 n_tiles = ceil_div_u32(n, MERGE_TILE);
         u32 *splits = ar.alloc<u32>((size_t)n_tiles + 1);

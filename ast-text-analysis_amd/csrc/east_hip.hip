@@ -206,12 +206,12 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
 
     // ---- suffix array of the whole shard, then partition by document -------------
     if (n_docs == 1) {
-        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa, 0, sigma_t + 1);
+        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr);
     } else {
         const size_t mark = ar.mark();
         SortBufs<u32> sb;
         for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n); sb.vals[k] = ar.alloc<u32>(n); }
-        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sb.vals[0], 0, sigma_t + 1);
+        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sb.vals[0], 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr);
         LAUNCH(ctx, doc_keys_kernel, gn, (const u32 *)sb.vals[0], (const u32 *)h->doc_off, n_docs, n, sb.keys[0]);
         const int r = radix_sort_pairs<u32>(ctx, sb, n, bit_width_u32(n_docs - 1));
         if (!ctx.dry)

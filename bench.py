@@ -88,8 +88,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # EAST_BENCH_FORCE_DIST=1 runs the collective path even with one rank (used to smoke-test it on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("EAST_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- synthetic inputs (seed = 20240 + config# + rank), outside the timed region ----
@@ -115,7 +118,7 @@ def main():
     # keyphrases: every rank contributes K/world sampled from its own document, the set is replicated
     share = [K // world + (1 if r < K % world else 0) for r in range(world)]
     q_local = synthetic.keyphrases(rng, symbols, share[rank])
-    if world > 1:
+    if use_dist:
         gathered = [None] * world
         dist.all_gather_object(gathered, (q_local[0], q_local[1]))
     else:
@@ -130,7 +133,7 @@ def main():
     doc_offsets = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.int64)
     n_strings = np.array(ms, dtype=np.int32)
     local_block = torch.empty((K, D), dtype=torch.float64, device=dev)    # K x D_local
-    full_table = torch.empty((world * K, D), dtype=torch.float64, device=dev) if world > 1 else None
+    full_table = torch.empty((world * K, D), dtype=torch.float64, device=dev) if use_dist else None
 
     index = hip_backend.HipIndex(local_rank, reserve_symbols=n)
     index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)    # also sizes the score scratch
@@ -139,12 +142,12 @@ def main():
     def step():
         index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)
         index.score_resident(not args.denormalized, local_block.data_ptr())
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(full_table, local_block)           # RCCL over xGMI
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -162,7 +165,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = index.profile_report()
     index.profile_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -215,7 +218,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, synthetic)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
