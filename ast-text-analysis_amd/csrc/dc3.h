@@ -80,6 +80,46 @@ template <class K> struct KeyNeqTermIn {
     }
 };
 
+// Level 0 with the byte stream: name the sample suffixes by their first w symbols
+// (w >= 3, w*bits <= 64) instead of 3.  Any order-preserving name over a window that
+// covers the triple keeps DC3 correct -- comparing (name(i), name(i+3), ...) still
+// walks the two suffixes left to right -- and with sigma^w >> n almost every name is
+// unique, so the whole recursion collapses into the in-place tie resolution below.
+// Same terminator rules as dc3_triple_keys_term_kernel.
+template <class K>
+__global__ __launch_bounds__(BLOCK) void dc3_window_keys_kernel(const uint8_t *__restrict__ s8, u32 n0,
+                                                                u32 n02, int w, int b, u32 term_first,
+                                                                K *__restrict__ keys, u32 *__restrict__ vals)
+{
+    const u32 u = blockIdx.x * BLOCK + threadIdx.x;
+    if (u >= n02) return;
+    const u32 q = u >> 1, r = u & 1u;
+    const u32 p = 3u * q + 1u + r;
+    K key = 0;
+    bool ended = false;
+    for (int i = 0; i < w; i++) {
+        const u32 x = ended ? 0u : (u32)s8[p + i];
+        ended = ended || x == 0xFFu;
+        key = (key << b) | (K)(x == 0xFFu ? term_first : x);
+    }
+    keys[u] = key;
+    vals[u] = r ? n0 + q : q;
+}
+
+template <class K> struct KeyNeqWindowIn {
+    const K *keys;
+    int w, b;
+    u32 term_first;
+    __device__ __forceinline__ u32 operator()(u32 i) const
+    {
+        const K k = keys[i];
+        const u32 mask = (1u << b) - 1u;
+        bool has_term = false;
+        for (int j = 0; j < w; j++) has_term = has_term || ((u32)(k >> (j * b)) & mask) == term_first;
+        return (i == 0 || has_term || k != keys[i - 1]) ? 1u : 0u;
+    }
+};
+
 // wide alphabets (3b > 64): stage A sorts by the third symbol ...
 __global__ __launch_bounds__(BLOCK) void dc3_third_keys_kernel(const u32 *__restrict__ s, u32 n0,
                                                                u32 n02, u32 *__restrict__ keys,
@@ -437,7 +477,25 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         u32 *names = ar.alloc<u32>(n02);
         const u32 *sorted_vals = nullptr;
         const int bt = bit_width_u32(term_first);          // bits of the compressed level-0 alphabet
-        if (term_first > 0 && 3 * bt <= 32) {
+        int w = 3;                                         // name window (symbols) on the byte path
+        if (s8) {
+            const int w_max = 64 / bt < 12 ? 64 / bt : 12;
+            double reach = (double)term_first * term_first * term_first;
+            while (w < w_max && reach < 64.0 * (double)n) { reach *= term_first; w++; }
+        }
+        if (s8 && w * bt <= 32) {
+            SortBufs<u32> sb;
+            for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
+            LAUNCH(ctx, (dc3_window_keys_kernel<u32>), g02, s8, n0, n02, w, bt, term_first, sb.keys[0], sb.vals[0]);
+            sorted_vals = dc3_sort_and_name<u32>(ctx, sb, n02, w * bt, names, [&](const u32 *k) {
+                return KeyNeqWindowIn<u32>{k, w, bt, term_first}; });
+        } else if (s8) {
+            SortBufs<u64> sb;
+            for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u64>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
+            LAUNCH(ctx, (dc3_window_keys_kernel<u64>), g02, s8, n0, n02, w, bt, term_first, sb.keys[0], sb.vals[0]);
+            sorted_vals = dc3_sort_and_name<u64>(ctx, sb, n02, w * bt, names, [&](const u64 *k) {
+                return KeyNeqWindowIn<u64>{k, w, bt, term_first}; });
+        } else if (term_first > 0 && 3 * bt <= 32) {
             SortBufs<u32> sb;
             for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
             LAUNCH(ctx, (dc3_triple_keys_term_kernel<u32>), g02, s, n0, n02, bt, term_first, sb.keys[0], sb.vals[0]);
