@@ -1,8 +1,11 @@
 // radix_sort.h -- stable LSD radix sort of (key, value) pairs, 8-bit digits.
 //
-// One pass = three streaming kernels:
-//   radix_hist_kernel     per-tile 256-bin histogram (LDS atomics)      -> hist[digit][tile]
-//   device_scan           exclusive scan of the digit-major histogram   -> global bases
+// One pass:
+//   radix_hist_kernel     per-tile 256-bin histogram (LDS atomics)      -> hist[tile][digit]
+//   hist_chunk_sums / hist_chunk_scan / hist_apply
+//                         exclusive scan in digit-major ORDER over the tile-major
+//                         LAYOUT: one thread per digit column, rows of 256
+//                         counters are read and written coalesced       -> global bases
 //   radix_scatter_kernel  wave64 ballot multisplit for the stable rank inside
 //                         the tile, tile re-ordered by digit in LDS, then
 //                         written out as contiguous per-digit runs.
@@ -33,7 +36,51 @@ __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const K *__restrict__
         if (i < n) atomicAdd(&bins[(u32)(keys[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    hist[threadIdx.x * n_tiles + blockIdx.x] = bins[threadIdx.x];
+    hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = bins[threadIdx.x];       // tile-major: one coalesced row
+}
+
+// ---- scan of the histogram: base[t][d] = sum_{d' < d, all t'} h[t'][d'] + sum_{t' < t} h[t'][d] ----
+#define HS_CHUNK 64                    // tiles per chunk
+
+__global__ __launch_bounds__(BLOCK) void hist_chunk_sums_kernel(const u32 *__restrict__ hist, u32 n_tiles,
+                                                                u32 *__restrict__ chunk_sums)
+{
+    const u32 d = threadIdx.x, t0 = blockIdx.x * HS_CHUNK;
+    const u32 t1 = t0 + HS_CHUNK < n_tiles ? t0 + HS_CHUNK : n_tiles;
+    u32 sum = 0;
+    for (u32 t = t0; t < t1; t++) sum += hist[(size_t)t * RS_BINS + d];
+    chunk_sums[(size_t)blockIdx.x * RS_BINS + d] = sum;
+}
+
+// one workgroup: per digit column, exclusive scan over the chunks; then the digit bases
+__global__ __launch_bounds__(BLOCK) void hist_chunk_scan_kernel(const u32 *__restrict__ chunk_sums,
+                                                                u32 n_chunks, u32 *__restrict__ chunk_prefix)
+{
+    __shared__ u32 lds4[WAVES_PER_BLOCK];
+    const u32 d = threadIdx.x;
+    u32 run = 0;
+#pragma unroll 8
+    for (u32 c = 0; c < n_chunks; c++) {       // separate in/out arrays: the loads pipeline
+        const u32 v = chunk_sums[(size_t)c * RS_BINS + d];
+        chunk_prefix[(size_t)c * RS_BINS + d] = run;
+        run += v;
+    }
+    u32 total;
+    const u32 digit_base = block_exclusive_sum(run, lds4, total);     // all smaller digits, all tiles
+    chunk_prefix[(size_t)n_chunks * RS_BINS + d] = digit_base;
+}
+
+__global__ __launch_bounds__(BLOCK) void hist_apply_kernel(u32 *__restrict__ hist, u32 n_tiles,
+                                                           const u32 *__restrict__ chunk_sums, u32 n_chunks)
+{
+    const u32 d = threadIdx.x, t0 = blockIdx.x * HS_CHUNK;
+    const u32 t1 = t0 + HS_CHUNK < n_tiles ? t0 + HS_CHUNK : n_tiles;
+    u32 run = chunk_sums[(size_t)n_chunks * RS_BINS + d] + chunk_sums[(size_t)blockIdx.x * RS_BINS + d];
+    for (u32 t = t0; t < t1; t++) {
+        const u32 v = hist[(size_t)t * RS_BINS + d];
+        hist[(size_t)t * RS_BINS + d] = run;
+        run += v;
+    }
 }
 
 // THREADS = 64*WAVES threads move one 4096-pair tile.  Wave w owns the contiguous
@@ -118,7 +165,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
         if (w > 1) start += lds4[1];
         if (w > 2) start += lds4[2];
         digit_start[tid] = start;
-        global_base[tid] = scanned_hist[tid * n_tiles + blockIdx.x] - start;
+        global_base[tid] = scanned_hist[(size_t)blockIdx.x * RS_BINS + tid] - start;
     }
     __syncthreads();
 
@@ -172,11 +219,16 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits)
     const u32 n_tiles = ceil_div_u32(n, RS_TILE);
     const size_t mark = ctx.arena->mark();
     u32 *hist = ctx.arena->alloc<u32>((size_t)RS_BINS * n_tiles);
+    const u32 n_chunks = ceil_div_u32(n_tiles, HS_CHUNK);
+    u32 *chunk_sums = ctx.arena->alloc<u32>((size_t)RS_BINS * n_chunks);
+    u32 *chunk_prefix = ctx.arena->alloc<u32>((size_t)RS_BINS * (n_chunks + 1));
     int cur = 0;
     for (int shift = 0; shift < bits; shift += 8) {
         LAUNCH_NAMED(ctx, sizeof(K) == 8 ? "radix_hist_kernel<u64>" : "radix_hist_kernel<u32>",
                      (radix_hist_kernel<K>), n_tiles, (const K *)b.keys[cur], n, shift, hist, n_tiles);
-        device_scan<ArrIn, false>(ctx, ArrIn{hist}, RS_BINS * n_tiles, hist);
+        LAUNCH(ctx, hist_chunk_sums_kernel, n_chunks, (const u32 *)hist, n_tiles, chunk_sums);
+        LAUNCH(ctx, hist_chunk_scan_kernel, 1, (const u32 *)chunk_sums, n_chunks, chunk_prefix);
+        LAUNCH(ctx, hist_apply_kernel, n_chunks, hist, n_tiles, (const u32 *)chunk_prefix, n_chunks);
         if (!ctx.dry) {
             const bool prof = ctx.prof && ctx.prof->enabled;
             if (prof) ctx.prof->begin(sizeof(K) == 8 ? "radix_scatter_kernel<u64>" : "radix_scatter_kernel<u32>", ctx.stream);
