@@ -95,10 +95,14 @@ __global__ __launch_bounds__(BLOCK) void dc3_window_keys_kernel(const uint8_t *_
     if (u >= n02) return;
     const u32 q = u >> 1, r = u & 1u;
     const u32 p = 3u * q + 1u + r;
+    u64 lo8, hi8;                                   // w <= 12 symbols: two unaligned 8-byte loads
+    __builtin_memcpy(&lo8, s8 + p, 8);
+    __builtin_memcpy(&hi8, s8 + p + 8, 8);
     K key = 0;
     bool ended = false;
     for (int i = 0; i < w; i++) {
-        const u32 x = ended ? 0u : (u32)s8[p + i];
+        const u32 byte = (u32)((i < 8 ? lo8 >> (8 * i) : hi8 >> (8 * (i - 8))) & 0xFFu);
+        const u32 x = ended ? 0u : byte;
         ended = ended || x == 0xFFu;
         key = (key << b) | (K)(x == 0xFFu ? term_first : x);
     }
@@ -218,6 +222,50 @@ __global__ __launch_bounds__(BLOCK) void dc3_resolve_ties_kernel(const u32 *__re
         } while (c1 == c2 && h <= RESOLVE_MAX_LEN);
         if (c1 == c2) { atomicOr(fail, 1u); return; }
         if (c2 < c1) r++;
+    }
+    sa12[a + r] = t;
+}
+
+// The same on the byte stream (level 0): tied samples share their whole name window,
+// so they are compared on the text itself, 8 symbols per step.  Two terminators at the
+// same offset are different symbols ordered by position.  No name string is needed,
+// which saves the random scatter of 2n/3 names whenever the level does not recurse.
+__global__ __launch_bounds__(BLOCK) void dc3_resolve_ties_text_kernel(const u32 *__restrict__ sorted_vals,
+                                                                      const u32 *__restrict__ names,
+                                                                      const uint8_t *__restrict__ s8, u32 n0,
+                                                                      u32 n02, u32 *__restrict__ sa12,
+                                                                      u32 *__restrict__ fail)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n02) return;
+    const u32 nm = names[i];
+    const u32 t = sorted_vals[i];
+    const bool left_same = i > 0 && names[i - 1] == nm;
+    const bool right_same = i + 1 < n02 && names[i + 1] == nm;
+    if (!left_same && !right_same) { sa12[i] = t; return; }
+    u32 a = i, b = i + 1;
+    while (a > 0 && names[a - 1] == nm && i - a <= RESOLVE_MAX_GROUP) a--;
+    while (b < n02 && names[b] == nm && b - i <= RESOLVE_MAX_GROUP) b++;
+    if (b - a > RESOLVE_MAX_GROUP) { atomicOr(fail, 1u); return; }
+    const u32 p = dc3_sample_pos(t, n0);
+    u32 r = 0;
+    for (u32 x = a; x < b; x++) {
+        if (x == i) continue;
+        const u32 p2 = dc3_sample_pos(sorted_vals[x], n0);
+        bool decided = false, less = false;                 // less: suffix p2 < suffix p
+        for (u32 h = 0; h < RESOLVE_MAX_LEN && !decided; h += 8) {
+            u64 u, v;
+            __builtin_memcpy(&u, s8 + p + h, 8);
+            __builtin_memcpy(&v, s8 + p2 + h, 8);
+            const u64 d = u ^ v, z = ~u;
+            const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+            const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+            const u32 term = tz ? (u32)__builtin_ctzll(tz) >> 3 : 8u;
+            if (term < mism) { less = p2 < p; decided = true; }          // both end in (different) terminators
+            else if (mism < 8u) { less = ((v >> (8 * mism)) & 0xFFu) < ((u >> (8 * mism)) & 0xFFu); decided = true; }
+        }
+        if (!decided) { atomicOr(fail, 1u); return; }
+        if (less) r++;
     }
     sa12[a + r] = t;
 }
@@ -536,8 +584,14 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
             device_scan<KeyNeq2In, true>(ctx, KeyNeq2In{sb.keys[rb], third}, n02, names);
             sorted_vals = sb.vals[rb];
         }
-        LAUNCH(ctx, dc3_scatter_names_kernel, ceil_div_u32((u64)n02 + 3, BLOCK), sorted_vals,
-               (const u32 *)names, n02, s12);
+        // the name string is only needed to recurse or to order ties by names
+        bool have_s12 = false;
+        auto scatter_names = [&]() {
+            LAUNCH(ctx, dc3_scatter_names_kernel, ceil_div_u32((u64)n02 + 3, BLOCK), sorted_vals,
+                   (const u32 *)names, n02, s12);
+            have_s12 = true;
+        };
+        if (!s8) scatter_names();
         if (ctx.dry) {
             n_names = n02 > 4 ? n02 - 1 : n02;        // worst case: keep recursing
         } else {
@@ -555,8 +609,12 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
             u32 *fail = ar.alloc<u32>(1);
             u32 h_fail = 0;
             HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
-            LAUNCH(ctx, dc3_resolve_ties_kernel, g02, sorted_vals, (const u32 *)names, (const u32 *)s12, n02, sa12,
-                   fail);
+            if (s8)
+                LAUNCH(ctx, dc3_resolve_ties_text_kernel, g02, sorted_vals, (const u32 *)names, s8, n0, n02, sa12,
+                       fail);
+            else
+                LAUNCH(ctx, dc3_resolve_ties_kernel, g02, sorted_vals, (const u32 *)names, (const u32 *)s12, n02,
+                       sa12, fail);
             HIP_CHECK(hipMemcpyAsync(&h_fail, fail, sizeof(u32), hipMemcpyDeviceToHost, ctx.stream));
             HIP_CHECK(hipStreamSynchronize(ctx.stream));
             if (!h_fail) {
@@ -564,6 +622,7 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
                 if (ctx.stats) ctx.stats->levels_resolved++;
             }
         }
+        if (n_names < n02 && !have_s12) scatter_names();       // recursion ahead
         ar.release(mark);
     }
 

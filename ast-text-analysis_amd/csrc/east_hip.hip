@@ -41,7 +41,10 @@ __global__ __launch_bounds__(BLOCK) void presence_kernel(const u32 *__restrict__
     const u32 stride = gridDim.x * BLOCK;
     for (u32 i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const u32 c = sym[i];
-        if (c < TEXT_SYMBOLS) atomicOr(&bits[c >> 5], 1u << (c & 31u));
+        // a plain LDS read filters the (overwhelmingly common) already-set case; a stale read only
+        // costs a redundant atomic
+        if (c < TEXT_SYMBOLS && !(((volatile u32 *)bits)[c >> 5] & (1u << (c & 31u))))
+            atomicOr(&bits[c >> 5], 1u << (c & 31u));
     }
     __syncthreads();
     if (threadIdx.x < PRESENT_WORDS && bits[threadIdx.x]) atomicOr(&present[threadIdx.x], bits[threadIdx.x]);

@@ -87,7 +87,6 @@ __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
     lcp[r] = h;
 }
 
-// out[i] = min of in[16i .. 16i+15]; the padding of out becomes NONE_U32
 // LCP for small text alphabets (sigma_text <= 254): the symbol stream is also
 // kept as one byte per symbol (text code, 0xFF = "a terminator"), a quarter of
 // the footprint, so the two random windows per rank mostly come out of the
@@ -107,23 +106,36 @@ __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__
                                                      u32 *__restrict__ lcp)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= n) {
+    const bool valid = r < n;
+    // every rank fetches the 8-symbol window of ITS suffix once; the window of the left
+    // neighbour comes from the lane below (only lane 0 of a wave gathers twice)
+    const u32 j = valid ? sa[r] : 0u;
+    const u64 b = load_u64_unaligned(s8 + j);
+    u32 i = __shfl_up(j, 1, WAVE);
+    u32 a_lo = __shfl_up((u32)b, 1, WAVE), a_hi = __shfl_up((u32)(b >> 32), 1, WAVE);
+    u64 a = ((u64)a_hi << 32) | a_lo;
+    if (lane_id() == 0 && valid && r > 0) {
+        i = sa[r - 1];
+        a = load_u64_unaligned(s8 + i);
+    }
+    if (!valid) {
         if (r < ((n + PYR_FAN - 1u) & ~(PYR_FAN - 1u))) lcp[r] = NONE_U32;     // pyramid padding
         return;
     }
     if (r == 0) { lcp[0] = 0; return; }
-    const u32 i = sa[r - 1], j = sa[r];
     u32 h = 0;
+    u64 x = a, y = b;
     while (true) {
-        const u64 a = load_u64_unaligned(s8 + i + h), b = load_u64_unaligned(s8 + j + h);
-        const u64 x = a ^ b;
-        const u64 z = ~a;                                            // zero byte <=> 0xFF in a
+        const u64 d = x ^ y;
+        const u64 z = ~x;                                            // zero byte <=> 0xFF in x
         const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
-        const u32 mism = x ? (u32)__builtin_ctzll(x) >> 3 : 8u;
+        const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
         const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
         const u32 step = mism < term ? mism : term;
         h += step;
         if (step < 8u) break;
+        x = load_u64_unaligned(s8 + i + h);
+        y = load_u64_unaligned(s8 + j + h);
     }
     if (n_docs > 1 && h > 0) {
         const u32 d = doc_of(doc_off, n_docs, r);
@@ -132,6 +144,7 @@ __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__
     lcp[r] = h;
 }
 
+// out[i] = min of in[16i .. 16i+15]; the padding of out becomes NONE_U32
 __global__ __launch_bounds__(BLOCK) void pyramid_level_kernel(const u32 *__restrict__ in, u32 len_out,
                                                               u32 len_out_padded, u32 *__restrict__ out)
 {
@@ -261,11 +274,18 @@ __global__ __launch_bounds__(BLOCK) void ann_kernel(Pyramid P, const u32 *__rest
         const u32 d = n_docs > 1 ? doc_of(doc_off, n_docs, k) : 0u;
         if (doc_off[d] == k) a = (doc_off[d + 1] - k) - n_strings[d];
     } else {
-        // first l-index of its interval <=> the previous value <= v is strictly smaller
-        const u32 pse = pyr_find_left<false>(P, k, v);          // exists: the segment start holds 0
-        if (lcp[pse] < v) {
-            u32 nsv = pyr_find_right<true>(P, k, v);            // stops at the next segment start
-            if (nsv == NONE_U32) nsv = n;
+        // first l-index of its interval <=> the previous value <= v is strictly smaller.
+        // Neighbouring ranks decide most cases without touching the pyramid.
+        const u32 left = lcp[k - 1];                            // k >= 1 here: lcp[0] == 0
+        u32 pse = k - 1;
+        if (left > v) pse = pyr_find_left<false>(P, k - 1, v);  // exists: the segment start holds 0
+        if (pse == k - 1 ? left < v : lcp[pse] < v) {
+            u32 nsv = k + 1;
+            if (nsv >= n) nsv = n;
+            else if (lcp[nsv] >= v) {
+                nsv = pyr_find_right<true>(P, k + 1, v);        // stops at the next segment start
+                if (nsv == NONE_U32) nsv = n;
+            }
             a = nsv - pse;                                      // pse == PSV here
         }
     }
