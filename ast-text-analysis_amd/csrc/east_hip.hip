@@ -232,7 +232,8 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     for (int l = 1; l < pyr.levels; l++)
         LAUNCH(ctx, pyramid_level_kernel, ceil_div_u32(pyr_padded(pyr.len[l]), BLOCK), pyr.ptr[l - 1], pyr.len[l],
                pyr_padded(pyr.len[l]), (u32 *)pyr.ptr[l]);
-    LAUNCH(ctx, ann_kernel, gn, pyr, (const u32 *)h->doc_off, (const u32 *)h->n_strings, n_docs, n, h->ann);
+    LAUNCH(ctx, ann_kernel, ceil_div_u32(n, ANN_TILE), pyr, (const u32 *)h->doc_off, (const u32 *)h->n_strings,
+           n_docs, n, h->ann);
     h->kg_built = false;
     h->child_built = false;      // childtab_up / down / next_l_index: built on first east_hip_get_tables request
 }

@@ -258,38 +258,66 @@ __device__ __forceinline__ u32 pyr_leftmost_argmin(const Pyramid &P, u32 a, u32 
     return pyr_find_right<false>(P, lo, best);
 }
 
-// anntab of one rank (easa.py:306-331).  doc segment starts carry lcp == 0,
-// which bounds every search inside the document.
+// anntab (easa.py:306-331).  Most ranks are decided by their nearest neighbours: phase 1
+// looks at most ANN_NEAR ranks to either side (coalesced, L1-resident) and parks the rest
+// -- the first l-indices of wide intervals, a few per cent -- in an LDS work list, which
+// phase 2 processes densely through the pyramid.  (With the pyramid search inlined,
+// nearly every wavefront paid for it because one lane in 64 needed it.)  doc segment
+// starts carry lcp == 0, which bounds every search inside the document.
+#define ANN_NEAR 8u
+#define ANN_IPT 8
+#define ANN_TILE (BLOCK * ANN_IPT)
+
 __global__ __launch_bounds__(BLOCK) void ann_kernel(Pyramid P, const u32 *__restrict__ doc_off,
                                                     const u32 *__restrict__ n_strings, u32 n_docs, u32 n,
                                                     u32 *__restrict__ ann)
 {
-    const u32 k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= n) return;
+    __shared__ u32 work[ANN_TILE];
+    __shared__ u32 work_count;
     const u32 *lcp = P.ptr[0];
-    const u32 v = lcp[k];
-    u32 a = 0;
-    if (v == 0) {
-        // only a document's first rank carries an annotation here: the root, n_d - m_d
-        const u32 d = n_docs > 1 ? doc_of(doc_off, n_docs, k) : 0u;
-        if (doc_off[d] == k) a = (doc_off[d + 1] - k) - n_strings[d];
-    } else {
-        // first l-index of its interval <=> the previous value <= v is strictly smaller.
-        // Neighbouring ranks decide most cases without touching the pyramid.
-        const u32 left = lcp[k - 1];                            // k >= 1 here: lcp[0] == 0
-        u32 pse = k - 1;
-        if (left > v) pse = pyr_find_left<false>(P, k - 1, v);  // exists: the segment start holds 0
-        if (pse == k - 1 ? left < v : lcp[pse] < v) {
-            u32 nsv = k + 1;
-            if (nsv >= n) nsv = n;
-            else if (lcp[nsv] >= v) {
-                nsv = pyr_find_right<true>(P, k + 1, v);        // stops at the next segment start
-                if (nsv == NONE_U32) nsv = n;
-            }
+    if (threadIdx.x == 0) work_count = 0;
+    __syncthreads();
+#pragma unroll 2
+    for (int j = 0; j < ANN_IPT; j++) {
+        const u32 k = blockIdx.x * ANN_TILE + j * BLOCK + threadIdx.x;
+        if (k >= n) continue;
+        const u32 v = lcp[k];
+        if (v == 0) {
+            // only a document's first rank carries an annotation here: the root, n_d - m_d
+            const u32 d = n_docs > 1 ? doc_of(doc_off, n_docs, k) : 0u;
+            ann[k] = doc_off[d] == k ? (doc_off[d + 1] - k) - n_strings[d] : 0u;
+            continue;
+        }
+        // previous value <= v (k >= 1 and lcp[0] == 0, so the scan cannot run off the front)
+        u32 p = k - 1, x = lcp[p];
+        const u32 p_lim = k > ANN_NEAR ? k - ANN_NEAR : 0u;
+        while (x > v && p > p_lim) { p--; x = lcp[p]; }
+        bool defer = x > v;
+        u32 a = 0;
+        if (!defer && x < v) {                  // first l-index of its interval: width = NSV - PSV
+            u32 q = k + 1;
+            const u32 q_lim = k + ANN_NEAR < n ? k + ANN_NEAR : n;
+            while (q < q_lim && lcp[q] >= v) q++;
+            if (q < q_lim || q == n) a = q - p;
+            else defer = true;
+        }
+        if (defer) work[atomicAdd(&work_count, 1u)] = k;
+        else ann[k] = a;
+    }
+    __syncthreads();
+    const u32 count = work_count;
+    for (u32 w = threadIdx.x; w < count; w += BLOCK) {
+        const u32 k = work[w];
+        const u32 v = lcp[k];
+        const u32 pse = pyr_find_left<false>(P, k, v);          // exists: the segment start holds 0
+        u32 a = 0;
+        if (lcp[pse] < v) {
+            u32 nsv = pyr_find_right<true>(P, k, v);            // stops at the next segment start
+            if (nsv == NONE_U32) nsv = n;
             a = nsv - pse;                                      // pse == PSV here
         }
+        ann[k] = a;
     }
-    ann[k] = a;
 }
 
 // The three child tables of one rank, positions local to the document, 0 = none
