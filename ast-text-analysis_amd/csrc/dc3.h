@@ -22,6 +22,7 @@
 #include "common.h"
 #include "radix_sort.h"
 #include "scan.h"
+#include <math.h>
 
 __device__ __forceinline__ u32 dc3_sample_pos(u32 t, u32 n0)
 {
@@ -527,9 +528,14 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         const int bt = bit_width_u32(term_first);          // bits of the compressed level-0 alphabet
         int w = 3;                                         // name window (symbols) on the byte path
         if (s8) {
+            // widest window: names almost unique (sigma^w >= 64 n) within 64-bit keys; but if the
+            // window that still fits 32-bit keys leaves only a few per cent of ties (sigma^w >= 4 n),
+            // the cheaper sort wins and the tie resolution absorbs the difference
             const int w_max = 64 / bt < 12 ? 64 / bt : 12;
             double reach = (double)term_first * term_first * term_first;
             while (w < w_max && reach < 64.0 * (double)n) { reach *= term_first; w++; }
+            const int w32 = 32 / bt;
+            if (w32 >= 3 && w32 < w && pow((double)term_first, w32) >= 4.0 * (double)n) w = w32;
         }
         if (s8 && w * bt <= 32) {
             SortBufs<u32> sb;
@@ -604,7 +610,7 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         if (n_names == n02 && !ctx.dry) {  // unique names: the sorted order is SA12 already
             HIP_CHECK(hipMemcpyAsync(sa12, sorted_vals, (size_t)n02 * sizeof(u32),
                                      hipMemcpyDeviceToDevice, ctx.stream));
-        } else if (!ctx.dry && n02 - n_names <= n02 / 16) {
+        } else if (!ctx.dry && n02 - n_names <= n02 / 8) {
             // few ties: order them in place instead of recursing (names[] doubles as the fail word's home)
             u32 *fail = ar.alloc<u32>(1);
             u32 h_fail = 0;

@@ -10,8 +10,9 @@
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts a wide coalesced streaming
 read at exactly half its bytes (MI355X_MICROARCH.md, HBM section); checked here on kernels
 with a known byte count (remap_kernel reads 8 B/symbol, radix_hist_kernel<u64> 8 B/element):
-the ratio printed below is ~0.49.  traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 for the
-streaming kernels; gather kernels are reported raw as well (their correction lies between 1x and 2x).
+the ratio printed below is ~0.50.  traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 for the
+streaming kernels.  Gather kernels (GATHER below) issue 64-byte sector requests, which the
+counter tallies at their true size, so their FETCH_SIZE is NOT doubled.
 """
 import collections
 import csv
@@ -25,6 +26,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
 DST = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+
+
+# kernels whose reads are dominated by random gathers / whose writes by random scatters
+GATHER = ("dc3_merge_tile_kernel", "dc3_merge_partition_kernel", "lcp8_kernel", "lcp_kernel",
+          "dc3_compact_s0_bytes_kernel", "dc3_compact_s0_kernel", "dc3_rank_kernel", "dc3_scatter_names_kernel",
+          "dc3_resolve_ties_text_kernel", "dc3_resolve_ties_kernel", "kgram_mark_kernel", "score_walk_kernel",
+          "dc3_pair_keys_kernel", "dc3_gather_third_kernel", "ann_kernel", "child_kernel", "doc_keys_kernel")
 
 
 def short(name):
@@ -53,20 +61,22 @@ bench = json.load(open(os.path.join(SRC, "bench.json")))
 n = bench["config"]["symbols_per_gpu"]
 traffic = {}
 with open(os.path.join(DST, tag + "_pmc_per_kernel.csv"), "w") as f:
-    f.write("kernel,launches,FETCH_SIZE_KiB_per_launch,WRITE_SIZE_KiB_per_launch,"
-            "hbm_bytes_per_launch_fetch_x2_plus_write\n")
+    f.write("kernel,launches,FETCH_SIZE_KiB_per_launch,WRITE_SIZE_KiB_per_launch,fetch_correction,"
+            "hbm_bytes_per_launch\n")
     for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 0])[1] + write.get(k, [0, 0])[1])):
         fc, fv = fetch.get(k, [0, 0.0])
         wc, wv = write.get(k, [0, 0.0])
         c = max(fc, wc, 1)
-        per = (2.0 * fv / max(fc, 1) + wv / max(wc, 1)) * 1024.0
-        f.write("%s,%d,%.1f,%.1f,%.0f\n" % (k, c, fv / max(fc, 1), wv / max(wc, 1), per))
+        corr = 1.0 if k in GATHER else 2.0
+        per = (corr * fv / max(fc, 1) + wv / max(wc, 1)) * 1024.0
+        f.write("%s,%d,%.1f,%.1f,%.0f,%.0f\n" % (k, c, fv / max(fc, 1), wv / max(wc, 1), corr, per))
         traffic[k] = per
 # bench.py's kernel names
 names = {"radix_scatter_kernel<u64>": "radix_scatter_kernel<u64>", "radix_scatter_kernel<u32>": "radix_scatter_kernel<u32>",
          "radix_hist_kernel<u64>": "radix_hist_kernel<u64>", "radix_hist_kernel<u32>": "radix_hist_kernel<u32>"}
-out = {"_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of "
-                "`python3 bench.py --steps 2 --warmup 1` (gfx950: FETCH_SIZE counts streaming reads at 1/2)",
+out = {"_note": "HBM bytes per launch = (c*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of "
+                "`python3 bench.py --steps 2 --warmup 1`; c = 2 for streaming kernels (gfx950 counts wide streaming "
+                "reads at 1/2, calibrated on remap_kernel), c = 1 for gather kernels (64-byte sector requests)",
        "_workload": bench["config"]["workload"]}
 for k, v in traffic.items():
     out[names.get(k, k)] = v
