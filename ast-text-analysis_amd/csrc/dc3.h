@@ -492,6 +492,183 @@ __global__ __launch_bounds__(BLOCK) void dc3_merge_tile_kernel(const uint2 *__re
     }
 }
 
+// ---- step 5b: merge + LCP in one pass (level 0 of a single-document byte-stream build) ----
+// REC[p] = { s8[p..p+7] (8 symbols, symbol p in the low byte), R[p+1], R[p+2] }: ONE aligned
+// 16-byte gather per suffix feeds both the merge comparator (symbols p, p+1 and the two
+// ranks) and the LCP of neighbouring outputs (8-symbol windows staged in LDS), which removes
+// the second random pass over the symbol stream that a separate LCP kernel needs.
+// Symbols are byte codes: 0xFF = terminator class, two 0xFF are different terminators
+// ordered by position (comparator) and end the common prefix (LCP).
+__global__ __launch_bounds__(BLOCK) void dc3_records_kernel(const uint8_t *__restrict__ s8,
+                                                            const u32 *__restrict__ r12, u32 n,
+                                                            uint4 *__restrict__ rec)
+{
+    const u32 p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= n) return;
+    u64 win;
+    __builtin_memcpy(&win, s8 + p, 8);
+    const u32 q = p / 3u, m = p - 3u * q;
+    u32 r1 = 0, r2 = 0;
+    if (m == 0) { r1 = r12[2u * q]; r2 = r12[2u * q + 1u]; }
+    else if (m == 1) r1 = r12[2u * q + 1u];
+    else r2 = r12[2u * q + 2u];
+    rec[p] = make_uint4((u32)win, (u32)(win >> 32), r1, r2);
+}
+
+// a: sample suffix at pa (a_mod1: pa mod 3 == 1), b: non-sample suffix at pb
+__device__ __forceinline__ bool dc3_rec_a_leq_b(u32 a_lo, u32 a_r1, u32 a_r2, bool a_mod1, u32 pa,
+                                                u32 b_lo, u32 b_r1, u32 b_r2, u32 pb)
+{
+    const u32 a0 = a_lo & 0xFFu, b0 = b_lo & 0xFFu;
+    if (a0 != b0) return a0 < b0;
+    if (a0 == 0xFFu) return pa < pb;
+    if (a_mod1) return a_r1 <= b_r1;
+    const u32 a1 = (a_lo >> 8) & 0xFFu, b1 = (b_lo >> 8) & 0xFFu;
+    if (a1 != b1) return a1 < b1;
+    if (a1 == 0xFFu) return pa < pb;
+    return a_r2 <= b_r2;
+}
+
+__global__ __launch_bounds__(BLOCK) void dc3_merge_partition_rec_kernel(const uint4 *__restrict__ rec,
+                                                                        const u32 *__restrict__ A, u32 nA,
+                                                                        const u32 *__restrict__ B, u32 nB,
+                                                                        u32 n0, u32 n_tiles,
+                                                                        u32 *__restrict__ splits)
+{
+    const u32 tile = blockIdx.x * BLOCK + threadIdx.x;
+    if (tile > n_tiles) return;
+    const u64 kk = (u64)tile * MERGE_TILE;
+    const u32 k = kk < (u64)nA + nB ? (u32)kk : nA + nB;
+    u32 lo = k > nB ? k - nB : 0u;
+    u32 hi = k < nA ? k : nA;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        const u32 t = A[mid];
+        const u32 pa = dc3_sample_pos(t, n0), pb = B[k - 1u - mid];
+        const uint4 a = rec[pa], b = rec[pb];
+        if (dc3_rec_a_leq_b(a.x, a.z, a.w, t < n0, pa, b.x, b.z, b.w, pb)) lo = mid + 1u; else hi = mid;
+    }
+    splits[tile] = lo;
+}
+
+// common prefix of two suffixes whose first 8 symbols are the windows wa, wb; beyond the
+// windows the byte stream is read directly (rare)
+__device__ __forceinline__ u32 dc3_window_lcp(u64 wa, u64 wb, const uint8_t *__restrict__ s8, u32 pa, u32 pb)
+{
+    u32 h = 0;
+    while (true) {
+        const u64 d = wa ^ wb, z = ~wa;
+        const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+        const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+        const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
+        const u32 step = mism < term ? mism : term;
+        h += step;
+        if (step < 8u) return h;
+        __builtin_memcpy(&wa, s8 + pa + h, 8);
+        __builtin_memcpy(&wb, s8 + pb + h, 8);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void dc3_merge_lcp_tile_kernel(const uint4 *__restrict__ rec,
+                                                                   const uint8_t *__restrict__ s8,
+                                                                   const u32 *__restrict__ A, u32 nA,
+                                                                   const u32 *__restrict__ B, u32 nB, u32 n0,
+                                                                   const u32 *__restrict__ splits,
+                                                                   u32 *__restrict__ sa_out,
+                                                                   u32 *__restrict__ lcp_out)
+{
+    __shared__ u32 l_lo[MERGE_TILE], l_hi[MERGE_TILE], l_r1[MERGE_TILE], l_r2[MERGE_TILE];
+    __shared__ u32 l_pos[MERGE_TILE];       // text position; bit 31 = "sample with p mod 3 == 1"
+    __shared__ u32 l_src[MERGE_TILE];       // staged slot that became output o
+    const u32 tid = threadIdx.x;
+    const u32 n = nA + nB;
+    const u32 k0 = blockIdx.x * MERGE_TILE;
+    const u32 count = n - k0 < (u32)MERGE_TILE ? n - k0 : (u32)MERGE_TILE;
+    const u32 a0 = splits[blockIdx.x], a1 = splits[blockIdx.x + 1];
+    const u32 na = a1 - a0, b0 = k0 - a0;
+    const u32 nb = count - na;
+
+#pragma unroll
+    for (int j = 0; j < MERGE_IPT; j++) {
+        const u32 idx = j * BLOCK + tid;
+        if (idx < count) {
+            u32 p, flag = 0;
+            if (idx < na) {
+                const u32 t = A[a0 + idx];
+                p = dc3_sample_pos(t, n0);
+                flag = t < n0 ? 0x80000000u : 0u;
+            } else {
+                p = B[b0 + (idx - na)];
+            }
+            const uint4 r = rec[p];
+            l_lo[idx] = r.x; l_hi[idx] = r.y; l_r1[idx] = r.z; l_r2[idx] = r.w;
+            l_pos[idx] = p | flag;
+        }
+    }
+    __syncthreads();
+
+    const u32 d0 = tid * MERGE_IPT;
+    if (d0 < count) {
+        u32 lo = d0 > nb ? d0 - nb : 0u;
+        u32 hi = d0 < na ? d0 : na;
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            const u32 y = na + (d0 - 1u - mid);
+            const u32 pa = l_pos[mid];
+            if (dc3_rec_a_leq_b(l_lo[mid], l_r1[mid], l_r2[mid], (pa >> 31) != 0, pa & 0x7FFFFFFFu,
+                                l_lo[y], l_r1[y], l_r2[y], l_pos[y])) lo = mid + 1u; else hi = mid;
+        }
+        u32 x = lo, y = d0 - lo;               // heads: slot x (A), slot na + y (B)
+#pragma unroll
+        for (int i = 0; i < MERGE_IPT; i++) {
+            if (d0 + i < count) {
+                bool take_a;
+                if (y >= nb) take_a = true;
+                else if (x >= na) take_a = false;
+                else {
+                    const u32 pa = l_pos[x], q = na + y;
+                    take_a = dc3_rec_a_leq_b(l_lo[x], l_r1[x], l_r2[x], (pa >> 31) != 0, pa & 0x7FFFFFFFu,
+                                             l_lo[q], l_r1[q], l_r2[q], l_pos[q]);
+                }
+                if (take_a) { l_src[d0 + i] = x; x++; }
+                else { l_src[d0 + i] = na + y; y++; }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MERGE_IPT; j++) {
+        const u32 o = j * BLOCK + tid;
+        if (o < count) {
+            const u32 sb = l_src[o];
+            const u32 pb = l_pos[sb] & 0x7FFFFFFFu;
+            sa_out[k0 + o] = pb;
+            if (o > 0) {                    // the first rank of a tile is finished by dc3_lcp_heads_kernel
+                const u32 sa_ = l_src[o - 1];
+                const u32 pa = l_pos[sa_] & 0x7FFFFFFFu;
+                lcp_out[k0 + o] = dc3_window_lcp(((u64)l_hi[sa_] << 32) | l_lo[sa_], ((u64)l_hi[sb] << 32) | l_lo[sb],
+                                                 s8, pa, pb);
+            }
+        }
+    }
+}
+
+// LCP of the first rank of every merge tile (its left neighbour lives in the previous tile)
+__global__ __launch_bounds__(BLOCK) void dc3_lcp_heads_kernel(const uint8_t *__restrict__ s8,
+                                                              const u32 *__restrict__ sa, u32 n,
+                                                              u32 *__restrict__ lcp)
+{
+    const u64 r64 = ((u64)blockIdx.x * BLOCK + threadIdx.x) * MERGE_TILE;
+    if (r64 >= n) return;
+    const u32 r = (u32)r64;
+    if (r == 0) { lcp[0] = 0; return; }
+    const u32 pa = sa[r - 1], pb = sa[r];
+    u64 wa, wb;
+    __builtin_memcpy(&wa, s8 + pa, 8);
+    __builtin_memcpy(&wb, s8 + pb, 8);
+    lcp[r] = dc3_window_lcp(wa, wb, s8, pa, pb);
+}
+
 // ---- host driver ----------------------------------------------------------------
 // s: n+3 symbols (three zero pads), values in [1, sigma].  sa_out: n words.
 // term_first > 0 (level 0 of an EASA build only): symbols >= term_first are
@@ -506,8 +683,9 @@ static const u32 *dc3_sort_and_name(Ctx &ctx, SortBufs<K> &sb, u32 n02, int bits
     return sb.vals[r];
 }
 
+// lcp_out (level 0 with s8 only): also emit the LCP table of the suffix array (single document).
 static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_out, int depth = 0,
-                            u32 term_first = 0, const uint8_t *s8 = nullptr)
+                            u32 term_first = 0, const uint8_t *s8 = nullptr, u32 *lcp_out = nullptr)
 {
     const u32 n0 = (n + 2) / 3, n1 = (n + 1) / 3, n2 = n / 3, n02 = n0 + n2;
     const int b = bit_width_u32(sigma);
@@ -642,8 +820,16 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         u32 *r12 = ar.alloc<u32>((size_t)2 * n0 + 4);
         if (!ctx.dry) HIP_CHECK(hipMemsetAsync(r12, 0, ((size_t)2 * n0 + 4) * sizeof(u32), ctx.stream));
         LAUNCH(ctx, dc3_rank_kernel, g02, (const u32 *)sa12, n0, n02, r12);
-        uint2 *sr = ar.alloc<uint2>((size_t)n + 3);
-        LAUNCH(ctx, dc3_interleave_kernel, ceil_div_u32((u64)n + 3, BLOCK), s, (const u32 *)r12, n + 3, sr);
+        const bool fused_lcp = s8 && lcp_out;
+        uint2 *sr = nullptr;
+        uint4 *rec = nullptr;
+        if (fused_lcp || (ctx.dry && term_first)) rec = ar.alloc<uint4>(n);   // (dry run: the larger of the two)
+        if (fused_lcp) {
+            LAUNCH(ctx, dc3_records_kernel, ceil_div_u32(n, BLOCK), s8, (const u32 *)r12, n, rec);
+        } else {
+            sr = ar.alloc<uint2>((size_t)n + 3);
+            LAUNCH(ctx, dc3_interleave_kernel, ceil_div_u32((u64)n + 3, BLOCK), s, (const u32 *)r12, n + 3, sr);
+        }
         u32 *slot = ar.alloc<u32>(n02);
         device_scan<LtIn, false>(ctx, LtIn{sa12, n0}, n02, slot);
         SortBufs<u32> s0;
@@ -666,10 +852,18 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         const u32 n_tiles = ceil_div_u32(n, MERGE_TILE);
         u32 *splits = ar.alloc<u32>((size_t)n_tiles + 1);
         if (ctx.stats) ctx.stats->merge_elems += n;
-        LAUNCH(ctx, dc3_merge_partition_kernel, ceil_div_u32((u64)n_tiles + 1, BLOCK), (const uint2 *)sr,
-               (const u32 *)sa12 + skip, nA, (const u32 *)s0.vals[r0], n0, n0, n_tiles, splits);
-        LAUNCH(ctx, dc3_merge_tile_kernel, n_tiles, (const uint2 *)sr, (const u32 *)sa12 + skip, nA,
-               (const u32 *)s0.vals[r0], n0, n0, (const u32 *)splits, sa_out);
+        if (fused_lcp) {
+            LAUNCH(ctx, dc3_merge_partition_rec_kernel, ceil_div_u32((u64)n_tiles + 1, BLOCK), (const uint4 *)rec,
+                   (const u32 *)sa12 + skip, nA, (const u32 *)s0.vals[r0], n0, n0, n_tiles, splits);
+            LAUNCH(ctx, dc3_merge_lcp_tile_kernel, n_tiles, (const uint4 *)rec, s8, (const u32 *)sa12 + skip, nA,
+                   (const u32 *)s0.vals[r0], n0, n0, (const u32 *)splits, sa_out, lcp_out);
+            LAUNCH(ctx, dc3_lcp_heads_kernel, ceil_div_u32(n_tiles, BLOCK), s8, (const u32 *)sa_out, n, lcp_out);
+        } else {
+            LAUNCH(ctx, dc3_merge_partition_kernel, ceil_div_u32((u64)n_tiles + 1, BLOCK), (const uint2 *)sr,
+                   (const u32 *)sa12 + skip, nA, (const u32 *)s0.vals[r0], n0, n0, n_tiles, splits);
+            LAUNCH(ctx, dc3_merge_tile_kernel, n_tiles, (const uint2 *)sr, (const u32 *)sa12 + skip, nA,
+                   (const u32 *)s0.vals[r0], n0, n0, (const u32 *)splits, sa_out);
+        }
     }
     ar.release(mark_level);
     return levels;

@@ -208,8 +208,10 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     h->bits0 = bit_width_u32(sigma);
 
     // ---- suffix array of the whole shard, then partition by document -------------
+    const bool fused_lcp = n_docs == 1 && h->use_s8;     // the level-0 merge also emits the LCP table
     if (n_docs == 1) {
-        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr);
+        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr,
+                                             fused_lcp ? h->lcp : nullptr);
     } else {
         const size_t mark = ar.mark();
         SortBufs<u32> sb;
@@ -223,7 +225,10 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     }
 
     // ---- LCP, min pyramid, annotation + child tables ------------------------------
-    if (h->use_s8)
+    if (fused_lcp) {
+        if (!ctx.dry && pyr_padded(n) > n)
+            HIP_CHECK(hipMemsetAsync(h->lcp + n, 0xFF, (size_t)(pyr_padded(n) - n) * sizeof(u32), ctx.stream));
+    } else if (h->use_s8)
         LAUNCH(ctx, lcp8_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const uint8_t *)h->s8, (const u32 *)h->sa,
                (const u32 *)h->doc_off, n_docs, n, h->lcp);
     else

@@ -66,6 +66,8 @@ def kernel_bytes(name, info, n, n_q, n_docs):
         "radix_hist_kernel<u64>": e64 * 8, "radix_hist_kernel<u32>": e32 * 4,
         # per merged suffix: 4 B sorted-list read + 24 B (symbol, rank) window gather + 4 B write
         "dc3_merge_tile_kernel": info["merge_elements"] * 32,
+        # fused merge + LCP: 4 B list read + one 16 B record gather + 4 B SA + 4 B LCP written per suffix
+        "dc3_merge_lcp_tile_kernel": n * 28,
         # 4 B SA read, 2 x 16 B symbol windows, 4 B LCP write per rank (first comparison step)
         "lcp_kernel": n * 40,
         # 4 B LCP read + 4 B annotation write per rank

@@ -29,7 +29,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 
 
 # kernels whose reads are dominated by random gathers / whose writes by random scatters
-GATHER = ("dc3_merge_tile_kernel", "dc3_merge_partition_kernel", "lcp8_kernel", "lcp_kernel",
+GATHER = ("dc3_merge_tile_kernel", "dc3_merge_partition_kernel", "dc3_merge_lcp_tile_kernel",
+          "dc3_merge_partition_rec_kernel", "dc3_lcp_heads_kernel", "lcp8_kernel", "lcp_kernel",
           "dc3_compact_s0_bytes_kernel", "dc3_compact_s0_kernel", "dc3_rank_kernel", "dc3_scatter_names_kernel",
           "dc3_resolve_ties_text_kernel", "dc3_resolve_ties_kernel", "kgram_mark_kernel", "score_walk_kernel",
           "dc3_pair_keys_kernel", "dc3_gather_third_kernel", "ann_kernel", "child_kernel", "doc_keys_kernel")
