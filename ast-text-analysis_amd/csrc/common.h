@@ -16,6 +16,12 @@ typedef int64_t i64;
 
 #include "../../include/east_hip.h"
 
+// Direct LCP comparison is capped: ranks whose common prefix reaches LCP_DIRECT_CAP symbols are
+// marked with LCP_CAP_MARK and finished by the Kasai-style pass in tables.h, so that a highly
+// repetitive input costs O(n + work of the marked ranks) instead of the sum of all LCPs.
+#define LCP_DIRECT_CAP (1u << 14)
+#define LCP_CAP_MARK 0xFFFFFFFEu
+
 #define WAVE 64
 #define BLOCK 256              // threads per workgroup everywhere
 #define WAVES_PER_BLOCK 4

@@ -564,6 +564,7 @@ __device__ __forceinline__ u32 dc3_window_lcp(u64 wa, u64 wb, const uint8_t *__r
         const u32 step = mism < term ? mism : term;
         h += step;
         if (step < 8u) return h;
+        if (h >= LCP_DIRECT_CAP) return LCP_CAP_MARK;          // finished by lcp_finish_kernel
         __builtin_memcpy(&wa, s8 + pa + h, 8);
         __builtin_memcpy(&wb, s8 + pb + h, 8);
     }
@@ -575,7 +576,8 @@ __global__ __launch_bounds__(BLOCK) void dc3_merge_lcp_tile_kernel(const uint4 *
                                                                    const u32 *__restrict__ B, u32 nB, u32 n0,
                                                                    const u32 *__restrict__ splits,
                                                                    u32 *__restrict__ sa_out,
-                                                                   u32 *__restrict__ lcp_out)
+                                                                   u32 *__restrict__ lcp_out,
+                                                                   u32 *__restrict__ capped)
 {
     __shared__ u32 l_lo[MERGE_TILE], l_hi[MERGE_TILE], l_r1[MERGE_TILE], l_r2[MERGE_TILE];
     __shared__ u32 l_pos[MERGE_TILE];       // text position; bit 31 = "sample with p mod 3 == 1"
@@ -646,8 +648,10 @@ __global__ __launch_bounds__(BLOCK) void dc3_merge_lcp_tile_kernel(const uint4 *
             if (o > 0) {                    // the first rank of a tile is finished by dc3_lcp_heads_kernel
                 const u32 sa_ = l_src[o - 1];
                 const u32 pa = l_pos[sa_] & 0x7FFFFFFFu;
-                lcp_out[k0 + o] = dc3_window_lcp(((u64)l_hi[sa_] << 32) | l_lo[sa_], ((u64)l_hi[sb] << 32) | l_lo[sb],
-                                                 s8, pa, pb);
+                const u32 h = dc3_window_lcp(((u64)l_hi[sa_] << 32) | l_lo[sa_], ((u64)l_hi[sb] << 32) | l_lo[sb],
+                                             s8, pa, pb);
+                if (h == LCP_CAP_MARK) atomicOr(capped, 1u);
+                lcp_out[k0 + o] = h;
             }
         }
     }
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_merge_lcp_tile_kernel(const uint4 *
 // LCP of the first rank of every merge tile (its left neighbour lives in the previous tile)
 __global__ __launch_bounds__(BLOCK) void dc3_lcp_heads_kernel(const uint8_t *__restrict__ s8,
                                                               const u32 *__restrict__ sa, u32 n,
-                                                              u32 *__restrict__ lcp)
+                                                              u32 *__restrict__ lcp, u32 *__restrict__ capped)
 {
     const u64 r64 = ((u64)blockIdx.x * BLOCK + threadIdx.x) * MERGE_TILE;
     if (r64 >= n) return;
@@ -666,7 +670,9 @@ __global__ __launch_bounds__(BLOCK) void dc3_lcp_heads_kernel(const uint8_t *__r
     u64 wa, wb;
     __builtin_memcpy(&wa, s8 + pa, 8);
     __builtin_memcpy(&wb, s8 + pb, 8);
-    lcp[r] = dc3_window_lcp(wa, wb, s8, pa, pb);
+    const u32 h = dc3_window_lcp(wa, wb, s8, pa, pb);
+    if (h == LCP_CAP_MARK) atomicOr(capped, 1u);
+    lcp[r] = h;
 }
 
 // ---- host driver ----------------------------------------------------------------
@@ -685,7 +691,8 @@ static const u32 *dc3_sort_and_name(Ctx &ctx, SortBufs<K> &sb, u32 n02, int bits
 
 // lcp_out (level 0 with s8 only): also emit the LCP table of the suffix array (single document).
 static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_out, int depth = 0,
-                            u32 term_first = 0, const uint8_t *s8 = nullptr, u32 *lcp_out = nullptr)
+                            u32 term_first = 0, const uint8_t *s8 = nullptr, u32 *lcp_out = nullptr,
+                            u32 *lcp_capped = nullptr)
 {
     const u32 n0 = (n + 2) / 3, n1 = (n + 1) / 3, n2 = n / 3, n02 = n0 + n2;
     const int b = bit_width_u32(sigma);
@@ -856,8 +863,9 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
             LAUNCH(ctx, dc3_merge_partition_rec_kernel, ceil_div_u32((u64)n_tiles + 1, BLOCK), (const uint4 *)rec,
                    (const u32 *)sa12 + skip, nA, (const u32 *)s0.vals[r0], n0, n0, n_tiles, splits);
             LAUNCH(ctx, dc3_merge_lcp_tile_kernel, n_tiles, (const uint4 *)rec, s8, (const u32 *)sa12 + skip, nA,
-                   (const u32 *)s0.vals[r0], n0, n0, (const u32 *)splits, sa_out, lcp_out);
-            LAUNCH(ctx, dc3_lcp_heads_kernel, ceil_div_u32(n_tiles, BLOCK), s8, (const u32 *)sa_out, n, lcp_out);
+                   (const u32 *)s0.vals[r0], n0, n0, (const u32 *)splits, sa_out, lcp_out, lcp_capped);
+            LAUNCH(ctx, dc3_lcp_heads_kernel, ceil_div_u32(n_tiles, BLOCK), s8, (const u32 *)sa_out, n, lcp_out,
+                   lcp_capped);
         } else {
             LAUNCH(ctx, dc3_merge_partition_kernel, ceil_div_u32((u64)n_tiles + 1, BLOCK), (const uint2 *)sr,
                    (const u32 *)sa12 + skip, nA, (const u32 *)s0.vals[r0], n0, n0, n_tiles, splits);

@@ -145,7 +145,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     h->next = ar.alloc<u32>(n);
     h->doc_off = ar.alloc<u32>((size_t)n_docs + 1);
     h->n_strings = ar.alloc<u32>(n_docs);
-    h->code_map = ar.alloc<u32>(TEXT_SYMBOLS);
+    h->code_map = ar.alloc<u32>(TEXT_SYMBOLS + 1);        // + the "LCP capped" flag word
     Pyramid pyr;
     pyr.levels = 1;
     pyr.ptr[0] = h->lcp;
@@ -209,9 +209,11 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
 
     // ---- suffix array of the whole shard, then partition by document -------------
     const bool fused_lcp = n_docs == 1 && h->use_s8;     // the level-0 merge also emits the LCP table
+    u32 *capped = h->code_map + TEXT_SYMBOLS;            // one flag word behind the code map
+    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(capped, 0, sizeof(u32), ctx.stream));
     if (n_docs == 1) {
         ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr,
-                                             fused_lcp ? h->lcp : nullptr);
+                                             fused_lcp ? h->lcp : nullptr, capped);
     } else {
         const size_t mark = ar.mark();
         SortBufs<u32> sb;
@@ -225,15 +227,41 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     }
 
     // ---- LCP, min pyramid, annotation + child tables ------------------------------
-    if (fused_lcp) {
-        if (!ctx.dry && pyr_padded(n) > n)
-            HIP_CHECK(hipMemsetAsync(h->lcp + n, 0xFF, (size_t)(pyr_padded(n) - n) * sizeof(u32), ctx.stream));
-    } else if (h->use_s8)
-        LAUNCH(ctx, lcp8_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const uint8_t *)h->s8, (const u32 *)h->sa,
-               (const u32 *)h->doc_off, n_docs, n, h->lcp);
-    else
-        LAUNCH(ctx, lcp_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const u32 *)h->s, (const u32 *)h->sa,
-               (const u32 *)h->doc_off, n_docs, n, h->lcp);
+    {
+        const size_t mark = ar.mark();
+        u32 *rank = ctx.dry ? ar.alloc<u32>(n) : nullptr;       // only allocated for real when needed
+        if (fused_lcp) {
+            if (!ctx.dry && pyr_padded(n) > n)
+                HIP_CHECK(hipMemsetAsync(h->lcp + n, 0xFF, (size_t)(pyr_padded(n) - n) * sizeof(u32), ctx.stream));
+        } else if (h->use_s8) {
+            LAUNCH(ctx, lcp8_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const uint8_t *)h->s8, (const u32 *)h->sa,
+                   (const u32 *)h->doc_off, n_docs, n, h->lcp, capped);
+        } else {
+            LAUNCH(ctx, lcp_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const u32 *)h->s, (const u32 *)h->sa,
+                   (const u32 *)h->doc_off, n_docs, n, h->lcp, capped);
+        }
+        if (!ctx.dry) {
+            // a repetitive input: finish the capped ranks with the Kasai carry (rare; costs one sync)
+            u32 h_capped = 0;
+            if (n > LCP_DIRECT_CAP) {           // shorter inputs cannot reach the cap
+                HIP_CHECK(hipMemcpyAsync(&h_capped, capped, sizeof(u32), hipMemcpyDeviceToHost, ctx.stream));
+                HIP_CHECK(hipStreamSynchronize(ctx.stream));
+            }
+            if (h_capped) {
+                rank = ar.alloc<u32>(n);
+                LAUNCH(ctx, inverse_sa_kernel, gn, (const u32 *)h->sa, n, rank);
+                const u32 kb = ceil_div_u32(ceil_div_u32(n, KASAI_BLOCK), BLOCK);
+                if (h->use_s8)
+                    LAUNCH(ctx, (lcp_finish_kernel<true>), kb, (const void *)h->s8, (const u32 *)h->sa,
+                           (const u32 *)rank, n, h->lcp);
+                else
+                    LAUNCH(ctx, (lcp_finish_kernel<false>), kb, (const void *)h->s, (const u32 *)h->sa,
+                           (const u32 *)rank, n, h->lcp);
+            }
+        }
+        (void)rank;
+        ar.release(mark);
+    }
     for (int l = 1; l < pyr.levels; l++)
         LAUNCH(ctx, pyramid_level_kernel, ceil_div_u32(pyr_padded(pyr.len[l]), BLOCK), pyr.ptr[l - 1], pyr.len[l],
                pyr_padded(pyr.len[l]), (u32 *)pyr.ptr[l]);

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(BLOCK) void doc_keys_kernel(const u32 *__restrict__
 __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
                                                     const u32 *__restrict__ sa,
                                                     const u32 *__restrict__ doc_off, u32 n_docs,
-                                                    u32 n, u32 *__restrict__ lcp)
+                                                    u32 n, u32 *__restrict__ lcp, u32 *__restrict__ capped)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) {
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
         if (a2 != b2) { h += 2; break; }
         if (a3 != b3) { h += 3; break; }
         h += 4;
+        if (h >= LCP_DIRECT_CAP) break;
     }
     // the first rank of a document compares against the previous document's
     // last suffix; the reference table starts every document with 0
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
         const u32 d = doc_of(doc_off, n_docs, r);
         if (doc_off[d] == r) h = 0;
     }
+    if (h >= LCP_DIRECT_CAP) { h = LCP_CAP_MARK; atomicOr(capped, 1u); }
     lcp[r] = h;
 }
 
@@ -103,7 +105,7 @@ __device__ __forceinline__ u64 load_u64_unaligned(const uint8_t *p)
 __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__ s8,
                                                      const u32 *__restrict__ sa,
                                                      const u32 *__restrict__ doc_off, u32 n_docs, u32 n,
-                                                     u32 *__restrict__ lcp)
+                                                     u32 *__restrict__ lcp, u32 *__restrict__ capped)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = r < n;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__
         const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
         const u32 step = mism < term ? mism : term;
         h += step;
-        if (step < 8u) break;
+        if (step < 8u || h >= LCP_DIRECT_CAP) break;
         x = load_u64_unaligned(s8 + i + h);
         y = load_u64_unaligned(s8 + j + h);
     }
@@ -141,7 +143,59 @@ __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__
         const u32 d = doc_of(doc_off, n_docs, r);
         if (doc_off[d] == r) h = 0;
     }
+    if (h >= LCP_DIRECT_CAP) { h = LCP_CAP_MARK; atomicOr(capped, 1u); }
     lcp[r] = h;
+}
+
+// ---- finishing pass for capped ranks (Kasai et al. 2001, blocked over the text) ----------
+// rank[p] = rank of the suffix at p.  One thread walks KASAI_BLOCK consecutive text
+// positions: h(p+1) >= h(p) - 1 inside a document, so after the first marked position of a
+// run the comparisons resume where the previous one ended.  Unmarked ranks only feed the
+// carry.  BYTES: byte stream with the 0xFF rule, else exact u32 symbols.
+#define KASAI_BLOCK 1024u
+
+__global__ __launch_bounds__(BLOCK) void inverse_sa_kernel(const u32 *__restrict__ sa, u32 n, u32 *__restrict__ rank)
+{
+    const u32 r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r < n) rank[sa[r]] = r;
+}
+
+template <bool BYTES>
+__global__ __launch_bounds__(BLOCK) void lcp_finish_kernel(const void *__restrict__ sym,
+                                                           const u32 *__restrict__ sa,
+                                                           const u32 *__restrict__ rank, u32 n,
+                                                           u32 *__restrict__ lcp)
+{
+    const u64 p0 = ((u64)blockIdx.x * BLOCK + threadIdx.x) * KASAI_BLOCK;
+    if (p0 >= n) return;
+    const u32 p1 = p0 + KASAI_BLOCK < n ? (u32)p0 + KASAI_BLOCK : n;
+    u32 carry = 0;                                 // lcp of the previous position
+    for (u32 p = (u32)p0; p < p1; p++) {
+        const u32 r = rank[p];
+        u32 h = lcp[r];
+        if (h == LCP_CAP_MARK) {                   // never a document's first rank (those hold 0)
+            const u32 q = sa[r - 1];
+            h = carry > LCP_DIRECT_CAP + 1u ? carry - 1u : LCP_DIRECT_CAP;
+            if (BYTES) {
+                const uint8_t *s8 = (const uint8_t *)sym;
+                while (true) {
+                    const u64 x = load_u64_unaligned(s8 + p + h), y = load_u64_unaligned(s8 + q + h);
+                    const u64 d = x ^ y, z = ~x;
+                    const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+                    const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+                    const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
+                    const u32 step = mism < term ? mism : term;
+                    h += step;
+                    if (step < 8u) break;
+                }
+            } else {
+                const u32 *s = (const u32 *)sym;
+                while (s[p + h] == s[q + h]) h++;
+            }
+            lcp[r] = h;
+        }
+        carry = h;
+    }
 }
 
 // out[i] = min of in[16i .. 16i+15]; the padding of out becomes NONE_U32

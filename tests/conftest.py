@@ -40,6 +40,9 @@ def oracle():
 def hip():
     """The ctypes binding; GPU tests fail (not skip) if the library or device is missing."""
     from east import hip_backend
+    if not os.path.exists(hip_backend.LIB_PATH):      # a fresh checkout: compile the library first
+        import __graft_entry__
+        __graft_entry__.build()
     hip_backend.load()
     assert hip_backend.device_count() >= 1, "no HIP device: the gpu tier must run on the GPU box"
     return hip_backend

@@ -411,3 +411,35 @@ def test_natural_language_like_16mib_vs_oracle(hip, oracle):
             for k in range(200):
                 assert tables[norm][k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=True)
     assert float(tables[False].max()) > 1.0          # denormalized scores exceed 1 on deep matches
+
+
+@pytest.mark.parametrize("case", ["one_symbol", "period3", "two_copies", "many_copies_multidoc"])
+def test_repetitive_inputs_lcp_beyond_the_direct_cap(hip, oracle, case):
+    """Common prefixes far beyond LCP_DIRECT_CAP (16384): the capped ranks are finished by the
+    Kasai-style pass; DC3 recurses to the bottom.  Tables bit-exact against the oracle."""
+    from east import hip_backend
+    from east.asts import utils as ast_utils
+    rng = np.random.default_rng(4)
+    if case == "one_symbol":
+        docs = [["A" * 60000]]
+    elif case == "period3":
+        docs = [["ABC" * 25000 + "X"]]
+    elif case == "two_copies":
+        blob = "".join(rng.choice(list("ABCD"), size=40000))
+        docs = [[blob + "Q" + blob]]
+    else:
+        blob = "".join(rng.choice(list("AB"), size=20000))
+        docs = [[blob, blob, "C" + blob], [blob[::-1], blob[::-1]]]
+    parts = [ast_utils.strings_to_symbols(sc) for sc in docs]
+    index = hip_backend.HipIndex()
+    index.build(np.concatenate(parts), np.concatenate([[0], np.cumsum([p.size for p in parts])]),
+                np.array([len(sc) for sc in docs]))
+    for d, sc in enumerate(docs):
+        o = oracle.OracleEASA(sc)
+        assert int(o.lcptab.max()) > 16384
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, case, d)
+    q = docs[0][0][:40]
+    qs, qo = hip_backend.pack_queries([q])
+    assert index.score_table(qs, qo, True)[0, 0] == oracle.OracleEASA(docs[0]).score(q)

@@ -102,6 +102,9 @@ def _header_functions():
 
 def test_c_abi_library_loads_and_exports_every_declared_symbol():
     from east import hip_backend
+    if not os.path.exists(hip_backend.LIB_PATH):      # a fresh checkout: hipcc cross-compiles without a GPU
+        import __graft_entry__
+        __graft_entry__.build()
     lib = hip_backend.load()
     declared = _header_functions()
     assert len(declared) >= 20
