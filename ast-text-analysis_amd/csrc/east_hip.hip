@@ -219,7 +219,13 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         SortBufs<u32> sb;
         for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n); sb.vals[k] = ar.alloc<u32>(n); }
         ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sb.vals[0], 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr);
-        LAUNCH(ctx, doc_keys_kernel, gn, (const u32 *)sb.vals[0], (const u32 *)h->doc_off, n_docs, n, sb.keys[0]);
+        const int shift = std::max(0, bit_width_u32(n) - 20);
+        const u32 n_coarse = (u32)(((u64)n >> shift) + 1);
+        u32 *coarse = ar.alloc<u32>(n_coarse);
+        LAUNCH(ctx, doc_coarse_kernel, ceil_div_u32(n_coarse, BLOCK), (const u32 *)h->doc_off, n_docs, n, shift,
+               n_coarse, coarse);
+        LAUNCH(ctx, doc_keys_kernel, gn, (const u32 *)sb.vals[0], (const u32 *)h->doc_off, (const u32 *)coarse, shift,
+               n, sb.keys[0]);
         const int r = radix_sort_pairs<u32>(ctx, sb, n, bit_width_u32(n_docs - 1));
         if (!ctx.dry)
             HIP_CHECK(hipMemcpyAsync(h->sa, sb.vals[r], (size_t)n * 4, hipMemcpyDeviceToDevice, ctx.stream));
@@ -240,6 +246,8 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
             LAUNCH(ctx, lcp_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const u32 *)h->s, (const u32 *)h->sa,
                    (const u32 *)h->doc_off, n_docs, n, h->lcp, capped);
         }
+        if (n_docs > 1)
+            LAUNCH(ctx, lcp_doc_starts_kernel, ceil_div_u32(n_docs, BLOCK), (const u32 *)h->doc_off, n_docs, h->lcp);
         if (!ctx.dry) {
             // a repetitive input: finish the capped ranks with the Kasai carry (rare; costs one sync)
             u32 h_capped = 0;

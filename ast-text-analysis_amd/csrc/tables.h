@@ -44,12 +44,36 @@ __device__ __forceinline__ u32 doc_of(const u32 *__restrict__ doc_off, u32 n_doc
     return lo;
 }
 
-__global__ __launch_bounds__(BLOCK) void doc_keys_kernel(const u32 *__restrict__ sa,
-                                                         const u32 *__restrict__ doc_off,
-                                                         u32 n_docs, u32 n, u32 *__restrict__ keys)
+// coarse[i] = document of position i << shift; a position's document is then found by
+// stepping forward from coarse[p >> shift] (almost always zero or one step)
+__global__ __launch_bounds__(BLOCK) void doc_coarse_kernel(const u32 *__restrict__ doc_off, u32 n_docs, u32 n,
+                                                           int shift, u32 n_coarse, u32 *__restrict__ coarse)
 {
     const u32 i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) keys[i] = doc_of(doc_off, n_docs, sa[i]);
+    if (i >= n_coarse) return;
+    const u64 p = (u64)i << shift;
+    coarse[i] = doc_of(doc_off, n_docs, p < n ? (u32)p : n - 1u);
+}
+
+__global__ __launch_bounds__(BLOCK) void doc_keys_kernel(const u32 *__restrict__ sa,
+                                                         const u32 *__restrict__ doc_off,
+                                                         const u32 *__restrict__ coarse, int shift,
+                                                         u32 n, u32 *__restrict__ keys)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const u32 p = sa[i];
+    u32 d = coarse[p >> shift];
+    while (doc_off[d + 1] <= p) d++;
+    keys[i] = d;
+}
+
+// every document's table starts with 0 (its first rank has no left neighbour inside the document)
+__global__ __launch_bounds__(BLOCK) void lcp_doc_starts_kernel(const u32 *__restrict__ doc_off, u32 n_docs,
+                                                               u32 *__restrict__ lcp)
+{
+    const u32 d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d < n_docs) lcp[doc_off[d]] = 0;
 }
 
 __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
@@ -79,12 +103,7 @@ __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
         h += 4;
         if (h >= LCP_DIRECT_CAP) break;
     }
-    // the first rank of a document compares against the previous document's
-    // last suffix; the reference table starts every document with 0
-    if (n_docs > 1 && h > 0) {
-        const u32 d = doc_of(doc_off, n_docs, r);
-        if (doc_off[d] == r) h = 0;
-    }
+    // (the first rank of every document is reset to 0 by lcp_doc_starts_kernel)
     if (h >= LCP_DIRECT_CAP) { h = LCP_CAP_MARK; atomicOr(capped, 1u); }
     lcp[r] = h;
 }
@@ -139,10 +158,7 @@ __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__
         x = load_u64_unaligned(s8 + i + h);
         y = load_u64_unaligned(s8 + j + h);
     }
-    if (n_docs > 1 && h > 0) {
-        const u32 d = doc_of(doc_off, n_docs, r);
-        if (doc_off[d] == r) h = 0;
-    }
+    // (the first rank of every document is reset to 0 by lcp_doc_starts_kernel)
     if (h >= LCP_DIRECT_CAP) { h = LCP_CAP_MARK; atomicOr(capped, 1u); }
     lcp[r] = h;
 }
