@@ -102,8 +102,11 @@ __global__ __launch_bounds__(BLOCK) void query_map_kernel(const u32 *__restrict_
     q_code[i] = code;
 }
 
+// SYM = uint8_t: the byte stream (a quarter of the footprint; 0xFF terminators sort above every
+// text code, which is all the binary search needs), SYM = u32: the dense symbol stream.
+template <class SYM>
 __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
-    const u32 *__restrict__ s, const u32 *__restrict__ sa, const u32 *__restrict__ doc_off,
+    const SYM *__restrict__ s, const u32 *__restrict__ sa, const u32 *__restrict__ doc_off,
     const u32 *__restrict__ n_strings, u32 n_docs, const u32 *__restrict__ q_code,
     const u32 *__restrict__ q_end, u32 n_q, int normalized, const u32 *__restrict__ kg, int kg_k, u32 kg_A,
     u32 kg_bins, double *__restrict__ suffix_out)
