@@ -645,7 +645,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_merge_lcp_tile_kernel(const uint4 *
             const u32 sb = l_src[o];
             const u32 pb = l_pos[sb] & 0x7FFFFFFFu;
             sa_out[k0 + o] = pb;
-            if (o > 0) {                    // the first rank of a tile is finished by dc3_lcp_heads_kernel
+            if (lcp_out && o > 0) {         // the first rank of a tile is finished by dc3_lcp_heads_kernel
                 const u32 sa_ = l_src[o - 1];
                 const u32 pa = l_pos[sa_] & 0x7FFFFFFFu;
                 const u32 h = dc3_window_lcp(((u64)l_hi[sa_] << 32) | l_lo[sa_], ((u64)l_hi[sb] << 32) | l_lo[sb],
@@ -689,7 +689,8 @@ static const u32 *dc3_sort_and_name(Ctx &ctx, SortBufs<K> &sb, u32 n02, int bits
     return sb.vals[r];
 }
 
-// lcp_out (level 0 with s8 only): also emit the LCP table of the suffix array (single document).
+// s8 (level 0 of an EASA build with sigma_text <= 254): the byte stream; `s` is then not read at all.
+// lcp_out (with s8 only): also emit the LCP table of the suffix array (single document).
 static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_out, int depth = 0,
                             u32 term_first = 0, const uint8_t *s8 = nullptr, u32 *lcp_out = nullptr,
                             u32 *lcp_capped = nullptr)
@@ -827,11 +828,11 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         u32 *r12 = ar.alloc<u32>((size_t)2 * n0 + 4);
         if (!ctx.dry) HIP_CHECK(hipMemsetAsync(r12, 0, ((size_t)2 * n0 + 4) * sizeof(u32), ctx.stream));
         LAUNCH(ctx, dc3_rank_kernel, g02, (const u32 *)sa12, n0, n02, r12);
-        const bool fused_lcp = s8 && lcp_out;
+        const bool byte_records = s8 != nullptr;       // level 0 on the byte stream: 16-byte records
         uint2 *sr = nullptr;
         uint4 *rec = nullptr;
-        if (fused_lcp || (ctx.dry && term_first)) rec = ar.alloc<uint4>(n);   // (dry run: the larger of the two)
-        if (fused_lcp) {
+        if (byte_records || (ctx.dry && term_first)) rec = ar.alloc<uint4>(n);   // (dry run: the larger of the two)
+        if (byte_records) {
             LAUNCH(ctx, dc3_records_kernel, ceil_div_u32(n, BLOCK), s8, (const u32 *)r12, n, rec);
         } else {
             sr = ar.alloc<uint2>((size_t)n + 3);
@@ -859,13 +860,14 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         const u32 n_tiles = ceil_div_u32(n, MERGE_TILE);
         u32 *splits = ar.alloc<u32>((size_t)n_tiles + 1);
         if (ctx.stats) ctx.stats->merge_elems += n;
-        if (fused_lcp) {
+        if (byte_records) {
             LAUNCH(ctx, dc3_merge_partition_rec_kernel, ceil_div_u32((u64)n_tiles + 1, BLOCK), (const uint4 *)rec,
                    (const u32 *)sa12 + skip, nA, (const u32 *)s0.vals[r0], n0, n0, n_tiles, splits);
             LAUNCH(ctx, dc3_merge_lcp_tile_kernel, n_tiles, (const uint4 *)rec, s8, (const u32 *)sa12 + skip, nA,
                    (const u32 *)s0.vals[r0], n0, n0, (const u32 *)splits, sa_out, lcp_out, lcp_capped);
-            LAUNCH(ctx, dc3_lcp_heads_kernel, ceil_div_u32(n_tiles, BLOCK), s8, (const u32 *)sa_out, n, lcp_out,
-                   lcp_capped);
+            if (lcp_out)
+                LAUNCH(ctx, dc3_lcp_heads_kernel, ceil_div_u32(n_tiles, BLOCK), s8, (const u32 *)sa_out, n, lcp_out,
+                       lcp_capped);
         } else {
             LAUNCH(ctx, dc3_merge_partition_kernel, ceil_div_u32((u64)n_tiles + 1, BLOCK), (const uint2 *)sr,
                    (const u32 *)sa12 + skip, nA, (const u32 *)s0.vals[r0], n0, n0, n_tiles, splits);

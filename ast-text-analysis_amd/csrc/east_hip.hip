@@ -59,18 +59,49 @@ struct TermIn {                                 // 1 at terminators; defined on 
     }
 };
 
-// status[0] |= 1: a document does not end in a terminator; |= 2: m_d mismatch
-__global__ __launch_bounds__(BLOCK) void validate_docs_kernel(const u32 *__restrict__ sym,
-                                                              const u32 *__restrict__ term_ex,
-                                                              const u32 *__restrict__ doc_off,
-                                                              const u32 *__restrict__ n_strings,
-                                                              u32 n_docs, u32 *__restrict__ status)
+// byte path: only the byte stream is built (0xFF = terminator); the exact terminator numbers are
+// never needed there, so no terminator scan runs
+__global__ __launch_bounds__(BLOCK) void remap_bytes_kernel(const u32 *__restrict__ sym,
+                                                            const u32 *__restrict__ code_map, u32 n,
+                                                            uint8_t *__restrict__ s8)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) {
+        const u32 c = sym[i];
+        s8[i] = c < TEXT_SYMBOLS ? (uint8_t)code_map[c] : (uint8_t)0xFF;
+    } else if (i < n + 16) {
+        s8[i] = 0;
+    }
+}
+
+// memory safety: every document must end in a terminator (it stops every suffix comparison)
+__global__ __launch_bounds__(BLOCK) void validate_last_symbol_kernel(const u32 *__restrict__ sym,
+                                                                     const u32 *__restrict__ doc_off, u32 n_docs,
+                                                                     u32 *__restrict__ status)
+{
+    const u32 d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d < n_docs && sym[doc_off[d + 1] - 1] < TEXT_SYMBOLS) atomicOr(status, 1u);
+}
+
+// n_strings[d] must equal the terminators of document d.  Terminators sort above every text
+// symbol, so the terminator-first suffixes are the tail of the document's suffix array: one
+// binary search per document on the finished array replaces a counting pass over the corpus.
+template <class SYM>
+__global__ __launch_bounds__(BLOCK) void validate_n_strings_kernel(const SYM *__restrict__ s, u32 term_first,
+                                                                   const u32 *__restrict__ sa,
+                                                                   const u32 *__restrict__ doc_off,
+                                                                   const u32 *__restrict__ n_strings, u32 n_docs,
+                                                                   u32 *__restrict__ status)
 {
     const u32 d = blockIdx.x * BLOCK + threadIdx.x;
     if (d >= n_docs) return;
-    const u32 b = doc_off[d], e = doc_off[d + 1];
-    if (sym[e - 1] < TEXT_SYMBOLS) atomicOr(status, 1u);
-    if (term_ex[e] - term_ex[b] != n_strings[d]) atomicOr(status, 2u);
+    u32 lo = doc_off[d], hi = doc_off[d + 1];
+    const u32 end = hi;
+    while (lo < hi) {                       // first rank whose suffix starts with a terminator
+        const u32 mid = (lo + hi) >> 1;
+        if ((u32)s[sa[mid]] >= term_first) hi = mid; else lo = mid + 1;
+    }
+    if (end - lo != n_strings[d]) atomicOr(status, 2u);
 }
 
 __global__ __launch_bounds__(BLOCK) void remap_kernel(const u32 *__restrict__ sym,
@@ -145,7 +176,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     h->next = ar.alloc<u32>(n);
     h->doc_off = ar.alloc<u32>((size_t)n_docs + 1);
     h->n_strings = ar.alloc<u32>(n_docs);
-    h->code_map = ar.alloc<u32>(TEXT_SYMBOLS + 1);        // + the "LCP capped" flag word
+    h->code_map = ar.alloc<u32>(TEXT_SYMBOLS + 2);        // + the "LCP capped" flag and the validation status
     Pyramid pyr;
     pyr.levels = 1;
     pyr.ptr[0] = h->lcp;
@@ -171,35 +202,39 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     const u32 gn = ceil_div_u32(n, BLOCK);
     u32 sigma_t = TEXT_SYMBOLS - 1, m_total = n;          // dry-run worst case
     {
-        // ---- alphabet, terminator numbering, validation, dense remap -----------
+        // ---- alphabet, dense remap ---------------------------------------------
         const size_t mark = ar.mark();
         u32 *present = ar.alloc<u32>(PRESENT_WORDS + 1);  // + status word
-        u32 *term_ex = ar.alloc<u32>((size_t)n + 1);
+        u32 *term_ex = ar.alloc<u32>((size_t)n + 1);      // wide-alphabet path only
         if (!ctx.dry) HIP_CHECK(hipMemsetAsync(present, 0, (PRESENT_WORDS + 1) * 4, ctx.stream));
         LAUNCH(ctx, presence_kernel, std::min<u32>(gn, 2048), d_sym, n, present);
-        device_scan<TermIn, false>(ctx, TermIn{d_sym, n}, n + 1, term_ex);
-        LAUNCH(ctx, validate_docs_kernel, ceil_div_u32(n_docs, BLOCK), d_sym, (const u32 *)term_ex,
-               (const u32 *)h->doc_off, (const u32 *)h->n_strings, n_docs, present + PRESENT_WORDS);
+        LAUNCH(ctx, validate_last_symbol_kernel, ceil_div_u32(n_docs, BLOCK), d_sym, (const u32 *)h->doc_off, n_docs,
+               present + PRESENT_WORDS);
         if (!ctx.dry) {
             u32 hp[PRESENT_WORDS + 1];
             HIP_CHECK(hipMemcpyAsync(hp, present, sizeof(hp), hipMemcpyDeviceToHost, ctx.stream));
-            HIP_CHECK(hipMemcpyAsync(&m_total, term_ex + n, 4, hipMemcpyDeviceToHost, ctx.stream));
             HIP_CHECK(hipStreamSynchronize(ctx.stream));
             if (hp[PRESENT_WORDS] & 1u)
                 east_throw(EAST_HIP_ERR_DOMAIN, "a document does not end in a string terminator (>= U+0A00)");
-            if (hp[PRESENT_WORDS] & 2u)
-                east_throw(EAST_HIP_ERR_DOMAIN, "n_strings does not match the terminators found in a document "
-                                                "(text symbols must be < U+0A00)");
             std::vector<u32> map(TEXT_SYMBOLS, 0u);
             sigma_t = 0;
             for (u32 c = 0; c < TEXT_SYMBOLS; c++)
                 if (hp[c >> 5] & (1u << (c & 31u))) map[c] = ++sigma_t;
             HIP_CHECK(hipMemcpyAsync(h->code_map, map.data(), TEXT_SYMBOLS * 4, hipMemcpyHostToDevice, ctx.stream));
             HIP_CHECK(hipStreamSynchronize(ctx.stream));   // `map` is a stack-lifetime source
+            m_total = 0;
+            for (u32 d = 0; d < n_docs; d++) m_total += (u32)n_strings[d];     // checked after the build
+            h->use_s8 = sigma_t <= 254;
         }
-        h->use_s8 = sigma_t <= 254;
-        LAUNCH(ctx, remap_kernel, ceil_div_u32((u64)n + 16, BLOCK), d_sym, (const u32 *)term_ex,
-               (const u32 *)h->code_map, sigma_t, n, h->s, h->use_s8 ? h->s8 : (uint8_t *)nullptr);
+        if (h->use_s8 && !ctx.dry) {
+            LAUNCH(ctx, remap_bytes_kernel, ceil_div_u32((u64)n + 16, BLOCK), d_sym, (const u32 *)h->code_map, n,
+                   h->s8);
+        } else {
+            // wide alphabets: dense u32 codes, terminators numbered globally by a scan
+            device_scan<TermIn, false>(ctx, TermIn{d_sym, n}, n + 1, term_ex);
+            LAUNCH(ctx, remap_kernel, ceil_div_u32((u64)n + 16, BLOCK), d_sym, (const u32 *)term_ex,
+                   (const u32 *)h->code_map, sigma_t, n, h->s, (uint8_t *)nullptr);
+        }
         ar.release(mark);
     }
     const u32 sigma = sigma_t + m_total;
@@ -209,8 +244,9 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
 
     // ---- suffix array of the whole shard, then partition by document -------------
     const bool fused_lcp = n_docs == 1 && h->use_s8;     // the level-0 merge also emits the LCP table
-    u32 *capped = h->code_map + TEXT_SYMBOLS;            // one flag word behind the code map
-    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(capped, 0, sizeof(u32), ctx.stream));
+    u32 *capped = h->code_map + TEXT_SYMBOLS;            // flag words behind the code map
+    u32 *status = capped + 1;
+    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(capped, 0, 2 * sizeof(u32), ctx.stream));
     if (n_docs == 1) {
         ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr,
                                              fused_lcp ? h->lcp : nullptr, capped);
@@ -231,6 +267,16 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
             HIP_CHECK(hipMemcpyAsync(h->sa, sb.vals[r], (size_t)n * 4, hipMemcpyDeviceToDevice, ctx.stream));
         ar.release(mark);
     }
+
+    // n_strings against the terminators actually present (read back at the end of the build)
+    if (h->use_s8)
+        LAUNCH_NAMED(ctx, "validate_n_strings_kernel", (validate_n_strings_kernel<uint8_t>), ceil_div_u32(n_docs, BLOCK),
+                     (const uint8_t *)h->s8, 0xFFu, (const u32 *)h->sa, (const u32 *)h->doc_off,
+                     (const u32 *)h->n_strings, n_docs, status);
+    else
+        LAUNCH_NAMED(ctx, "validate_n_strings_kernel", (validate_n_strings_kernel<u32>), ceil_div_u32(n_docs, BLOCK),
+                     (const u32 *)h->s, sigma_t + 1u, (const u32 *)h->sa, (const u32 *)h->doc_off,
+                     (const u32 *)h->n_strings, n_docs, status);
 
     // ---- LCP, min pyramid, annotation + child tables ------------------------------
     {
@@ -354,7 +400,12 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));
     build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings);
     HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    u32 status = 0;
+    HIP_CHECK(hipMemcpyAsync(&status, h->code_map + TEXT_SYMBOLS + 1, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (status & 2u)
+        east_throw(EAST_HIP_ERR_DOMAIN, "n_strings does not match the terminators found in a document "
+                                        "(text symbols must be < U+0A00)");
     h->prof.collect();
     HIP_CHECK(hipEventElapsedTime(&h->last_build_ms, h->ev0, h->ev1));
     h->n = n;

@@ -443,3 +443,20 @@ def test_repetitive_inputs_lcp_beyond_the_direct_cap(hip, oracle, case):
     q = docs[0][0][:40]
     qs, qo = hip_backend.pack_queries([q])
     assert index.score_table(qs, qo, True)[0, 0] == oracle.OracleEASA(docs[0]).score(q)
+
+
+def test_c_abi_rejects_inconsistent_input(hip):
+    """n_strings that does not match the terminators, or a document without a final terminator,
+    is an EAST_HIP_ERR_DOMAIN error (not silent garbage, not an out-of-bounds comparison)."""
+    from east import exceptions, hip_backend
+    sym = np.array([65, 66, 0x0A00, 67, 0x0A01], dtype=np.uint32)
+    index = hip_backend.HipIndex()
+    index.build(sym, np.array([0, 5]), np.array([2]))                        # fine
+    with pytest.raises(exceptions.HipBackendError, match="n_strings"):
+        index.build(sym, np.array([0, 5]), np.array([1]))
+    with pytest.raises(exceptions.HipBackendError, match="terminator"):
+        index.build(sym[:4], np.array([0, 4]), np.array([1]))
+    with pytest.raises(exceptions.HipBackendError, match="n_strings"):
+        index.build(sym, np.array([0, 3, 5]), np.array([1, 2]))
+    with pytest.raises(exceptions.HipBackendError):
+        index.score_table(np.array([65], np.uint32), np.array([0, 1]))       # no valid index after a failed build
