@@ -23,6 +23,7 @@
 #include "radix_sort.h"
 #include "scan.h"
 #include <math.h>
+#include <algorithm>
 
 __device__ __forceinline__ u32 dc3_sample_pos(u32 t, u32 n0)
 {
@@ -87,10 +88,13 @@ template <class K> struct KeyNeqTermIn {
 // walks the two suffixes left to right -- and with sigma^w >> n almost every name is
 // unique, so the whole recursion collapses into the in-place tie resolution below.
 // Same terminator rules as dc3_triple_keys_term_kernel.
+// The key bits left over below the w full symbols (`spare`) take the top bits of symbol w+1:
+// still order-preserving, and it thins the ties out further for free.
 template <class K>
 __global__ __launch_bounds__(BLOCK) void dc3_window_keys_kernel(const uint8_t *__restrict__ s8, u32 n0,
-                                                                u32 n02, int w, int b, u32 term_first,
-                                                                K *__restrict__ keys, u32 *__restrict__ vals)
+                                                                u32 n02, int w, int b, int spare,
+                                                                u32 term_first, K *__restrict__ keys,
+                                                                u32 *__restrict__ vals)
 {
     const u32 u = blockIdx.x * BLOCK + threadIdx.x;
     if (u >= n02) return;
@@ -107,20 +111,25 @@ __global__ __launch_bounds__(BLOCK) void dc3_window_keys_kernel(const uint8_t *_
         ended = ended || x == 0xFFu;
         key = (key << b) | (K)(x == 0xFFu ? term_first : x);
     }
+    if (spare > 0) {
+        const u32 byte = (u32)((w < 8 ? lo8 >> (8 * w) : hi8 >> (8 * (w - 8))) & 0xFFu);
+        const u32 x = ended ? 0u : (byte == 0xFFu ? term_first : byte);
+        key = (key << spare) | (K)(x >> (b - spare));
+    }
     keys[u] = key;
     vals[u] = r ? n0 + q : q;
 }
 
 template <class K> struct KeyNeqWindowIn {
     const K *keys;
-    int w, b;
+    int w, b, spare;
     u32 term_first;
     __device__ __forceinline__ u32 operator()(u32 i) const
     {
         const K k = keys[i];
         const u32 mask = (1u << b) - 1u;
-        bool has_term = false;
-        for (int j = 0; j < w; j++) has_term = has_term || ((u32)(k >> (j * b)) & mask) == term_first;
+        bool has_term = false;                  // among the w full symbols (the partial one does not count)
+        for (int j = 0; j < w; j++) has_term = has_term || ((u32)(k >> (spare + j * b)) & mask) == term_first;
         return (i == 0 || has_term || k != keys[i - 1]) ? 1u : 0u;
     }
 };
@@ -385,8 +394,8 @@ __device__ __forceinline__ bool dc3_a_leq_b(const MergeTup &a, bool a_mod1, cons
     return a.r2 <= b.r2;
 }
 
-#define MERGE_IPT 8
-#define MERGE_TILE (BLOCK * MERGE_IPT)     // 2048 outputs per workgroup
+#define MERGE_IPT 4
+#define MERGE_TILE (BLOCK * MERGE_IPT)     // outputs per workgroup
 
 // splits[i] = number of A elements among the first i*MERGE_TILE outputs
 __global__ __launch_bounds__(BLOCK) void dc3_merge_partition_kernel(const uint2 *__restrict__ sr,
@@ -724,17 +733,24 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
             if (w32 >= 3 && w32 < w && pow((double)term_first, w32) >= 4.0 * (double)n) w = w32;
         }
         if (s8 && w * bt <= 32) {
+            // whole passes are paid for anyway: fill the last digit with the top bits of the next symbol
+            const int total = ((w * bt + 7) / 8) * 8;
+            const int spare = w < 12 ? std::min(total - w * bt, bt - 1) : 0;
             SortBufs<u32> sb;
             for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
-            LAUNCH(ctx, (dc3_window_keys_kernel<u32>), g02, s8, n0, n02, w, bt, term_first, sb.keys[0], sb.vals[0]);
-            sorted_vals = dc3_sort_and_name<u32>(ctx, sb, n02, w * bt, names, [&](const u32 *k) {
-                return KeyNeqWindowIn<u32>{k, w, bt, term_first}; });
+            LAUNCH(ctx, (dc3_window_keys_kernel<u32>), g02, s8, n0, n02, w, bt, spare, term_first, sb.keys[0],
+                   sb.vals[0]);
+            sorted_vals = dc3_sort_and_name<u32>(ctx, sb, n02, w * bt + spare, names, [&](const u32 *k) {
+                return KeyNeqWindowIn<u32>{k, w, bt, spare, term_first}; });
         } else if (s8) {
+            const int total = ((w * bt + 7) / 8) * 8;
+            const int spare = w < 12 ? std::min(total - w * bt, bt - 1) : 0;
             SortBufs<u64> sb;
             for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u64>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
-            LAUNCH(ctx, (dc3_window_keys_kernel<u64>), g02, s8, n0, n02, w, bt, term_first, sb.keys[0], sb.vals[0]);
-            sorted_vals = dc3_sort_and_name<u64>(ctx, sb, n02, w * bt, names, [&](const u64 *k) {
-                return KeyNeqWindowIn<u64>{k, w, bt, term_first}; });
+            LAUNCH(ctx, (dc3_window_keys_kernel<u64>), g02, s8, n0, n02, w, bt, spare, term_first, sb.keys[0],
+                   sb.vals[0]);
+            sorted_vals = dc3_sort_and_name<u64>(ctx, sb, n02, w * bt + spare, names, [&](const u64 *k) {
+                return KeyNeqWindowIn<u64>{k, w, bt, spare, term_first}; });
         } else if (term_first > 0 && 3 * bt <= 32) {
             SortBufs<u32> sb;
             for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n02); sb.vals[k] = ar.alloc<u32>(n02); }

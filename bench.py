@@ -72,6 +72,10 @@ def kernel_bytes(name, info, n, n_q, n_docs):
         "lcp_kernel": n * 40,
         # 4 B LCP read + 4 B annotation write per rank
         "ann_kernel": n * 8,
+        # 4 B sorted sample read + one random 4 B rank store per sample
+        "dc3_rank_kernel": info["merge_elements"] * 2 // 3 * 8,
+        # 8 symbols + 2 ranks read, one 16 B record written per symbol
+        "dc3_records_kernel": n * 26,
     }
     return table.get(name)
 
@@ -193,9 +197,21 @@ def main():
         else:
             roofline.update({"achieved": None, "frac": None})
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        traffic = {}
         if os.path.exists(traffic_file):
             with open(traffic_file) as f:
-                roofline["traffic"] = json.load(f).get(dom_name)
+                traffic = json.load(f)
+        roofline["traffic"] = traffic.get(dom_name)
+        # the same accounting for every kernel with a byte model, largest first (the time is spread
+        # over several kernels of two kinds: streaming sort passes and random-sector gathers)
+        by_kernel = []
+        for name, (launches, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:8]:
+            b = kernel_bytes(name, info, n, int(q_offsets[-1]), D)
+            entry = {"kernel": name, "ms_per_step": ms / args.steps, "share_of_kernel_time": ms / total_kernel_ms}
+            if b is not None:
+                gbs = b * args.steps / (ms * 1e-3) / 1e9
+                entry.update({"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(name)})
+            by_kernel.append(entry)
         out = {
             "metric": "corpus chars/sec (SA+annotation build + keyphrase score table)",
             "value": value, "unit": "chars/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -214,7 +230,7 @@ def main():
             "build_algorithmic_GBps": 16.0 * n / (float(np.mean(build_ms)) * 1e-3) / 1e9,
             "dc3_levels": info["dc3_levels"], "dc3_levels_resolved": info["dc3_levels_resolved"],
             "radix_passes": info["radix_passes"],
-            "roofline": roofline,
+            "roofline": roofline, "roofline_by_kernel": by_kernel,
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in
                                     sorted(prof.items(), key=lambda kv: -kv[1][1])},
         }
