@@ -22,6 +22,7 @@
 #include "scan.h"
 #include "score.h"
 #include "tables.h"
+#include "textprep.h"
 
 #include <algorithm>
 #include <string.h>
@@ -153,7 +154,13 @@ struct east_hip_index {
     int kg_k = 0;
     u32 kg_A = 0, kg_bins = 0;
     bool kg_built = false;
-    float last_build_ms = -1.f, last_score_ms = -1.f;
+    float last_build_ms = -1.f, last_score_ms = -1.f, last_prep_ms = -1.f;
+    // symbols prepared on the device by east_hip_build_texts (own allocation)
+    u32 *prep_sym = nullptr;
+    size_t prep_cap = 0;
+    i64 prep_n = 0;
+    std::vector<i64> prep_doc_off;
+    std::vector<int32_t> prep_n_strings;
 };
 
 static void use_device(east_hip_index *h) { HIP_CHECK(hipSetDevice(h->device)); }
@@ -416,6 +423,146 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     h->built = true;
 }
 
+// ---------------------------------------------------------------- text prep --
+#define TP_WORD_HI_WORDS ((0x110000u - TP_TEXT_LIMIT + 31u) / 32u)
+
+// bytes: the texts concatenated, each followed by one 0xFF byte (host pointer).
+static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_bytes64, const i64 *text_offsets,
+                             int32_t n_docs, const uint8_t *cp_class, const u32 *cp_upper, const u32 *word_hi,
+                             const u32 *digit_hi, const u32 *hi_upper_from, const u32 *hi_upper_to, int32_t n_hi_upper)
+{
+    if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
+    if (!bytes || !text_offsets || !cp_class || !cp_upper || !word_hi || !digit_hi || n_docs < 1 || n_hi_upper < 0 ||
+        (n_hi_upper > 0 && (!hi_upper_from || !hi_upper_to)))
+        east_throw(EAST_HIP_ERR_INVALID, "null argument or no documents");
+    if (n_bytes64 < n_docs || n_bytes64 >= (i64)0x7FFFFFF0) east_throw(EAST_HIP_ERR_INVALID, "total bytes out of range");
+    if (text_offsets[0] != 0 || text_offsets[n_docs] != n_bytes64)
+        east_throw(EAST_HIP_ERR_INVALID, "text_offsets must start at 0 and end at the total");
+    for (int32_t d = 0; d < n_docs; d++) {
+        if (text_offsets[d + 1] <= text_offsets[d]) east_throw(EAST_HIP_ERR_INVALID, "text_offsets must increase");
+        if (bytes[text_offsets[d + 1] - 1] != 0xFFu)
+            east_throw(EAST_HIP_ERR_INVALID, "every text must be followed by one 0xFF separator byte");
+    }
+    use_device(h);
+    h->built = false;
+    const u32 n_bytes = (u32)n_bytes64, D = (u32)n_docs;
+    ensure_arena(h, (size_t)n_bytes * 44 + (size_t)D * 64 + (8u << 20));
+    Arena &ar = h->arena;
+    ar.release(0);
+    ar.high = 0;
+    Ctx ctx;
+    ctx.stream = h->stream;
+    ctx.arena = &ar;
+    ctx.stats = &h->stats;
+    ctx.prof = &h->prof;
+    HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+
+    uint8_t *d_bytes = ar.alloc<uint8_t>((size_t)n_bytes + 8);
+    u32 *d_text_off = ar.alloc<u32>((size_t)D + 1);
+    uint8_t *d_class = ar.alloc<uint8_t>(TP_TEXT_LIMIT);
+    u32 *d_upper = ar.alloc<u32>(TP_TEXT_LIMIT);
+    u32 *d_word_hi = ar.alloc<u32>(TP_WORD_HI_WORDS);
+    u32 *d_digit_hi = ar.alloc<u32>(TP_WORD_HI_WORDS);
+    u32 *d_hi_from = ar.alloc<u32>((size_t)n_hi_upper + 1), *d_hi_to = ar.alloc<u32>((size_t)n_hi_upper + 1);
+    u32 *d_bad = ar.alloc<u32>(1);
+    std::vector<u32> off32((size_t)D + 1);
+    for (u32 d = 0; d <= D; d++) off32[d] = (u32)text_offsets[d];
+    HIP_CHECK(hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemsetAsync(d_bytes + n_bytes, 0, 8, h->stream));
+    HIP_CHECK(hipMemcpyAsync(d_text_off, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(d_class, cp_class, TP_TEXT_LIMIT, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(d_upper, cp_upper, TP_TEXT_LIMIT * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(d_word_hi, word_hi, TP_WORD_HI_WORDS * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(d_digit_hi, digit_hi, TP_WORD_HI_WORDS * 4, hipMemcpyHostToDevice, h->stream));
+    if (n_hi_upper) {
+        HIP_CHECK(hipMemcpyAsync(d_hi_from, hi_upper_from, (size_t)n_hi_upper * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_CHECK(hipMemcpyAsync(d_hi_to, hi_upper_to, (size_t)n_hi_upper * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_CHECK(hipMemsetAsync(d_bad, 0xFF, 4, h->stream));
+    const TpTables tables{d_class, d_upper, d_word_hi, d_digit_hi, d_hi_from, d_hi_to, (u32)n_hi_upper};
+
+    // bytes -> code points
+    u32 *cp_index = ar.alloc<u32>((size_t)n_bytes + 1);
+    device_scan<TpStartIn, false>(ctx, TpStartIn{d_bytes, n_bytes}, n_bytes + 1, cp_index);
+    u32 n_cp = 0;
+    HIP_CHECK(hipMemcpyAsync(&n_cp, cp_index + n_bytes, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));          // also covers off32
+    u32 *cpu = ar.alloc<u32>(n_cp);
+    uint8_t *cw = ar.alloc<uint8_t>((size_t)n_cp + 1);
+    u32 *doc_cp_off = ar.alloc<u32>((size_t)D + 1);
+    LAUNCH(ctx, tp_decode_kernel, ceil_div_u32(n_bytes, BLOCK), (const uint8_t *)d_bytes, n_bytes, (const u32 *)cp_index,
+           tables, cpu, cw);
+    LAUNCH(ctx, tp_doc_cp_offsets_kernel, ceil_div_u32(D + 1, BLOCK), (const u32 *)cp_index, (const u32 *)d_text_off, D,
+           doc_cp_off);
+
+    // code points -> tokens
+    u32 *tok_inc = ar.alloc<u32>(n_cp);
+    u32 *nd_ex = ar.alloc<u32>((size_t)n_cp + 1);
+    device_scan<TpTokStartIn, true>(ctx, TpTokStartIn{cw, n_cp}, n_cp, tok_inc);
+    device_scan<TpNonDigitIn, false>(ctx, TpNonDigitIn{cw, n_cp}, n_cp + 1, nd_ex);
+    u32 n_tok = 0, bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&n_tok, tok_inc + (n_cp - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    u32 *tstart = ar.alloc<u32>((size_t)n_tok + 1), *tend = ar.alloc<u32>((size_t)n_tok + 1);
+    u32 *keep = ar.alloc<u32>((size_t)n_tok + 1), *klen = ar.alloc<u32>((size_t)n_tok + 1);
+    u32 *keep_ex = ar.alloc<u32>((size_t)n_tok + 1), *klen_ex = ar.alloc<u32>((size_t)n_tok + 1);
+    HIP_CHECK(hipMemsetAsync(keep + n_tok, 0, 4, h->stream));
+    HIP_CHECK(hipMemsetAsync(klen + n_tok, 0, 4, h->stream));
+    if (n_tok) {
+        LAUNCH(ctx, tp_token_bounds_kernel, ceil_div_u32(n_cp, BLOCK), (const uint8_t *)cw, (const u32 *)tok_inc, n_cp,
+               tstart, tend);
+        LAUNCH(ctx, tp_token_keep_kernel, ceil_div_u32(n_tok, BLOCK), (const u32 *)tstart, (const u32 *)tend,
+               (const u32 *)nd_ex, n_tok, keep, klen);
+    }
+    device_scan<ArrIn, false>(ctx, ArrIn{keep}, n_tok + 1, keep_ex);
+    device_scan<ArrIn, false>(ctx, ArrIn{klen}, n_tok + 1, klen_ex);
+
+    // tokens -> per-document strings and symbols
+    u32 *first_tok = ar.alloc<u32>((size_t)D + 1), *m_d = ar.alloc<u32>(D), *n_d = ar.alloc<u32>((size_t)D + 1);
+    u32 *doc_sym_off = ar.alloc<u32>((size_t)D + 1);
+    HIP_CHECK(hipMemsetAsync(n_d + D, 0, 4, h->stream));
+    LAUNCH(ctx, tp_doc_counts_kernel, ceil_div_u32(D + 1, BLOCK), (const u32 *)doc_cp_off, (const u32 *)tok_inc,
+           (const u32 *)keep_ex, (const u32 *)klen_ex, D, first_tok, m_d, n_d);
+    device_scan<ArrIn, false>(ctx, ArrIn{n_d}, D + 1, doc_sym_off);
+    std::vector<u32> h_off((size_t)D + 1), h_m(D);
+    HIP_CHECK(hipMemcpyAsync(h_off.data(), doc_sym_off, h_off.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(h_m.data(), m_d, h_m.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    const u32 n_sym = h_off[D];
+    if ((size_t)n_sym * 4 > h->prep_cap) {
+        if (h->prep_sym) HIP_CHECK(hipFree(h->prep_sym));
+        h->prep_sym = nullptr;
+        h->prep_cap = 0;
+        void *p = nullptr;
+        if (hipMalloc(&p, (size_t)n_sym * 4) != hipSuccess) east_throw(EAST_HIP_ERR_OOM, "hipMalloc of the prepared symbols failed");
+        h->prep_sym = (u32 *)p;
+        h->prep_cap = (size_t)n_sym * 4;
+    }
+    if (n_tok)
+        LAUNCH(ctx, tp_emit_kernel, ceil_div_u32(n_cp, BLOCK), (const u32 *)cpu, (const uint8_t *)cw, (const u32 *)tok_inc,
+               (const u32 *)tstart, (const u32 *)tend, (const u32 *)keep_ex, (const u32 *)klen_ex,
+               (const u32 *)doc_cp_off, (const u32 *)first_tok, (const u32 *)doc_sym_off, D, n_cp, h->prep_sym, d_bad);
+    LAUNCH(ctx, tp_empty_docs_kernel, ceil_div_u32(D, BLOCK), (const u32 *)first_tok, (const u32 *)keep_ex,
+           (const u32 *)doc_sym_off, D, h->prep_sym);
+    HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(hipEventElapsedTime(&h->last_prep_ms, h->ev0, h->ev1));
+    if (bad != 0xFFFFFFFFu) {
+        h->prep_doc_off.clear();
+        char msg[160];
+        snprintf(msg, sizeof(msg), "text contains the word character U+%04X >= U+0A00 (outside the method's domain)", bad);
+        east_throw(EAST_HIP_ERR_DOMAIN, msg);
+    }
+
+    h->prep_n = n_sym;
+    h->prep_doc_off.resize((size_t)D + 1);
+    h->prep_n_strings.resize(D);
+    for (u32 d = 0; d <= D; d++) h->prep_doc_off[d] = h_off[d];
+    for (u32 d = 0; d < D; d++) h->prep_n_strings[d] = (int32_t)h_m[d];
+    build_common(h, h->prep_sym, false, n_sym, h->prep_doc_off.data(), h->prep_n_strings.data(), n_docs);
+}
+
 // ------------------------------------------------------------------ score --
 static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q_offsets, int32_t n_kp)
 {
@@ -599,6 +746,7 @@ void east_hip_destroy(east_hip_handle_t h)
     if (h->arena.base) (void)hipFree(h->arena.base);
     if (h->q_buf) (void)hipFree(h->q_buf);
     if (h->kg) (void)hipFree(h->kg);
+    if (h->prep_sym) (void)hipFree(h->prep_sym);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -616,6 +764,36 @@ int east_hip_build_device(east_hip_handle_t h, const uint32_t *d_symbols, int64_
 {
     return guarded([&] { build_common(h, d_symbols, false, n_total, doc_offsets, n_strings, n_docs); });
 }
+
+int east_hip_build_texts(east_hip_handle_t h, const uint8_t *bytes, int64_t n_bytes, const int64_t *text_offsets,
+                         int32_t n_docs, const uint8_t *cp_class, const uint32_t *cp_upper, const uint32_t *word_hi,
+                         const uint32_t *digit_hi, const uint32_t *hi_upper_from, const uint32_t *hi_upper_to,
+                         int32_t n_hi_upper)
+{
+    return guarded([&] {
+        build_from_texts(h, bytes, n_bytes, text_offsets, n_docs, cp_class, cp_upper, word_hi, digit_hi, hi_upper_from,
+                         hi_upper_to, n_hi_upper);
+    });
+}
+
+int east_hip_get_prepared(east_hip_handle_t h, int64_t *n_total, int64_t *doc_offsets, int32_t *n_strings,
+                          uint32_t *symbols)
+{
+    return guarded([&] {
+        if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
+        if (!h->prep_sym || h->prep_doc_off.empty()) east_throw(EAST_HIP_ERR_NOT_BUILT, "no texts have been prepared on this handle");
+        use_device(h);
+        if (n_total) *n_total = h->prep_n;
+        if (doc_offsets) memcpy(doc_offsets, h->prep_doc_off.data(), h->prep_doc_off.size() * sizeof(i64));
+        if (n_strings) memcpy(n_strings, h->prep_n_strings.data(), h->prep_n_strings.size() * sizeof(int32_t));
+        if (symbols) {
+            HIP_CHECK(hipMemcpyAsync(symbols, h->prep_sym, (size_t)h->prep_n * 4, hipMemcpyDeviceToHost, h->stream));
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+        }
+    });
+}
+
+double east_hip_last_prep_ms(east_hip_handle_t h) { return h ? (double)h->last_prep_ms : -1.0; }
 
 int east_hip_get_tables(east_hip_handle_t h, int32_t doc, int32_t *suftab, int32_t *lcptab, int32_t *anntab,
                         int32_t *childtab_up, int32_t *childtab_down, int32_t *childtab_next_l_index)

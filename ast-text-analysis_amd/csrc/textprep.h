@@ -1,0 +1,245 @@
+// textprep.h -- text preparation on the device: raw UTF-8 bytes of all documents ->
+// the EASA symbol stream east_hip_build consumes.
+//
+// Replaces, for a whole collection at once, the host-side chain in front of the hot
+// path (reference east/utils.py:31-79 and east/asts/utils.py:25-40):
+//   prepare_text      utf-8 decode (errors='replace') + upper()                 utils.py:31-34
+//   tokenize          re.findall("[\w']+", re.U)                                utils.py:37-38
+//   text_to_strings_collection   keep tokens with len > 2 and not isdigit(),
+//                     concatenate groups of 3, empty -> [" "]                   utils.py:49-79
+//   make_unique_endings + "".join   string i followed by U+0A00+i               asts/utils.py:25-40
+//
+// The Unicode knowledge stays in Python: the caller passes, for every code point below
+// U+0A00 (the method's text domain), its class (bit 0: matches [\w'], bit 1: str.isdigit)
+// and its 1:1 upper-case mapping; for the code points from U+0A00 up, bitmaps of the word
+// and digit characters and the (few hundred) 1:1 upper mappings.  A word character beyond
+// U+0A00 that survives the token filter is outside the method's domain and raises.
+// Input layout: the texts concatenated, every text followed by one 0xFF byte (never valid
+// UTF-8: it decodes to a U+FFFD separator and ends a truncated sequence exactly like the
+// end of the data does).
+//
+// Everything is flags + prefix sums + scatters, all streaming:
+//   bytes  --is_start / scan-->  code points  --class-->  token starts/ends  --scan-->
+//   tokens --keep / scans-->  per-document counts  -->  symbols
+#pragma once
+#include "common.h"
+#include "scan.h"
+
+#define TP_TEXT_LIMIT EAST_HIP_TERMINATOR_START      // 0x0A00
+#define TP_REPLACEMENT 0xFFFDu
+#define TP_CLASS_WORD 1u
+#define TP_CLASS_DIGIT 2u
+
+// ---- UTF-8, errors='replace' (CPython: every maximal ill-formed subpart -> one U+FFFD) ----
+// Length of the unit that starts at byte i and its code point (U+FFFD if ill-formed).
+__device__ __forceinline__ u32 tp_unit(const uint8_t *__restrict__ b, u64 i, u64 end, u32 &cp)
+{
+    const u32 x = b[i];
+    cp = TP_REPLACEMENT;
+    if (x < 0x80u) { cp = x; return 1; }
+    u32 need, lo2 = 0x80u, hi2 = 0xBFu;
+    if (x >= 0xC2u && x <= 0xDFu) need = 2;
+    else if (x >= 0xE0u && x <= 0xEFu) { need = 3; if (x == 0xE0u) lo2 = 0xA0u; if (x == 0xEDu) hi2 = 0x9Fu; }
+    else if (x >= 0xF0u && x <= 0xF4u) { need = 4; if (x == 0xF0u) lo2 = 0x90u; if (x == 0xF4u) hi2 = 0x8Fu; }
+    else return 1;                                   // C0, C1, F5..FF, stray continuation
+    if (i + 1 >= end) return 1;
+    const u32 b1 = b[i + 1];
+    if (b1 < lo2 || b1 > hi2) return 1;
+    if (need == 2) { cp = ((x & 0x1Fu) << 6) | (b1 & 0x3Fu); return 2; }
+    if (i + 2 >= end) return 2;
+    const u32 b2 = b[i + 2];
+    if (b2 < 0x80u || b2 > 0xBFu) return 2;
+    if (need == 3) { cp = ((x & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu); return 3; }
+    if (i + 3 >= end) return 3;
+    const u32 b3 = b[i + 3];
+    if (b3 < 0x80u || b3 > 0xBFu) return 3;
+    cp = ((x & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
+    return 4;
+}
+
+// A byte starts a unit unless it is a continuation byte consumed by the unit of the nearest
+// non-continuation byte at most 3 positions before it (UTF-8 is self-synchronising).
+struct TpStartIn {
+    const uint8_t *b;
+    u32 n;
+    __device__ __forceinline__ u32 operator()(u32 i) const
+    {
+        if (i >= n) return 0u;
+        const u32 x = b[i];
+        if (x < 0x80u || x > 0xBFu) return 1u;
+        for (u32 back = 1; back <= 3 && back <= i; back++) {
+            const u32 y = b[i - back];
+            if (y < 0x80u || y > 0xBFu) {
+                u32 cp;
+                return back < tp_unit(b, i - back, n, cp) ? 0u : 1u;
+            }
+        }
+        return 1u;
+    }
+};
+
+// Unicode data of the caller's interpreter (see include/east_hip.h)
+struct TpTables {
+    const uint8_t *cp_class;      // [0x0A00] bit 0 word, bit 1 digit
+    const u32 *cp_upper;          // [0x0A00] 1:1 upper
+    const u32 *word_hi;           // bitmaps over [0x0A00, 0x110000)
+    const u32 *digit_hi;
+    const u32 *hi_from, *hi_to;   // sorted 1:1 upper mappings of code points >= 0x0A00
+    u32 n_hi;
+};
+
+// per start byte: decode, upper, classify; cpu[idx] = code point after upper, cw[idx] = class
+__global__ __launch_bounds__(BLOCK) void tp_decode_kernel(const uint8_t *__restrict__ b, u32 n_bytes,
+                                                          const u32 *__restrict__ cp_index, TpTables T,
+                                                          u32 *__restrict__ cpu, uint8_t *__restrict__ cw)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_bytes) return;
+    const TpStartIn st{b, n_bytes};
+    if (!st(i)) return;
+    u32 cp;
+    (void)tp_unit(b, i, n_bytes, cp);
+    if (cp < TP_TEXT_LIMIT) {
+        cp = T.cp_upper[cp];
+    } else {                                       // rare: a handful of high code points have a 1:1 upper
+        u32 lo = 0, hi = T.n_hi;
+        while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (T.hi_from[mid] < cp) lo = mid + 1; else hi = mid; }
+        if (lo < T.n_hi && T.hi_from[lo] == cp) cp = T.hi_to[lo];
+    }
+    u32 cls;
+    if (cp < TP_TEXT_LIMIT) {
+        cls = T.cp_class[cp];
+    } else {                                       // words beyond the domain are refused when (if) they are emitted
+        const u32 k = cp - TP_TEXT_LIMIT;
+        cls = ((T.word_hi[k >> 5] >> (k & 31u)) & 1u) | (((T.digit_hi[k >> 5] >> (k & 31u)) & 1u) << 1);
+    }
+    const u32 idx = cp_index[i];
+    cpu[idx] = cp;
+    cw[idx] = (uint8_t)cls;
+}
+
+// code-point index of every document's first byte
+__global__ __launch_bounds__(BLOCK) void tp_doc_cp_offsets_kernel(const u32 *__restrict__ cp_index,
+                                                                  const u32 *__restrict__ text_off, u32 n_docs,
+                                                                  u32 *__restrict__ doc_cp_off)
+{
+    const u32 d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d <= n_docs) doc_cp_off[d] = cp_index[text_off[d]];          // cp_index has n_bytes + 1 entries
+}
+
+struct TpTokStartIn {                            // 1 at the first code point of a token; defined on [0, n]
+    const uint8_t *cw;
+    u32 n;
+    __device__ __forceinline__ u32 operator()(u32 p) const
+    {
+        return (p < n && (cw[p] & TP_CLASS_WORD) && !(p > 0 && (cw[p - 1] & TP_CLASS_WORD))) ? 1u : 0u;
+    }
+};
+
+struct TpNonDigitIn {                            // 1 at word characters that are not digits; defined on [0, n]
+    const uint8_t *cw;
+    u32 n;
+    __device__ __forceinline__ u32 operator()(u32 p) const
+    {
+        return (p < n && (cw[p] & (TP_CLASS_WORD | TP_CLASS_DIGIT)) == TP_CLASS_WORD) ? 1u : 0u;
+    }
+};
+
+// tok_inc[p] = inclusive count of token starts: a word position p belongs to token tok_inc[p]-1
+__global__ __launch_bounds__(BLOCK) void tp_token_bounds_kernel(const uint8_t *__restrict__ cw,
+                                                                const u32 *__restrict__ tok_inc, u32 n_cp,
+                                                                u32 *__restrict__ tstart, u32 *__restrict__ tend)
+{
+    const u32 p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= n_cp || !(cw[p] & TP_CLASS_WORD)) return;
+    const u32 k = tok_inc[p] - 1u;
+    if (!(p > 0 && (cw[p - 1] & TP_CLASS_WORD))) tstart[k] = p;
+    if (!(p + 1 < n_cp && (cw[p + 1] & TP_CLASS_WORD))) tend[k] = p;
+}
+
+// keep[k] = len > 2 and not all digits (utils.py:63); klen[k] = kept length or 0
+__global__ __launch_bounds__(BLOCK) void tp_token_keep_kernel(const u32 *__restrict__ tstart,
+                                                              const u32 *__restrict__ tend,
+                                                              const u32 *__restrict__ nd_ex, u32 n_tok,
+                                                              u32 *__restrict__ keep, u32 *__restrict__ klen)
+{
+    const u32 k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n_tok) return;
+    const u32 a = tstart[k], e = tend[k];
+    const u32 len = e - a + 1u;
+    const bool kp = len > 2u && nd_ex[e + 1u] != nd_ex[a];
+    keep[k] = kp ? 1u : 0u;
+    klen[k] = kp ? len : 0u;
+}
+
+// per document: first token, kept tokens, strings m_d, symbols n_d
+__global__ __launch_bounds__(BLOCK) void tp_doc_counts_kernel(const u32 *__restrict__ doc_cp_off,
+                                                              const u32 *__restrict__ tok_inc,
+                                                              const u32 *__restrict__ keep_ex,
+                                                              const u32 *__restrict__ klen_ex, u32 n_docs,
+                                                              u32 *__restrict__ first_tok, u32 *__restrict__ m_d,
+                                                              u32 *__restrict__ n_d)
+{
+    const u32 d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d > n_docs) return;
+    const u32 c = doc_cp_off[d];
+    const u32 ft = c == 0 ? 0u : tok_inc[c - 1u];           // tokens that start before the document
+    first_tok[d] = ft;
+    if (d == n_docs) return;
+    const u32 c1 = doc_cp_off[d + 1];
+    const u32 ft1 = c1 == 0 ? 0u : tok_inc[c1 - 1u];
+    const u32 kd = keep_ex[ft1] - keep_ex[ft];
+    const u32 chars = klen_ex[ft1] - klen_ex[ft];
+    m_d[d] = kd ? (kd + 2u) / 3u : 1u;                       // utils.py:76-77: an empty collection becomes [" "]
+    n_d[d] = kd ? chars + (kd + 2u) / 3u : 2u;
+}
+
+__device__ __forceinline__ u32 tp_doc_of_cp(const u32 *__restrict__ doc_cp_off, u32 n_docs, u32 p)
+{
+    u32 lo = 0, hi = n_docs;          // doc_cp_off[lo] <= p < doc_cp_off[hi]
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (doc_cp_off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// every code point of a kept token goes to its place; the last one of a group writes the terminator
+__global__ __launch_bounds__(BLOCK) void tp_emit_kernel(const u32 *__restrict__ cpu, const uint8_t *__restrict__ cw,
+                                                        const u32 *__restrict__ tok_inc,
+                                                        const u32 *__restrict__ tstart, const u32 *__restrict__ tend,
+                                                        const u32 *__restrict__ keep_ex,
+                                                        const u32 *__restrict__ klen_ex,
+                                                        const u32 *__restrict__ doc_cp_off,
+                                                        const u32 *__restrict__ first_tok,
+                                                        const u32 *__restrict__ doc_sym_off, u32 n_docs, u32 n_cp,
+                                                        u32 *__restrict__ sym, u32 *__restrict__ bad_cp)
+{
+    const u32 p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= n_cp || !(cw[p] & TP_CLASS_WORD)) return;
+    const u32 k = tok_inc[p] - 1u;
+    if (keep_ex[k + 1u] == keep_ex[k]) return;              // token dropped
+    const u32 d = tp_doc_of_cp(doc_cp_off, n_docs, p);
+    const u32 ft = first_tok[d], ft1 = first_tok[d + 1];
+    const u32 kidx = keep_ex[k] - keep_ex[ft];               // index among the document's kept tokens
+    const u32 kd = keep_ex[ft1] - keep_ex[ft];
+    const u32 g = kidx / 3u;
+    const u32 out = doc_sym_off[d] + (klen_ex[k] - klen_ex[ft]) + (p - tstart[k]) + g;
+    const u32 cp = cpu[p];
+    if (cp >= TP_TEXT_LIMIT) atomicMin(bad_cp, cp);         // a kept word character outside the method's domain
+    sym[out] = cp;
+    if (p == tend[k] && (kidx % 3u == 2u || kidx + 1u == kd)) sym[out + 1u] = TP_TEXT_LIMIT + g;
+}
+
+__global__ __launch_bounds__(BLOCK) void tp_empty_docs_kernel(const u32 *__restrict__ first_tok,
+                                                              const u32 *__restrict__ keep_ex,
+                                                              const u32 *__restrict__ doc_sym_off, u32 n_docs,
+                                                              u32 *__restrict__ sym)
+{
+    const u32 d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d >= n_docs) return;
+    if (keep_ex[first_tok[d + 1]] == keep_ex[first_tok[d]]) {
+        sym[doc_sym_off[d]] = 32u;                          // [" "]
+        sym[doc_sym_off[d] + 1u] = TP_TEXT_LIMIT;
+    }
+}

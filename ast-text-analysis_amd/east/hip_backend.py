@@ -31,6 +31,11 @@ SIGNATURES = {
     "east_hip_build": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, ctypes.c_int64, _c_i64p, _c_i32p, ctypes.c_int32]),
     "east_hip_build_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _c_i64p, _c_i32p,
                                              ctypes.c_int32]),
+    "east_hip_build_texts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, _c_i64p, ctypes.c_int32,
+                                            ctypes.POINTER(ctypes.c_uint8), _c_u32p, _c_u32p, _c_u32p, _c_u32p,
+                                            _c_u32p, ctypes.c_int32]),
+    "east_hip_get_prepared": (ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_i64p, _c_i32p, _c_u32p]),
+    "east_hip_last_prep_ms": (ctypes.c_double, [ctypes.c_void_p]),
     "east_hip_get_tables": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [_c_i32p] * 6),
     "east_hip_score_table": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, _c_i64p, ctypes.c_int32, ctypes.c_int,
                                             _c_dblp, _c_dblp]),
@@ -102,6 +107,45 @@ def default_device():
     return 0
 
 
+_unicode_tables = None
+
+
+def unicode_tables():
+    """The interpreter's own Unicode data for east_hip_build_texts: per code point below U+0A00 the
+    class (bit 0: matches [\\w'] under re.U, i.e. str.isalnum() or '_' or "'"; bit 1: str.isdigit())
+    and the 1:1 upper-case mapping; a bitmap of the word characters from U+0A00 up."""
+    global _unicode_tables
+    if _unicode_tables is None:
+        lim = 0x0A00
+        cls = np.zeros(lim, dtype=np.uint8)
+        upper = np.arange(lim, dtype=np.uint32)
+        for cp in range(lim):
+            ch = chr(cp)
+            cls[cp] = (1 if (ch.isalnum() or ch in "_'") else 0) | (2 if ch.isdigit() else 0)
+            up = ch.upper()
+            if len(up) == 1:
+                upper[cp] = ord(up)
+        n_hi = 0x110000 - lim
+        wbits = np.zeros(n_hi, dtype=np.uint8)
+        dbits = np.zeros(n_hi, dtype=np.uint8)
+        hi_from, hi_to = [], []
+        for cp in range(lim, 0x110000):
+            ch = chr(cp)
+            if ch.isalnum():
+                wbits[cp - lim] = 1
+                if ch.isdigit():
+                    dbits[cp - lim] = 1
+            up = ch.upper()
+            if len(up) == 1 and up != ch:
+                hi_from.append(cp)
+                hi_to.append(ord(up))
+        word_hi = np.packbits(wbits, bitorder="little").view(np.uint32).copy()
+        digit_hi = np.packbits(dbits, bitorder="little").view(np.uint32).copy()
+        _unicode_tables = (cls, upper, word_hi, digit_hi, np.array(hi_from, dtype=np.uint32),
+                           np.array(hi_to, dtype=np.uint32))
+    return _unicode_tables
+
+
 class HipIndex(object):
     """One device-resident batch of annotated suffix arrays (an AST shard)."""
 
@@ -138,6 +182,39 @@ class HipIndex(object):
                                                _ptr(doc_offsets, _c_i64p), _ptr(n_strings, _c_i32p), n_strings.size))
         self.n_docs = int(n_strings.size)
         self.doc_offsets = doc_offsets.copy()
+
+    def build_texts(self, texts):
+        """Text preparation + build on the device.  texts: list of bytes (UTF-8, decoded with
+        errors='replace' semantics) or str."""
+        raw = [t if isinstance(t, bytes) else t.encode("utf-8", errors="surrogatepass") for t in texts]
+        blob = b"\xff".join(raw) + b"\xff"
+        offsets = np.zeros(len(raw) + 1, dtype=np.int64)
+        np.cumsum([len(t) + 1 for t in raw], out=offsets[1:])
+        cls, upper, word_hi, digit_hi, hi_from, hi_to = unicode_tables()
+        _check(self._lib.east_hip_build_texts(self._h, blob, len(blob), _ptr(offsets, _c_i64p), len(raw),
+                                              _ptr(cls, ctypes.POINTER(ctypes.c_uint8)), _ptr(upper, _c_u32p),
+                                              _ptr(word_hi, _c_u32p), _ptr(digit_hi, _c_u32p),
+                                              _ptr(hi_from, _c_u32p), _ptr(hi_to, _c_u32p), hi_from.size))
+        self.n_docs = len(raw)
+        doc_offsets = np.zeros(self.n_docs + 1, dtype=np.int64)
+        n_total = ctypes.c_int64(0)
+        _check(self._lib.east_hip_get_prepared(self._h, ctypes.byref(n_total), _ptr(doc_offsets, _c_i64p), None, None))
+        self.doc_offsets = doc_offsets
+
+    def prepared(self):
+        """(symbols uint32, doc_offsets int64, n_strings int32) of the last build_texts."""
+        n_total = ctypes.c_int64(0)
+        _check(self._lib.east_hip_get_prepared(self._h, ctypes.byref(n_total), None, None, None))
+        doc_offsets = np.zeros(self.n_docs + 1, dtype=np.int64)
+        n_strings = np.zeros(self.n_docs, dtype=np.int32)
+        symbols = np.zeros(n_total.value, dtype=np.uint32)
+        _check(self._lib.east_hip_get_prepared(self._h, ctypes.byref(n_total), _ptr(doc_offsets, _c_i64p),
+                                               _ptr(n_strings, _c_i32p), _ptr(symbols, _c_u32p)))
+        return symbols, doc_offsets, n_strings
+
+    @property
+    def last_prep_ms(self):
+        return float(self._lib.east_hip_last_prep_ms(self._h))
 
     def tables(self, doc=0, names=("suftab", "lcptab", "anntab", "childtab_up", "childtab_down",
                                    "childtab_next_l_index")):

@@ -7,9 +7,12 @@ text collection (the documents become one device-resident shard of annotated
 suffix arrays) and `relevance_table`, ONE score call for all keyphrases.
 CosineRelevanceMeasure is a different method and out of scope.
 """
+import os
+
 import numpy as np
 
 from east import consts
+from east import exceptions
 from east import hip_backend
 from east import utils
 from east.asts import utils as ast_utils
@@ -54,6 +57,20 @@ class ASTRelevanceMeasure(RelevanceMeasure):
     def set_text_collection(self, texts, language=consts.Language.ENGLISH):
         self.texts = texts
         self.language = language
+        if os.environ.get("EAST_HIP_TEXT_PREP", "device") == "device":
+            # utils.text_to_strings_collection + make_unique_endings (relevance.py:44-45) on the device
+            if self.index is None:
+                self.index = hip_backend.HipIndex(self.device)
+            try:
+                self.index.build_texts(list(texts))
+            except exceptions.HipBackendError as e:
+                if "outside the method's domain" in str(e):
+                    code = int(str(e).split("U+")[1].split()[0], 16)
+                    raise exceptions.SymbolOutOfDomainException(code=code)
+                raise
+            self.asts = [_DocumentAST(self, d) for d in range(len(texts))]
+            self._row_cache = (None, None, None)
+            return
         collections = [utils.text_to_strings_collection(text) for text in texts]   # relevance.py:44-45
         self.set_strings_collections(collections)
 

@@ -85,6 +85,34 @@ int east_hip_build_device(east_hip_handle_t h, const uint32_t *d_symbols, int64_
                           const int64_t *doc_offsets, const int32_t *n_strings, int32_t n_docs);
 
 /*
+ * The same build straight from raw texts: text preparation on the device.  Replaces, for the
+ * whole collection, the chain in front of the AST construction
+ *   utils.prepare_text (utf-8 decode with errors='replace' + upper)      east/utils.py:31-34
+ *   utils.tokenize ([\w']+ under re.U)                                    east/utils.py:37-38
+ *   utils.text_to_strings_collection (tokens with len > 2 and not isdigit,
+ *       groups of 3, empty -> [" "])                                       east/utils.py:49-79
+ *   asts.utils.make_unique_endings + "".join                              east/asts/utils.py:25-40
+ * and then runs east_hip_build on the result.
+ *
+ *   bytes         the texts concatenated, EVERY text followed by one 0xFF byte
+ *   text_offsets  D+1 offsets: text d is bytes[text_offsets[d] .. text_offsets[d+1]-1) + its 0xFF
+ *   cp_class      0x0A00 bytes: bit 0 = the code point matches [\w'], bit 1 = str.isdigit()
+ *   cp_upper      0x0A00 words: 1:1 upper-case mapping (identity where upper() is not one code point)
+ *   word_hi       bitmap of the [\w'] code points in [0x0A00, 0x110000), bit (cp - 0x0A00); such
+ *                 characters are outside the method's domain and fail with EAST_HIP_ERR_DOMAIN
+ * The Unicode tables come from the caller's interpreter, so the device agrees with the host's
+ * re / str semantics by construction.  east_hip_get_prepared returns what was built:
+ * n_total symbols, D+1 symbol offsets, D string counts, and the symbols (each pointer nullable).
+ */
+int east_hip_build_texts(east_hip_handle_t h, const uint8_t *bytes, int64_t n_bytes,
+                         const int64_t *text_offsets, int32_t n_docs, const uint8_t *cp_class,
+                         const uint32_t *cp_upper, const uint32_t *word_hi, const uint32_t *digit_hi,
+                         const uint32_t *hi_upper_from, const uint32_t *hi_upper_to, int32_t n_hi_upper);
+int east_hip_get_prepared(east_hip_handle_t h, int64_t *n_total, int64_t *doc_offsets,
+                          int32_t *n_strings, uint32_t *symbols);
+double east_hip_last_prep_ms(east_hip_handle_t h);
+
+/*
  * Copy one document's tables to the host (each pointer nullable, n_d int32
  * values each, positions local to the document): the reference attributes
  * suftab, lcptab, anntab (easa.py:20-24) and childtab_up / childtab_down /

@@ -460,3 +460,91 @@ def test_c_abi_rejects_inconsistent_input(hip):
         index.build(sym, np.array([0, 3, 5]), np.array([1, 2]))
     with pytest.raises(exceptions.HipBackendError):
         index.score_table(np.array([65], np.uint32), np.array([0, 1]))       # no valid index after a failed build
+
+
+def _host_prepared(texts):
+    from east import utils
+    from east.asts import utils as ast_utils
+    colls = [utils.text_to_strings_collection(t) for t in texts]
+    parts = [ast_utils.strings_to_symbols(sc) for sc in colls]
+    return (np.concatenate(parts), np.concatenate([[0], np.cumsum([p.size for p in parts])]),
+            np.array([len(sc) for sc in colls]))
+
+
+def _check_device_prep(hip, texts):
+    from east import exceptions
+    index = hip.HipIndex()
+    try:
+        _host_prepared(texts)
+    except exceptions.SymbolOutOfDomainException:             # a word character beyond U+0A00: both must refuse
+        with pytest.raises(exceptions.HipBackendError, match="outside the method's domain"):
+            index.build_texts(texts)
+        return None
+    index.build_texts(texts)
+    sym, off, m = index.prepared()
+    want_sym, want_off, want_m = _host_prepared(texts)
+    assert off.tolist() == want_off.tolist() and m.tolist() == want_m.tolist()
+    assert np.array_equal(sym, want_sym)
+    return index
+
+
+def test_device_text_preparation_fixtures(hip):
+    """east_hip_build_texts == prepare_text + tokenize + text_to_strings_collection + make_unique_endings
+    on the reference-derived vectors and the HSE corpus."""
+    g = load_golden("utils_vectors.json")
+    texts = [v["text_utf8"].encode("utf-8") for v in g["text_to_strings_collection"]]
+    _check_device_prep(hip, texts)
+    for t in texts:                                           # also one document at a time
+        _check_device_prep(hip, [t])
+    h = load_golden("hse_config1.json")
+    _check_device_prep(hip, [t.encode("utf-8") for t in h["texts"].values()])
+    _check_device_prep(hip, ["str input: no decoding, just upper", "ß stays ß, ŉ stays ŉ"])
+
+
+def test_device_text_preparation_fuzz(hip):
+    """Random mixtures of ASCII, Latin-1, Greek, Cyrillic, Arabic-Indic digits, superscripts, fractions,
+    apostrophes, underscores, non-word characters beyond U+0A00 (emoji, dashes, BOM) and malformed
+    UTF-8 (stray continuations, truncated and overlong sequences, surrogates, > U+10FFFF)."""
+    import random
+    rng = random.Random(20240)
+    chars = list("abcXYZ'_ 019,.-\n\t") + ["ß", "é", "Ж", "ж", "λ", "Σ", "ς", "٣", "²", "½", "ŉ", "ǅ", "ſ", "ı",
+                                            "\U0001F600", "—", "’", "﻿", " ", "İ", "ͅ"]
+    junk = [b"\x80", b"\xbf", b"\xc0", b"\xc1\x81", b"\xc2", b"\xe0\x80", b"\xe0\xa0", b"\xe4\xb8", b"\xed\xa0\x80",
+            b"\xf0\x90\x80", b"\xf4\x90\x80\x80", b"\xf5", b"\xff", b"\xe2\x82", b"\xf0\x9f\x98"]
+    for it in range(120):
+        texts = []
+        for _ in range(rng.randint(1, 6)):
+            parts = []
+            for _ in range(rng.randint(0, 40)):
+                if rng.random() < 0.12:
+                    parts.append(rng.choice(junk))
+                else:
+                    parts.append("".join(rng.choice(chars) for _ in range(rng.randint(1, 6))).encode("utf-8"))
+            texts.append(b"".join(parts))
+        _check_device_prep(hip, texts)
+
+
+def test_device_text_preparation_large_and_domain(hip):
+    from east import exceptions, relevance, synthetic
+    rng = np.random.default_rng(3)
+    text, sym, m = synthetic.word_stream_document(rng, 16 << 20)
+    index = hip.HipIndex()
+    index.build_texts([text, text[: 1 << 20], b"", b"12 345 ab"])
+    got, off, ms = index.prepared()
+    assert ms[0] == m and np.array_equal(got[: off[1]], sym)
+    assert got[off[2]:off[3]].tolist() == [32, 0x0A00] and got[off[3]:].tolist() == [32, 0x0A00]
+    measure = relevance.ASTRelevanceMeasure()
+    with pytest.raises(exceptions.SymbolOutOfDomainException) as e:
+        measure.set_text_collection([b"fine text", "word 中文字 here".encode("utf-8")])
+    assert "4E2D" in str(e.value)
+
+
+def test_host_and_device_text_preparation_give_the_same_table(hip, monkeypatch):
+    from east import applications, relevance
+    g = load_golden("zipf_docs.json")
+    texts = {k: v.encode("utf-8") for k, v in g["texts"].items()}
+    tables = {}
+    for mode in ("host", "device"):
+        monkeypatch.setenv("EAST_HIP_TEXT_PREP", mode)
+        tables[mode] = applications.keyphrases_table(g["keyphrases"], texts, relevance.ASTRelevanceMeasure())
+    assert tables["host"] == tables["device"] == g["normalized"]

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Time text preparation + build from raw UTF-8 on the device against the host chain
+(prepare_text / tokenize / text_to_strings_collection / make_unique_endings in Python)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ast-text-analysis_amd"))
+from east import hip_backend, synthetic, utils  # noqa: E402
+from east.asts import utils as ast_utils  # noqa: E402
+
+mib = float(sys.argv[1]) if len(sys.argv) > 1 else 64.0
+rng = np.random.default_rng(20240 + 2)
+text, sym, m = synthetic.word_stream_document(rng, int(mib * (1 << 20)))
+hip_backend.unicode_tables()
+index = hip_backend.HipIndex()
+index.build_texts([text])                      # warm-up (allocations)
+t0 = time.perf_counter()
+index.build_texts([text])
+t_dev = time.perf_counter() - t0
+got, off, ms = index.prepared()
+assert ms[0] == m and np.array_equal(got, sym)
+t0 = time.perf_counter()
+ref = ast_utils.strings_to_symbols(utils.text_to_strings_collection(text))
+t_host = time.perf_counter() - t0
+assert np.array_equal(ref, sym)
+print("%g MiB text: device prep kernels %.2f ms, build %.2f ms, wall incl. H2D of the raw bytes %.1f ms; "
+      "host Python chain %.0f ms (%.0fx)" % (mib, index.last_prep_ms, index.last_build_ms, t_dev * 1e3,
+                                              t_host * 1e3, t_host / t_dev))
