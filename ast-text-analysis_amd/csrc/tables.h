@@ -342,33 +342,41 @@ __global__ __launch_bounds__(BLOCK) void ann_kernel(Pyramid P, const u32 *__rest
                                                     const u32 *__restrict__ n_strings, u32 n_docs, u32 n,
                                                     u32 *__restrict__ ann)
 {
+    __shared__ u32 tile[ANN_TILE + 2 * ANN_NEAR];       // the tile's LCP values with ANN_NEAR ranks of halo
     __shared__ u32 work[ANN_TILE];
     __shared__ u32 work_count;
     const u32 *lcp = P.ptr[0];
+    const u32 base = blockIdx.x * ANN_TILE;
     if (threadIdx.x == 0) work_count = 0;
+    for (u32 i = threadIdx.x; i < ANN_TILE + 2 * ANN_NEAR; i += BLOCK) {
+        const u64 g = (u64)base + i;                     // global rank + ANN_NEAR
+        tile[i] = (g >= ANN_NEAR && g - ANN_NEAR < n) ? lcp[g - ANN_NEAR] : 0u;   // 0 stops every scan
+    }
     __syncthreads();
 #pragma unroll 2
     for (int j = 0; j < ANN_IPT; j++) {
-        const u32 k = blockIdx.x * ANN_TILE + j * BLOCK + threadIdx.x;
+        const u32 t = j * BLOCK + threadIdx.x;           // position inside the tile
+        const u32 k = base + t;
         if (k >= n) continue;
-        const u32 v = lcp[k];
+        const u32 *c = tile + t + ANN_NEAR;              // c[0] = lcp[k], c[-1] = lcp[k-1], ...
+        const u32 v = c[0];
         if (v == 0) {
             // only a document's first rank carries an annotation here: the root, n_d - m_d
             const u32 d = n_docs > 1 ? doc_of(doc_off, n_docs, k) : 0u;
             ann[k] = doc_off[d] == k ? (doc_off[d + 1] - k) - n_strings[d] : 0u;
             continue;
         }
-        // previous value <= v (k >= 1 and lcp[0] == 0, so the scan cannot run off the front)
-        u32 p = k - 1, x = lcp[p];
-        const u32 p_lim = k > ANN_NEAR ? k - ANN_NEAR : 0u;
-        while (x > v && p > p_lim) { p--; x = lcp[p]; }
+        // previous value <= v within ANN_NEAR ranks (lcp[0] == 0 and the zero halo stop the scan)
+        u32 back = 1;
+        while (back < ANN_NEAR && c[-(int)back] > v) back++;
+        const u32 x = c[-(int)back];
         bool defer = x > v;
         u32 a = 0;
         if (!defer && x < v) {                  // first l-index of its interval: width = NSV - PSV
-            u32 q = k + 1;
-            const u32 q_lim = k + ANN_NEAR < n ? k + ANN_NEAR : n;
-            while (q < q_lim && lcp[q] >= v) q++;
-            if (q < q_lim || q == n) a = q - p;
+            u32 fwd = 1;
+            while (fwd < ANN_NEAR && k + fwd < n && c[fwd] >= v) fwd++;
+            if (k + fwd >= n) a = n - (k - back);
+            else if (c[fwd] < v) a = fwd + back;
             else defer = true;
         }
         if (defer) work[atomicAdd(&work_count, 1u)] = k;
