@@ -122,14 +122,24 @@ __global__ __launch_bounds__(BLOCK) void dc3_window_keys_kernel(const uint8_t *_
 
 template <class K> struct KeyNeqWindowIn {
     const K *keys;
-    int w, b, spare;
-    u32 term_first;
+    K rep_t, ones, highs;       // terminator code / 1 / top bit replicated into every full-symbol field
+    // "does any of the w full symbols equal the terminator code": xor turns such a field into zero,
+    // then the zero-field test (x - ones) & ~x & highs (exact for "any field is zero")
+    static KeyNeqWindowIn make(const K *keys, int w, int b, int spare, u32 term_first)
+    {
+        KeyNeqWindowIn f{keys, 0, 0, 0};
+        for (int j = 0; j < w; j++) {
+            f.rep_t |= (K)term_first << (spare + j * b);
+            f.ones |= (K)1 << (spare + j * b);
+            f.highs |= (K)1 << (spare + j * b + b - 1);
+        }
+        return f;
+    }
     __device__ __forceinline__ u32 operator()(u32 i) const
     {
         const K k = keys[i];
-        const u32 mask = (1u << b) - 1u;
-        bool has_term = false;                  // among the w full symbols (the partial one does not count)
-        for (int j = 0; j < w; j++) has_term = has_term || ((u32)(k >> (spare + j * b)) & mask) == term_first;
+        const K x = k ^ rep_t;
+        const bool has_term = ((x - ones) & ~x & highs) != 0;
         return (i == 0 || has_term || k != keys[i - 1]) ? 1u : 0u;
     }
 };
@@ -240,22 +250,24 @@ __global__ __launch_bounds__(BLOCK) void dc3_resolve_ties_kernel(const u32 *__re
 // so they are compared on the text itself, 8 symbols per step.  Two terminators at the
 // same offset are different symbols ordered by position.  No name string is needed,
 // which saves the random scatter of 2n/3 names whenever the level does not recurse.
+// `starts(i)` = 1 where sorted sample i opens a new name (the naming predicate on the sorted keys):
+// a group of tied samples is a maximal run [a, b) with starts(a) = 1 and starts = 0 inside.
+template <class Starts>
 __global__ __launch_bounds__(BLOCK) void dc3_resolve_ties_text_kernel(const u32 *__restrict__ sorted_vals,
-                                                                      const u32 *__restrict__ names,
+                                                                      Starts starts,
                                                                       const uint8_t *__restrict__ s8, u32 n0,
                                                                       u32 n02, u32 *__restrict__ sa12,
                                                                       u32 *__restrict__ fail)
 {
     const u32 i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n02) return;
-    const u32 nm = names[i];
     const u32 t = sorted_vals[i];
-    const bool left_same = i > 0 && names[i - 1] == nm;
-    const bool right_same = i + 1 < n02 && names[i + 1] == nm;
+    const bool left_same = i > 0 && !starts(i);
+    const bool right_same = i + 1 < n02 && !starts(i + 1);
     if (!left_same && !right_same) { sa12[i] = t; return; }
     u32 a = i, b = i + 1;
-    while (a > 0 && names[a - 1] == nm && i - a <= RESOLVE_MAX_GROUP) a--;
-    while (b < n02 && names[b] == nm && b - i <= RESOLVE_MAX_GROUP) b++;
+    while (a > 0 && !starts(a) && i - a <= RESOLVE_MAX_GROUP) a--;
+    while (b < n02 && !starts(b) && b - i <= RESOLVE_MAX_GROUP) b++;
     if (b - a > RESOLVE_MAX_GROUP) { atomicOr(fail, 1u); return; }
     const u32 p = dc3_sample_pos(t, n0);
     u32 r = 0;
@@ -700,6 +712,64 @@ static const u32 *dc3_sort_and_name(Ctx &ctx, SortBufs<K> &sb, u32 n02, int bits
 
 // s8 (level 0 of an EASA build with sigma_text <= 254): the byte stream; `s` is then not read at all.
 // lcp_out (with s8 only): also emit the LCP table of the suffix array (single document).
+// Level 0 on the byte stream: window keys, sort, count the distinct names; unique names or a few
+// ties ordered on the text make sa12 final (returns true, no name string is ever written).
+// Otherwise the names are scanned and scattered into s12 for the recursion (returns false).
+template <class K>
+static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w, int bt, u32 term_first, u32 *sa12,
+                             u32 *s12, u32 &n_names)
+{
+    Arena &ar = *ctx.arena;
+    const u32 g02 = ceil_div_u32(n02, BLOCK);
+    // whole passes are paid for anyway: fill the last digit with the top bits of the next symbol
+    const int total = ((w * bt + 7) / 8) * 8;
+    const int spare = w < 12 ? std::min(total - w * bt, bt - 1) : 0;
+    SortBufs<K> sb;
+    for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<K>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
+    LAUNCH(ctx, (dc3_window_keys_kernel<K>), g02, s8, n0, n02, w, bt, spare, term_first, sb.keys[0], sb.vals[0]);
+    const int r = radix_sort_pairs<K>(ctx, sb, n02, w * bt + spare);
+    const KeyNeqWindowIn<K> starts = KeyNeqWindowIn<K>::make(sb.keys[r], w, bt, spare, term_first);
+    const u32 *sorted_vals = sb.vals[r];
+
+    // number of distinct names = sum of the naming predicate (a reduction, not yet a scan)
+    const u32 nb = ceil_div_u32(n02, SCAN_TILE);
+    u32 *block_sums = ar.alloc<u32>(nb);
+    LAUNCH(ctx, (scan_reduce_kernel<KeyNeqWindowIn<K>>), nb, starts, n02, block_sums);
+    if (ctx.dry) {
+        n_names = n02 > 4 ? n02 - 1 : n02;            // worst case: recurse
+    } else {
+        std::vector<u32> h_sums(nb);
+        HIP_CHECK(hipMemcpyAsync(h_sums.data(), block_sums, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        u64 total_names = 0;
+        for (u32 x : h_sums) total_names += x;
+        if (total_names == 0 || total_names > n02) east_throw(EAST_HIP_ERR_INTERNAL, "dc3: impossible name count");
+        n_names = (u32)total_names;
+        if (n_names == n02) {                          // unique names: the sorted order is SA12 already
+            HIP_CHECK(hipMemcpyAsync(sa12, sorted_vals, (size_t)n02 * sizeof(u32), hipMemcpyDeviceToDevice, ctx.stream));
+            return true;
+        }
+        if (n02 - n_names <= n02 / 8) {                // few ties: order them on the text
+            u32 *fail = ar.alloc<u32>(1);
+            u32 h_fail = 0;
+            HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
+            LAUNCH_NAMED(ctx, "dc3_resolve_ties_text_kernel", (dc3_resolve_ties_text_kernel<KeyNeqWindowIn<K>>), g02,
+                         sorted_vals, starts, s8, n0, n02, sa12, fail);
+            HIP_CHECK(hipMemcpyAsync(&h_fail, fail, sizeof(u32), hipMemcpyDeviceToHost, ctx.stream));
+            HIP_CHECK(hipStreamSynchronize(ctx.stream));
+            if (!h_fail) {
+                if (ctx.stats) ctx.stats->levels_resolved++;
+                return true;
+            }
+        }
+    }
+    // recursion ahead: names by an inclusive scan of the predicate, scattered into the name string
+    u32 *names = ar.alloc<u32>(n02);
+    device_scan<KeyNeqWindowIn<K>, true>(ctx, starts, n02, names);
+    LAUNCH(ctx, dc3_scatter_names_kernel, ceil_div_u32((u64)n02 + 3, BLOCK), sorted_vals, (const u32 *)names, n02, s12);
+    return false;
+}
+
 static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_out, int depth = 0,
                             u32 term_first = 0, const uint8_t *s8 = nullptr, u32 *lcp_out = nullptr,
                             u32 *lcp_capped = nullptr)
@@ -716,42 +786,29 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
 
     // -- sort the sample triples, name them --------------------------------
     u32 n_names = 0;
-    {
+    if (s8) {
+        const size_t mark = ar.mark();
+        const int bt = bit_width_u32(term_first);          // bits of the compressed level-0 alphabet
+        // widest window: names almost unique (sigma^w >= 64 n) within 64-bit keys; but if the
+        // window that still fits 32-bit keys leaves only a few per cent of ties (sigma^w >= 4 n),
+        // the cheaper sort wins and the tie resolution absorbs the difference
+        int w = 3;
+        const int w_max = 64 / bt < 12 ? 64 / bt : 12;
+        double reach = (double)term_first * term_first * term_first;
+        while (w < w_max && reach < 64.0 * (double)n) { reach *= term_first; w++; }
+        const int w32 = 32 / bt;
+        if (w32 >= 3 && w32 < w && pow((double)term_first, w32) >= 4.0 * (double)n) w = w32;
+        const bool final_order = w * bt <= 32
+            ? dc3_level0_bytes<u32>(ctx, s8, n0, n02, w, bt, term_first, sa12, s12, n_names)
+            : dc3_level0_bytes<u64>(ctx, s8, n0, n02, w, bt, term_first, sa12, s12, n_names);
+        if (final_order) n_names = n02;
+        ar.release(mark);
+    } else {
         const size_t mark = ar.mark();
         u32 *names = ar.alloc<u32>(n02);
         const u32 *sorted_vals = nullptr;
         const int bt = bit_width_u32(term_first);          // bits of the compressed level-0 alphabet
-        int w = 3;                                         // name window (symbols) on the byte path
-        if (s8) {
-            // widest window: names almost unique (sigma^w >= 64 n) within 64-bit keys; but if the
-            // window that still fits 32-bit keys leaves only a few per cent of ties (sigma^w >= 4 n),
-            // the cheaper sort wins and the tie resolution absorbs the difference
-            const int w_max = 64 / bt < 12 ? 64 / bt : 12;
-            double reach = (double)term_first * term_first * term_first;
-            while (w < w_max && reach < 64.0 * (double)n) { reach *= term_first; w++; }
-            const int w32 = 32 / bt;
-            if (w32 >= 3 && w32 < w && pow((double)term_first, w32) >= 4.0 * (double)n) w = w32;
-        }
-        if (s8 && w * bt <= 32) {
-            // whole passes are paid for anyway: fill the last digit with the top bits of the next symbol
-            const int total = ((w * bt + 7) / 8) * 8;
-            const int spare = w < 12 ? std::min(total - w * bt, bt - 1) : 0;
-            SortBufs<u32> sb;
-            for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
-            LAUNCH(ctx, (dc3_window_keys_kernel<u32>), g02, s8, n0, n02, w, bt, spare, term_first, sb.keys[0],
-                   sb.vals[0]);
-            sorted_vals = dc3_sort_and_name<u32>(ctx, sb, n02, w * bt + spare, names, [&](const u32 *k) {
-                return KeyNeqWindowIn<u32>{k, w, bt, spare, term_first}; });
-        } else if (s8) {
-            const int total = ((w * bt + 7) / 8) * 8;
-            const int spare = w < 12 ? std::min(total - w * bt, bt - 1) : 0;
-            SortBufs<u64> sb;
-            for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u64>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
-            LAUNCH(ctx, (dc3_window_keys_kernel<u64>), g02, s8, n0, n02, w, bt, spare, term_first, sb.keys[0],
-                   sb.vals[0]);
-            sorted_vals = dc3_sort_and_name<u64>(ctx, sb, n02, w * bt + spare, names, [&](const u64 *k) {
-                return KeyNeqWindowIn<u64>{k, w, bt, spare, term_first}; });
-        } else if (term_first > 0 && 3 * bt <= 32) {
+        if (term_first > 0 && 3 * bt <= 32) {
             SortBufs<u32> sb;
             for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
             LAUNCH(ctx, (dc3_triple_keys_term_kernel<u32>), g02, s, n0, n02, bt, term_first, sb.keys[0], sb.vals[0]);
@@ -792,14 +849,8 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
             device_scan<KeyNeq2In, true>(ctx, KeyNeq2In{sb.keys[rb], third}, n02, names);
             sorted_vals = sb.vals[rb];
         }
-        // the name string is only needed to recurse or to order ties by names
-        bool have_s12 = false;
-        auto scatter_names = [&]() {
-            LAUNCH(ctx, dc3_scatter_names_kernel, ceil_div_u32((u64)n02 + 3, BLOCK), sorted_vals,
-                   (const u32 *)names, n02, s12);
-            have_s12 = true;
-        };
-        if (!s8) scatter_names();
+        LAUNCH(ctx, dc3_scatter_names_kernel, ceil_div_u32((u64)n02 + 3, BLOCK), sorted_vals,
+               (const u32 *)names, n02, s12);
         if (ctx.dry) {
             n_names = n02 > 4 ? n02 - 1 : n02;        // worst case: keep recursing
         } else {
@@ -817,12 +868,8 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
             u32 *fail = ar.alloc<u32>(1);
             u32 h_fail = 0;
             HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
-            if (s8)
-                LAUNCH(ctx, dc3_resolve_ties_text_kernel, g02, sorted_vals, (const u32 *)names, s8, n0, n02, sa12,
-                       fail);
-            else
-                LAUNCH(ctx, dc3_resolve_ties_kernel, g02, sorted_vals, (const u32 *)names, (const u32 *)s12, n02,
-                       sa12, fail);
+            LAUNCH(ctx, dc3_resolve_ties_kernel, g02, sorted_vals, (const u32 *)names, (const u32 *)s12, n02, sa12,
+                   fail);
             HIP_CHECK(hipMemcpyAsync(&h_fail, fail, sizeof(u32), hipMemcpyDeviceToHost, ctx.stream));
             HIP_CHECK(hipStreamSynchronize(ctx.stream));
             if (!h_fail) {
@@ -830,7 +877,6 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
                 if (ctx.stats) ctx.stats->levels_resolved++;
             }
         }
-        if (n_names < n02 && !have_s12) scatter_names();       // recursion ahead
         ar.release(mark);
     }
 
