@@ -797,7 +797,12 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         double reach = (double)term_first * term_first * term_first;
         while (w < w_max && reach < 64.0 * (double)n) { reach *= term_first; w++; }
         const int w32 = 32 / bt;
-        if (w32 >= 3 && w32 < w && pow((double)term_first, w32) >= 4.0 * (double)n) w = w32;
+        if (w32 >= 3 && w32 < w) {
+            // the spare bits of the last digit hold the top bits of one more symbol: that many more buckets
+            const int spare32 = std::min(((w32 * bt + 7) / 8) * 8 - w32 * bt, bt - 1);
+            const double buckets = spare32 > 0 ? (double)((term_first >> (bt - spare32)) + 1u) : 1.0;
+            if (pow((double)term_first, w32) * buckets >= 4.0 * (double)n) w = w32;
+        }
         const bool final_order = w * bt <= 32
             ? dc3_level0_bytes<u32>(ctx, s8, n0, n02, w, bt, term_first, sa12, s12, n_names)
             : dc3_level0_bytes<u64>(ctx, s8, n0, n02, w, bt, term_first, sa12, s12, n_names);
