@@ -308,6 +308,29 @@ __global__ __launch_bounds__(BLOCK) void dc3_rank_kernel(const u32 *__restrict__
     if (i < n02) r12[dc3_r12_index(sa12[i], n0)] = i + 1;
 }
 
+static size_t g_rank_bucket_bytes = (size_t)192 << 20;      // east_hip_debug_set_rank_bucket_bytes (tests)
+
+// Beyond the Infinity Cache (R12 > ~192 MB) the random 4-byte stores above each cost a
+// read-modify-write of a 64-byte sector in HBM.  Then the (slot, rank) pairs are first
+// bucketed by the top 8 bits of the slot -- one stable radix pass -- so that the stores of a
+// bucket land in a window of R12 that fits the L2.
+__global__ __launch_bounds__(BLOCK) void dc3_rank_pairs_kernel(const u32 *__restrict__ sa12, u32 n0, u32 n02,
+                                                               u32 *__restrict__ slots, u32 *__restrict__ ranks)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n02) return;
+    slots[i] = dc3_r12_index(sa12[i], n0);
+    ranks[i] = i + 1;
+}
+
+__global__ __launch_bounds__(BLOCK) void dc3_rank_store_kernel(const u32 *__restrict__ slots,
+                                                               const u32 *__restrict__ ranks, u32 n02,
+                                                               u32 *__restrict__ r12)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n02) r12[slots[i]] = ranks[i];
+}
+
 // SR[p] = (s[p], R[p]) with R[p] = 0 for p mod 3 == 0 and past the end: symbols and
 // ranks interleaved in text order, so that ONE 24-byte window SR[p..p+2] holds
 // everything the merge comparator needs for the suffix at p:
@@ -894,7 +917,18 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         // (unique names: sa12 is the sorted order itself, so rank = index + 1 either way)
         u32 *r12 = ar.alloc<u32>((size_t)2 * n0 + 4);
         if (!ctx.dry) HIP_CHECK(hipMemsetAsync(r12, 0, ((size_t)2 * n0 + 4) * sizeof(u32), ctx.stream));
-        LAUNCH(ctx, dc3_rank_kernel, g02, (const u32 *)sa12, n0, n02, r12);
+        if (((size_t)2 * n0 + 4) * sizeof(u32) > g_rank_bucket_bytes || ctx.dry) {
+            const size_t mark = ar.mark();
+            SortBufs<u32> rp;
+            for (int k = 0; k < 2; k++) { rp.keys[k] = ar.alloc<u32>(n02); rp.vals[k] = ar.alloc<u32>(n02); }
+            LAUNCH(ctx, dc3_rank_pairs_kernel, g02, (const u32 *)sa12, n0, n02, rp.keys[0], rp.vals[0]);
+            const int top = bit_width_u32(2 * n0 + 1);
+            const int rr = radix_sort_pairs<u32>(ctx, rp, n02, top, top > 8 ? top - 8 : 0);
+            LAUNCH(ctx, dc3_rank_store_kernel, g02, (const u32 *)rp.keys[rr], (const u32 *)rp.vals[rr], n02, r12);
+            ar.release(mark);
+        } else {
+            LAUNCH(ctx, dc3_rank_kernel, g02, (const u32 *)sa12, n0, n02, r12);
+        }
         const bool byte_records = s8 != nullptr;       // level 0 on the byte stream: 16-byte records
         uint2 *sr = nullptr;
         uint4 *rec = nullptr;

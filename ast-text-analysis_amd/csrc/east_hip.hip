@@ -975,6 +975,13 @@ template <class K> static void debug_sort(int device, K *keys, u32 *vals, i64 n,
 
 extern "C" {
 
+int east_hip_debug_set_rank_bucket_bytes(int64_t bytes)
+{
+    if (bytes < 0) return EAST_HIP_ERR_INVALID;
+    g_rank_bucket_bytes = (size_t)bytes;
+    return EAST_HIP_OK;
+}
+
 int east_hip_debug_radix_sort_u64(int device, uint64_t *keys, uint32_t *vals, int64_t n, int bits)
 {
     return guarded([&] { debug_sort<u64>(device, keys, vals, n, bits); });

@@ -210,10 +210,10 @@ template <class K> struct SortBufs {
     u32 *vals[2];
 };
 
-// Sorts on key bits [0, bits).  Input in buffers [0]; returns the index (0/1)
+// Sorts on key bits [begin_bit, bits).  Input in buffers [0]; returns the index (0/1)
 // of the buffers that hold the sorted pairs.
 template <class K>
-static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits)
+static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin_bit = 0)
 {
     if (n == 0) return 0;
     const u32 n_tiles = ceil_div_u32(n, RS_TILE);
@@ -223,7 +223,7 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits)
     u32 *chunk_sums = ctx.arena->alloc<u32>((size_t)RS_BINS * n_chunks);
     u32 *chunk_prefix = ctx.arena->alloc<u32>((size_t)RS_BINS * (n_chunks + 1));
     int cur = 0;
-    for (int shift = 0; shift < bits; shift += 8) {
+    for (int shift = begin_bit; shift < bits; shift += 8) {
         LAUNCH_NAMED(ctx, sizeof(K) == 8 ? "radix_hist_kernel<u64>" : "radix_hist_kernel<u32>",
                      (radix_hist_kernel<K>), n_tiles, (const K *)b.keys[cur], n, shift, hist, n_tiles);
         LAUNCH(ctx, hist_chunk_sums_kernel, n_chunks, (const u32 *)hist, n_tiles, chunk_sums);

@@ -198,6 +198,9 @@ int east_hip_debug_radix_sort_u32(int device, uint32_t *keys, uint32_t *vals, in
 int east_hip_debug_exclusive_scan(int device, const uint32_t *in, uint32_t *out, int64_t n);
 int east_hip_debug_suffix_array(int device, const uint32_t *symbols, int64_t n, uint32_t sigma,
                                 int32_t *sa_out, int32_t *levels_out);
+/* Test knob: rank arrays larger than this many bytes are filled through the bucketed scatter
+ * (default 192 MiB, the Infinity Cache); 0 forces the bucketed path on every input. */
+int east_hip_debug_set_rank_bucket_bytes(int64_t bytes);
 /* Host-only: bytes of device arena a build of n_total symbols / n_docs documents
  * reserves (worst case over inputs).  Needs no device. */
 int64_t east_hip_plan_arena_bytes(int64_t n_total, int32_t n_docs);

@@ -548,3 +548,31 @@ def test_host_and_device_text_preparation_give_the_same_table(hip, monkeypatch):
         monkeypatch.setenv("EAST_HIP_TEXT_PREP", mode)
         tables[mode] = applications.keyphrases_table(g["keyphrases"], texts, relevance.ASTRelevanceMeasure())
     assert tables["host"] == tables["device"] == g["normalized"]
+
+
+def test_bucketed_rank_scatter_path(hip, oracle):
+    """Inputs whose rank array exceeds the Infinity Cache take a bucketed scatter; force that
+    path on small inputs (multi-document, single document, deep recursion) and compare with the oracle."""
+    from east import relevance
+    lib = hip.load()
+    assert lib.east_hip_debug_set_rank_bucket_bytes(0) == 0
+    try:
+        rng = np.random.default_rng(12)
+        docs = _random_collections(rng, 5, "ABCD", max_strings=40, max_len=30)
+        docs.append(["AB" * 3000 + "C"])
+        measure = relevance.ASTRelevanceMeasure()
+        measure.set_strings_collections(docs)
+        for d, sc in enumerate(docs):
+            o = oracle.OracleEASA(sc)
+            t = measure.index.tables(d)
+            for name in TABLES:
+                assert np.array_equal(t[name], getattr(o, name)), (name, d)
+        text = word_stream(rng, 1 << 20)
+        measure.set_text_collection([text])
+        from east import utils
+        o = oracle.OracleEASA(utils.text_to_strings_collection(text))
+        t = measure.index.tables(0, names=("suftab", "lcptab", "anntab"))
+        for name in ("suftab", "lcptab", "anntab"):
+            assert np.array_equal(t[name], getattr(o, name)), name
+    finally:
+        assert lib.east_hip_debug_set_rank_bucket_bytes(192 << 20) == 0
