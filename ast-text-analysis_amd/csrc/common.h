@@ -1,7 +1,8 @@
 // common.h -- shared host/device helpers for the gfx950 EASA backend.
 //
 // Everything here is written for CDNA4 only: 64-lane wavefronts, 256-thread
-// workgroups (4 waves = one wave per SIMD), 160 KiB LDS per CU.
+// workgroups by default (4 waves = one per SIMD; the radix scatter runs 1024-thread
+// workgroups to keep 32 waves per CU resident), 160 KiB LDS per CU.
 #pragma once
 
 #include <hip/hip_runtime.h>

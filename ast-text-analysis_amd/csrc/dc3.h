@@ -892,7 +892,7 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
             HIP_CHECK(hipMemcpyAsync(sa12, sorted_vals, (size_t)n02 * sizeof(u32),
                                      hipMemcpyDeviceToDevice, ctx.stream));
         } else if (!ctx.dry && n02 - n_names <= n02 / 8) {
-            // few ties: order them in place instead of recursing (names[] doubles as the fail word's home)
+            // few ties: order them in place instead of recursing
             u32 *fail = ar.alloc<u32>(1);
             u32 h_fail = 0;
             HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));

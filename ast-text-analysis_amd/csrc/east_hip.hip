@@ -294,10 +294,10 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
                 HIP_CHECK(hipMemsetAsync(h->lcp + n, 0xFF, (size_t)(pyr_padded(n) - n) * sizeof(u32), ctx.stream));
         } else if (h->use_s8) {
             LAUNCH(ctx, lcp8_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const uint8_t *)h->s8, (const u32 *)h->sa,
-                   (const u32 *)h->doc_off, n_docs, n, h->lcp, capped);
+                   n, h->lcp, capped);
         } else {
             LAUNCH(ctx, lcp_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const u32 *)h->s, (const u32 *)h->sa,
-                   (const u32 *)h->doc_off, n_docs, n, h->lcp, capped);
+                   n, h->lcp, capped);
         }
         if (n_docs > 1)
             LAUNCH(ctx, lcp_doc_starts_kernel, ceil_div_u32(n_docs, BLOCK), (const u32 *)h->doc_off, n_docs, h->lcp);

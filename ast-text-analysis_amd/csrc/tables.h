@@ -78,7 +78,6 @@ __global__ __launch_bounds__(BLOCK) void lcp_doc_starts_kernel(const u32 *__rest
 
 __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
                                                     const u32 *__restrict__ sa,
-                                                    const u32 *__restrict__ doc_off, u32 n_docs,
                                                     u32 n, u32 *__restrict__ lcp, u32 *__restrict__ capped)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
@@ -122,8 +121,7 @@ __device__ __forceinline__ u64 load_u64_unaligned(const uint8_t *p)
 }
 
 __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__ s8,
-                                                     const u32 *__restrict__ sa,
-                                                     const u32 *__restrict__ doc_off, u32 n_docs, u32 n,
+                                                     const u32 *__restrict__ sa, u32 n,
                                                      u32 *__restrict__ lcp, u32 *__restrict__ capped)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
