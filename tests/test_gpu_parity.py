@@ -576,3 +576,32 @@ def test_bucketed_rank_scatter_path(hip, oracle):
             assert np.array_equal(t[name], getattr(o, name)), name
     finally:
         assert lib.east_hip_debug_set_rank_bucket_bytes(192 << 20) == 0
+
+
+def test_many_small_documents(hip, oracle):
+    """Single-file mode of the CLI (one text per line): 20 000 tiny documents in one batched build,
+    including empty lines (-> [" "]) and lines without any kept token."""
+    from east import relevance, utils
+    rng = np.random.default_rng(21)
+    lines = []
+    for i in range(20000):
+        kind = i % 11
+        if kind == 0:
+            lines.append(b"")
+        elif kind == 1:
+            lines.append(b"a bb 123 4567")
+        else:
+            lines.append(word_stream(rng, int(rng.integers(8, 120))))
+    measure = relevance.ASTRelevanceMeasure()
+    measure.set_text_collection(lines)
+    kps = [utils.prepare_text(word_stream(rng, 10).decode()) for _ in range(20)] + ["A", "BB 12"]
+    kps = [k for k in kps if k.replace(" ", "")]
+    table = measure.relevance_table(kps)
+    assert table.shape == (len(kps), len(lines))
+    for d in list(range(0, 40)) + list(range(19960, 20000)) + rng.integers(0, 20000, size=60).tolist():
+        o = oracle.OracleEASA(utils.text_to_strings_collection(lines[d]))
+        t = measure.index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+        for k, kp in enumerate(kps):
+            assert table[k, d] == o.score(kp, fast=True), (d, kp)
