@@ -1,6 +1,5 @@
 # -*- coding: utf-8 -*-
 """keyphrases_table / keyphrases_graph (reference east/applications.py:11-149)."""
-import itertools
 
 from east import consts
 from east import logging
@@ -10,22 +9,12 @@ from east import utils
 
 def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=None,
                      language=consts.Language.ENGLISH):
-    """
-    Constructs the keyphrases table, containing their matching scores in a set of texts.
+    """Matching score of every keyphrase in every text (reference east/applications.py:11-56).
 
-    The resulting table is stored as a dictionary of dictionaries,
-    where the entry table["keyphrase"]["text"] corresponds
-    to the matching score (0 <= score <= 1) of keyphrase "keyphrase"
-    in the text named "text".
-
-    :param keyphrases: list of strings
-    :param texts: dictionary of form {text_name: text}
-    :param similarity_measure: similarity measure to use
-    :param synonimizer: SynonymExtractor object to be used
-    :param language: Language of the text collection / keyphrases
-
-    :returns: dictionary of dictionaries, having keyphrases on its first level and texts
-              on the second level.
+    :param keyphrases: raw keyphrase strings (empty ones are skipped, duplicates collapse)
+    :param texts: {text name: text}
+    :param similarity_measure: defaults to ASTRelevanceMeasure() (easa, normalized)
+    :returns: {raw keyphrase: {text name: score}}
     """
     similarity_measure = similarity_measure or relevance.ASTRelevanceMeasure()
 
@@ -63,52 +52,39 @@ def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=Non
 def keyphrases_graph(keyphrases, texts, referral_confidence=0.6, relevance_threshold=0.25,
                      support_threshold=1, similarity_measure=None, synonimizer=None,
                      language=consts.Language.ENGLISH):
-    """
-    Constructs the keyphrases relation graph based on the given texts corpus
-    (reference east/applications.py:59-149): a keyphrase occurs in a text if its
-    matching score reaches relevance_threshold; A -> B if at least
-    referral_confidence of the texts containing A also contain B; nodes with
-    fewer than support_threshold texts are dropped.
+    """Keyphrase implication graph over a text corpus (reference east/applications.py:59-149).
+
+    A keyphrase *occurs* in a text when its matching score reaches `relevance_threshold`; its
+    *support* is the number of such texts.  Keyphrases with support below `support_threshold` are
+    dropped; for every ordered pair (A, B) of the remaining ones an edge A -> B is drawn when at
+    least `referral_confidence` of the texts containing A also contain B.
 
     :returns: {"nodes": [{"id", "label", "support"}], "edges": [{"source", "target", "confidence"}],
-               "referral_confidence", "relevance_threshold", "support_threshold"}
+               "referral_confidence", "relevance_threshold", "support_threshold"}; node ids are the
+               positions of the keyphrases in the input list.
     """
-    similarity_measure = similarity_measure or relevance.ASTRelevanceMeasure()
+    measure = similarity_measure or relevance.ASTRelevanceMeasure()
+    table = keyphrases_table(keyphrases, texts, measure, synonimizer, language)
 
-    table = keyphrases_table(keyphrases, texts, similarity_measure, synonimizer, language)
+    occurs_in = {}
+    for keyphrase in keyphrases:
+        row = table[keyphrase]
+        occurs_in[keyphrase] = set(name for name in texts if row[name] >= relevance_threshold)
 
-    keyphrase_texts = {keyphrase: set([text for text in texts
-                                       if table[keyphrase][text] >= relevance_threshold])
-                       for keyphrase in keyphrases}
+    nodes = [{"id": position, "label": keyphrase, "support": len(occurs_in[keyphrase])}
+             for position, keyphrase in enumerate(keyphrases)
+             if len(occurs_in[keyphrase]) >= support_threshold]
 
-    graph = {
-        "nodes": [
-            {
-                "id": i,
-                "label": keyphrase,
-                "support": len(keyphrase_texts[keyphrase])
-            } for i, keyphrase in enumerate(keyphrases)
-        ],
-        "edges": [],
-        "referral_confidence": referral_confidence,
-        "relevance_threshold": relevance_threshold,
-        "support_threshold": support_threshold
-    }
+    edges = []
+    for source in nodes:
+        source_texts = occurs_in[source["label"]]
+        for target in nodes:
+            if target is source:
+                continue
+            shared = len(source_texts & occurs_in[target["label"]])
+            confidence = float(shared) / max(len(source_texts), 1)
+            if confidence >= referral_confidence:
+                edges.append({"source": source["id"], "target": target["id"], "confidence": confidence})
 
-    graph["nodes"] = [n for n in graph["nodes"]
-                      if len(keyphrase_texts[n["label"]]) >= support_threshold]
-
-    for i1, i2 in itertools.permutations(range(len(graph["nodes"])), 2):
-        node1 = graph["nodes"][i1]
-        node2 = graph["nodes"][i2]
-        confidence = (float(len(keyphrase_texts[node1["label"]] &
-                                keyphrase_texts[node2["label"]])) /
-                      max(len(keyphrase_texts[node1["label"]]), 1))
-        if confidence >= referral_confidence:
-            graph["edges"].append({
-                "source": node1["id"],
-                "target": node2["id"],
-                "confidence": confidence
-            })
-
-    return graph
+    return {"nodes": nodes, "edges": edges, "referral_confidence": referral_confidence,
+            "relevance_threshold": relevance_threshold, "support_threshold": support_threshold}

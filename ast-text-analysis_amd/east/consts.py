@@ -1,71 +1,45 @@
 # -*- coding: utf-8 -*-
-"""String enums of the EAST surface (names/values as in reference east/consts.py:6-74)."""
+"""Names and values of the EAST option strings (the values a user passes to the reference:
+east/consts.py:6-74).  Each group is a read-only namespace that can be iterated."""
 
 
-class _Enum(object):
-    def __iter__(self):
-        for k in dir(self):
-            if not k.startswith("_"):
-                yield getattr(self, k)
+class _Group(object):
+    """Immutable bag of named string constants; iterating yields the values."""
 
-    def __setattr__(self, key, value):
+    def __init__(self, **values):
+        object.__setattr__(self, "_values", dict(values))
+        for name, value in values.items():
+            object.__setattr__(self, name, value)
+
+    def __setattr__(self, name, value):
         raise AttributeError("constants are immutable")
 
+    def __iter__(self):
+        return iter(sorted(self._values.values(), key=str))
 
-class _TraversalOrder(_Enum):
-    DEPTH_FIRST_PRE_ORDER = "depth-first|pre-order"
-    DEPTH_FIRST_POST_ORDER = "depth-first|post-order"
-    BREADTH_FIRST = "breadth-first"
-
-
-class _String(_Enum):
-    UNICODE_SPECIAL_SYMBOLS_START = 0x0A00
+    def __contains__(self, value):
+        return value in self._values.values()
 
 
-class _RelevanceMeasure(_Enum):
-    AST = "AST"
-    COSINE = "cosine"
+# order in which AST.traverse() visits nodes (base.py:28-34)
+TraversalOrder = _Group(DEPTH_FIRST_PRE_ORDER="depth-first|pre-order",
+                        DEPTH_FIRST_POST_ORDER="depth-first|post-order",
+                        BREADTH_FIRST="breadth-first")
 
+# first code point of the per-string terminators (asts/utils.py:25-40)
+String = _Group(UNICODE_SPECIAL_SYMBOLS_START=0x0A00)
 
-class _ASTAlgorithm(_Enum):
-    AST_LINEAR = "ast_linear"
-    AST_NAIVE = "ast_naive"
-    EASA = "easa"
-    EASA_HIP = "easa_hip"      # new: explicit name of the MI355X backend
+# -s option of the CLI
+RelevanceMeasure = _Group(AST="AST", COSINE="cosine")
 
+# -a option of the CLI / second argument of AST.get_ast; "easa_hip" names the MI355X backend explicitly
+ASTAlgorithm = _Group(EASA="easa", AST_LINEAR="ast_linear", AST_NAIVE="ast_naive", EASA_HIP="easa_hip")
 
-class _TermWeighting(_Enum):
-    TF = "tf"
-    TF_IDF = "tf-idf"
+# -w / -v options (cosine measure only; kept so that option parsing stays compatible)
+TermWeighting = _Group(TF="tf", TF_IDF="tf-idf")
+VectorSpace = _Group(WORDS="words", STEMS="stems", LEMMATA="lemmata")
 
-
-class _VectorSpace(_Enum):
-    WORDS = "words"
-    STEMS = "stems"
-    LEMMATA = "lemmata"
-
-
-class _Language(_Enum):
-    DANISH = "danish"
-    DUTCH = "dutch"
-    ENGLISH = "english"
-    FINNISH = "finnish"
-    FRENCH = "french"
-    GERMAN = "german"
-    HUNGARIAN = "hungarian"
-    ITALIAN = "italian"
-    NORWEGIAN = "norwegian"
-    PORTUGUESE = "portuguese"
-    ROMANIAN = "romanian"
-    RUSSIAN = "russian"
-    SPANISH = "spanish"
-    SWEDISH = "swedish"
-
-
-TraversalOrder = _TraversalOrder()
-String = _String()
-RelevanceMeasure = _RelevanceMeasure()
-ASTAlgorithm = _ASTAlgorithm()
-TermWeighting = _TermWeighting()
-VectorSpace = _VectorSpace()
-Language = _Language()
+# -l option
+Language = _Group(**{name.upper(): name for name in (
+    "danish", "dutch", "english", "finnish", "french", "german", "hungarian", "italian",
+    "norwegian", "portuguese", "romanian", "russian", "spanish", "swedish")})

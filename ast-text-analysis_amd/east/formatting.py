@@ -1,84 +1,75 @@
 # -*- coding: utf-8 -*-
-"""Table and graph output formats (reference east/formatting.py:4-80, with the
-documented behaviour: the reference's format_table references an undefined name and
-its graph2edges indexes nodes by list position, which breaks once a node was filtered)."""
+"""Text renderings of the keyphrase table and the keyphrase graph.
+
+Byte-for-byte the outputs of the reference's east/formatting.py (table2xml, table2csv,
+graph2gml, graph2edges) -- pinned by fixtures generated from it -- with two documented fixes:
+format_table works (the reference refers to an undefined name) and graph2edges looks nodes up
+by id (the reference indexes the node list, which breaks once a node was filtered out).
+"""
+
+_SCORE = "%.3f"
 
 
 def format_table(table, format):
-    if format == "xml":
-        return table2xml(table)
-    elif format == "csv":
-        return table2csv(table)
-    else:
-        raise Exception("Unknown table format: '%s'. "
-                        "Please use one of: 'xml', 'csv'." % format)
+    renderers = {"xml": table2xml, "csv": table2csv}
+    if format not in renderers:
+        raise Exception("Unknown table format: '%s'. Please use one of: 'xml', 'csv'." % format)
+    return renderers[format](table)
 
 
 def table2xml(keyphrases_table):
-    res = "<table>\n"
-    for keyphrase in sorted(keyphrases_table.keys()):
-        res += '  <keyphrase value="%s">\n' % keyphrase
-        for text in sorted(keyphrases_table[keyphrase].keys()):
-            res += '    <text name="%s">' % text
-            res += '%.3f' % keyphrases_table[keyphrase][text]
-            res += '</text>\n'
-        res += '  </keyphrase>\n'
-    res += "</table>\n"
-    return res
+    """<table> / <keyphrase value=..> / <text name=..>score</text>, keyphrases and texts sorted."""
+    lines = ["<table>"]
+    for keyphrase in sorted(keyphrases_table):
+        row = keyphrases_table[keyphrase]
+        lines.append('  <keyphrase value="%s">' % keyphrase)
+        lines.extend('    <text name="%s">%s</text>' % (text, _SCORE % row[text]) for text in sorted(row))
+        lines.append("  </keyphrase>")
+    lines.append("</table>")
+    return "\n".join(lines) + "\n"
+
+
+def _csv_quote(value):
+    return '"%s"' % value.replace('"', "'")
 
 
 def table2csv(keyphrases_table):
-
-    def quote(s):
-        return '"' + s.replace('"', "'") + '"'
-
-    keyphrases = sorted(keyphrases_table.keys())
-    texts = sorted(keyphrases_table[keyphrases[0]].keys())
-    res = "," + ",".join(map(quote, keyphrases)) + "\n"  # Heading
+    """Header row of quoted keyphrases, then one row per text: "name",score,score,..."""
+    keyphrases = sorted(keyphrases_table)
+    texts = sorted(keyphrases_table[keyphrases[0]])
+    rows = ["," + ",".join(_csv_quote(k) for k in keyphrases)]
     for text in texts:
-        scores = ["%.3f" % keyphrases_table[keyphrase][text] for keyphrase in keyphrases]
-        res += (quote(text) + "," + ",".join(scores) + "\n")
-    return res
+        scores = [_SCORE % keyphrases_table[k][text] for k in keyphrases]
+        rows.append(",".join([_csv_quote(text)] + scores))
+    return "\n".join(rows) + "\n"
 
 
 def format_graph(graph, format):
-    if format == "gml":
-        return graph2gml(graph)
-    elif format == "edges":
-        return graph2edges(graph)
-    else:
-        raise Exception("Unknown graph format: '%s'. "
-                        "Please use one of: 'gml', 'edges'." % format)
+    renderers = {"gml": graph2gml, "edges": graph2edges}
+    if format not in renderers:
+        raise Exception("Unknown graph format: '%s'. Please use one of: 'gml', 'edges'." % format)
+    return renderers[format](graph)
 
 
 def graph2edges(graph):
-    """`label -> label, label` lines (formatting.py:52-64); nodes are looked up by id."""
-    res = ""
-    labels = {node["id"]: node["label"] for node in graph["nodes"]}
-    node_edges = {}
+    """One line per source node: `label -> label, label`, in order of first appearance."""
+    label_of = dict((node["id"], node["label"]) for node in graph["nodes"])
+    targets = {}
     for edge in graph["edges"]:
-        source_label = labels[edge["source"]]
-        target_label = labels[edge["target"]]
-        if source_label not in node_edges:
-            node_edges[source_label] = []
-        node_edges[source_label].append(target_label)
-    for node in node_edges:
-        res += "%s -> %s\n" % (node, ", ".join(node_edges[node]))
-    return res
+        targets.setdefault(label_of[edge["source"]], []).append(label_of[edge["target"]])
+    return "".join("%s -> %s\n" % (source, ", ".join(found)) for source, found in targets.items())
 
 
 def graph2gml(graph):
-    """formatting.py:67-80."""
-    res = "graph\n[\n"
-    res += "  directed 1\n"
-    res += "  referral_confidence %.2f\n" % graph["referral_confidence"]
-    res += "  relevance_threshold %.2f\n" % graph["relevance_threshold"]
-    res += "  support_threshold %i\n" % graph["support_threshold"]
+    """Graph Modelling Language: header with the three thresholds, a node block per node, an edge block per edge."""
+    out = ["graph", "[", "  directed 1",
+           "  referral_confidence %.2f" % graph["referral_confidence"],
+           "  relevance_threshold %.2f" % graph["relevance_threshold"],
+           "  support_threshold %i" % graph["support_threshold"]]
     for node in graph["nodes"]:
-        res += ('  node\n  [\n    id %i\n    label "%s"\n  ]\n' %
-                (node["id"], node["label"]))
+        out += ["  node", "  [", "    id %i" % node["id"], '    label "%s"' % node["label"], "  ]"]
     for edge in graph["edges"]:
-        res += ('  edge\n  [\n    source %i\n    target %i\n    confidence %.2f\n  ]\n' %
-                (edge["source"], edge["target"], edge["confidence"]))
-    res += "]\n"
-    return res
+        out += ["  edge", "  [", "    source %i" % edge["source"], "    target %i" % edge["target"],
+                "    confidence %.2f" % edge["confidence"], "  ]"]
+    out.append("]")
+    return "\n".join(out) + "\n"
