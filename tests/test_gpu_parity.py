@@ -605,3 +605,32 @@ def test_many_small_documents(hip, oracle):
             assert np.array_equal(t[name], getattr(o, name)), (name, d)
         for k, kp in enumerate(kps):
             assert table[k, d] == o.score(kp, fast=True), (d, kp)
+
+
+def test_half_gib_symbols(hip):
+    """Maximum-size leg: one document of 2^29 symbols (a quarter of the 2^31 index range; 20 GB arena).
+    Checked through size-independent properties: permutation checksums, and on 2 M sampled ranks
+    the exact LCP plus the order of the first differing symbol."""
+    from east import hip_backend, synthetic
+    n = 1 << 29
+    rng = np.random.default_rng(29)
+    sym, m = synthetic.direct_document(rng, n)
+    index = hip_backend.HipIndex()
+    index.build(sym, np.array([0, n]), np.array([m]))
+    info = index.info()
+    assert info["n_total"] == n and info["dc3_levels"] >= 1
+    t = index.tables(0, names=("suftab", "lcptab"))
+    sa, lcp = t["suftab"], t["lcptab"]
+    assert int(sa.sum()) == n * (n - 1) // 2
+    squares = int((sa.astype(np.uint64) * sa.astype(np.uint64)).sum(dtype=np.uint64))      # mod 2^64
+    assert squares == ((n - 1) * n * (2 * n - 1) // 6) % (1 << 64)
+    r = np.sort(rng.integers(1, n, size=2_000_000))
+    a, b, h = sa[r - 1], sa[r], lcp[r]
+    pad = np.concatenate([sym.astype(np.int64), np.full(64, -1, dtype=np.int64)])
+    assert (pad[a + h] < pad[b + h]).all()
+    for off in range(int(h.max())):
+        sel = h > off
+        assert (pad[a[sel] + off] == pad[b[sel] + off]).all()
+    qs, qo = synthetic.keyphrases(rng, sym[: 1 << 20], 100)
+    table = index.score_table(qs, qo, True)
+    assert (table >= 0).all() and (table <= 1).all() and (table[0::2] > 0).all()
