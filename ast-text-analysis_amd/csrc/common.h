@@ -71,7 +71,7 @@ struct Arena {
 };
 
 struct Stats {
-    i64 levels = 0, levels_resolved = 0, merge_elems = 0, radix_passes = 0, radix_elems = 0, radix_elem_bytes = 0;
+    i64 levels = 0, levels_resolved = 0, refine_rounds = 0, window_sorted = 0, merge_elems = 0, radix_passes = 0, radix_elems = 0, radix_elem_bytes = 0;
     i64 radix_elems_u32 = 0, radix_elems_u64 = 0, radix_passes_u32 = 0, radix_passes_u64 = 0;
 };
 
@@ -147,6 +147,13 @@ static inline int bit_width_u32(u32 x) { int b = 0; while (x) { b++; x >>= 1; } 
     } while (0)
 
 // ---------------------------------------------------------- device utils ----
+__device__ __forceinline__ u64 load_u64_unaligned(const uint8_t *p)
+{
+    u64 x;
+    __builtin_memcpy(&x, p, 8);
+    return x;
+}
+
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
 

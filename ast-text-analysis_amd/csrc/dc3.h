@@ -30,6 +30,10 @@ __device__ __forceinline__ u32 dc3_sample_pos(u32 t, u32 n0)
     return t < n0 ? 3u * t + 1u : 3u * (t - n0) + 2u;
 }
 
+// Level 0 on the byte stream runs either over the DC3 sample (element t = sample number, n0 > 0)
+// or over ALL suffixes (n0 == 0: element t = text position), see window_suffix_sort.
+__device__ __forceinline__ u32 lvl0_pos(u32 t, u32 n0) { return n0 ? dc3_sample_pos(t, n0) : t; }
+
 // ---- step 1: keys -----------------------------------------------------------
 template <class K>
 __global__ __launch_bounds__(BLOCK) void dc3_triple_keys_kernel(const u32 *__restrict__ s, u32 n0,
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_window_keys_kernel(const uint8_t *_
     const u32 u = blockIdx.x * BLOCK + threadIdx.x;
     if (u >= n02) return;
     const u32 q = u >> 1, r = u & 1u;
-    const u32 p = 3u * q + 1u + r;
+    const u32 p = n0 ? 3u * q + 1u + r : u;         // text order either way (the sort is stable)
     u64 lo8, hi8;                                   // w <= 12 symbols: two unaligned 8-byte loads
     __builtin_memcpy(&lo8, s8 + p, 8);
     __builtin_memcpy(&hi8, s8 + p + 8, 8);
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_window_keys_kernel(const uint8_t *_
         key = (key << spare) | (K)(x >> (b - spare));
     }
     keys[u] = key;
-    vals[u] = r ? n0 + q : q;
+    vals[u] = n0 ? (r ? n0 + q : q) : u;
 }
 
 template <class K> struct KeyNeqWindowIn {
@@ -269,11 +273,11 @@ __global__ __launch_bounds__(BLOCK) void dc3_resolve_ties_text_kernel(const u32 
     while (a > 0 && !starts(a) && i - a <= RESOLVE_MAX_GROUP) a--;
     while (b < n02 && !starts(b) && b - i <= RESOLVE_MAX_GROUP) b++;
     if (b - a > RESOLVE_MAX_GROUP) { atomicOr(fail, 1u); return; }
-    const u32 p = dc3_sample_pos(t, n0);
+    const u32 p = lvl0_pos(t, n0);
     u32 r = 0;
     for (u32 x = a; x < b; x++) {
         if (x == i) continue;
-        const u32 p2 = dc3_sample_pos(sorted_vals[x], n0);
+        const u32 p2 = lvl0_pos(sorted_vals[x], n0);
         bool decided = false, less = false;                 // less: suffix p2 < suffix p
         for (u32 h = 0; h < RESOLVE_MAX_LEN && !decided; h += 8) {
             u64 u, v;
@@ -309,6 +313,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_rank_kernel(const u32 *__restrict__
 }
 
 static size_t g_rank_bucket_bytes = (size_t)192 << 20;      // east_hip_debug_set_rank_bucket_bytes (tests)
+static bool g_window_sort = true;                            // east_hip_debug_set_window_sort (tests)
 
 // Beyond the Infinity Cache (R12 > ~192 MB) the random 4-byte stores above each cost a
 // read-modify-write of a 64-byte sector in HBM.  Then the (slot, rank) pairs are first
@@ -735,12 +740,144 @@ static const u32 *dc3_sort_and_name(Ctx &ctx, SortBufs<K> &sb, u32 n02, int bits
 
 // s8 (level 0 of an EASA build with sigma_text <= 254): the byte stream; `s` is then not read at all.
 // lcp_out (with s8 only): also emit the LCP table of the suffix array (single document).
+// ---- step 2c: refinement of tied names by further windows (level 0, byte stream) -------------
+// Natural-language text repeats words and phrases, so a third or more of the samples can share
+// their w-symbol name and a whole DC3 recursion would follow.  Instead only the tied samples are
+// refined: keyed by (their group, the NEXT window of symbols) and sorted -- the groups stay where
+// they are, their members get ordered by the next symbols, the naming predicate is updated in
+// place.  A few rounds cover a whole 3-word string; whatever is still tied is then ordered
+// directly (dc3_resolve_ties_text_kernel) or, failing that, the refined names feed the normal
+// recursion (any order-preserving name over a window that covers the triple is a valid DC3 name).
+template <class Starts>
+__global__ __launch_bounds__(BLOCK) void dc3_flags_kernel(Starts starts, u32 n02, u32 *__restrict__ flags)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n02) flags[i] = starts(i);
+}
+
+struct FlagArrIn {                              // the naming predicate once it has been materialised
+    const u32 *flags;
+    __device__ __forceinline__ u32 operator()(u32 i) const { return flags[i]; }
+};
+
+struct TiedIn {                                 // 1 where sorted sample i shares its name; defined on [0, n]
+    const u32 *flags;
+    u32 n;
+    __device__ __forceinline__ u32 operator()(u32 i) const
+    {
+        return (i < n && (!flags[i] || (i + 1 < n && !flags[i + 1]))) ? 1u : 0u;
+    }
+};
+
+__global__ __launch_bounds__(BLOCK) void dc3_compact_tied_kernel(const u32 *__restrict__ flags,
+                                                                 const u32 *__restrict__ order,
+                                                                 const u32 *__restrict__ slot_ex, u32 n02,
+                                                                 u32 *__restrict__ slots, u32 *__restrict__ elems,
+                                                                 u32 *__restrict__ group_start)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n02) return;
+    if (!flags[i] || (i + 1 < n02 && !flags[i + 1])) {
+        const u32 j = slot_ex[i];
+        slots[j] = i;
+        elems[j] = order[i];
+        group_start[j] = flags[i];
+    }
+}
+
+// key = (dense group number << w2*b) | next window of w2 symbols at offset `depth`
+__global__ __launch_bounds__(BLOCK) void dc3_refine_keys_kernel(const uint8_t *__restrict__ s8,
+                                                                const u32 *__restrict__ elems,
+                                                                const u32 *__restrict__ group, u32 n_tied, u32 n0,
+                                                                u32 depth, int w2, int b, u32 term_first,
+                                                                u64 *__restrict__ keys, u32 *__restrict__ vals)
+{
+    const u32 j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= n_tied) return;
+    const u32 p = lvl0_pos(elems[j], n0) + depth;
+    u64 lo8, hi8;
+    __builtin_memcpy(&lo8, s8 + p, 8);
+    __builtin_memcpy(&hi8, s8 + p + 8, 8);
+    u64 key = group[j];
+    bool ended = false;
+    for (int i = 0; i < w2; i++) {
+        const u32 byte = (u32)((i < 8 ? lo8 >> (8 * i) : hi8 >> (8 * (i - 8))) & 0xFFu);
+        const u32 x = ended ? 0u : byte;
+        ended = ended || x == 0xFFu;
+        key = (key << b) | (u64)(x == 0xFFu ? term_first : x);
+    }
+    keys[j] = key;
+    vals[j] = j;
+}
+
+// the tied slots receive their members in refined order; the naming predicate is updated
+__global__ __launch_bounds__(BLOCK) void dc3_refine_writeback_kernel(const u64 *__restrict__ keys,
+                                                                     const u32 *__restrict__ vals,
+                                                                     const u32 *__restrict__ slots,
+                                                                     const u32 *__restrict__ elems, u32 n_tied,
+                                                                     u64 rep_t, u64 ones, u64 highs,
+                                                                     u32 *__restrict__ order, u32 *__restrict__ flags)
+{
+    const u32 r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n_tied) return;
+    const u64 k = keys[r];
+    const u64 x = k ^ rep_t;
+    const bool has_term = ((x - ones) & ~x & highs) != 0;       // a terminator inside the window: unique
+    const u32 slot = slots[r];
+    order[slot] = elems[vals[r]];
+    flags[slot] = (r == 0 || has_term || k != keys[r - 1]) ? 1u : 0u;
+}
+
+// LCP table straight from the sorted window keys (all-suffix mode, one document): neighbours with
+// different keys share exactly the leading symbol fields the two keys have in common, cut at the
+// first terminator field (equal terminator codes are two DIFFERENT terminators) -- no text is
+// touched.  Only neighbours whose whole window agrees (the tied ones, reordered in place since)
+// read their suffixes, from offset w on.  Same cap rule as lcp8_kernel.
+template <class K>
+__global__ __launch_bounds__(BLOCK) void lvl0_lcp_keys_kernel(KeyNeqWindowIn<K> f, int w, int b, int spare,
+                                                              const uint8_t *__restrict__ s8,
+                                                              const u32 *__restrict__ sa, u32 n,
+                                                              u32 *__restrict__ lcp, u32 *__restrict__ capped)
+{
+    const u32 r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    if (r == 0) { lcp[0] = 0; return; }
+    const K k = f.keys[r];
+    const u64 d = (u64)(k ^ f.keys[r - 1]);
+    u32 mism = (u32)w;                                   // leading symbol fields in common
+    if (d) {
+        const int hb = 63 - __builtin_clzll(d);
+        if (hb >= spare) mism = (u32)(w - 1 - (hb - spare) / b);
+    }
+    const K x = k ^ f.rep_t;
+    const u64 tz = (u64)((K)(x - f.ones) & ~x & f.highs);    // at most one field holds the terminator code
+    const u32 term = tz ? (u32)(w - 1 - (__builtin_ctzll(tz) - spare) / b) : (u32)w;
+    u32 h = mism < term ? mism : term;
+    if (h == (u32)w && d == 0) {                         // the whole window agrees: continue on the text
+        const u32 i = sa[r - 1], j = sa[r];
+        while (true) {
+            const u64 xa = load_u64_unaligned(s8 + i + h), xb = load_u64_unaligned(s8 + j + h);
+            const u64 dd = xa ^ xb, z = ~xa;
+            const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+            const u32 mm = dd ? (u32)__builtin_ctzll(dd) >> 3 : 8u;
+            const u32 tt = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
+            const u32 step = mm < tt ? mm : tt;
+            h += step;
+            if (step < 8u || h >= LCP_DIRECT_CAP) break;
+        }
+        if (h >= LCP_DIRECT_CAP) { h = LCP_CAP_MARK; atomicOr(capped, 1u); }
+    }
+    lcp[r] = h;
+}
+
+#define REFINE_MAX_ROUNDS 6
+
 // Level 0 on the byte stream: window keys, sort, count the distinct names; unique names or a few
 // ties ordered on the text make sa12 final (returns true, no name string is ever written).
 // Otherwise the names are scanned and scattered into s12 for the recursion (returns false).
 template <class K>
 static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w, int bt, u32 term_first, u32 *sa12,
-                             u32 *s12, u32 &n_names)
+                             u32 *s12, u32 &n_names, u32 *lcp_out = nullptr, u32 *lcp_capped = nullptr)
 {
     Arena &ar = *ctx.arena;
     const u32 g02 = ceil_div_u32(n02, BLOCK);
@@ -753,6 +890,13 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     const int r = radix_sort_pairs<K>(ctx, sb, n02, w * bt + spare);
     const KeyNeqWindowIn<K> starts = KeyNeqWindowIn<K>::make(sb.keys[r], w, bt, spare, term_first);
     const u32 *sorted_vals = sb.vals[r];
+    // all-suffix mode, one document: once sa12 holds the final order, the LCP table follows from the keys
+    auto finish = [&]() {
+        if (lcp_out)
+            LAUNCH_NAMED(ctx, "lvl0_lcp_keys_kernel", (lvl0_lcp_keys_kernel<K>), g02, starts, w, bt, spare, s8,
+                         (const u32 *)sa12, n02, lcp_out, lcp_capped);
+        return true;
+    };
 
     // number of distinct names = sum of the naming predicate (a reduction, not yet a scan)
     const u32 nb = ceil_div_u32(n02, SCAN_TILE);
@@ -770,7 +914,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         n_names = (u32)total_names;
         if (n_names == n02) {                          // unique names: the sorted order is SA12 already
             HIP_CHECK(hipMemcpyAsync(sa12, sorted_vals, (size_t)n02 * sizeof(u32), hipMemcpyDeviceToDevice, ctx.stream));
-            return true;
+            return finish();
         }
         if (n02 - n_names <= n02 / 8) {                // few ties: order them on the text
             u32 *fail = ar.alloc<u32>(1);
@@ -782,15 +926,123 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             HIP_CHECK(hipStreamSynchronize(ctx.stream));
             if (!h_fail) {
                 if (ctx.stats) ctx.stats->levels_resolved++;
-                return true;
+                return finish();
             }
         }
     }
-    // recursion ahead: names by an inclusive scan of the predicate, scattered into the name string
+    // many ties (natural language): refine the tied samples by further windows, a few rounds
+    u32 *order = sb.vals[r];                           // current order of the samples (refined in place)
+    u32 *flags = ar.alloc<u32>(n02);                   // the naming predicate, materialised
+    LAUNCH_NAMED(ctx, "dc3_flags_kernel", (dc3_flags_kernel<KeyNeqWindowIn<K>>), g02, starts, n02, flags);
+    {
+        const size_t mark_rounds = ar.mark();
+        u32 *slot_ex = ar.alloc<u32>((size_t)n02 + 1);
+        const u32 cap_tied = (u32)(0.6 * n02) + 1;     // refinement is only tried below this share of ties
+        u32 *slots = ar.alloc<u32>(cap_tied), *elems = ar.alloc<u32>(cap_tied);
+        u32 *gstart = ar.alloc<u32>(cap_tied), *group = ar.alloc<u32>(cap_tied);
+        SortBufs<u64> rb;
+        for (int k = 0; k < 2; k++) { rb.keys[k] = ar.alloc<u64>(cap_tied); rb.vals[k] = ar.alloc<u32>(cap_tied); }
+        if (ctx.dry) {                                  // sizing run: the transient buffers of one round
+            device_scan<TiedIn, false>(ctx, TiedIn{flags, n02}, n02 + 1, slot_ex);
+            (void)radix_sort_pairs<u64>(ctx, rb, cap_tied, 8);
+        }
+        u32 depth = (u32)w, prev_tied = n02;
+        for (int round = 0; round < REFINE_MAX_ROUNDS && !ctx.dry; round++) {
+            device_scan<TiedIn, false>(ctx, TiedIn{flags, n02}, n02 + 1, slot_ex);
+            u32 n_tied = 0;
+            HIP_CHECK(hipMemcpyAsync(&n_tied, slot_ex + n02, 4, hipMemcpyDeviceToHost, ctx.stream));
+            HIP_CHECK(hipStreamSynchronize(ctx.stream));
+            if (n_tied == 0) {
+                HIP_CHECK(hipMemcpyAsync(sa12, order, (size_t)n02 * sizeof(u32), hipMemcpyDeviceToDevice, ctx.stream));
+                if (ctx.stats) ctx.stats->levels_resolved++;
+                ar.release(mark_rounds);
+                return finish();
+            }
+            if (round > 0 && n_tied <= n02 / 4) {       // few enough: order the rest directly
+                u32 *fail = ar.alloc<u32>(1);
+                u32 h_fail = 0;
+                HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
+                LAUNCH_NAMED(ctx, "dc3_resolve_ties_text_kernel", (dc3_resolve_ties_text_kernel<FlagArrIn>), g02,
+                             (const u32 *)order, FlagArrIn{flags}, s8, n0, n02, sa12, fail);
+                HIP_CHECK(hipMemcpyAsync(&h_fail, fail, sizeof(u32), hipMemcpyDeviceToHost, ctx.stream));
+                HIP_CHECK(hipStreamSynchronize(ctx.stream));
+                if (!h_fail) {
+                    if (ctx.stats) ctx.stats->levels_resolved++;
+                    ar.release(mark_rounds);
+                    return finish();
+                }
+            }
+            if (n_tied >= cap_tied || n_tied > prev_tied - prev_tied / 4) break;      // not worth another round
+            prev_tied = n_tied;
+            const u32 gt = ceil_div_u32(n_tied, BLOCK);
+            LAUNCH(ctx, dc3_compact_tied_kernel, g02, (const u32 *)flags, (const u32 *)order, (const u32 *)slot_ex, n02,
+                   slots, elems, gstart);
+            device_scan<ArrIn, true>(ctx, ArrIn{gstart}, n_tied, group);
+            u32 n_groups = 0;
+            HIP_CHECK(hipMemcpyAsync(&n_groups, group + (n_tied - 1), 4, hipMemcpyDeviceToHost, ctx.stream));
+            HIP_CHECK(hipStreamSynchronize(ctx.stream));
+            const int gbits = bit_width_u32(n_groups);
+            const int w2 = std::min(12, (64 - gbits) / bt);
+            if (w2 < 1) break;
+            LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)elems, (const u32 *)group, n_tied, n0, depth, w2, bt,
+                   term_first, rb.keys[0], rb.vals[0]);
+            const int rr = radix_sort_pairs<u64>(ctx, rb, n_tied, gbits + w2 * bt);
+            const KeyNeqWindowIn<u64> f = KeyNeqWindowIn<u64>::make(nullptr, w2, bt, 0, term_first);
+            LAUNCH(ctx, dc3_refine_writeback_kernel, gt, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr],
+                   (const u32 *)slots, (const u32 *)elems, n_tied, f.rep_t, f.ones, f.highs, order, flags);
+            depth += (u32)w2;
+            if (ctx.stats) ctx.stats->refine_rounds++;
+        }
+        ar.release(mark_rounds);
+    }
+    if (!s12) return false;                            // all-suffix mode: the caller falls back to DC3
+    // recursion ahead: names by an inclusive scan of the (refined) predicate, scattered into the name string
     u32 *names = ar.alloc<u32>(n02);
-    device_scan<KeyNeqWindowIn<K>, true>(ctx, starts, n02, names);
-    LAUNCH(ctx, dc3_scatter_names_kernel, ceil_div_u32((u64)n02 + 3, BLOCK), sorted_vals, (const u32 *)names, n02, s12);
+    device_scan<FlagArrIn, true>(ctx, FlagArrIn{flags}, n02, names);
+    if (!ctx.dry) {
+        HIP_CHECK(hipMemcpyAsync(&n_names, names + (n02 - 1), 4, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    }
+    LAUNCH(ctx, dc3_scatter_names_kernel, ceil_div_u32((u64)n02 + 3, BLOCK), (const u32 *)order, (const u32 *)names, n02,
+           s12);
     return false;
+}
+
+// Width of the level-0 name window.  Widest window: names almost unique (sigma^w >= 64 n) within
+// 64-bit keys; but if the window that still fits 32-bit keys leaves only a few per cent of ties
+// (sigma^w >= 4 n), the cheaper sort wins and the tie resolution absorbs the difference.
+static int lvl0_window(u32 n, int bt, u32 term_first)
+{
+    int w = 3;
+    const int w_max = 64 / bt < 12 ? 64 / bt : 12;
+    double reach = (double)term_first * term_first * term_first;
+    while (w < w_max && reach < 64.0 * (double)n) { reach *= term_first; w++; }
+    const int w32 = 32 / bt;
+    if (w32 >= 3 && w32 < w) {
+        // the spare bits of the last digit hold the top bits of one more symbol: that many more buckets
+        const int spare32 = std::min(((w32 * bt + 7) / 8) * 8 - w32 * bt, bt - 1);
+        const double buckets = spare32 > 0 ? (double)((term_first >> (bt - spare32)) + 1u) : 1.0;
+        if (pow((double)term_first, w32) * buckets >= 4.0 * (double)n) w = w32;
+    }
+    return w;
+}
+
+// The fast path for text: ALL n suffixes keyed by their first w symbols, one stable sort, the tied
+// ones refined by further windows / ordered directly -- no sample, no ranks, no merge.  Ordinary text
+// (few and short repeats) ends here; returns false when the ties do not dissolve (long or many
+// repeats), and the caller runs DC3, whose work is bounded whatever the input.
+static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_first, u32 *sa_out, u32 *lcp_out,
+                               u32 *lcp_capped)
+{
+    Arena &ar = *ctx.arena;
+    const size_t mark = ar.mark();
+    const int bt = bit_width_u32(term_first);
+    const int w = lvl0_window(n, bt, term_first);
+    u32 n_names = 0;
+    const bool ok = w * bt <= 32 ? dc3_level0_bytes<u32>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped)
+                     : dc3_level0_bytes<u64>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped);
+    ar.release(mark);
+    return ok;
 }
 
 static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_out, int depth = 0,
@@ -812,20 +1064,7 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
     if (s8) {
         const size_t mark = ar.mark();
         const int bt = bit_width_u32(term_first);          // bits of the compressed level-0 alphabet
-        // widest window: names almost unique (sigma^w >= 64 n) within 64-bit keys; but if the
-        // window that still fits 32-bit keys leaves only a few per cent of ties (sigma^w >= 4 n),
-        // the cheaper sort wins and the tie resolution absorbs the difference
-        int w = 3;
-        const int w_max = 64 / bt < 12 ? 64 / bt : 12;
-        double reach = (double)term_first * term_first * term_first;
-        while (w < w_max && reach < 64.0 * (double)n) { reach *= term_first; w++; }
-        const int w32 = 32 / bt;
-        if (w32 >= 3 && w32 < w) {
-            // the spare bits of the last digit hold the top bits of one more symbol: that many more buckets
-            const int spare32 = std::min(((w32 * bt + 7) / 8) * 8 - w32 * bt, bt - 1);
-            const double buckets = spare32 > 0 ? (double)((term_first >> (bt - spare32)) + 1u) : 1.0;
-            if (pow((double)term_first, w32) * buckets >= 4.0 * (double)n) w = w32;
-        }
+        const int w = lvl0_window(n, bt, term_first);
         const bool final_order = w * bt <= 32
             ? dc3_level0_bytes<u32>(ctx, s8, n0, n02, w, bt, term_first, sa12, s12, n_names)
             : dc3_level0_bytes<u64>(ctx, s8, n0, n02, w, bt, term_first, sa12, s12, n_names);

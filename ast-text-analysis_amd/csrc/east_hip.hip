@@ -250,18 +250,31 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     h->bits0 = bit_width_u32(sigma);
 
     // ---- suffix array of the whole shard, then partition by document -------------
-    const bool fused_lcp = n_docs == 1 && h->use_s8;     // the level-0 merge also emits the LCP table
     u32 *capped = h->code_map + TEXT_SYMBOLS;            // flag words behind the code map
     u32 *status = capped + 1;
     if (!ctx.dry) HIP_CHECK(hipMemsetAsync(capped, 0, 2 * sizeof(u32), ctx.stream));
-    if (n_docs == 1) {
+    // text first goes through the window sort over all suffixes; DC3 is the bounded-work fallback
+    bool window_sorted = false;
+    const size_t mark_sa = ar.mark();
+    SortBufs<u32> sb;                                    // several documents: (document, suffix) pairs
+    if (n_docs > 1)
+        for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n); sb.vals[k] = ar.alloc<u32>(n); }
+    u32 *sa_whole = n_docs == 1 ? h->sa : sb.vals[0];
+    if ((h->use_s8 || ctx.dry) && g_window_sort)         // (the sizing run prices it with 64-bit keys)
+        window_sorted = window_suffix_sort(ctx, h->s8, n, sigma_t + 1, sa_whole, n_docs == 1 ? h->lcp : nullptr, capped);
+    ctx.stats->window_sorted = window_sorted;
+    // one document on the byte stream: the LCP table comes with the suffix array (from the window
+    // keys, or out of the level-0 merge of DC3)
+    const bool fused_lcp = n_docs == 1 && h->use_s8;
+    if (window_sorted) {
+        ctx.stats->levels = 0;
+    } else if (n_docs == 1) {
         ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr,
                                              fused_lcp ? h->lcp : nullptr, capped);
     } else {
-        const size_t mark = ar.mark();
-        SortBufs<u32> sb;
-        for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n); sb.vals[k] = ar.alloc<u32>(n); }
         ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sb.vals[0], 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr);
+    }
+    if (n_docs > 1) {
         const int shift = std::max(0, bit_width_u32(n) - 20);
         const u32 n_coarse = (u32)(((u64)n >> shift) + 1);
         u32 *coarse = ar.alloc<u32>(n_coarse);
@@ -272,8 +285,8 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         const int r = radix_sort_pairs<u32>(ctx, sb, n, bit_width_u32(n_docs - 1));
         if (!ctx.dry)
             HIP_CHECK(hipMemcpyAsync(h->sa, sb.vals[r], (size_t)n * 4, hipMemcpyDeviceToDevice, ctx.stream));
-        ar.release(mark);
     }
+    ar.release(mark_sa);
 
     // n_strings against the terminators actually present (read back at the end of the build)
     if (h->use_s8)
@@ -876,13 +889,14 @@ void *east_hip_stream(east_hip_handle_t h) { return h ? (void *)h->stream : null
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap)
 {
     if (!h || !out) return EAST_HIP_ERR_INVALID;
-    const int64_t v[17] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
+    const int64_t v[19] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
                            (int64_t)h->arena.cap, (int64_t)h->arena.high, h->stats.radix_passes,
                            h->stats.radix_elems, h->stats.radix_elem_bytes, h->stats.radix_passes_u32,
                            h->stats.radix_elems_u32, h->stats.radix_passes_u64, h->stats.radix_elems_u64,
-                           h->stats.levels_resolved, h->stats.merge_elems};
-    for (int i = 0; i < 17 && i < cap; i++) out[i] = v[i];
-    return 17;
+                           h->stats.levels_resolved, h->stats.merge_elems, h->stats.refine_rounds,
+                           h->stats.window_sorted};
+    for (int i = 0; i < 19 && i < cap; i++) out[i] = v[i];
+    return 19;
 }
 
 int east_hip_profile_enable(east_hip_handle_t h, int on)
@@ -979,6 +993,12 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes)
 {
     if (bytes < 0) return EAST_HIP_ERR_INVALID;
     g_rank_bucket_bytes = (size_t)bytes;
+    return EAST_HIP_OK;
+}
+
+int east_hip_debug_set_window_sort(int enabled)
+{
+    g_window_sort = enabled != 0;
     return EAST_HIP_OK;
 }
 

@@ -113,13 +113,6 @@ __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
 // Infinity Cache.  Eight symbols per step: first differing byte by xor + ctz;
 // equal 0xFF bytes are two DIFFERENT terminators, so a 0xFF byte also ends the
 // common prefix.  The stream is padded with 16 zero bytes.
-__device__ __forceinline__ u64 load_u64_unaligned(const uint8_t *p)
-{
-    u64 x;
-    __builtin_memcpy(&x, p, 8);
-    return x;
-}
-
 __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__ s8,
                                                      const u32 *__restrict__ sa, u32 n,
                                                      u32 *__restrict__ lcp, u32 *__restrict__ capped)

@@ -70,6 +70,8 @@ def kernel_bytes(name, info, n, n_q, n_docs):
         "dc3_merge_lcp_tile_kernel": n * 28,
         # 4 B SA read, 2 x 16 B symbol windows, 4 B LCP write per rank (first comparison step)
         "lcp_kernel": n * 40,
+        # byte stream: 4 B SA read, 2 x 8 B symbol windows, 4 B LCP write per rank
+        "lcp8_kernel": n * 24,
         # 4 B LCP read + 4 B annotation write per rank
         "ann_kernel": n * 8,
         # 4 B sorted sample read + one random 4 B rank store per sample
@@ -228,7 +230,7 @@ def main():
             "build_chars_per_s": n_bytes / (float(np.mean(build_ms)) * 1e-3),
             "keyphrase_scores_per_s": K * D / (float(np.mean(score_ms)) * 1e-3),
             "build_algorithmic_GBps": 16.0 * n / (float(np.mean(build_ms)) * 1e-3) / 1e9,
-            "dc3_levels": info["dc3_levels"], "dc3_levels_resolved": info["dc3_levels_resolved"],
+            "dc3_levels": info["dc3_levels"], "dc3_levels_resolved": info["dc3_levels_resolved"], "dc3_refine_rounds": info["refine_rounds"], "window_sorted": info["window_sorted"],
             "radix_passes": info["radix_passes"],
             "roofline": roofline, "roofline_by_kernel": by_kernel,
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in

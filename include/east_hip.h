@@ -168,7 +168,9 @@ void *east_hip_stream(east_hip_handle_t h);
  * moved (sum over passes), [10] bytes of one radix element (key+value) at the
  * widest level, [11] passes and [12] elements with 32-bit keys, [13] passes and
  * [14] elements with 64-bit keys, [15] DC3 levels whose few tied names were
- * ordered directly instead of recursing, [16] suffixes merged (sum over levels).
+ * ordered directly instead of recursing, [16] suffixes merged (sum over levels), [17] rounds of
+ * tie refinement by further windows, [18] 1 if the all-suffix window sort produced the suffix array
+ * (no DC3 level ran; [5] is 0 then).
  */
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap);
 
@@ -201,6 +203,9 @@ int east_hip_debug_suffix_array(int device, const uint32_t *symbols, int64_t n, 
 /* Test knob: rank arrays larger than this many bytes are filled through the bucketed scatter
  * (default 192 MiB, the Infinity Cache); 0 forces the bucketed path on every input. */
 int east_hip_debug_set_rank_bucket_bytes(int64_t bytes);
+/* Test knob: 0 skips the all-suffix window sort, so that every build goes through DC3 (the
+ * fallback for repetitive inputs); 1 (default) restores it. */
+int east_hip_debug_set_window_sort(int enabled);
 /* Host-only: bytes of device arena a build of n_total symbols / n_docs documents
  * reserves (worst case over inputs).  Needs no device. */
 int64_t east_hip_plan_arena_bytes(int64_t n_total, int32_t n_docs);
