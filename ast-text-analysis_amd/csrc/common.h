@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -126,6 +127,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     Arena *arena = nullptr;
     bool dry = false;
+    bool lean = false;          // no tie-refinement rounds (their buffers did not fit the device)
     Stats *stats = nullptr;
     Profiler *prof = nullptr;
 };

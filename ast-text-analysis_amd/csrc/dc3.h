@@ -313,6 +313,8 @@ __global__ __launch_bounds__(BLOCK) void dc3_rank_kernel(const u32 *__restrict__
 }
 
 static size_t g_rank_bucket_bytes = (size_t)192 << 20;      // east_hip_debug_set_rank_bucket_bytes (tests)
+static const bool g_trace = getenv("EAST_HIP_TRACE") != nullptr;   // per-round progress on stderr
+static bool g_force_lean = false;                           // east_hip_debug_set_window_sort(2) (tests)
 static bool g_window_sort = true;                            // east_hip_debug_set_window_sort (tests)
 
 // Beyond the Infinity Cache (R12 > ~192 MB) the random 4-byte stores above each cost a
@@ -740,49 +742,110 @@ static const u32 *dc3_sort_and_name(Ctx &ctx, SortBufs<K> &sb, u32 n02, int bits
 
 // s8 (level 0 of an EASA build with sigma_text <= 254): the byte stream; `s` is then not read at all.
 // lcp_out (with s8 only): also emit the LCP table of the suffix array (single document).
-// ---- step 2c: refinement of tied names by further windows (level 0, byte stream) -------------
-// Natural-language text repeats words and phrases, so a third or more of the samples can share
-// their w-symbol name and a whole DC3 recursion would follow.  Instead only the tied samples are
-// refined: keyed by (their group, the NEXT window of symbols) and sorted -- the groups stay where
-// they are, their members get ordered by the next symbols, the naming predicate is updated in
-// place.  A few rounds cover a whole 3-word string; whatever is still tied is then ordered
-// directly (dc3_resolve_ties_text_kernel) or, failing that, the refined names feed the normal
-// recursion (any order-preserving name over a window that covers the triple is a valid DC3 name).
-template <class Starts>
-__global__ __launch_bounds__(BLOCK) void dc3_flags_kernel(Starts starts, u32 n02, u32 *__restrict__ flags)
-{
-    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n02) flags[i] = starts(i);
-}
+// ---- step 2c: refinement of tied names (level 0, byte stream) ---------------------------------
+// Natural-language text repeats words and phrases, so half of the suffixes can share their
+// w-symbol name.  The tied ones are worked off in rounds, each on the compacted list of what is
+// still tied (`domain`: elem[] = the suffixes in their current order, flag[] = 1 where a group of
+// equal names starts, slot[] = where each sits in the global order):
+//   * small groups (<= REFINE_SMALL_GROUP) are ordered directly on the text, for good;
+//   * the members of larger groups are keyed by (group, the NEXT window of symbols) and radix
+//     sorted -- the groups stay where they are, their members get ordered by the next symbols --
+//     and what is still tied afterwards forms the next, smaller domain.
+// A few rounds cover a whole 3-word string.  If ties survive all rounds (long repeats), the refined
+// names still are valid DC3 names (order-preserving over a window that covers the triple) and feed
+// the recursion; in all-suffix mode the caller falls back to DC3.
+#define REFINE_SMALL_GROUP 8
+#define REFINE_MAX_ROUNDS 8
 
-struct FlagArrIn {                              // the naming predicate once it has been materialised
+struct FlagArrIn {                              // the naming predicate of a compacted domain
     const u32 *flags;
     __device__ __forceinline__ u32 operator()(u32 i) const { return flags[i]; }
 };
 
-struct TiedIn {                                 // 1 where sorted sample i shares its name; defined on [0, n]
-    const u32 *flags;
-    u32 n;
-    __device__ __forceinline__ u32 operator()(u32 i) const
-    {
-        return (i < n && (!flags[i] || (i + 1 < n && !flags[i + 1]))) ? 1u : 0u;
-    }
-};
-
-__global__ __launch_bounds__(BLOCK) void dc3_compact_tied_kernel(const u32 *__restrict__ flags,
-                                                                 const u32 *__restrict__ order,
-                                                                 const u32 *__restrict__ slot_ex, u32 n02,
-                                                                 u32 *__restrict__ slots, u32 *__restrict__ elems,
-                                                                 u32 *__restrict__ group_start)
+// One pass over a domain of m elements.  Untied elements and small groups get their final place
+// in order_g (first domain only: later domains had theirs written by the previous write-back);
+// members of large groups are marked in keep[] for the radix round.  first domain: slot == nullptr
+// (identity), and names_g (sample mode, may be null) receives the naming predicate as refined so far.
+template <class Starts>
+__global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *__restrict__ elem, Starts starts,
+                                                                    const u32 *__restrict__ slot, u32 m,
+                                                                    const uint8_t *__restrict__ s8, u32 n0, u32 depth,
+                                                                    u32 *__restrict__ order_g, u32 *__restrict__ names_g,
+                                                                    u32 *__restrict__ keep, u32 *__restrict__ fail)
 {
-    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n02) return;
-    if (!flags[i] || (i + 1 < n02 && !flags[i + 1])) {
-        const u32 j = slot_ex[i];
-        slots[j] = i;
-        elems[j] = order[i];
-        group_start[j] = flags[i];
+    const u32 j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j > m) return;
+    if (j == m) { keep[m] = 0; return; }           // (the exclusive scan over m + 1 entries yields the total)
+    const u32 e = elem[j];
+    const bool first = slot == nullptr;
+    const u32 start = starts(j);
+    const bool left_same = j > 0 && !start;
+    const bool right_same = j + 1 < m && !starts(j + 1);
+    if (!left_same && !right_same) {
+        keep[j] = 0;
+        if (first) { order_g[j] = e; if (names_g) names_g[j] = 1; }
+        return;
     }
+    u32 a = j, b = j + 1;
+    while (a > 0 && !starts(a) && j - a <= REFINE_SMALL_GROUP) a--;
+    while (b < m && !starts(b) && b - j <= REFINE_SMALL_GROUP) b++;
+    if (b - a > REFINE_SMALL_GROUP) {
+        keep[j] = 1;
+        if (first) { order_g[j] = e; if (names_g) names_g[j] = start; }
+        return;
+    }
+    keep[j] = 0;
+    const u32 p = lvl0_pos(e, n0);
+    u32 r = 0;
+    for (u32 x = a; x < b; x++) {
+        if (x == j) continue;
+        const u32 p2 = lvl0_pos(elem[x], n0);
+        bool decided = false, less = false;                 // less: suffix p2 < suffix p
+        for (u32 h = depth; h < depth + RESOLVE_MAX_LEN && !decided; h += 8) {
+            const u64 u = load_u64_unaligned(s8 + p + h), v = load_u64_unaligned(s8 + p2 + h);
+            const u64 d = u ^ v, z = ~u;
+            const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+            const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+            const u32 term = tz ? (u32)__builtin_ctzll(tz) >> 3 : 8u;
+            if (term < mism) { less = p2 < p; decided = true; }          // both end in (different) terminators
+            else if (mism < 8u) { less = ((v >> (8 * mism)) & 0xFFu) < ((u >> (8 * mism)) & 0xFFu); decided = true; }
+        }
+        if (!decided) { atomicOr(fail, 1u); return; }
+        if (less) r++;
+    }
+    order_g[first ? a + r : slot[a + r]] = e;
+    if (names_g) names_g[first ? j : slot[j]] = 1;
+}
+
+// A repeat too long for the direct ordering leaves its group half written: put the whole domain back
+// the way it was before the classify pass (elem[] and the domain's predicate are untouched by it).
+template <class Starts>
+__global__ __launch_bounds__(BLOCK) void dc3_refine_restore_kernel(const u32 *__restrict__ elem, Starts starts,
+                                                                   const u32 *__restrict__ slot, u32 m,
+                                                                   u32 *__restrict__ order_g, u32 *__restrict__ names_g)
+{
+    const u32 j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    const u32 g = slot ? slot[j] : j;
+    order_g[g] = elem[j];
+    if (names_g) names_g[g] = starts(j);
+}
+
+// the members of large groups, compacted: the radix round's input
+template <class Starts>
+__global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__restrict__ elem, Starts starts,
+                                                                   const u32 *__restrict__ slot,
+                                                                   const u32 *__restrict__ keep,
+                                                                   const u32 *__restrict__ idx, u32 m,
+                                                                   u32 *__restrict__ slot_out, u32 *__restrict__ elem_out,
+                                                                   u32 *__restrict__ group_start)
+{
+    const u32 j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m || !keep[j]) return;
+    const u32 k = idx[j];
+    slot_out[k] = slot ? slot[j] : j;
+    elem_out[k] = elem[j];
+    group_start[k] = starts(j);
 }
 
 // key = (dense group number << w2*b) | next window of w2 symbols at offset `depth`
@@ -810,22 +873,27 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_keys_kernel(const uint8_t *_
     vals[j] = j;
 }
 
-// the tied slots receive their members in refined order; the naming predicate is updated
+// after the sort: the slots of the domain receive their members in refined order (globally and as
+// the next domain's elem[]), and the naming predicate is updated
 __global__ __launch_bounds__(BLOCK) void dc3_refine_writeback_kernel(const u64 *__restrict__ keys,
                                                                      const u32 *__restrict__ vals,
                                                                      const u32 *__restrict__ slots,
                                                                      const u32 *__restrict__ elems, u32 n_tied,
                                                                      u64 rep_t, u64 ones, u64 highs,
-                                                                     u32 *__restrict__ order, u32 *__restrict__ flags)
+                                                                     u32 *__restrict__ order_g, u32 *__restrict__ names_g,
+                                                                     u32 *__restrict__ elem_out, u32 *__restrict__ flag_out)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n_tied) return;
     const u64 k = keys[r];
     const u64 x = k ^ rep_t;
     const bool has_term = ((x - ones) & ~x & highs) != 0;       // a terminator inside the window: unique
-    const u32 slot = slots[r];
-    order[slot] = elems[vals[r]];
-    flags[slot] = (r == 0 || has_term || k != keys[r - 1]) ? 1u : 0u;
+    const u32 slot = slots[r], e = elems[vals[r]];
+    const u32 f = (r == 0 || has_term || k != keys[r - 1]) ? 1u : 0u;
+    order_g[slot] = e;
+    if (names_g) names_g[slot] = f;
+    elem_out[r] = e;
+    flag_out[r] = f;
 }
 
 // LCP table straight from the sorted window keys (all-suffix mode, one document): neighbours with
@@ -870,8 +938,6 @@ __global__ __launch_bounds__(BLOCK) void lvl0_lcp_keys_kernel(KeyNeqWindowIn<K> 
     lcp[r] = h;
 }
 
-#define REFINE_MAX_ROUNDS 6
-
 // Level 0 on the byte stream: window keys, sort, count the distinct names; unique names or a few
 // ties ordered on the text make sa12 final (returns true, no name string is ever written).
 // Otherwise the names are scanned and scattered into s12 for the recursion (returns false).
@@ -885,7 +951,8 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     const int total = ((w * bt + 7) / 8) * 8;
     const int spare = w < 12 ? std::min(total - w * bt, bt - 1) : 0;
     SortBufs<K> sb;
-    for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<K>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
+    // (one spare element each: the idle half later serves the refinement rounds as scratch)
+    for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<K>((size_t)n02 + 1); sb.vals[k] = ar.alloc<u32>((size_t)n02 + 1); }
     LAUNCH(ctx, (dc3_window_keys_kernel<K>), g02, s8, n0, n02, w, bt, spare, term_first, sb.keys[0], sb.vals[0]);
     const int r = radix_sort_pairs<K>(ctx, sb, n02, w * bt + spare);
     const KeyNeqWindowIn<K> starts = KeyNeqWindowIn<K>::make(sb.keys[r], w, bt, spare, term_first);
@@ -930,81 +997,104 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             }
         }
     }
-    // many ties (natural language): refine the tied samples by further windows, a few rounds
-    u32 *order = sb.vals[r];                           // current order of the samples (refined in place)
-    u32 *flags = ar.alloc<u32>(n02);                   // the naming predicate, materialised
-    LAUNCH_NAMED(ctx, "dc3_flags_kernel", (dc3_flags_kernel<KeyNeqWindowIn<K>>), g02, starts, n02, flags);
-    {
+    // many ties (natural language): work the tied ones off in rounds (see step 2c)
+    // (ctx.lean: the device is short of memory for the rounds' buffers -- straight on to the recursion / DC3)
+    u32 *names_g = s12 && !ctx.lean ? ar.alloc<u32>(n02) : nullptr;    // sample mode: the refined naming predicate
+    if (!ctx.lean) {
         const size_t mark_rounds = ar.mark();
-        u32 *slot_ex = ar.alloc<u32>((size_t)n02 + 1);
-        const u32 cap_tied = (u32)(0.6 * n02) + 1;     // refinement is only tried below this share of ties
-        u32 *slots = ar.alloc<u32>(cap_tied), *elems = ar.alloc<u32>(cap_tied);
-        u32 *gstart = ar.alloc<u32>(cap_tied), *group = ar.alloc<u32>(cap_tied);
+        const u32 cap = (u32)(0.6 * n02) + 1;          // a radix round is only tried below this share of the input
+        u32 *keep = (u32 *)sb.keys[r ^ 1], *idx = sb.vals[r ^ 1];      // n02 + 1 entries each, idle since the sort
+        u32 *fail = ar.alloc<u32>(1);
+        u32 *ebuf[3], *sbuf[2], *fbuf[2];
+        for (auto &e : ebuf) e = ar.alloc<u32>(cap);
+        for (auto &e : sbuf) e = ar.alloc<u32>(cap);
+        for (auto &e : fbuf) e = ar.alloc<u32>(cap);
+        u32 *gstart = ar.alloc<u32>(cap), *group = ar.alloc<u32>(cap);
         SortBufs<u64> rb;
-        for (int k = 0; k < 2; k++) { rb.keys[k] = ar.alloc<u64>(cap_tied); rb.vals[k] = ar.alloc<u32>(cap_tied); }
+        for (int k = 0; k < 2; k++) { rb.keys[k] = ar.alloc<u64>(cap); rb.vals[k] = ar.alloc<u32>(cap); }
         if (ctx.dry) {                                  // sizing run: the transient buffers of one round
-            device_scan<TiedIn, false>(ctx, TiedIn{flags, n02}, n02 + 1, slot_ex);
-            (void)radix_sort_pairs<u64>(ctx, rb, cap_tied, 8);
+            device_scan<ArrIn, false>(ctx, ArrIn{keep}, n02 + 1, idx);
+            (void)radix_sort_pairs<u64>(ctx, rb, cap, 8);
+        } else {
+            HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
         }
-        u32 depth = (u32)w, prev_tied = n02;
-        for (int round = 0; round < REFINE_MAX_ROUNDS && !ctx.dry; round++) {
-            device_scan<TiedIn, false>(ctx, TiedIn{flags, n02}, n02 + 1, slot_ex);
-            u32 n_tied = 0;
-            HIP_CHECK(hipMemcpyAsync(&n_tied, slot_ex + n02, 4, hipMemcpyDeviceToHost, ctx.stream));
+        // the current domain: first the whole sorted input (slot = identity, predicate on the keys)
+        u32 m = n02, depth = (u32)w;
+        const u32 *elem = sorted_vals, *slot = nullptr, *flag = nullptr;
+        int e_dom = -1, s_dom = 0, f_dom = 0;           // which of the rotating buffers hold the domain
+        bool done = false;
+        for (int round = 0; round <= REFINE_MAX_ROUNDS && !ctx.dry; round++) {
+            const u32 gm = ceil_div_u32((u64)m + 1, BLOCK);
+            if (!slot)
+                LAUNCH_NAMED(ctx, "dc3_refine_classify_kernel", (dc3_refine_classify_kernel<KeyNeqWindowIn<K>>), gm, elem,
+                             starts, slot, m, s8, n0, depth, sa12, names_g, keep, fail);
+            else
+                LAUNCH_NAMED(ctx, "dc3_refine_classify_kernel", (dc3_refine_classify_kernel<FlagArrIn>), gm, elem,
+                             FlagArrIn{flag}, slot, m, s8, n0, depth, sa12, names_g, keep, fail);
+            device_scan<ArrIn, false>(ctx, ArrIn{keep}, m + 1, idx);
+            u32 h_fail = 0, m_next = 0;
+            HIP_CHECK(hipMemcpyAsync(&m_next, idx + m, 4, hipMemcpyDeviceToHost, ctx.stream));
+            HIP_CHECK(hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, ctx.stream));
             HIP_CHECK(hipStreamSynchronize(ctx.stream));
-            if (n_tied == 0) {
-                HIP_CHECK(hipMemcpyAsync(sa12, order, (size_t)n02 * sizeof(u32), hipMemcpyDeviceToDevice, ctx.stream));
-                if (ctx.stats) ctx.stats->levels_resolved++;
-                ar.release(mark_rounds);
-                return finish();
+            if (g_trace)
+                fprintf(stderr, "[east_hip] level-0 round %d: domain %u of %u, %u in large groups, depth %u%s\n", round, m,
+                        n02, m_next, depth, h_fail ? ", a repeat too long to order directly" : "");
+            if (h_fail) {
+                if (!slot)
+                    LAUNCH(ctx, (dc3_refine_restore_kernel<KeyNeqWindowIn<K>>), gm, elem, starts, slot, m, sa12, names_g);
+                else
+                    LAUNCH(ctx, (dc3_refine_restore_kernel<FlagArrIn>), gm, elem, FlagArrIn{flag}, slot, m, sa12, names_g);
+                break;
             }
-            if (round > 0 && n_tied <= n02 / 4) {       // few enough: order the rest directly
-                u32 *fail = ar.alloc<u32>(1);
-                u32 h_fail = 0;
-                HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
-                LAUNCH_NAMED(ctx, "dc3_resolve_ties_text_kernel", (dc3_resolve_ties_text_kernel<FlagArrIn>), g02,
-                             (const u32 *)order, FlagArrIn{flags}, s8, n0, n02, sa12, fail);
-                HIP_CHECK(hipMemcpyAsync(&h_fail, fail, sizeof(u32), hipMemcpyDeviceToHost, ctx.stream));
-                HIP_CHECK(hipStreamSynchronize(ctx.stream));
-                if (!h_fail) {
-                    if (ctx.stats) ctx.stats->levels_resolved++;
-                    ar.release(mark_rounds);
-                    return finish();
-                }
-            }
-            if (n_tied >= cap_tied || n_tied > prev_tied - prev_tied / 4) break;      // not worth another round
-            prev_tied = n_tied;
-            const u32 gt = ceil_div_u32(n_tied, BLOCK);
-            LAUNCH(ctx, dc3_compact_tied_kernel, g02, (const u32 *)flags, (const u32 *)order, (const u32 *)slot_ex, n02,
-                   slots, elems, gstart);
-            device_scan<ArrIn, true>(ctx, ArrIn{gstart}, n_tied, group);
+            if (m_next == 0) { done = true; break; }
+            if (round == REFINE_MAX_ROUNDS || m_next >= cap || (round > 0 && m_next > m - m / 4)) break;
+            // compact the members of large groups, number their groups, sort by (group, next window)
+            const int e_c = (e_dom + 4) % 3, e_out = (e_dom + 5) % 3;      // the two buffers the domain is not in
+            u32 *slot_c = sbuf[s_dom ^ 1];
+            if (!slot)
+                LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<KeyNeqWindowIn<K>>), gm, elem,
+                             starts, slot, (const u32 *)keep, (const u32 *)idx, m, slot_c, ebuf[e_c], gstart);
+            else
+                LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<FlagArrIn>), gm, elem,
+                             FlagArrIn{flag}, slot, (const u32 *)keep, (const u32 *)idx, m, slot_c, ebuf[e_c], gstart);
+            m = m_next;
+            device_scan<ArrIn, true>(ctx, ArrIn{gstart}, m, group);
             u32 n_groups = 0;
-            HIP_CHECK(hipMemcpyAsync(&n_groups, group + (n_tied - 1), 4, hipMemcpyDeviceToHost, ctx.stream));
+            HIP_CHECK(hipMemcpyAsync(&n_groups, group + (m - 1), 4, hipMemcpyDeviceToHost, ctx.stream));
             HIP_CHECK(hipStreamSynchronize(ctx.stream));
             const int gbits = bit_width_u32(n_groups);
             const int w2 = std::min(12, (64 - gbits) / bt);
             if (w2 < 1) break;
-            LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)elems, (const u32 *)group, n_tied, n0, depth, w2, bt,
+            const u32 gt = ceil_div_u32(m, BLOCK);
+            LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)ebuf[e_c], (const u32 *)group, m, n0, depth, w2, bt,
                    term_first, rb.keys[0], rb.vals[0]);
-            const int rr = radix_sort_pairs<u64>(ctx, rb, n_tied, gbits + w2 * bt);
+            const int rr = radix_sort_pairs<u64>(ctx, rb, m, gbits + w2 * bt);
             const KeyNeqWindowIn<u64> f = KeyNeqWindowIn<u64>::make(nullptr, w2, bt, 0, term_first);
             LAUNCH(ctx, dc3_refine_writeback_kernel, gt, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr],
-                   (const u32 *)slots, (const u32 *)elems, n_tied, f.rep_t, f.ones, f.highs, order, flags);
+                   (const u32 *)slot_c, (const u32 *)ebuf[e_c], m, f.rep_t, f.ones, f.highs, sa12, names_g, ebuf[e_out],
+                   fbuf[f_dom ^ 1]);
+            e_dom = e_out; s_dom ^= 1; f_dom ^= 1;
+            elem = ebuf[e_dom]; slot = sbuf[s_dom]; flag = fbuf[f_dom];
             depth += (u32)w2;
             if (ctx.stats) ctx.stats->refine_rounds++;
         }
         ar.release(mark_rounds);
+        if (done) {
+            if (ctx.stats) ctx.stats->levels_resolved++;
+            return finish();
+        }
     }
     if (!s12) return false;                            // all-suffix mode: the caller falls back to DC3
-    // recursion ahead: names by an inclusive scan of the (refined) predicate, scattered into the name string
+    // recursion ahead: names by an inclusive scan of the refined predicate, scattered into the name string
     u32 *names = ar.alloc<u32>(n02);
-    device_scan<FlagArrIn, true>(ctx, FlagArrIn{flags}, n02, names);
+    if (names_g) device_scan<FlagArrIn, true>(ctx, FlagArrIn{names_g}, n02, names);
+    else device_scan<KeyNeqWindowIn<K>, true>(ctx, starts, n02, names);
     if (!ctx.dry) {
         HIP_CHECK(hipMemcpyAsync(&n_names, names + (n02 - 1), 4, hipMemcpyDeviceToHost, ctx.stream));
         HIP_CHECK(hipStreamSynchronize(ctx.stream));
     }
-    LAUNCH(ctx, dc3_scatter_names_kernel, ceil_div_u32((u64)n02 + 3, BLOCK), (const u32 *)order, (const u32 *)names, n02,
-           s12);
+    LAUNCH(ctx, dc3_scatter_names_kernel, ceil_div_u32((u64)n02 + 3, BLOCK), names_g ? (const u32 *)sa12 : sorted_vals,
+           (const u32 *)names, n02, s12);
     return false;
 }
 
@@ -1061,6 +1151,12 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
 
     // -- sort the sample triples, name them --------------------------------
     u32 n_names = 0;
+    if (ctx.dry && depth == 0 && term_first) {         // sizing run: the byte-stream level 0, priced with 64-bit keys
+        const size_t mark = ar.mark();
+        u32 unused = 0;
+        (void)dc3_level0_bytes<u64>(ctx, nullptr, n0, n02, 5, 12, term_first, sa12, s12, unused);
+        ar.release(mark);
+    }
     if (s8) {
         const size_t mark = ar.mark();
         const int bt = bit_width_u32(term_first);          // bits of the compressed level-0 alphabet

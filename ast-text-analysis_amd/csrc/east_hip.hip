@@ -345,7 +345,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     h->child_built = false;      // childtab_up / down / next_l_index: built on first east_hip_get_tables request
 }
 
-static size_t plan_arena_bytes(u32 n, u32 n_docs)
+static size_t plan_arena_bytes(u32 n, u32 n_docs, bool lean = false)
 {
     east_hip_index tmp;
     Arena dry;
@@ -354,6 +354,7 @@ static size_t plan_arena_bytes(u32 n, u32 n_docs)
     Ctx ctx;
     ctx.arena = &dry;
     ctx.dry = true;
+    ctx.lean = lean;
     ctx.stats = &st;
     build_impl(&tmp, ctx, nullptr, n, n_docs, nullptr, nullptr);
     return dry.high + (1u << 20);
@@ -401,9 +402,18 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     use_device(h);
     h->built = false;
     const u32 n = (u32)n_total;
-    size_t need = plan_arena_bytes(n, (u32)n_docs);
+    const size_t staging_bytes = sym_on_host ? ((size_t)n * 4 + 255) & ~(size_t)255 : 0;
+    size_t need = plan_arena_bytes(n, (u32)n_docs) + staging_bytes;
+    bool lean = g_force_lean;
+    if (!lean && need > h->arena.cap) {
+        // the tie-refinement rounds are the largest consumer: when they do not fit next to what else
+        // lives on the device, build without them (heavy ties then take the DC3 recursion)
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        lean = need > (size_t)(0.92 * (double)(free_b + h->arena.cap));
+    }
+    if (lean) need = plan_arena_bytes(n, (u32)n_docs, true) + staging_bytes;
     u32 *staging = nullptr;
-    if (sym_on_host) need += ((size_t)n * 4 + 255) & ~(size_t)255;
     ensure_arena(h, need);
     if (sym_on_host) {   // raw symbols are staged at the top of the arena
         staging = (u32 *)(h->arena.base + (h->arena.cap - (((size_t)n * 4 + 255) & ~(size_t)255)));
@@ -417,6 +427,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     ctx.arena = &h->arena;
     ctx.stats = &h->stats;
     ctx.prof = &h->prof;
+    ctx.lean = lean;
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));
     build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings);
     HIP_CHECK(hipEventRecord(h->ev1, h->stream));
@@ -999,6 +1010,7 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes)
 int east_hip_debug_set_window_sort(int enabled)
 {
     g_window_sort = enabled != 0;
+    g_force_lean = enabled == 2;
     return EAST_HIP_OK;
 }
 

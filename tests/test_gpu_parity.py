@@ -446,6 +446,27 @@ def test_small_vocabulary_text_tie_refinement_vs_oracle(hip, oracle, seed):
             assert np.array_equal(t[name], getattr(o, name)), (name, d, index.info())
 
 
+def test_lean_build_without_refinement_rounds(hip, oracle):
+    """When the buffers of the tie-refinement rounds do not fit the device, the build runs without
+    them: heavy ties go straight to the DC3 recursion.  Forced here on a small-vocabulary text."""
+    from east import hip_backend, synthetic
+    assert hip.load().east_hip_debug_set_window_sort(2) == 0          # (the autouse fixture restores the default)
+    rng = np.random.default_rng(77)
+    vocab = synthetic.zipf_vocabulary(rng, size=40, exponent=1.0)
+    docs = [synthetic.zipf_document(rng, 200000, vocab) for _ in range(2)]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    index = hip_backend.HipIndex()
+    index.build(sym, off, np.array([d[1] for d in docs]))
+    info = index.info()
+    assert info["refine_rounds"] == 0 and info["window_sorted"] == 0 and info["dc3_levels"] > 1
+    for d in range(2):
+        o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+
+
 @pytest.mark.parametrize("case", ["one_symbol", "period3", "two_copies", "many_copies_multidoc"])
 def test_repetitive_inputs_lcp_beyond_the_direct_cap(hip, oracle, case):
     """Common prefixes far beyond LCP_DIRECT_CAP (16384): the capped ranks are finished by the
