@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 typedef uint32_t u32;

@@ -94,35 +94,34 @@ template <class K> struct KeyNeqTermIn {
 // Same terminator rules as dc3_triple_keys_term_kernel.
 // The key bits left over below the w full symbols (`spare`) take the top bits of symbol w+1:
 // still order-preserving, and it thins the ties out further for free.
-template <class K>
-__global__ __launch_bounds__(BLOCK) void dc3_window_keys_kernel(const uint8_t *__restrict__ s8, u32 n0,
-                                                                u32 n02, int w, int b, int spare,
-                                                                u32 term_first, K *__restrict__ keys,
-                                                                u32 *__restrict__ vals)
-{
-    const u32 u = blockIdx.x * BLOCK + threadIdx.x;
-    if (u >= n02) return;
-    const u32 q = u >> 1, r = u & 1u;
-    const u32 p = n0 ? 3u * q + 1u + r : u;         // text order either way (the sort is stable)
-    u64 lo8, hi8;                                   // w <= 12 symbols: two unaligned 8-byte loads
-    __builtin_memcpy(&lo8, s8 + p, 8);
-    __builtin_memcpy(&hi8, s8 + p + 8, 8);
-    K key = 0;
-    bool ended = false;
-    for (int i = 0; i < w; i++) {
-        const u32 byte = (u32)((i < 8 ? lo8 >> (8 * i) : hi8 >> (8 * (i - 8))) & 0xFFu);
-        const u32 x = ended ? 0u : byte;
-        ended = ended || x == 0xFFu;
-        key = (key << b) | (K)(x == 0xFFu ? term_first : x);
+template <class K> struct WindowSrc {          // the (window key, element) pairs, generated by the first radix pass
+    const uint8_t *s8;
+    u32 n0;
+    int w, b, spare;
+    u32 term_first;
+    __device__ __forceinline__ K key(u32 u) const
+    {
+        const u32 p = n0 ? 3u * (u >> 1) + 1u + (u & 1u) : u;     // text order either way (the sort is stable)
+        u64 lo8, hi8;                               // w <= 12 symbols: two unaligned 8-byte loads
+        __builtin_memcpy(&lo8, s8 + p, 8);
+        __builtin_memcpy(&hi8, s8 + p + 8, 8);
+        K key = 0;
+        bool ended = false;
+        for (int i = 0; i < w; i++) {
+            const u32 byte = (u32)((i < 8 ? lo8 >> (8 * i) : hi8 >> (8 * (i - 8))) & 0xFFu);
+            const u32 x = ended ? 0u : byte;
+            ended = ended || x == 0xFFu;
+            key = (key << b) | (K)(x == 0xFFu ? term_first : x);
+        }
+        if (spare > 0) {
+            const u32 byte = (u32)((w < 8 ? lo8 >> (8 * w) : hi8 >> (8 * (w - 8))) & 0xFFu);
+            const u32 x = ended ? 0u : (byte == 0xFFu ? term_first : byte);
+            key = (key << spare) | (K)(x >> (b - spare));
+        }
+        return key;
     }
-    if (spare > 0) {
-        const u32 byte = (u32)((w < 8 ? lo8 >> (8 * w) : hi8 >> (8 * (w - 8))) & 0xFFu);
-        const u32 x = ended ? 0u : (byte == 0xFFu ? term_first : byte);
-        key = (key << spare) | (K)(x >> (b - spare));
-    }
-    keys[u] = key;
-    vals[u] = n0 ? (r ? n0 + q : q) : u;
-}
+    __device__ __forceinline__ u32 val(u32 u) const { return n0 ? ((u & 1u) ? n0 + (u >> 1) : (u >> 1)) : u; }
+};
 
 template <class K> struct KeyNeqWindowIn {
     const K *keys;
@@ -762,59 +761,109 @@ struct FlagArrIn {                              // the naming predicate of a com
     __device__ __forceinline__ u32 operator()(u32 i) const { return flags[i]; }
 };
 
+// LCP of sorted neighbours r-1, r from their window keys alone: the leading symbol fields the two
+// keys have in common, cut at the first terminator field (equal terminator codes are two DIFFERENT
+// terminators).  Returns w with whole = true when the full windows agree and hold no terminator --
+// only then does the text have to be read, from offset w on.
+template <class K>
+__device__ __forceinline__ u32 lvl0_lcp_of_keys(const KeyNeqWindowIn<K> &f, int w, int b, int spare, u32 r, bool &whole)
+{
+    const K k = f.keys[r];
+    const u64 d = (u64)(k ^ f.keys[r - 1]);
+    u32 mism = (u32)w;                                   // leading symbol fields in common
+    if (d) {
+        const int hb = 63 - __builtin_clzll(d);
+        if (hb >= spare) mism = (u32)(w - 1 - (hb - spare) / b);
+    }
+    const K x = k ^ f.rep_t;
+    const u64 tz = (u64)((K)(x - f.ones) & ~x & f.highs);    // at most one field holds the terminator code
+    const u32 term = tz ? (u32)(w - 1 - (__builtin_ctzll(tz) - spare) / b) : (u32)w;
+    const u32 h = mism < term ? mism : term;
+    whole = h == (u32)w && d == 0;
+    return h;
+}
+
 // One pass over a domain of m elements.  Untied elements and small groups get their final place
 // in order_g (first domain only: later domains had theirs written by the previous write-back);
-// members of large groups are marked in keep[] for the radix round.  first domain: slot == nullptr
-// (identity), and names_g (sample mode, may be null) receives the naming predicate as refined so far.
-template <class Starts>
+// members of large groups are marked in keep[] for the radix round (block_keep: their number per
+// workgroup).  First domain: slot == nullptr (identity), names_g (sample mode, may be null)
+// receives the naming predicate as refined so far, and with WITH_LCP (all-suffix mode, one
+// document) the LCP entry of every element placed here is written as well -- from the keys where
+// the neighbours' windows differ, from the comparisons just made inside a small group.
+template <class Starts, bool WITH_LCP>
 __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *__restrict__ elem, Starts starts,
                                                                     const u32 *__restrict__ slot, u32 m,
                                                                     const uint8_t *__restrict__ s8, u32 n0, u32 depth,
+                                                                    int w, int b, int spare,
                                                                     u32 *__restrict__ order_g, u32 *__restrict__ names_g,
-                                                                    u32 *__restrict__ keep, u32 *__restrict__ fail)
+                                                                    u32 *__restrict__ lcp_g, u32 *__restrict__ keep,
+                                                                    u32 *__restrict__ block_keep, u32 *__restrict__ fail)
 {
+    __shared__ u32 wave_keep[WAVES_PER_BLOCK];
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j > m) return;
-    if (j == m) { keep[m] = 0; return; }           // (the exclusive scan over m + 1 entries yields the total)
-    const u32 e = elem[j];
     const bool first = slot == nullptr;
-    const u32 start = starts(j);
-    const bool left_same = j > 0 && !start;
-    const bool right_same = j + 1 < m && !starts(j + 1);
-    if (!left_same && !right_same) {
-        keep[j] = 0;
-        if (first) { order_g[j] = e; if (names_g) names_g[j] = 1; }
-        return;
-    }
-    u32 a = j, b = j + 1;
-    while (a > 0 && !starts(a) && j - a <= REFINE_SMALL_GROUP) a--;
-    while (b < m && !starts(b) && b - j <= REFINE_SMALL_GROUP) b++;
-    if (b - a > REFINE_SMALL_GROUP) {
-        keep[j] = 1;
-        if (first) { order_g[j] = e; if (names_g) names_g[j] = start; }
-        return;
-    }
-    keep[j] = 0;
-    const u32 p = lvl0_pos(e, n0);
-    u32 r = 0;
-    for (u32 x = a; x < b; x++) {
-        if (x == j) continue;
-        const u32 p2 = lvl0_pos(elem[x], n0);
-        bool decided = false, less = false;                 // less: suffix p2 < suffix p
-        for (u32 h = depth; h < depth + RESOLVE_MAX_LEN && !decided; h += 8) {
-            const u64 u = load_u64_unaligned(s8 + p + h), v = load_u64_unaligned(s8 + p2 + h);
-            const u64 d = u ^ v, z = ~u;
-            const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
-            const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
-            const u32 term = tz ? (u32)__builtin_ctzll(tz) >> 3 : 8u;
-            if (term < mism) { less = p2 < p; decided = true; }          // both end in (different) terminators
-            else if (mism < 8u) { less = ((v >> (8 * mism)) & 0xFFu) < ((u >> (8 * mism)) & 0xFFu); decided = true; }
+    u32 my_keep = 0;
+    if (j < m) {
+        const u32 e = elem[j];
+        const u32 start = starts(j);
+        const bool left_same = j > 0 && !start;
+        const bool right_same = j + 1 < m && !starts(j + 1);
+        u32 a = j, bnd = j + 1;
+        if (left_same || right_same) {
+            while (a > 0 && !starts(a) && j - a <= REFINE_SMALL_GROUP) a--;
+            while (bnd < m && !starts(bnd) && bnd - j <= REFINE_SMALL_GROUP) bnd++;
         }
-        if (!decided) { atomicOr(fail, 1u); return; }
-        if (less) r++;
+        if (bnd - a > REFINE_SMALL_GROUP) {             // a large group: left to the radix round
+            my_keep = 1;
+            if (first) { order_g[j] = e; if (names_g) names_g[j] = start; }
+        } else {
+            // rank inside the (possibly one-element) group, by comparing the suffixes from `depth` on
+            const u32 p = lvl0_pos(e, n0);
+            u32 r = 0, best = 0;                            // best: longest common prefix with a smaller member
+            bool ok = true;
+            for (u32 x = a; x < bnd && ok; x++) {
+                if (x == j) continue;
+                const u32 p2 = lvl0_pos(elem[x], n0);
+                bool decided = false, less = false;         // less: suffix p2 < suffix p
+                u32 h = depth;
+                for (; h < depth + RESOLVE_MAX_LEN && !decided; h += 8) {
+                    const u64 u = load_u64_unaligned(s8 + p + h), v = load_u64_unaligned(s8 + p2 + h);
+                    const u64 d = u ^ v, z = ~u;
+                    const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+                    const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+                    const u32 term = tz ? (u32)__builtin_ctzll(tz) >> 3 : 8u;
+                    if (term < mism) { less = p2 < p; decided = true; h += term; break; }     // both end in (different) terminators
+                    if (mism < 8u) { less = ((v >> (8 * mism)) & 0xFFu) < ((u >> (8 * mism)) & 0xFFu); decided = true; h += mism; break; }
+                }
+                if (!decided) { ok = false; break; }
+                if (less) { r++; best = h > best ? h : best; }
+            }
+            if (!ok) {
+                atomicOr(fail, 1u);                         // (the host restores the domain and gives up on it)
+            } else {
+                const u32 at = a + r;                       // final place inside the domain
+                if (first || bnd - a > 1) order_g[first ? at : slot[at]] = e;
+                if (names_g && (first || bnd - a > 1)) names_g[first ? j : slot[j]] = 1;
+                if constexpr (WITH_LCP) {
+                    u32 h = 0;
+                    if (r > 0) h = best;
+                    else if (at > 0) { bool whole; h = lvl0_lcp_of_keys(starts, w, b, spare, at, whole); }
+                    lcp_g[at] = h;
+                }
+            }
+        }
     }
-    order_g[first ? a + r : slot[a + r]] = e;
-    if (names_g) names_g[first ? j : slot[j]] = 1;
+    if (j <= m) keep[j] = my_keep;                      // (entry m = 0: the exclusive scan over m + 1 yields the total)
+    if (block_keep) {
+        const u32 c = (u32)__popcll(__ballot(my_keep != 0));
+        if (lane_id() == 0) wave_keep[wave_id()] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u32 t = 0;
+            for (int k = 0; k < WAVES_PER_BLOCK; k++) t += wave_keep[k];
+            block_keep[blockIdx.x] = t;
+        }
+    }
 }
 
 // A repeat too long for the direct ordering leaves its group half written: put the whole domain back
@@ -910,18 +959,9 @@ __global__ __launch_bounds__(BLOCK) void lvl0_lcp_keys_kernel(KeyNeqWindowIn<K> 
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
     if (r == 0) { lcp[0] = 0; return; }
-    const K k = f.keys[r];
-    const u64 d = (u64)(k ^ f.keys[r - 1]);
-    u32 mism = (u32)w;                                   // leading symbol fields in common
-    if (d) {
-        const int hb = 63 - __builtin_clzll(d);
-        if (hb >= spare) mism = (u32)(w - 1 - (hb - spare) / b);
-    }
-    const K x = k ^ f.rep_t;
-    const u64 tz = (u64)((K)(x - f.ones) & ~x & f.highs);    // at most one field holds the terminator code
-    const u32 term = tz ? (u32)(w - 1 - (__builtin_ctzll(tz) - spare) / b) : (u32)w;
-    u32 h = mism < term ? mism : term;
-    if (h == (u32)w && d == 0) {                         // the whole window agrees: continue on the text
+    bool whole;
+    u32 h = lvl0_lcp_of_keys(f, w, b, spare, r, whole);
+    if (whole) {                                         // the whole window agrees: continue on the text
         const u32 i = sa[r - 1], j = sa[r];
         while (true) {
             const u64 xa = load_u64_unaligned(s8 + i + h), xb = load_u64_unaligned(s8 + j + h);
@@ -938,73 +978,69 @@ __global__ __launch_bounds__(BLOCK) void lvl0_lcp_keys_kernel(KeyNeqWindowIn<K> 
     lcp[r] = h;
 }
 
-// Level 0 on the byte stream: window keys, sort, count the distinct names; unique names or a few
-// ties ordered on the text make sa12 final (returns true, no name string is ever written).
-// Otherwise the names are scanned and scattered into s12 for the recursion (returns false).
+// Level 0 on the byte stream: the window keys are sorted, then one classify pass places everything
+// that is untied or tied in a small group (ordered directly on the text); large groups go through
+// refinement rounds (step 2c).  Returns true when sa12 is final (no name string is ever written);
+// otherwise the refined names are scanned and scattered into s12 for the recursion (sample mode),
+// or the caller falls back to DC3 (all-suffix mode, s12 == nullptr).
 template <class K>
 static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w, int bt, u32 term_first, u32 *sa12,
                              u32 *s12, u32 &n_names, u32 *lcp_out = nullptr, u32 *lcp_capped = nullptr)
 {
     Arena &ar = *ctx.arena;
-    const u32 g02 = ceil_div_u32(n02, BLOCK);
+    const u32 g02 = ceil_div_u32((u64)n02 + 1, BLOCK);
     // whole passes are paid for anyway: fill the last digit with the top bits of the next symbol
     const int total = ((w * bt + 7) / 8) * 8;
     const int spare = w < 12 ? std::min(total - w * bt, bt - 1) : 0;
     SortBufs<K> sb;
-    // (one spare element each: the idle half later serves the refinement rounds as scratch)
+    // (one spare element each: the idle half serves as scratch after the sort)
     for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<K>((size_t)n02 + 1); sb.vals[k] = ar.alloc<u32>((size_t)n02 + 1); }
-    LAUNCH(ctx, (dc3_window_keys_kernel<K>), g02, s8, n0, n02, w, bt, spare, term_first, sb.keys[0], sb.vals[0]);
-    const int r = radix_sort_pairs<K>(ctx, sb, n02, w * bt + spare);
+    const int r = radix_sort_pairs<K, WindowSrc<K>>(ctx, sb, n02, w * bt + spare, 0,
+                                                    WindowSrc<K>{s8, n0, w, bt, spare, term_first});
     const KeyNeqWindowIn<K> starts = KeyNeqWindowIn<K>::make(sb.keys[r], w, bt, spare, term_first);
     const u32 *sorted_vals = sb.vals[r];
-    // all-suffix mode, one document: once sa12 holds the final order, the LCP table follows from the keys
-    auto finish = [&]() {
-        if (lcp_out)
-            LAUNCH_NAMED(ctx, "lvl0_lcp_keys_kernel", (lvl0_lcp_keys_kernel<K>), g02, starts, w, bt, spare, s8,
-                         (const u32 *)sa12, n02, lcp_out, lcp_capped);
-        return true;
-    };
-
-    // number of distinct names = sum of the naming predicate (a reduction, not yet a scan)
-    const u32 nb = ceil_div_u32(n02, SCAN_TILE);
+    u32 *keep = (u32 *)sb.keys[r ^ 1], *idx = sb.vals[r ^ 1];          // n02 + 1 entries each, idle since the sort
+    u32 *names_g = s12 ? ar.alloc<u32>(n02) : nullptr;  // sample mode: the naming predicate as refined so far
+    u32 *fail = ar.alloc<u32>(1);
+    u32 *block_keep = ar.alloc<u32>(g02);
+    const u32 nb = ceil_div_u32(g02, SCAN_TILE);
     u32 *block_sums = ar.alloc<u32>(nb);
-    LAUNCH(ctx, (scan_reduce_kernel<KeyNeqWindowIn<K>>), nb, starts, n02, block_sums);
-    if (ctx.dry) {
-        n_names = n02 > 4 ? n02 - 1 : n02;            // worst case: recurse
-    } else {
+    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
+
+    // ---- the whole sorted input as the first domain --------------------------------------
+    if (lcp_out)
+        LAUNCH_NAMED(ctx, "dc3_refine_classify_kernel", (dc3_refine_classify_kernel<KeyNeqWindowIn<K>, true>), g02,
+                     sorted_vals, starts, (const u32 *)nullptr, n02, s8, n0, (u32)w, w, bt, spare, sa12, names_g, lcp_out,
+                     keep, block_keep, fail);
+    else
+        LAUNCH_NAMED(ctx, "dc3_refine_classify_kernel", (dc3_refine_classify_kernel<KeyNeqWindowIn<K>, false>), g02,
+                     sorted_vals, starts, (const u32 *)nullptr, n02, s8, n0, (u32)w, w, bt, spare, sa12, names_g,
+                     (u32 *)nullptr, keep, block_keep, fail);
+    LAUNCH(ctx, (scan_reduce_kernel<ArrIn>), nb, ArrIn{block_keep}, g02, block_sums);
+    u32 m = n02, m_next = n02, h_fail = 0;              // (sizing run: as if everything were tied)
+    if (!ctx.dry) {
         std::vector<u32> h_sums(nb);
         HIP_CHECK(hipMemcpyAsync(h_sums.data(), block_sums, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx.stream));
+        HIP_CHECK(hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, ctx.stream));
         HIP_CHECK(hipStreamSynchronize(ctx.stream));
-        u64 total_names = 0;
-        for (u32 x : h_sums) total_names += x;
-        if (total_names == 0 || total_names > n02) east_throw(EAST_HIP_ERR_INTERNAL, "dc3: impossible name count");
-        n_names = (u32)total_names;
-        if (n_names == n02) {                          // unique names: the sorted order is SA12 already
-            HIP_CHECK(hipMemcpyAsync(sa12, sorted_vals, (size_t)n02 * sizeof(u32), hipMemcpyDeviceToDevice, ctx.stream));
-            return finish();
-        }
-        if (n02 - n_names <= n02 / 8) {                // few ties: order them on the text
-            u32 *fail = ar.alloc<u32>(1);
-            u32 h_fail = 0;
-            HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
-            LAUNCH_NAMED(ctx, "dc3_resolve_ties_text_kernel", (dc3_resolve_ties_text_kernel<KeyNeqWindowIn<K>>), g02,
-                         sorted_vals, starts, s8, n0, n02, sa12, fail);
-            HIP_CHECK(hipMemcpyAsync(&h_fail, fail, sizeof(u32), hipMemcpyDeviceToHost, ctx.stream));
-            HIP_CHECK(hipStreamSynchronize(ctx.stream));
-            if (!h_fail) {
-                if (ctx.stats) ctx.stats->levels_resolved++;
-                return finish();
-            }
+        m_next = 0;
+        for (u32 x : h_sums) m_next += x;
+        if (g_trace)
+            fprintf(stderr, "[east_hip] level-0 (%s, %u elements, w = %d): %u in large groups%s\n", n0 ? "sample" : "all suffixes",
+                    n02, w, m_next, h_fail ? ", a repeat too long to order directly" : "");
+        if (h_fail) LAUNCH(ctx, (dc3_refine_restore_kernel<KeyNeqWindowIn<K>>), g02, sorted_vals, starts, (const u32 *)nullptr, n02, sa12, names_g);
+        if (!h_fail && m_next == 0) {                   // everything is in place (and the LCP table written)
+            if (ctx.stats) ctx.stats->levels_resolved++;
+            return true;
         }
     }
-    // many ties (natural language): work the tied ones off in rounds (see step 2c)
+
+    // ---- refinement rounds on the members of large groups ---------------------------------
     // (ctx.lean: the device is short of memory for the rounds' buffers -- straight on to the recursion / DC3)
-    u32 *names_g = s12 && !ctx.lean ? ar.alloc<u32>(n02) : nullptr;    // sample mode: the refined naming predicate
-    if (!ctx.lean) {
+    bool done = false;
+    if (!ctx.lean && !h_fail) {
         const size_t mark_rounds = ar.mark();
         const u32 cap = (u32)(0.6 * n02) + 1;          // a radix round is only tried below this share of the input
-        u32 *keep = (u32 *)sb.keys[r ^ 1], *idx = sb.vals[r ^ 1];      // n02 + 1 entries each, idle since the sort
-        u32 *fail = ar.alloc<u32>(1);
         u32 *ebuf[3], *sbuf[2], *fbuf[2];
         for (auto &e : ebuf) e = ar.alloc<u32>(cap);
         for (auto &e : sbuf) e = ar.alloc<u32>(cap);
@@ -1015,39 +1051,16 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         if (ctx.dry) {                                  // sizing run: the transient buffers of one round
             device_scan<ArrIn, false>(ctx, ArrIn{keep}, n02 + 1, idx);
             (void)radix_sort_pairs<u64>(ctx, rb, cap, 8);
-        } else {
-            HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
         }
-        // the current domain: first the whole sorted input (slot = identity, predicate on the keys)
-        u32 m = n02, depth = (u32)w;
+        u32 depth = (u32)w;
         const u32 *elem = sorted_vals, *slot = nullptr, *flag = nullptr;
         int e_dom = -1, s_dom = 0, f_dom = 0;           // which of the rotating buffers hold the domain
-        bool done = false;
-        for (int round = 0; round <= REFINE_MAX_ROUNDS && !ctx.dry; round++) {
-            const u32 gm = ceil_div_u32((u64)m + 1, BLOCK);
-            if (!slot)
-                LAUNCH_NAMED(ctx, "dc3_refine_classify_kernel", (dc3_refine_classify_kernel<KeyNeqWindowIn<K>>), gm, elem,
-                             starts, slot, m, s8, n0, depth, sa12, names_g, keep, fail);
-            else
-                LAUNCH_NAMED(ctx, "dc3_refine_classify_kernel", (dc3_refine_classify_kernel<FlagArrIn>), gm, elem,
-                             FlagArrIn{flag}, slot, m, s8, n0, depth, sa12, names_g, keep, fail);
-            device_scan<ArrIn, false>(ctx, ArrIn{keep}, m + 1, idx);
-            u32 h_fail = 0, m_next = 0;
-            HIP_CHECK(hipMemcpyAsync(&m_next, idx + m, 4, hipMemcpyDeviceToHost, ctx.stream));
-            HIP_CHECK(hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, ctx.stream));
-            HIP_CHECK(hipStreamSynchronize(ctx.stream));
-            if (g_trace)
-                fprintf(stderr, "[east_hip] level-0 round %d: domain %u of %u, %u in large groups, depth %u%s\n", round, m,
-                        n02, m_next, depth, h_fail ? ", a repeat too long to order directly" : "");
-            if (h_fail) {
-                if (!slot)
-                    LAUNCH(ctx, (dc3_refine_restore_kernel<KeyNeqWindowIn<K>>), gm, elem, starts, slot, m, sa12, names_g);
-                else
-                    LAUNCH(ctx, (dc3_refine_restore_kernel<FlagArrIn>), gm, elem, FlagArrIn{flag}, slot, m, sa12, names_g);
-                break;
-            }
+        bool have_idx = false;                          // idx = exclusive scan of keep over the domain
+        for (int round = 0; !ctx.dry; round++) {
             if (m_next == 0) { done = true; break; }
             if (round == REFINE_MAX_ROUNDS || m_next >= cap || (round > 0 && m_next > m - m / 4)) break;
+            const u32 gm = ceil_div_u32((u64)m + 1, BLOCK);
+            if (!have_idx) device_scan<ArrIn, false>(ctx, ArrIn{keep}, m + 1, idx);
             // compact the members of large groups, number their groups, sort by (group, next window)
             const int e_c = (e_dom + 4) % 3, e_out = (e_dom + 5) % 3;      // the two buffers the domain is not in
             u32 *slot_c = sbuf[s_dom ^ 1];
@@ -1065,7 +1078,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             const int gbits = bit_width_u32(n_groups);
             const int w2 = std::min(12, (64 - gbits) / bt);
             if (w2 < 1) break;
-            const u32 gt = ceil_div_u32(m, BLOCK);
+            const u32 gt = ceil_div_u32((u64)m + 1, BLOCK);
             LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)ebuf[e_c], (const u32 *)group, m, n0, depth, w2, bt,
                    term_first, rb.keys[0], rb.vals[0]);
             const int rr = radix_sort_pairs<u64>(ctx, rb, m, gbits + w2 * bt);
@@ -1077,24 +1090,45 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             elem = ebuf[e_dom]; slot = sbuf[s_dom]; flag = fbuf[f_dom];
             depth += (u32)w2;
             if (ctx.stats) ctx.stats->refine_rounds++;
+            // the new, smaller domain: place what is untied or in small groups now, count the rest
+            LAUNCH_NAMED(ctx, "dc3_refine_classify_kernel", (dc3_refine_classify_kernel<FlagArrIn, false>), gt, elem,
+                         FlagArrIn{flag}, slot, m, s8, n0, depth, 0, 0, 0, sa12, names_g, (u32 *)nullptr, keep,
+                         (u32 *)nullptr, fail);
+            device_scan<ArrIn, false>(ctx, ArrIn{keep}, m + 1, idx);
+            have_idx = true;
+            HIP_CHECK(hipMemcpyAsync(&m_next, idx + m, 4, hipMemcpyDeviceToHost, ctx.stream));
+            HIP_CHECK(hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, ctx.stream));
+            HIP_CHECK(hipStreamSynchronize(ctx.stream));
+            if (g_trace)
+                fprintf(stderr, "[east_hip]   round %d: domain %u, %u still in large groups, depth %u%s\n", round, m, m_next,
+                        depth, h_fail ? ", a repeat too long to order directly" : "");
+            if (h_fail) {
+                LAUNCH(ctx, (dc3_refine_restore_kernel<FlagArrIn>), gt, elem, FlagArrIn{flag}, slot, m, sa12, names_g);
+                break;
+            }
         }
         ar.release(mark_rounds);
-        if (done) {
-            if (ctx.stats) ctx.stats->levels_resolved++;
-            return finish();
-        }
+    }
+    if (done) {
+        if (ctx.stats) ctx.stats->levels_resolved++;
+        if (lcp_out)                                    // (the entries written by the first pass are overwritten)
+            LAUNCH_NAMED(ctx, "lvl0_lcp_keys_kernel", (lvl0_lcp_keys_kernel<K>), ceil_div_u32(n02, BLOCK), starts, w, bt,
+                         spare, s8, (const u32 *)sa12, n02, lcp_out, lcp_capped);
+        return true;
     }
     if (!s12) return false;                            // all-suffix mode: the caller falls back to DC3
     // recursion ahead: names by an inclusive scan of the refined predicate, scattered into the name string
     u32 *names = ar.alloc<u32>(n02);
-    if (names_g) device_scan<FlagArrIn, true>(ctx, FlagArrIn{names_g}, n02, names);
-    else device_scan<KeyNeqWindowIn<K>, true>(ctx, starts, n02, names);
-    if (!ctx.dry) {
+    device_scan<FlagArrIn, true>(ctx, FlagArrIn{names_g}, n02, names);
+    if (ctx.dry) {
+        n_names = n02 > 4 ? n02 - 1 : n02;            // worst case: recurse
+    } else {
         HIP_CHECK(hipMemcpyAsync(&n_names, names + (n02 - 1), 4, hipMemcpyDeviceToHost, ctx.stream));
         HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        if (n_names == 0 || n_names > n02) east_throw(EAST_HIP_ERR_INTERNAL, "dc3: impossible name count");
     }
-    LAUNCH(ctx, dc3_scatter_names_kernel, ceil_div_u32((u64)n02 + 3, BLOCK), names_g ? (const u32 *)sa12 : sorted_vals,
-           (const u32 *)names, n02, s12);
+    LAUNCH(ctx, dc3_scatter_names_kernel, ceil_div_u32((u64)n02 + 3, BLOCK), (const u32 *)sa12, (const u32 *)names, n02,
+           s12);
     return false;
 }
 

@@ -21,9 +21,18 @@
 #define RS_TILE 4096                   // pairs per workgroup, both kernels
 #define RS_BINS 256
 
-template <class K>
-__global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const K *__restrict__ keys, u32 n,
-                                                           int shift, u32 *__restrict__ hist,
+// Where a pass reads its pairs from: the buffers of the previous pass, or -- first pass only -- a
+// generator that computes pair i on the fly (the keys then never make a round trip through HBM
+// before the first scatter).
+template <class K> struct PairSrc {
+    const K *keys;
+    const u32 *vals;
+    __device__ __forceinline__ K key(u32 i) const { return keys[i]; }
+    __device__ __forceinline__ u32 val(u32 i) const { return vals[i]; }
+};
+
+template <class K, class Src>
+__global__ __launch_bounds__(BLOCK) void radix_hist_kernel(Src src, u32 n, int shift, u32 *__restrict__ hist,
                                                            u32 n_tiles)
 {
     __shared__ u32 bins[RS_BINS];
@@ -33,7 +42,7 @@ __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const K *__restrict__
 #pragma unroll 4
     for (int j = 0; j < RS_TILE / BLOCK; j++) {
         const u32 i = base + j * BLOCK + threadIdx.x;
-        if (i < n) atomicAdd(&bins[(u32)(keys[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&bins[(u32)(src.key(i) >> shift) & 255u], 1u);
     }
     __syncthreads();
     hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = bins[threadIdx.x];       // tile-major: one coalesced row
@@ -90,10 +99,10 @@ __global__ __launch_bounds__(BLOCK) void hist_apply_kernel(u32 *__restrict__ his
 // (the per-pair destination is kept in registers), which keeps the workgroup at
 // 4096*sizeof(K) + 4*WAVES*256 + 2 KiB of LDS: two 16-wave workgroups (32 waves,
 // the hardware maximum) fit a CU.
-template <class K, int THREADS>
+template <class K, int THREADS, class Src>
 __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
-    const K *__restrict__ keys_in, const u32 *__restrict__ vals_in, K *__restrict__ keys_out,
-    u32 *__restrict__ vals_out, u32 n, int shift, const u32 *__restrict__ scanned_hist, u32 n_tiles)
+    Src src, K *__restrict__ keys_out, u32 *__restrict__ vals_out, u32 n, int shift,
+    const u32 *__restrict__ scanned_hist, u32 n_tiles)
 {
     constexpr int WAVES = THREADS / WAVE;
     constexpr int IPT = RS_TILE / THREADS;
@@ -107,7 +116,14 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     u32 *s_vals = reinterpret_cast<u32 *>(s_keys);
 
     const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    const u32 tile_base = blockIdx.x * RS_TILE;
+    // XCD-aware tile order: workgroups go round-robin over the 8 XCDs, each with its own L2.  The
+    // per-digit runs of NEIGHBOURING tiles are neighbours in the output, so neighbouring tiles are
+    // given to the same XCD (XCD x takes the x-th eighth of the tiles): the partial lines at the
+    // seams of the runs meet in one L2 instead of reaching memory as masked writes from two.
+    const u32 per_xcd = (n_tiles + 7u) / 8u;
+    const u32 tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const u32 tile_base = tile * RS_TILE;
     const u32 tile_count = (n - tile_base) < (u32)RS_TILE ? (n - tile_base) : (u32)RS_TILE;
 
     for (u32 i = tid; i < WAVES * RS_BINS; i += THREADS) (&wave_cnt[0][0])[i] = 0;
@@ -121,8 +137,8 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     for (int j = 0; j < IPT; j++) {
         const u32 local = w * WAVE_ITEMS + j * WAVE + lane;
         const bool valid = local < tile_count;
-        key[j] = valid ? keys_in[tile_base + local] : (K)0;
-        val[j] = valid ? vals_in[tile_base + local] : 0u;
+        key[j] = valid ? src.key(tile_base + local) : (K)0;
+        val[j] = valid ? src.val(tile_base + local) : 0u;
         const u32 digit = (u32)(key[j] >> shift) & 255u;
         // wave64 multisplit: lanes holding the same digit find each other with 8 ballots
         u64 mask = __ballot(valid);
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
         if (w > 1) start += lds4[1];
         if (w > 2) start += lds4[2];
         digit_start[tid] = start;
-        global_base[tid] = scanned_hist[(size_t)blockIdx.x * RS_BINS + tid] - start;
+        global_base[tid] = scanned_hist[(size_t)tile * RS_BINS + tid] - start;
     }
     __syncthreads();
 
@@ -210,11 +226,15 @@ template <class K> struct SortBufs {
     u32 *vals[2];
 };
 
-// Sorts on key bits [begin_bit, bits).  Input in buffers [0]; returns the index (0/1)
-// of the buffers that hold the sorted pairs.
-template <class K>
-static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin_bit = 0)
+struct NoGen {};
+
+// Sorts on key bits [begin_bit, bits).  Input in buffers [0] -- or, with a generator (a Src with
+// key(i) / val(i)), produced on the fly by the first pass, which then writes into buffers [0].
+// Returns the index (0/1) of the buffers that hold the sorted pairs.
+template <class K, class Gen = NoGen>
+static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin_bit = 0, Gen gen = Gen())
 {
+    constexpr bool HAS_GEN = !std::is_same<Gen, NoGen>::value;
     if (n == 0) return 0;
     const u32 n_tiles = ceil_div_u32(n, RS_TILE);
     const size_t mark = ctx.arena->mark();
@@ -222,31 +242,51 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin
     const u32 n_chunks = ceil_div_u32(n_tiles, HS_CHUNK);
     u32 *chunk_sums = ctx.arena->alloc<u32>((size_t)RS_BINS * n_chunks);
     u32 *chunk_prefix = ctx.arena->alloc<u32>((size_t)RS_BINS * (n_chunks + 1));
+    const bool prof = ctx.prof && ctx.prof->enabled;
     int cur = 0;
+    bool first = HAS_GEN;                       // the generator pass reads no buffers and writes [0]
     for (int shift = begin_bit; shift < bits; shift += 8) {
-        LAUNCH_NAMED(ctx, sizeof(K) == 8 ? "radix_hist_kernel<u64>" : "radix_hist_kernel<u32>",
-                     (radix_hist_kernel<K>), n_tiles, (const K *)b.keys[cur], n, shift, hist, n_tiles);
+        const PairSrc<K> src{b.keys[cur], b.vals[cur]};
+        const int out = first ? 0 : cur ^ 1;
+        if constexpr (HAS_GEN) {
+            if (first)
+                LAUNCH_NAMED(ctx, sizeof(K) == 8 ? "radix_hist_kernel<u64,gen>" : "radix_hist_kernel<u32,gen>",
+                             (radix_hist_kernel<K, Gen>), n_tiles, gen, n, shift, hist, n_tiles);
+        }
+        if (!first)
+            LAUNCH_NAMED(ctx, sizeof(K) == 8 ? "radix_hist_kernel<u64>" : "radix_hist_kernel<u32>",
+                         (radix_hist_kernel<K, PairSrc<K>>), n_tiles, src, n, shift, hist, n_tiles);
         LAUNCH(ctx, hist_chunk_sums_kernel, n_chunks, (const u32 *)hist, n_tiles, chunk_sums);
         LAUNCH(ctx, hist_chunk_scan_kernel, 1, (const u32 *)chunk_sums, n_chunks, chunk_prefix);
         LAUNCH(ctx, hist_apply_kernel, n_chunks, hist, n_tiles, (const u32 *)chunk_prefix, n_chunks);
         if (!ctx.dry) {
-            const bool prof = ctx.prof && ctx.prof->enabled;
-            if (prof) ctx.prof->begin(sizeof(K) == 8 ? "radix_scatter_kernel<u64>" : "radix_scatter_kernel<u32>", ctx.stream);
-            hipLaunchKernelGGL((radix_scatter_kernel<K, RS_THREADS>), dim3(n_tiles), dim3(RS_THREADS), 0, ctx.stream,
-                               (const K *)b.keys[cur], (const u32 *)b.vals[cur], b.keys[cur ^ 1], b.vals[cur ^ 1], n,
-                               shift, (const u32 *)hist, n_tiles);
+            if constexpr (HAS_GEN) {
+                if (first) {
+                    if (prof) ctx.prof->begin(sizeof(K) == 8 ? "radix_scatter_kernel<u64,gen>" : "radix_scatter_kernel<u32,gen>", ctx.stream);
+                    hipLaunchKernelGGL((radix_scatter_kernel<K, RS_THREADS, Gen>), dim3(8 * ((n_tiles + 7) / 8)), dim3(RS_THREADS), 0,
+                                       ctx.stream, gen, b.keys[out], b.vals[out], n, shift, (const u32 *)hist, n_tiles);
+                }
+            }
+            if (!first) {
+                if (prof) ctx.prof->begin(sizeof(K) == 8 ? "radix_scatter_kernel<u64>" : "radix_scatter_kernel<u32>", ctx.stream);
+                hipLaunchKernelGGL((radix_scatter_kernel<K, RS_THREADS, PairSrc<K>>), dim3(8 * ((n_tiles + 7) / 8)), dim3(RS_THREADS), 0,
+                                   ctx.stream, src, b.keys[out], b.vals[out], n, shift, (const u32 *)hist, n_tiles);
+            }
             HIP_CHECK(hipGetLastError());
             if (prof) ctx.prof->end(ctx.stream);
         }
-        cur ^= 1;
+        cur = out;
         if (ctx.stats) {
             ctx.stats->radix_passes++;
-            ctx.stats->radix_elems += n;
-            if (sizeof(K) == 8) { ctx.stats->radix_elems_u64 += n; ctx.stats->radix_passes_u64++; }
-            else { ctx.stats->radix_elems_u32 += n; ctx.stats->radix_passes_u32++; }
+            if (!first) {                       // (generator passes are accounted under their own kernel names)
+                ctx.stats->radix_elems += n;
+                if (sizeof(K) == 8) { ctx.stats->radix_elems_u64 += n; ctx.stats->radix_passes_u64++; }
+                else { ctx.stats->radix_elems_u32 += n; ctx.stats->radix_passes_u32++; }
+            }
             if ((i64)(sizeof(K) + 4) > ctx.stats->radix_elem_bytes)
                 ctx.stats->radix_elem_bytes = sizeof(K) + 4;
         }
+        first = false;
     }
     ctx.arena->release(mark);
     return cur;
