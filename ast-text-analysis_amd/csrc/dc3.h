@@ -249,52 +249,6 @@ __global__ __launch_bounds__(BLOCK) void dc3_resolve_ties_kernel(const u32 *__re
     sa12[a + r] = t;
 }
 
-// The same on the byte stream (level 0): tied samples share their whole name window,
-// so they are compared on the text itself, 8 symbols per step.  Two terminators at the
-// same offset are different symbols ordered by position.  No name string is needed,
-// which saves the random scatter of 2n/3 names whenever the level does not recurse.
-// `starts(i)` = 1 where sorted sample i opens a new name (the naming predicate on the sorted keys):
-// a group of tied samples is a maximal run [a, b) with starts(a) = 1 and starts = 0 inside.
-template <class Starts>
-__global__ __launch_bounds__(BLOCK) void dc3_resolve_ties_text_kernel(const u32 *__restrict__ sorted_vals,
-                                                                      Starts starts,
-                                                                      const uint8_t *__restrict__ s8, u32 n0,
-                                                                      u32 n02, u32 *__restrict__ sa12,
-                                                                      u32 *__restrict__ fail)
-{
-    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n02) return;
-    const u32 t = sorted_vals[i];
-    const bool left_same = i > 0 && !starts(i);
-    const bool right_same = i + 1 < n02 && !starts(i + 1);
-    if (!left_same && !right_same) { sa12[i] = t; return; }
-    u32 a = i, b = i + 1;
-    while (a > 0 && !starts(a) && i - a <= RESOLVE_MAX_GROUP) a--;
-    while (b < n02 && !starts(b) && b - i <= RESOLVE_MAX_GROUP) b++;
-    if (b - a > RESOLVE_MAX_GROUP) { atomicOr(fail, 1u); return; }
-    const u32 p = lvl0_pos(t, n0);
-    u32 r = 0;
-    for (u32 x = a; x < b; x++) {
-        if (x == i) continue;
-        const u32 p2 = lvl0_pos(sorted_vals[x], n0);
-        bool decided = false, less = false;                 // less: suffix p2 < suffix p
-        for (u32 h = 0; h < RESOLVE_MAX_LEN && !decided; h += 8) {
-            u64 u, v;
-            __builtin_memcpy(&u, s8 + p + h, 8);
-            __builtin_memcpy(&v, s8 + p2 + h, 8);
-            const u64 d = u ^ v, z = ~u;
-            const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
-            const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
-            const u32 term = tz ? (u32)__builtin_ctzll(tz) >> 3 : 8u;
-            if (term < mism) { less = p2 < p; decided = true; }          // both end in (different) terminators
-            else if (mism < 8u) { less = ((v >> (8 * mism)) & 0xFFu) < ((u >> (8 * mism)) & 0xFFu); decided = true; }
-        }
-        if (!decided) { atomicOr(fail, 1u); return; }
-        if (less) r++;
-    }
-    sa12[a + r] = t;
-}
-
 // ---- step 3: ranks of the sample suffixes, dense in text order --------------------
 // R12[2q]   = rank of the sample suffix at position 3q+1
 // R12[2q+1] = rank of the sample suffix at position 3q+2      (1-based, 0 = past the end)
@@ -756,6 +710,11 @@ static const u32 *dc3_sort_and_name(Ctx &ctx, SortBufs<K> &sb, u32 n02, int bits
 #define REFINE_SMALL_GROUP 8
 #define REFINE_MAX_ROUNDS 8
 
+struct BitIn {                                  // one flag per element, 64 to a word (written by wave ballots)
+    const u64 *bits;
+    __device__ __forceinline__ u32 operator()(u32 i) const { return (u32)(bits[i >> 6] >> (i & 63u)) & 1u; }
+};
+
 struct FlagArrIn {                              // the naming predicate of a compacted domain
     const u32 *flags;
     __device__ __forceinline__ u32 operator()(u32 i) const { return flags[i]; }
@@ -796,7 +755,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
                                                                     const uint8_t *__restrict__ s8, u32 n0, u32 depth,
                                                                     int w, int b, int spare,
                                                                     u32 *__restrict__ order_g, u32 *__restrict__ names_g,
-                                                                    u32 *__restrict__ lcp_g, u32 *__restrict__ keep,
+                                                                    u32 *__restrict__ lcp_g, u64 *__restrict__ keep,
                                                                     u32 *__restrict__ block_keep, u32 *__restrict__ fail)
 {
     __shared__ u32 wave_keep[WAVES_PER_BLOCK];
@@ -853,9 +812,11 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
             }
         }
     }
-    if (j <= m) keep[j] = my_keep;                      // (entry m = 0: the exclusive scan over m + 1 yields the total)
+    // keep[]: one bit per element (entries m.. of the last word are 0: the exclusive scan over m + 1 yields the total)
+    const u64 bal = __ballot(my_keep != 0);
+    if (lane_id() == 0) keep[j >> 6] = bal;
     if (block_keep) {
-        const u32 c = (u32)__popcll(__ballot(my_keep != 0));
+        const u32 c = (u32)__popcll(bal);
         if (lane_id() == 0) wave_keep[wave_id()] = c;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -883,14 +844,13 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_restore_kernel(const u32 *__
 // the members of large groups, compacted: the radix round's input
 template <class Starts>
 __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__restrict__ elem, Starts starts,
-                                                                   const u32 *__restrict__ slot,
-                                                                   const u32 *__restrict__ keep,
+                                                                   const u32 *__restrict__ slot, BitIn keep,
                                                                    const u32 *__restrict__ idx, u32 m,
                                                                    u32 *__restrict__ slot_out, u32 *__restrict__ elem_out,
                                                                    u32 *__restrict__ group_start)
 {
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= m || !keep[j]) return;
+    if (j >= m || !keep(j)) return;
     const u32 k = idx[j];
     slot_out[k] = slot ? slot[j] : j;
     elem_out[k] = elem[j];
@@ -999,7 +959,8 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                                                     WindowSrc<K>{s8, n0, w, bt, spare, term_first});
     const KeyNeqWindowIn<K> starts = KeyNeqWindowIn<K>::make(sb.keys[r], w, bt, spare, term_first);
     const u32 *sorted_vals = sb.vals[r];
-    u32 *keep = (u32 *)sb.keys[r ^ 1], *idx = sb.vals[r ^ 1];          // n02 + 1 entries each, idle since the sort
+    u64 *keep = (u64 *)sb.keys[r ^ 1];                   // n02 + 1 bits, in the keys idle since the sort
+    u32 *idx = sb.vals[r ^ 1];                          // n02 + 1 entries, likewise
     u32 *names_g = s12 ? ar.alloc<u32>(n02) : nullptr;  // sample mode: the naming predicate as refined so far
     u32 *fail = ar.alloc<u32>(1);
     u32 *block_keep = ar.alloc<u32>(g02);
@@ -1049,7 +1010,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         SortBufs<u64> rb;
         for (int k = 0; k < 2; k++) { rb.keys[k] = ar.alloc<u64>(cap); rb.vals[k] = ar.alloc<u32>(cap); }
         if (ctx.dry) {                                  // sizing run: the transient buffers of one round
-            device_scan<ArrIn, false>(ctx, ArrIn{keep}, n02 + 1, idx);
+            device_scan<BitIn, false>(ctx, BitIn{keep}, n02 + 1, idx);
             (void)radix_sort_pairs<u64>(ctx, rb, cap, 8);
         }
         u32 depth = (u32)w;
@@ -1060,16 +1021,16 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             if (m_next == 0) { done = true; break; }
             if (round == REFINE_MAX_ROUNDS || m_next >= cap || (round > 0 && m_next > m - m / 4)) break;
             const u32 gm = ceil_div_u32((u64)m + 1, BLOCK);
-            if (!have_idx) device_scan<ArrIn, false>(ctx, ArrIn{keep}, m + 1, idx);
+            if (!have_idx) device_scan<BitIn, false>(ctx, BitIn{keep}, m + 1, idx);
             // compact the members of large groups, number their groups, sort by (group, next window)
             const int e_c = (e_dom + 4) % 3, e_out = (e_dom + 5) % 3;      // the two buffers the domain is not in
             u32 *slot_c = sbuf[s_dom ^ 1];
             if (!slot)
                 LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<KeyNeqWindowIn<K>>), gm, elem,
-                             starts, slot, (const u32 *)keep, (const u32 *)idx, m, slot_c, ebuf[e_c], gstart);
+                             starts, slot, BitIn{keep}, (const u32 *)idx, m, slot_c, ebuf[e_c], gstart);
             else
                 LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<FlagArrIn>), gm, elem,
-                             FlagArrIn{flag}, slot, (const u32 *)keep, (const u32 *)idx, m, slot_c, ebuf[e_c], gstart);
+                             FlagArrIn{flag}, slot, BitIn{keep}, (const u32 *)idx, m, slot_c, ebuf[e_c], gstart);
             m = m_next;
             device_scan<ArrIn, true>(ctx, ArrIn{gstart}, m, group);
             u32 n_groups = 0;
@@ -1094,7 +1055,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             LAUNCH_NAMED(ctx, "dc3_refine_classify_kernel", (dc3_refine_classify_kernel<FlagArrIn, false>), gt, elem,
                          FlagArrIn{flag}, slot, m, s8, n0, depth, 0, 0, 0, sa12, names_g, (u32 *)nullptr, keep,
                          (u32 *)nullptr, fail);
-            device_scan<ArrIn, false>(ctx, ArrIn{keep}, m + 1, idx);
+            device_scan<BitIn, false>(ctx, BitIn{keep}, m + 1, idx);
             have_idx = true;
             HIP_CHECK(hipMemcpyAsync(&m_next, idx + m, 4, hipMemcpyDeviceToHost, ctx.stream));
             HIP_CHECK(hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, ctx.stream));
