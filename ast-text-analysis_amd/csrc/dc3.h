@@ -1,10 +1,23 @@
-// dc3.h -- data-parallel DC3 / skew suffix array construction (Karkkainen &
-// Sanders 2003), the algorithm the reference runs in _kark_sort
-// (east/asts/easa.py:155-228), re-designed for the GPU:
+// dc3.h -- suffix array construction on the GPU.
 //
-//   1. sample positions i mod 3 != 0 become packed (s[i],s[i+1],s[i+2]) keys,
-//      read coalesced from the symbol stream (no gathers), and are sorted by the
-//      LDS-staged wave64 radix sort (radix_sort.h)            [easa.py:163-167]
+// Two constructions produce the one suffix array the reference computes in _kark_sort
+// (east/asts/easa.py:155-228); the suffix array is unique for a given symbol order, so the
+// result is bit-identical to the reference's suftab although none of its sequential
+// dict-counting / list-merging code is reproduced.
+//
+// A. window_suffix_sort (text on the byte stream, the path ordinary inputs take):
+//      ALL suffixes are keyed by their first w symbols (w*bits <= 32 or 64), generated inside the
+//      first pass of one stable LSD radix sort; one classify pass then places every suffix whose
+//      key is unique and orders small groups of equal keys directly on the text; members of
+//      larger groups are refined in rounds keyed by (group, next window).  With one document the
+//      LCP table falls out of the sorted keys.  No sample, no ranks, no merge -- but the work is
+//      only bounded for inputs whose repeats are short, so it gives up when ties persist and
+//
+// B. dc3_suffix_array, data-parallel DC3 / skew (Karkkainen & Sanders 2003), takes over:
+//   1. sample positions i mod 3 != 0 become packed keys -- at level 0 on the byte stream the same
+//      w-symbol windows and the same classify / refinement as in A, otherwise (s[i],s[i+1],s[i+2])
+//      read coalesced from the symbol stream -- sorted by the LDS-staged wave64 radix sort
+//      (radix_sort.h)                                           [easa.py:163-167]
 //   2. naming = inclusive scan of "key differs from predecessor"  [easa.py:169-182]
 //   3. if names are not unique: recurse on the name string, all on device,
 //      the host only reads one word per level                  [easa.py:184-190]
@@ -12,10 +25,6 @@
 //      (scan) + one radix sort by first symbol                 [easa.py:192-194]
 //   5. merge-path merge of the two sorted sets with the DC3 comparator
 //                                                               [easa.py:196-228]
-//
-// The suffix array is unique for a given symbol order, so the result is
-// bit-identical to the reference's suftab although none of its sequential
-// dict-counting / list-merging code is reproduced.
 //
 // Symbol string convention: s[0..n) in [1, sigma], s[n..n+3) == 0.
 #pragma once

@@ -947,6 +947,14 @@ int64_t east_hip_plan_arena_bytes(int64_t n_total, int32_t n_docs)
     return r;
 }
 
+int64_t east_hip_plan_arena_bytes_lean(int64_t n_total, int32_t n_docs)
+{
+    if (n_total < 1 || n_total >= (i64)0x7FFFFFF0 || n_docs < 1) return EAST_HIP_ERR_INVALID;
+    int64_t r = EAST_HIP_ERR_INTERNAL;
+    guarded([&] { r = (int64_t)plan_arena_bytes((u32)n_total, (u32)n_docs, true); });
+    return r;
+}
+
 double east_hip_last_build_ms(east_hip_handle_t h) { return h ? (double)h->last_build_ms : -1.0; }
 double east_hip_last_score_ms(east_hip_handle_t h) { return h ? (double)h->last_score_ms : -1.0; }
 

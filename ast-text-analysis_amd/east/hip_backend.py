@@ -53,6 +53,7 @@ SIGNATURES = {
     "east_hip_debug_suffix_array": (ctypes.c_int, [ctypes.c_int, _c_u32p, ctypes.c_int64, ctypes.c_uint32, _c_i32p,
                                                    _c_i32p]),
     "east_hip_plan_arena_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32]),
+    "east_hip_plan_arena_bytes_lean": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32]),
     "east_hip_debug_set_rank_bucket_bytes": (ctypes.c_int, [ctypes.c_int64]),
     "east_hip_debug_set_window_sort": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

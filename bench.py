@@ -59,7 +59,11 @@ def parse():
 def kernel_bytes(name, info, n, n_q, n_docs):
     """Algorithmic HBM bytes of ALL launches of one kernel in one step."""
     e32, e64 = info["radix_elements_u32"], info["radix_elements_u64"]
+    first = n if info["window_sorted"] else 2 * n // 3      # elements of the level-0 window sort
     table = {
+        # first radix pass: the window keys are generated from the byte stream (1 B/symbol), pairs written once
+        "radix_scatter_kernel<u32,gen>": first * 9, "radix_scatter_kernel<u64,gen>": first * 13,
+        "radix_hist_kernel<u32,gen>": first, "radix_hist_kernel<u64,gen>": first,
         # read key+value, write key+value
         "radix_scatter_kernel<u64>": e64 * 24, "radix_scatter_kernel<u32>": e32 * 16,
         # read keys once
@@ -72,6 +76,10 @@ def kernel_bytes(name, info, n, n_q, n_docs):
         "lcp_kernel": n * 40,
         # byte stream: 4 B SA read, 2 x 8 B symbol windows, 4 B LCP write per rank
         "lcp8_kernel": n * 24,
+        # level-0 placement pass (no refinement rounds): 4 B element + 4 B key read, 4 B SA (+ 4 B LCP with one
+        # document) written per suffix; the tied ones add two 8 B text gathers each
+        "dc3_refine_classify_kernel": (first * (16 if n_docs == 1 and info["window_sorted"] else 12)
+                                       if info["refine_rounds"] == 0 else None),
         # 4 B LCP read + 4 B annotation write per rank
         "ann_kernel": n * 8,
         # 4 B sorted sample read + one random 4 B rank store per sample

@@ -210,6 +210,9 @@ int east_hip_debug_set_window_sort(int enabled);
 /* Host-only: bytes of device arena a build of n_total symbols / n_docs documents
  * reserves (worst case over inputs).  Needs no device. */
 int64_t east_hip_plan_arena_bytes(int64_t n_total, int32_t n_docs);
+/* The same for a "lean" build: what a build falls back to when the full plan does not fit the
+ * free device memory (no buffers for the tie-refinement rounds). */
+int64_t east_hip_plan_arena_bytes_lean(int64_t n_total, int32_t n_docs);
 
 #ifdef __cplusplus
 }

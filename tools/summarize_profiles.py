@@ -9,7 +9,7 @@
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts a wide coalesced streaming
 read at exactly half its bytes (MI355X_MICROARCH.md, HBM section); checked here on kernels
-with a known byte count (remap_kernel reads 8 B/symbol, radix_hist_kernel<u64> 8 B/element):
+with a known byte count (remap_bytes_kernel and presence_kernel read 4 B/symbol):
 the ratio printed below is ~0.50.  traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 for the
 streaming kernels.  Gather kernels (GATHER below) issue 64-byte sector requests, which the
 counter tallies at their true size, so their FETCH_SIZE is NOT doubled.
@@ -33,12 +33,24 @@ GATHER = ("dc3_merge_tile_kernel", "dc3_merge_partition_kernel", "dc3_merge_lcp_
           "dc3_merge_partition_rec_kernel", "dc3_lcp_heads_kernel", "lcp8_kernel", "lcp_kernel",
           "dc3_compact_s0_bytes_kernel", "dc3_compact_s0_kernel", "dc3_rank_kernel", "dc3_scatter_names_kernel",
           "dc3_resolve_ties_text_kernel", "dc3_resolve_ties_kernel", "kgram_mark_kernel", "score_walk_kernel",
-          "dc3_pair_keys_kernel", "dc3_gather_third_kernel", "ann_kernel", "child_kernel", "doc_keys_kernel")
+          "dc3_pair_keys_kernel", "dc3_gather_third_kernel", "ann_kernel", "child_kernel", "doc_keys_kernel",
+          # mixed: a streaming pass (counted at 1/2) plus text gathers for the tied suffixes (counted in full);
+          # with c = 1 the figure is a lower bound, short by the streamed half (4 B/suffix)
+          "dc3_refine_classify_kernel", "lvl0_lcp_keys_kernel", "dc3_refine_keys_kernel")
 
 
 def short(name):
+    """rocprofv3's demangled name -> the name bench.py / east_hip_profile_report use."""
     name = name.split("(")[0].replace("void ", "")
-    return name.replace("unsigned long", "u64").replace("unsigned int", "u32").replace(", 1024", "")
+    name = name.replace("unsigned long", "u64").replace("unsigned int", "u32").replace(", 1024", "")
+    name = name.replace("> >", ">>")
+    for k in ("u32", "u64"):
+        name = name.replace(", PairSrc<%s>>" % k, ">").replace(", WindowSrc<%s>>" % k, ",gen>")
+    for plain in ("dc3_refine_classify_kernel", "dc3_refine_compact_kernel", "dc3_refine_restore_kernel",
+                  "lvl0_lcp_keys_kernel", "validate_n_strings_kernel", "score_walk_kernel"):
+        if name.startswith(plain + "<"):
+            name = plain
+    return name
 
 
 def agg(pattern, counter):
@@ -82,7 +94,18 @@ out = {"_note": "HBM bytes per launch = (c*FETCH_SIZE + WRITE_SIZE)*1024 from se
 for k, v in traffic.items():
     out[names.get(k, k)] = v
 json.dump(out, open(os.path.join(DST, "traffic.json"), "w"), indent=1, sort_keys=True)
-for k, expect in (("remap_kernel", 8.0 * n), ("radix_hist_kernel<u64>", None)):
+# the bench lines of this very run carry the PMC traffic of this run (bench.py itself reads the
+# traffic.json that was committed before it started)
+for name in (tag + "_bench.json", tag + "_bench_profiled.json"):
+    path = os.path.join(DST, name)
+    line = json.load(open(path))
+    line["roofline"]["traffic"] = out.get(line["roofline"]["kernel"])
+    for e in line.get("roofline_by_kernel", []):
+        if "traffic" in e or e["kernel"] in out:
+            e["traffic"] = out.get(e["kernel"])
+    with open(path, "w") as f:
+        f.write(json.dumps(line) + "\n")
+for k, expect in (("remap_kernel", 8.0 * n), ("remap_bytes_kernel", 4.0 * n), ("presence_kernel", 4.0 * n)):
     if k in fetch and expect:
         print("calibration %s: FETCH_SIZE*1024 / known read bytes = %.3f"
               % (k, fetch[k][1] / fetch[k][0] * 1024.0 / expect))
