@@ -99,10 +99,10 @@ __global__ __launch_bounds__(BLOCK) void hist_apply_kernel(u32 *__restrict__ his
 // (the per-pair destination is kept in registers), which keeps the workgroup at
 // 4096*sizeof(K) + 4*WAVES*256 + 2 KiB of LDS: two 16-wave workgroups (32 waves,
 // the hardware maximum) fit a CU.
-template <class K, int THREADS, class Src>
-__global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
-    Src src, K *__restrict__ keys_out, u32 *__restrict__ vals_out, u32 n, int shift,
-    const u32 *__restrict__ scanned_hist, u32 n_tiles)
+template <class K, int THREADS, class Src, bool FULL>
+__device__ __forceinline__ void radix_scatter_tile(
+    const Src &src, K *__restrict__ keys_out, u32 *__restrict__ vals_out, int shift,
+    const u32 *__restrict__ scanned_hist, u32 tile, u32 tile_count)
 {
     constexpr int WAVES = THREADS / WAVE;
     constexpr int IPT = RS_TILE / THREADS;
@@ -116,15 +116,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     u32 *s_vals = reinterpret_cast<u32 *>(s_keys);
 
     const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    // XCD-aware tile order: workgroups go round-robin over the 8 XCDs, each with its own L2.  The
-    // per-digit runs of NEIGHBOURING tiles are neighbours in the output, so neighbouring tiles are
-    // given to the same XCD (XCD x takes the x-th eighth of the tiles): the partial lines at the
-    // seams of the runs meet in one L2 instead of reaching memory as masked writes from two.
-    const u32 per_xcd = (n_tiles + 7u) / 8u;
-    const u32 tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= n_tiles) return;
     const u32 tile_base = tile * RS_TILE;
-    const u32 tile_count = (n - tile_base) < (u32)RS_TILE ? (n - tile_base) : (u32)RS_TILE;
 
     for (u32 i = tid; i < WAVES * RS_BINS; i += THREADS) (&wave_cnt[0][0])[i] = 0;
     __syncthreads();
@@ -136,19 +128,29 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
 #pragma unroll
     for (int j = 0; j < IPT; j++) {
         const u32 local = w * WAVE_ITEMS + j * WAVE + lane;
-        const bool valid = local < tile_count;
+        const bool valid = FULL || local < tile_count;
         key[j] = valid ? src.key(tile_base + local) : (K)0;
         val[j] = valid ? src.val(tile_base + local) : 0u;
         const u32 digit = (u32)(key[j] >> shift) & 255u;
-        // wave64 multisplit: lanes holding the same digit find each other with 8 ballots
-        u64 mask = __ballot(valid);
+        // wave64 multisplit: lanes holding the same digit find each other with 8 ballots.  Per bit:
+        // s = the bit spread over a word (one v_bfe_i32), the ballot of it, and the lanes that
+        // differ from this one in that bit accumulate in `diff` (xor + or per half).  (The kernel is
+        // bound by instruction issue, not by HBM: 9 -> 5 VALU per bit here was worth 10 % of a pass;
+        // interleaving the rows' chains to fill the ballot hazards was measured and is slower --
+        // the rows then cannot start before all four loads have landed.)
+        u32 diff_lo = 0, diff_hi = 0;
 #pragma unroll
         for (int bit = 0; bit < 8; bit++) {
-            const bool b = (digit >> bit) & 1u;
-            const u64 bal = __ballot(b);
-            mask &= b ? bal : ~bal;
+            const u32 sbit = (u32)__builtin_amdgcn_sbfe((int)digit, (u32)bit, 1u);      // 0 or ~0
+            const u64 bal = __ballot((int)sbit < 0);
+            diff_lo |= (u32)bal ^ sbit;
+            diff_hi |= (u32)(bal >> 32) ^ sbit;
         }
-        if (!valid) mask = 1ull << lane;
+        u64 mask = ~(((u64)diff_hi << 32) | diff_lo);
+        if (!FULL) {
+            mask &= __ballot(valid);
+            if (!valid) mask = 1ull << lane;
+        }
         const u32 cnt = (u32)__popcll(mask);
         // set bits of `mask` below this lane (v_mbcnt_lo/hi take a per-lane mask)
         const u32 before = __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
 #pragma unroll
     for (int j = 0; j < IPT; j++) {
         const u32 local = w * WAVE_ITEMS + j * WAVE + lane;
-        if (local < tile_count) {
+        if (FULL || local < tile_count) {
             const u32 digit = (u32)(key[j] >> shift) & 255u;
             slot[j] = digit_start[digit] + wave_cnt[w][digit] + slot[j];
             s_keys[slot[j]] = key[j];
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
 #pragma unroll
     for (int j = 0; j < IPT; j++) {
         const u32 pos = j * THREADS + tid;
-        if (pos < tile_count) {
+        if (FULL || pos < tile_count) {
             const K k = s_keys[pos];
             dst[j] = global_base[(u32)(k >> shift) & 255u] + pos;
             keys_out[dst[j]] = k;
@@ -211,14 +213,34 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
 #pragma unroll
     for (int j = 0; j < IPT; j++) {
         const u32 local = w * WAVE_ITEMS + j * WAVE + lane;
-        if (local < tile_count) s_vals[slot[j]] = val[j];
+        if (FULL || local < tile_count) s_vals[slot[j]] = val[j];
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < IPT; j++) {
         const u32 pos = j * THREADS + tid;
-        if (pos < tile_count) vals_out[dst[j]] = s_vals[pos];
+        if (FULL || pos < tile_count) vals_out[dst[j]] = s_vals[pos];
     }
+}
+
+template <class K, int THREADS, class Src>
+__global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
+    Src src, K *__restrict__ keys_out, u32 *__restrict__ vals_out, u32 n, int shift,
+    const u32 *__restrict__ scanned_hist, u32 n_tiles)
+{
+    // XCD-aware tile order: workgroups go round-robin over the 8 XCDs, each with its own L2.  The
+    // per-digit runs of NEIGHBOURING tiles are neighbours in the output, so neighbouring tiles are
+    // given to the same XCD (XCD x takes the x-th eighth of the tiles): the partial lines at the
+    // seams of the runs meet in one L2 instead of reaching memory as masked writes from two.
+    const u32 per_xcd = (n_tiles + 7u) / 8u;
+    const u32 tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const u32 tile_count = (n - tile * RS_TILE) < (u32)RS_TILE ? (n - tile * RS_TILE) : (u32)RS_TILE;
+    // every tile but the last is full: no bounds tests in its code path
+    if (tile_count == (u32)RS_TILE)
+        radix_scatter_tile<K, THREADS, Src, true>(src, keys_out, vals_out, shift, scanned_hist, tile, tile_count);
+    else
+        radix_scatter_tile<K, THREADS, Src, false>(src, keys_out, vals_out, shift, scanned_hist, tile, tile_count);
 }
 
 template <class K> struct SortBufs {
