@@ -729,15 +729,15 @@ struct FlagArrIn {                              // the naming predicate of a com
     __device__ __forceinline__ u32 operator()(u32 i) const { return flags[i]; }
 };
 
-// LCP of sorted neighbours r-1, r from their window keys alone: the leading symbol fields the two
-// keys have in common, cut at the first terminator field (equal terminator codes are two DIFFERENT
-// terminators).  Returns w with whole = true when the full windows agree and hold no terminator --
-// only then does the text have to be read, from offset w on.
+// LCP of sorted neighbours from their window keys k (the later one) and kp alone: the leading symbol
+// fields the two keys have in common, cut at the first terminator field (equal terminator codes
+// are two DIFFERENT terminators).  Returns w with whole = true when the full windows agree and hold
+// no terminator -- only then does the text have to be read, from offset w on.
 template <class K>
-__device__ __forceinline__ u32 lvl0_lcp_of_keys(const KeyNeqWindowIn<K> &f, int w, int b, int spare, u32 r, bool &whole)
+__device__ __forceinline__ u32 lvl0_lcp_of_key_pair(const KeyNeqWindowIn<K> &f, int w, int b, int spare, K k, K kp,
+                                                    bool &whole)
 {
-    const K k = f.keys[r];
-    const u64 d = (u64)(k ^ f.keys[r - 1]);
+    const u64 d = (u64)(k ^ kp);
     u32 mism = (u32)w;                                   // leading symbol fields in common
     if (d) {
         const int hb = 63 - __builtin_clzll(d);
@@ -751,89 +751,181 @@ __device__ __forceinline__ u32 lvl0_lcp_of_keys(const KeyNeqWindowIn<K> &f, int 
     return h;
 }
 
-// One pass over a domain of m elements.  Untied elements and small groups get their final place
-// in order_g (first domain only: later domains had theirs written by the previous write-back);
-// members of large groups are marked in keep[] for the radix round (block_keep: their number per
-// workgroup).  First domain: slot == nullptr (identity), names_g (sample mode, may be null)
-// receives the naming predicate as refined so far, and with WITH_LCP (all-suffix mode, one
-// document) the LCP entry of every element placed here is written as well -- from the keys where
-// the neighbours' windows differ, from the comparisons just made inside a small group.
-template <class Starts, bool WITH_LCP>
-__global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *__restrict__ elem, Starts starts,
+template <class K>
+__device__ __forceinline__ u32 lvl0_lcp_of_keys(const KeyNeqWindowIn<K> &f, int w, int b, int spare, u32 r, bool &whole)
+{
+    return lvl0_lcp_of_key_pair(f, w, b, spare, f.keys[r], f.keys[r - 1], whole);
+}
+
+// A tied element j of a domain (elem[], naming predicate `starts`, slot[] or identity): if its group
+// of equal names is small (<= REFINE_SMALL_GROUP), its rank inside the group is found by comparing
+// the suffixes themselves from offset `depth` on, 8 symbols per step, and it is placed for good:
+// order_g, names_g (sample mode) and -- keyed first domain, one document -- its LCP entry, which is
+// the longest common prefix with a smaller member found on the way, or comes from the keys for the
+// first of the group (lcp_first).  Returns 1 when the group is large: left to the radix round.
+template <class Starts, class LcpFirst>
+__device__ __forceinline__ u32 lvl0_place_tied(u32 j, const u32 *__restrict__ elem, const Starts &starts,
+                                               const u32 *__restrict__ slot, u32 m, const uint8_t *__restrict__ s8,
+                                               u32 n0, u32 depth, u32 *__restrict__ order_g,
+                                               u32 *__restrict__ names_g, u32 *__restrict__ lcp_g, LcpFirst lcp_first,
+                                               u32 *__restrict__ fail)
+{
+    const bool first = slot == nullptr;
+    const u32 e = elem[j];
+    u32 a = j, bnd = j + 1;
+    while (a > 0 && !starts(a) && j - a <= REFINE_SMALL_GROUP) a--;
+    while (bnd < m && !starts(bnd) && bnd - j <= REFINE_SMALL_GROUP) bnd++;
+    if (bnd - a > REFINE_SMALL_GROUP) {
+        if (first) { order_g[j] = e; if (names_g) names_g[j] = starts(j); }
+        return 1;
+    }
+    const u32 p = lvl0_pos(e, n0);
+    u32 r = 0, best = 0;                                // best: longest common prefix with a smaller member
+    for (u32 x = a; x < bnd; x++) {
+        if (x == j) continue;
+        const u32 p2 = lvl0_pos(elem[x], n0);
+        bool decided = false, less = false;             // less: suffix p2 < suffix p
+        u32 h = depth;
+        for (; h < depth + RESOLVE_MAX_LEN && !decided; h += 8) {
+            const u64 u = load_u64_unaligned(s8 + p + h), v = load_u64_unaligned(s8 + p2 + h);
+            const u64 d = u ^ v, z = ~u;
+            const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+            const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+            const u32 term = tz ? (u32)__builtin_ctzll(tz) >> 3 : 8u;
+            if (term < mism) { less = p2 < p; decided = true; h += term; break; }     // both end in (different) terminators
+            if (mism < 8u) { less = ((v >> (8 * mism)) & 0xFFu) < ((u >> (8 * mism)) & 0xFFu); decided = true; h += mism; break; }
+        }
+        if (!decided) { atomicOr(fail, 1u); return 0; } // (the host restores the domain and gives up on it)
+        if (less) { r++; best = h > best ? h : best; }
+    }
+    const u32 at = a + r;                               // final place inside the domain
+    order_g[first ? at : slot[at]] = e;
+    if (names_g) names_g[first ? j : slot[j]] = 1;
+    if (lcp_g) lcp_g[at] = r > 0 ? best : lcp_first(at);
+    return 0;
+}
+
+struct NoLcp {
+    __device__ __forceinline__ u32 operator()(u32) const { return 0u; }
+};
+
+// First domain = the whole sorted input, 4 consecutive elements per thread (16-byte loads and
+// stores).  A suffix whose key differs from both neighbours' (or holds a terminator) is final:
+// suffix array entry, name flag (sample mode) and LCP entry (lcp_g: all-suffix mode, one document;
+// from the two keys, no text is read) are written at once; tied ones go through lvl0_place_tied.
+// keep[]: one bit per element, set for members of large groups; block_keep: their number per workgroup.
+#define PLACE_IPT 4
+template <class K>
+__global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, const u32 *__restrict__ vals, u32 m,
+                                                          const uint8_t *__restrict__ s8, u32 n0, int w, int b,
+                                                          int spare, u32 *__restrict__ order_g,
+                                                          u32 *__restrict__ names_g, u32 *__restrict__ lcp_g,
+                                                          u64 *__restrict__ keep, u32 *__restrict__ block_keep,
+                                                          u32 *__restrict__ fail)
+{
+    __shared__ u32 keep_bits[BLOCK * PLACE_IPT / 32];
+    __shared__ u32 work[BLOCK * PLACE_IPT];             // the tied elements of this workgroup's stretch
+    __shared__ u32 n_keep, n_work;
+    if (threadIdx.x < BLOCK * PLACE_IPT / 32) keep_bits[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { n_keep = 0; n_work = 0; }
+    __syncthreads();
+    const u32 j0 = (blockIdx.x * BLOCK + threadIdx.x) * PLACE_IPT;
+    if (j0 < m) {
+        // keys j0-1 .. j0+4 (the arrays carry 8 spare entries behind m), elements j0 .. j0+3
+        K k[PLACE_IPT + 2];
+        k[0] = j0 > 0 ? f.keys[j0 - 1] : (K)0;
+#pragma unroll
+        for (int e = 0; e < PLACE_IPT; e++) k[e + 1] = f.keys[j0 + e];
+        k[PLACE_IPT + 1] = f.keys[j0 + PLACE_IPT];
+        u32 v[PLACE_IPT];
+#pragma unroll
+        for (int e = 0; e < PLACE_IPT; e++) v[e] = vals[j0 + e];
+        bool start[PLACE_IPT + 1];
+#pragma unroll
+        for (int e = 0; e <= PLACE_IPT; e++) {
+            const K x = k[e + 1] ^ f.rep_t;
+            const bool has_term = ((x - f.ones) & ~x & f.highs) != 0;
+            start[e] = j0 + e == 0 || j0 + e >= m || has_term || k[e + 1] != k[e];
+        }
+        bool all_final = j0 + PLACE_IPT <= m;
+#pragma unroll
+        for (int e = 0; e < PLACE_IPT; e++) all_final = all_final && start[e] && start[e + 1];
+        if (all_final) {
+            uint4 o = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<uint4 *>(order_g + j0) = o;
+            if (names_g) *reinterpret_cast<uint4 *>(names_g + j0) = uint4{1u, 1u, 1u, 1u};
+            if (lcp_g) {
+                u32 h[PLACE_IPT];
+#pragma unroll
+                for (int e = 0; e < PLACE_IPT; e++) {
+                    bool whole;
+                    h[e] = j0 + e > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, k[e + 1], k[e], whole) : 0u;
+                }
+                *reinterpret_cast<uint4 *>(lcp_g + j0) = uint4{h[0], h[1], h[2], h[3]};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < PLACE_IPT; e++) {
+                const u32 j = j0 + e;
+                if (j >= m) break;
+                if (start[e] && start[e + 1]) {
+                    order_g[j] = v[e];
+                    if (names_g) names_g[j] = 1;
+                    if (lcp_g) {
+                        bool whole;
+                        lcp_g[j] = j > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, k[e + 1], k[e], whole) : 0u;
+                    }
+                } else {
+                    work[atomicAdd(&n_work, 1u)] = j;    // phase 2
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // phase 2: the tied elements, one per thread, so that their text gathers run side by side
+    // instead of one after the other inside the thread that met them
+    const u32 todo = n_work;
+    for (u32 i = threadIdx.x; i < todo; i += BLOCK) {
+        const u32 j = work[i];
+        auto lcp_first = [&](u32 at) -> u32 {
+            bool whole;
+            return at > 0 ? lvl0_lcp_of_keys(f, w, b, spare, at, whole) : 0u;
+        };
+        if (lvl0_place_tied(j, vals, f, (const u32 *)nullptr, m, s8, n0, (u32)w, order_g, names_g, lcp_g, lcp_first, fail)) {
+            const u32 local = j - blockIdx.x * (BLOCK * PLACE_IPT);
+            atomicOr(&keep_bits[local >> 5], 1u << (local & 31u));
+            atomicAdd(&n_keep, 1u);
+        }
+    }
+    __syncthreads();
+    // (entries m.. are 0: the exclusive scan over m + 1 entries yields the total)
+    if (threadIdx.x < BLOCK * PLACE_IPT / 64)
+        keep[(size_t)blockIdx.x * (BLOCK * PLACE_IPT / 64) + threadIdx.x] =
+            ((u64)keep_bits[2 * threadIdx.x + 1] << 32) | keep_bits[2 * threadIdx.x];
+    if (threadIdx.x == 0) block_keep[blockIdx.x] = n_keep;
+}
+
+// A later, compacted domain of m elements (slot[] = where each sits in the global order): untied
+// elements already have their place (written by the previous round's write-back); small groups are
+// placed by lvl0_place_tied; members of large groups are marked in keep[] (one bit each).
+__global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *__restrict__ elem, FlagArrIn starts,
                                                                     const u32 *__restrict__ slot, u32 m,
                                                                     const uint8_t *__restrict__ s8, u32 n0, u32 depth,
-                                                                    int w, int b, int spare,
                                                                     u32 *__restrict__ order_g, u32 *__restrict__ names_g,
-                                                                    u32 *__restrict__ lcp_g, u64 *__restrict__ keep,
-                                                                    u32 *__restrict__ block_keep, u32 *__restrict__ fail)
+                                                                    u64 *__restrict__ keep, u32 *__restrict__ fail)
 {
-    __shared__ u32 wave_keep[WAVES_PER_BLOCK];
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
-    const bool first = slot == nullptr;
     u32 my_keep = 0;
     if (j < m) {
-        const u32 e = elem[j];
-        const u32 start = starts(j);
-        const bool left_same = j > 0 && !start;
+        const bool left_same = j > 0 && !starts(j);
         const bool right_same = j + 1 < m && !starts(j + 1);
-        u32 a = j, bnd = j + 1;
-        if (left_same || right_same) {
-            while (a > 0 && !starts(a) && j - a <= REFINE_SMALL_GROUP) a--;
-            while (bnd < m && !starts(bnd) && bnd - j <= REFINE_SMALL_GROUP) bnd++;
-        }
-        if (bnd - a > REFINE_SMALL_GROUP) {             // a large group: left to the radix round
-            my_keep = 1;
-            if (first) { order_g[j] = e; if (names_g) names_g[j] = start; }
-        } else {
-            // rank inside the (possibly one-element) group, by comparing the suffixes from `depth` on
-            const u32 p = lvl0_pos(e, n0);
-            u32 r = 0, best = 0;                            // best: longest common prefix with a smaller member
-            bool ok = true;
-            for (u32 x = a; x < bnd && ok; x++) {
-                if (x == j) continue;
-                const u32 p2 = lvl0_pos(elem[x], n0);
-                bool decided = false, less = false;         // less: suffix p2 < suffix p
-                u32 h = depth;
-                for (; h < depth + RESOLVE_MAX_LEN && !decided; h += 8) {
-                    const u64 u = load_u64_unaligned(s8 + p + h), v = load_u64_unaligned(s8 + p2 + h);
-                    const u64 d = u ^ v, z = ~u;
-                    const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
-                    const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
-                    const u32 term = tz ? (u32)__builtin_ctzll(tz) >> 3 : 8u;
-                    if (term < mism) { less = p2 < p; decided = true; h += term; break; }     // both end in (different) terminators
-                    if (mism < 8u) { less = ((v >> (8 * mism)) & 0xFFu) < ((u >> (8 * mism)) & 0xFFu); decided = true; h += mism; break; }
-                }
-                if (!decided) { ok = false; break; }
-                if (less) { r++; best = h > best ? h : best; }
-            }
-            if (!ok) {
-                atomicOr(fail, 1u);                         // (the host restores the domain and gives up on it)
-            } else {
-                const u32 at = a + r;                       // final place inside the domain
-                if (first || bnd - a > 1) order_g[first ? at : slot[at]] = e;
-                if (names_g && (first || bnd - a > 1)) names_g[first ? j : slot[j]] = 1;
-                if constexpr (WITH_LCP) {
-                    u32 h = 0;
-                    if (r > 0) h = best;
-                    else if (at > 0) { bool whole; h = lvl0_lcp_of_keys(starts, w, b, spare, at, whole); }
-                    lcp_g[at] = h;
-                }
-            }
-        }
+        if (left_same || right_same)
+            my_keep = lvl0_place_tied(j, elem, starts, slot, m, s8, n0, depth, order_g, names_g, (u32 *)nullptr, NoLcp(),
+                                      fail);
     }
     // keep[]: one bit per element (entries m.. of the last word are 0: the exclusive scan over m + 1 yields the total)
     const u64 bal = __ballot(my_keep != 0);
     if (lane_id() == 0) keep[j >> 6] = bal;
-    if (block_keep) {
-        const u32 c = (u32)__popcll(bal);
-        if (lane_id() == 0) wave_keep[wave_id()] = c;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            u32 t = 0;
-            for (int k = 0; k < WAVES_PER_BLOCK; k++) t += wave_keep[k];
-            block_keep[blockIdx.x] = t;
-        }
-    }
 }
 
 // A repeat too long for the direct ordering leaves its group half written: put the whole domain back
@@ -963,7 +1055,9 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     const int spare = w < 12 ? std::min(total - w * bt, bt - 1) : 0;
     SortBufs<K> sb;
     // (one spare element each: the idle half serves as scratch after the sort)
-    for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<K>((size_t)n02 + 1); sb.vals[k] = ar.alloc<u32>((size_t)n02 + 1); }
+    // (8 spare entries: the placement pass reads whole 16-byte groups; >= 64 so that the idle half can hold its scratch)
+    const size_t n_alloc = (size_t)(n02 > 56 ? n02 : 56) + 8;
+    for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<K>(n_alloc); sb.vals[k] = ar.alloc<u32>(n_alloc); }
     const int r = radix_sort_pairs<K, WindowSrc<K>>(ctx, sb, n02, w * bt + spare, 0,
                                                     WindowSrc<K>{s8, n0, w, bt, spare, term_first});
     const KeyNeqWindowIn<K> starts = KeyNeqWindowIn<K>::make(sb.keys[r], w, bt, spare, term_first);
@@ -972,21 +1066,16 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     u32 *idx = sb.vals[r ^ 1];                          // n02 + 1 entries, likewise
     u32 *names_g = s12 ? ar.alloc<u32>(n02) : nullptr;  // sample mode: the naming predicate as refined so far
     u32 *fail = ar.alloc<u32>(1);
-    u32 *block_keep = ar.alloc<u32>(g02);
-    const u32 nb = ceil_div_u32(g02, SCAN_TILE);
+    const u32 gp = ceil_div_u32((u64)n02 + 1, BLOCK * PLACE_IPT);      // workgroups of the placement pass
+    u32 *block_keep = ar.alloc<u32>(gp);
+    const u32 nb = ceil_div_u32(gp, SCAN_TILE);
     u32 *block_sums = ar.alloc<u32>(nb);
     if (!ctx.dry) HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
 
     // ---- the whole sorted input as the first domain --------------------------------------
-    if (lcp_out)
-        LAUNCH_NAMED(ctx, "dc3_refine_classify_kernel", (dc3_refine_classify_kernel<KeyNeqWindowIn<K>, true>), g02,
-                     sorted_vals, starts, (const u32 *)nullptr, n02, s8, n0, (u32)w, w, bt, spare, sa12, names_g, lcp_out,
-                     keep, block_keep, fail);
-    else
-        LAUNCH_NAMED(ctx, "dc3_refine_classify_kernel", (dc3_refine_classify_kernel<KeyNeqWindowIn<K>, false>), g02,
-                     sorted_vals, starts, (const u32 *)nullptr, n02, s8, n0, (u32)w, w, bt, spare, sa12, names_g,
-                     (u32 *)nullptr, keep, block_keep, fail);
-    LAUNCH(ctx, (scan_reduce_kernel<ArrIn>), nb, ArrIn{block_keep}, g02, block_sums);
+    LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K>), gp, starts, sorted_vals, n02, s8, n0, w, bt, spare, sa12,
+                 names_g, lcp_out, keep, block_keep, fail);
+    LAUNCH(ctx, (scan_reduce_kernel<ArrIn>), nb, ArrIn{block_keep}, gp, block_sums);
     u32 m = n02, m_next = n02, h_fail = 0;              // (sizing run: as if everything were tied)
     if (!ctx.dry) {
         std::vector<u32> h_sums(nb);
@@ -1061,9 +1150,8 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             depth += (u32)w2;
             if (ctx.stats) ctx.stats->refine_rounds++;
             // the new, smaller domain: place what is untied or in small groups now, count the rest
-            LAUNCH_NAMED(ctx, "dc3_refine_classify_kernel", (dc3_refine_classify_kernel<FlagArrIn, false>), gt, elem,
-                         FlagArrIn{flag}, slot, m, s8, n0, depth, 0, 0, 0, sa12, names_g, (u32 *)nullptr, keep,
-                         (u32 *)nullptr, fail);
+            LAUNCH(ctx, dc3_refine_classify_kernel, gt, elem, FlagArrIn{flag}, slot, m, s8, n0, depth, sa12, names_g, keep,
+                   fail);
             device_scan<BitIn, false>(ctx, BitIn{keep}, m + 1, idx);
             have_idx = true;
             HIP_CHECK(hipMemcpyAsync(&m_next, idx + m, 4, hipMemcpyDeviceToHost, ctx.stream));

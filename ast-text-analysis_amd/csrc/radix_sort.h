@@ -99,20 +99,28 @@ __global__ __launch_bounds__(BLOCK) void hist_apply_kernel(u32 *__restrict__ his
 // (the per-pair destination is kept in registers), which keeps the workgroup at
 // 4096*sizeof(K) + 4*WAVES*256 + 2 KiB of LDS: two 16-wave workgroups (32 waves,
 // the hardware maximum) fit a CU.
+template <class K, int WAVES> struct ScatterLds {      // (declared once in the kernel: both tile paths share it)
+    K s_keys[RS_TILE];
+    u32 wave_cnt[WAVES][RS_BINS];           // per-wave digit counts, then wave bases
+    u32 digit_start[RS_BINS];               // first slot of the digit inside the tile
+    u32 global_base[RS_BINS];               // output index of slot 0 of the digit
+    u32 lds4[4];
+};
+
 template <class K, int THREADS, class Src, bool FULL>
 __device__ __forceinline__ void radix_scatter_tile(
-    const Src &src, K *__restrict__ keys_out, u32 *__restrict__ vals_out, int shift,
+    ScatterLds<K, THREADS / WAVE> &lds, const Src &src, K *__restrict__ keys_out, u32 *__restrict__ vals_out, int shift,
     const u32 *__restrict__ scanned_hist, u32 tile, u32 tile_count)
 {
     constexpr int WAVES = THREADS / WAVE;
     constexpr int IPT = RS_TILE / THREADS;
     constexpr int WAVE_ITEMS = WAVE * IPT;
     static_assert(THREADS >= RS_BINS && RS_TILE % THREADS == 0, "bad scatter geometry");
-    __shared__ K s_keys[RS_TILE];
-    __shared__ u32 wave_cnt[WAVES][RS_BINS];            // per-wave digit counts, then wave bases
-    __shared__ u32 digit_start[RS_BINS];                // first slot of the digit inside the tile
-    __shared__ u32 global_base[RS_BINS];                // output index of slot 0 of the digit
-    __shared__ u32 lds4[4];
+    K (&s_keys)[RS_TILE] = lds.s_keys;
+    u32 (&wave_cnt)[WAVES][RS_BINS] = lds.wave_cnt;
+    u32 (&digit_start)[RS_BINS] = lds.digit_start;
+    u32 (&global_base)[RS_BINS] = lds.global_base;
+    u32 (&lds4)[4] = lds.lds4;
     u32 *s_vals = reinterpret_cast<u32 *>(s_keys);
 
     const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -237,10 +245,11 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     if (tile >= n_tiles) return;
     const u32 tile_count = (n - tile * RS_TILE) < (u32)RS_TILE ? (n - tile * RS_TILE) : (u32)RS_TILE;
     // every tile but the last is full: no bounds tests in its code path
+    __shared__ ScatterLds<K, THREADS / WAVE> lds;
     if (tile_count == (u32)RS_TILE)
-        radix_scatter_tile<K, THREADS, Src, true>(src, keys_out, vals_out, shift, scanned_hist, tile, tile_count);
+        radix_scatter_tile<K, THREADS, Src, true>(lds, src, keys_out, vals_out, shift, scanned_hist, tile, tile_count);
     else
-        radix_scatter_tile<K, THREADS, Src, false>(src, keys_out, vals_out, shift, scanned_hist, tile, tile_count);
+        radix_scatter_tile<K, THREADS, Src, false>(lds, src, keys_out, vals_out, shift, scanned_hist, tile, tile_count);
 }
 
 template <class K> struct SortBufs {
