@@ -325,53 +325,77 @@ __device__ __forceinline__ u32 pyr_leftmost_argmin(const Pyramid &P, u32 a, u32 
 // phase 2 processes densely through the pyramid.  (With the pyramid search inlined,
 // nearly every wavefront paid for it because one lane in 64 needed it.)  doc segment
 // starts carry lcp == 0, which bounds every search inside the document.
-#define ANN_NEAR 8u
-#define ANN_IPT 8
+#define ANN_NEAR 8
+#define ANN_IPT 4                       // consecutive ranks per thread: 16-byte loads and stores
 #define ANN_TILE (BLOCK * ANN_IPT)
 
 __global__ __launch_bounds__(BLOCK) void ann_kernel(Pyramid P, const u32 *__restrict__ doc_off,
                                                     const u32 *__restrict__ n_strings, u32 n_docs, u32 n,
                                                     u32 *__restrict__ ann)
 {
-    __shared__ u32 tile[ANN_TILE + 2 * ANN_NEAR];       // the tile's LCP values with ANN_NEAR ranks of halo
     __shared__ u32 work[ANN_TILE];
     __shared__ u32 work_count;
     const u32 *lcp = P.ptr[0];
-    const u32 base = blockIdx.x * ANN_TILE;
     if (threadIdx.x == 0) work_count = 0;
-    for (u32 i = threadIdx.x; i < ANN_TILE + 2 * ANN_NEAR; i += BLOCK) {
-        const u64 g = (u64)base + i;                     // global rank + ANN_NEAR
-        tile[i] = (g >= ANN_NEAR && g - ANN_NEAR < n) ? lcp[g - ANN_NEAR] : 0u;   // 0 stops every scan
-    }
     __syncthreads();
-#pragma unroll 2
-    for (int j = 0; j < ANN_IPT; j++) {
-        const u32 t = j * BLOCK + threadIdx.x;           // position inside the tile
-        const u32 k = base + t;
-        if (k >= n) continue;
-        const u32 *c = tile + t + ANN_NEAR;              // c[0] = lcp[k], c[-1] = lcp[k-1], ...
-        const u32 v = c[0];
-        if (v == 0) {
-            // only a document's first rank carries an annotation here: the root, n_d - m_d
-            const u32 d = n_docs > 1 ? doc_of(doc_off, n_docs, k) : 0u;
-            ann[k] = doc_off[d] == k ? (doc_off[d + 1] - k) - n_strings[d] : 0u;
-            continue;
+    const u32 k0 = (blockIdx.x * BLOCK + threadIdx.x) * ANN_IPT;
+    if (k0 < n) {
+        // c[i] = lcp[k0 - ANN_NEAR + i] for the thread's 4 ranks and ANN_NEAR ranks to either side, five 16-byte
+        // loads (the neighbours' loads hit the same lines); ranks outside [0, n) read as 0, which stops every scan
+        u32 c[ANN_IPT + 2 * ANN_NEAR];
+#pragma unroll
+        for (int q = 0; q < (ANN_IPT + 2 * ANN_NEAR) / 4; q++) {
+            const u32 g = k0 + 4u * q;                  // global rank + ANN_NEAR
+            uint4 x = {0u, 0u, 0u, 0u};
+            if (g >= ANN_NEAR && g - ANN_NEAR < n) x = *reinterpret_cast<const uint4 *>(lcp + (g - ANN_NEAR));
+            c[4 * q] = x.x; c[4 * q + 1] = x.y; c[4 * q + 2] = x.z; c[4 * q + 3] = x.w;
+            if (g - ANN_NEAR + 4u > n) {                // (pyramid padding behind n holds 0xFFFFFFFF)
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (g >= ANN_NEAR && g - ANN_NEAR + e >= n) c[4 * q + e] = 0u;
+            }
         }
-        // previous value <= v within ANN_NEAR ranks (lcp[0] == 0 and the zero halo stop the scan)
-        u32 back = 1;
-        while (back < ANN_NEAR && c[-(int)back] > v) back++;
-        const u32 x = c[-(int)back];
-        bool defer = x > v;
-        u32 a = 0;
-        if (!defer && x < v) {                  // first l-index of its interval: width = NSV - PSV
-            u32 fwd = 1;
-            while (fwd < ANN_NEAR && k + fwd < n && c[fwd] >= v) fwd++;
-            if (k + fwd >= n) a = n - (k - back);
-            else if (c[fwd] < v) a = fwd + back;
-            else defer = true;
+        u32 out[ANN_IPT];
+        bool direct[ANN_IPT];
+#pragma unroll
+        for (int e = 0; e < ANN_IPT; e++) {
+            const u32 k = k0 + e;
+            const int i = ANN_NEAR + e;                  // c[i] = lcp[k]
+            const u32 v = c[i];
+            out[e] = 0;
+            direct[e] = true;
+            if (k >= n) continue;
+            if (v == 0) {
+                // only a document's first rank carries an annotation here: the root, n_d - m_d
+                const u32 d = n_docs > 1 ? doc_of(doc_off, n_docs, k) : 0u;
+                out[e] = doc_off[d] == k ? (doc_off[d + 1] - k) - n_strings[d] : 0u;
+                continue;
+            }
+            // nearest previous value <= v within ANN_NEAR ranks (lcp[0] == 0 and the zero halo stop the scan)
+            u32 back = 0, x = 0;
+#pragma unroll
+            for (int t = ANN_NEAR; t >= 1; t--)
+                if (c[i - t] <= v) { back = (u32)t; x = c[i - t]; }
+            if (back == 0) { direct[e] = false; continue; }      // further away: phase 2
+            if (x < v) {                        // first l-index of its interval: width = NSV - PSV
+                u32 fwd = 0;
+#pragma unroll
+                for (int t = ANN_NEAR; t >= 1; t--)
+                    if (c[i + t] < v) fwd = (u32)t;
+                if (fwd == 0) direct[e] = false;
+                else out[e] = fwd + back;
+            }
         }
-        if (defer) work[atomicAdd(&work_count, 1u)] = k;
-        else ann[k] = a;
+        if (direct[0] && direct[1] && direct[2] && direct[3] && k0 + ANN_IPT <= n) {
+            *reinterpret_cast<uint4 *>(ann + k0) = uint4{out[0], out[1], out[2], out[3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < ANN_IPT; e++) {
+                if (k0 + e >= n) break;
+                if (direct[e]) ann[k0 + e] = out[e];
+                else work[atomicAdd(&work_count, 1u)] = k0 + e;
+            }
+        }
     }
     __syncthreads();
     const u32 count = work_count;
