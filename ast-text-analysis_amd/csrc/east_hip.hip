@@ -33,20 +33,27 @@
 static thread_local std::string g_last_error;
 
 // ------------------------------------------------------------ prep kernels --
-__global__ __launch_bounds__(BLOCK) void presence_kernel(const u32 *__restrict__ sym, u32 n,
+// (vec: the caller's symbol array is 16-byte aligned, as every allocation is; a misaligned view of a
+// larger buffer takes the symbol-by-symbol path)
+__global__ __launch_bounds__(BLOCK) void presence_kernel(const u32 *__restrict__ sym, u32 n, int vec,
                                                          u32 *__restrict__ present)
 {
     __shared__ u32 bits[PRESENT_WORDS];
     if (threadIdx.x < PRESENT_WORDS) bits[threadIdx.x] = 0;
     __syncthreads();
-    const u32 stride = gridDim.x * BLOCK;
-    for (u32 i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-        const u32 c = sym[i];
-        // a plain LDS read filters the (overwhelmingly common) already-set case; a stale read only
-        // costs a redundant atomic
+    // a plain LDS read filters the (overwhelmingly common) already-set case; a stale read only
+    // costs a redundant atomic
+    auto mark = [&](u32 c) {
         if (c < TEXT_SYMBOLS && !(((volatile u32 *)bits)[c >> 5] & (1u << (c & 31u))))
             atomicOr(&bits[c >> 5], 1u << (c & 31u));
+    };
+    const u32 stride = gridDim.x * BLOCK;
+    const u32 n4 = vec ? n >> 2 : 0u;                      // four symbols per 16-byte load
+    for (u32 i = blockIdx.x * BLOCK + threadIdx.x; i < n4; i += stride) {
+        const uint4 c = reinterpret_cast<const uint4 *>(sym)[i];
+        mark(c.x); mark(c.y); mark(c.z); mark(c.w);
     }
+    for (u32 i = (n4 << 2) + blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) mark(sym[i]);
     __syncthreads();
     if (threadIdx.x < PRESENT_WORDS && bits[threadIdx.x]) atomicOr(&present[threadIdx.x], bits[threadIdx.x]);
 }
@@ -63,15 +70,22 @@ struct TermIn {                                 // 1 at terminators; defined on 
 // byte path: only the byte stream is built (0xFF = terminator); the exact terminator numbers are
 // never needed there, so no terminator scan runs
 __global__ __launch_bounds__(BLOCK) void remap_bytes_kernel(const u32 *__restrict__ sym,
-                                                            const u32 *__restrict__ code_map, u32 n,
+                                                            const u32 *__restrict__ code_map, u32 n, int vec,
                                                             uint8_t *__restrict__ s8)
 {
-    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) {
-        const u32 c = sym[i];
-        s8[i] = c < TEXT_SYMBOLS ? (uint8_t)code_map[c] : (uint8_t)0xFF;
-    } else if (i < n + 16) {
-        s8[i] = 0;
+    // four symbols per thread: one 16-byte load, one 4-byte store (the grid covers n + 16 bytes)
+    const u32 i = (blockIdx.x * BLOCK + threadIdx.x) * 4u;
+    if (vec && i + 4u <= n) {
+        const uint4 c = *reinterpret_cast<const uint4 *>(sym + i);
+        const u32 b0 = c.x < TEXT_SYMBOLS ? code_map[c.x] & 0xFFu : 0xFFu, b1 = c.y < TEXT_SYMBOLS ? code_map[c.y] & 0xFFu : 0xFFu;
+        const u32 b2 = c.z < TEXT_SYMBOLS ? code_map[c.z] & 0xFFu : 0xFFu, b3 = c.w < TEXT_SYMBOLS ? code_map[c.w] & 0xFFu : 0xFFu;
+        *reinterpret_cast<u32 *>(s8 + i) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    } else {
+        for (u32 j = i; j < i + 4u && j < n + 16u; j++) {
+            uint8_t v = 0;
+            if (j < n) { const u32 c = sym[j]; v = c < TEXT_SYMBOLS ? (uint8_t)code_map[c] : (uint8_t)0xFF; }
+            s8[j] = v;
+        }
     }
 }
 
@@ -214,7 +228,8 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         u32 *present = ar.alloc<u32>(PRESENT_WORDS + 1);  // + status word
         u32 *term_ex = ar.alloc<u32>((size_t)n + 1);      // wide-alphabet path only
         if (!ctx.dry) HIP_CHECK(hipMemsetAsync(present, 0, (PRESENT_WORDS + 1) * 4, ctx.stream));
-        LAUNCH(ctx, presence_kernel, std::min<u32>(gn, 2048), d_sym, n, present);
+        const int vec = ((uintptr_t)d_sym & 15u) == 0;
+        LAUNCH(ctx, presence_kernel, std::min<u32>(gn, 2048), d_sym, n, vec, present);
         LAUNCH(ctx, validate_last_symbol_kernel, ceil_div_u32(n_docs, BLOCK), d_sym, (const u32 *)h->doc_off, n_docs,
                present + PRESENT_WORDS);
         if (!ctx.dry) {
@@ -234,8 +249,8 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
             h->use_s8 = sigma_t <= 254;
         }
         if (h->use_s8 && !ctx.dry) {
-            LAUNCH(ctx, remap_bytes_kernel, ceil_div_u32((u64)n + 16, BLOCK), d_sym, (const u32 *)h->code_map, n,
-                   h->s8);
+            LAUNCH(ctx, remap_bytes_kernel, ceil_div_u32((u64)n + 16, BLOCK * 4), d_sym, (const u32 *)h->code_map, n,
+                   vec, h->s8);
         } else {
             // wide alphabets: dense u32 codes, terminators numbered globally by a scan
             device_scan<TermIn, false>(ctx, TermIn{d_sym, n}, n + 1, term_ex);

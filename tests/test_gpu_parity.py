@@ -446,6 +446,26 @@ def test_small_vocabulary_text_tie_refinement_vs_oracle(hip, oracle, seed):
             assert np.array_equal(t[name], getattr(o, name)), (name, d, index.info())
 
 
+@pytest.mark.parametrize("shift", [0, 1, 2, 3])
+def test_build_from_resident_symbols_at_any_alignment(hip, oracle, shift):
+    """east_hip_build_device on a symbol array that starts 0..3 words into a device buffer (a view of
+    a larger tensor is only 4-byte aligned): the 16-byte fast paths must not be taken blindly."""
+    import torch
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(31 + shift)
+    sym, m = synthetic.word_stream_document(rng, 50001 + shift, want_text=False)[1:]
+    buf = torch.zeros(sym.size + 8, dtype=torch.int32, device="cuda:0")
+    buf[shift:shift + sym.size] = torch.from_numpy(sym.astype(np.int32)).to(buf.device)
+    view = buf[shift:shift + sym.size]
+    assert view.data_ptr() % 16 == (4 * shift) % 16
+    index = hip_backend.HipIndex()
+    index.build_device(view.data_ptr(), sym.size, np.array([0, sym.size]), np.array([m]))
+    o = oracle.OracleEASA(symbols=sym, n_strings=m)
+    t = index.tables(0)
+    for name in TABLES:
+        assert np.array_equal(t[name], getattr(o, name)), name
+
+
 def test_lean_build_without_refinement_rounds(hip, oracle):
     """When the buffers of the tie-refinement rounds do not fit the device, the build runs without
     them: heavy ties go straight to the DC3 recursion.  Forced here on a small-vocabulary text."""
