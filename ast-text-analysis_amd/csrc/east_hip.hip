@@ -271,9 +271,15 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     // text first goes through the window sort over all suffixes; DC3 is the bounded-work fallback
     bool window_sorted = false;
     const size_t mark_sa = ar.mark();
-    SortBufs<u32> sb;                                    // several documents: (document, suffix) pairs
-    if (n_docs > 1)
-        for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>(n); sb.vals[k] = ar.alloc<u32>(n); }
+    // several documents: the suffix array of the whole shard lands in vals[0]; the partition by document
+    // is a stable radix sort of (document, suffix) pairs whose last pass writes into h->sa (pass i
+    // reads buffers [i % 2] and writes the other pair)
+    SortBufs<u32> sb;
+    const int doc_bits = n_docs > 1 ? bit_width_u32(n_docs - 1) : 0;
+    if (n_docs > 1) {
+        const int last = ((doc_bits + 7) / 8) & 1;
+        for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>((size_t)n + 4); sb.vals[k] = k == last ? h->sa : ar.alloc<u32>((size_t)n + 4); }
+    }
     u32 *sa_whole = n_docs == 1 ? h->sa : sb.vals[0];
     if ((h->use_s8 || ctx.dry) && g_window_sort)         // (the sizing run prices it with 64-bit keys)
         window_sorted = window_suffix_sort(ctx, h->s8, n, sigma_t + 1, sa_whole, n_docs == 1 ? h->lcp : nullptr, capped);
@@ -287,19 +293,23 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr,
                                              fused_lcp ? h->lcp : nullptr, capped);
     } else {
-        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sb.vals[0], 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr);
+        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sa_whole, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr);
     }
     if (n_docs > 1) {
-        const int shift = std::max(0, bit_width_u32(n) - 20);
-        const u32 n_coarse = (u32)(((u64)n >> shift) + 1);
-        u32 *coarse = ar.alloc<u32>(n_coarse);
-        LAUNCH(ctx, doc_coarse_kernel, ceil_div_u32(n_coarse, BLOCK), (const u32 *)h->doc_off, n_docs, n, shift,
-               n_coarse, coarse);
-        LAUNCH(ctx, doc_keys_kernel, gn, (const u32 *)sb.vals[0], (const u32 *)h->doc_off, (const u32 *)coarse, shift,
-               n, sb.keys[0]);
-        const int r = radix_sort_pairs<u32>(ctx, sb, n, bit_width_u32(n_docs - 1));
-        if (!ctx.dry)
-            HIP_CHECK(hipMemcpyAsync(h->sa, sb.vals[r], (size_t)n * 4, hipMemcpyDeviceToDevice, ctx.stream));
+        if (n_docs <= DOC_LDS_MAX) {
+            LAUNCH(ctx, doc_keys_lds_kernel, ceil_div_u32(n, BLOCK * 4), (const u32 *)sa_whole, (const u32 *)h->doc_off, n_docs,
+                   n, sb.keys[0]);
+        } else {
+            const int shift = std::max(0, bit_width_u32(n) - 20);
+            const u32 n_coarse = (u32)(((u64)n >> shift) + 1);
+            u32 *coarse = ar.alloc<u32>(n_coarse);
+            LAUNCH(ctx, doc_coarse_kernel, ceil_div_u32(n_coarse, BLOCK), (const u32 *)h->doc_off, n_docs, n, shift,
+                   n_coarse, coarse);
+            LAUNCH(ctx, doc_keys_kernel, ceil_div_u32(n, BLOCK * 4), (const u32 *)sa_whole, (const u32 *)h->doc_off,
+                   (const u32 *)coarse, shift, n, sb.keys[0]);
+        }
+        const int r = radix_sort_pairs<u32>(ctx, sb, n, doc_bits);
+        if (sb.vals[r] != h->sa) east_throw(EAST_HIP_ERR_INTERNAL, "document partition ended in the wrong buffer");
     }
     ar.release(mark_sa);
 
@@ -681,8 +691,13 @@ static void ensure_kgram(east_hip_index *h, Ctx &ctx)
     HIP_CHECK(hipMemsetAsync(h->kg, 0xFF, bytes, h->stream));
     i64 longest = 0;
     for (u32 d = 0; d < h->n_docs; d++) longest = std::max(longest, h->h_doc_off[d + 1] - h->h_doc_off[d]);
-    LAUNCH(ctx, kgram_mark_kernel, dim3(ceil_div_u32((u64)longest, BLOCK), h->n_docs), (const u32 *)h->lcp, (const u32 *)h->sa,
-           (const uint8_t *)h->s8, (const u32 *)h->doc_off, h->n_docs, h->n, k, A, (u32)bins, h->kg);
+    if (h->n_docs > 1)
+        LAUNCH_NAMED(ctx, "kgram_mark_kernel", kgram_mark_tiled_kernel, dim3(ceil_div_u32((u64)longest + 3, BLOCK * 4), h->n_docs),
+                     (const u32 *)h->lcp, (const u32 *)h->sa, (const uint8_t *)h->s8, (const u32 *)h->doc_off, h->n_docs,
+                     h->n, k, A, (u32)bins, h->kg);
+    else
+        LAUNCH(ctx, kgram_mark_kernel, dim3(ceil_div_u32((u64)longest, BLOCK), h->n_docs), (const u32 *)h->lcp,
+               (const u32 *)h->sa, (const uint8_t *)h->s8, (const u32 *)h->doc_off, h->n_docs, h->n, k, A, (u32)bins, h->kg);
     LAUNCH(ctx, kgram_fill_kernel, h->n_docs, (const u32 *)h->doc_off, (u32)bins, h->kg);
     h->kg_k = k;
     h->kg_A = A;

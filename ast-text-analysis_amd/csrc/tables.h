@@ -55,17 +55,52 @@ __global__ __launch_bounds__(BLOCK) void doc_coarse_kernel(const u32 *__restrict
     coarse[i] = doc_of(doc_off, n_docs, p < n ? (u32)p : n - 1u);
 }
 
+// keys[i] = document of the suffix sa[i]; four suffixes per thread (16-byte loads and stores; the
+// arrays are padded to a multiple of 4 by the arena's 256-byte granularity)
 __global__ __launch_bounds__(BLOCK) void doc_keys_kernel(const u32 *__restrict__ sa,
                                                          const u32 *__restrict__ doc_off,
                                                          const u32 *__restrict__ coarse, int shift,
                                                          u32 n, u32 *__restrict__ keys)
 {
-    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    const u32 i = (blockIdx.x * BLOCK + threadIdx.x) * 4u;
     if (i >= n) return;
-    const u32 p = sa[i];
-    u32 d = coarse[p >> shift];
-    while (doc_off[d + 1] <= p) d++;
-    keys[i] = d;
+    const uint4 p4 = *reinterpret_cast<const uint4 *>(sa + i);
+    const u32 p[4] = {p4.x, p4.y, p4.z, p4.w};
+    u32 d[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        d[e] = 0;
+        if (i + e < n) {
+            d[e] = coarse[p[e] >> shift];
+            while (doc_off[d[e] + 1] <= p[e]) d[e]++;
+        }
+    }
+    *reinterpret_cast<uint4 *>(keys + i) = uint4{d[0], d[1], d[2], d[3]};
+}
+
+// The same for up to DOC_LDS_MAX documents: the offsets live in LDS and every suffix is located by a
+// branch-free binary search there (no gathers into the coarse table)
+#define DOC_LDS_MAX 4096
+__global__ __launch_bounds__(BLOCK) void doc_keys_lds_kernel(const u32 *__restrict__ sa,
+                                                             const u32 *__restrict__ doc_off, u32 n_docs,
+                                                             u32 n, u32 *__restrict__ keys)
+{
+    __shared__ u32 off[DOC_LDS_MAX + 1];
+    for (u32 t = threadIdx.x; t <= n_docs; t += BLOCK) off[t] = doc_off[t];
+    __syncthreads();
+    const u32 i = (blockIdx.x * BLOCK + threadIdx.x) * 4u;
+    if (i >= n) return;
+    const uint4 p4 = *reinterpret_cast<const uint4 *>(sa + i);
+    const u32 p[4] = {p4.x, p4.y, p4.z, p4.w};
+    u32 lo[4] = {0, 0, 0, 0};                    // last d with off[d] <= p
+    for (u32 step = 1u << (31 - __builtin_clz(n_docs)); step > 0; step >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const u32 mid = lo[e] + step;
+            if (mid < n_docs && off[mid] <= p[e]) lo[e] = mid;
+        }
+    }
+    *reinterpret_cast<uint4 *>(keys + i) = uint4{lo[0], lo[1], lo[2], lo[3]};
 }
 
 // every document's table starts with 0 (its first rank has no left neighbour inside the document)
