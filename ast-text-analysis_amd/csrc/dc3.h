@@ -130,6 +130,33 @@ template <class K> struct WindowSrc {          // the (window key, element) pair
         return key;
     }
     __device__ __forceinline__ u32 val(u32 u) const { return n0 ? ((u & 1u) ? n0 + (u >> 1) : (u >> 1)) : u; }
+    // the low 8 bits of key(u) alone -- all the first pass's histogram needs: only the last one or two
+    // symbols of the window (and the partial one) are decoded; where the first terminator sits comes from a
+    // zero-byte test on the loaded bytes
+    __device__ __forceinline__ u32 low_digit(u32 u) const
+    {
+        const u32 p = n0 ? 3u * (u >> 1) + 1u + (u & 1u) : u;
+        u64 lo8, hi8;
+        __builtin_memcpy(&lo8, s8 + p, 8);
+        __builtin_memcpy(&hi8, s8 + p + 8, 8);
+        const u64 zl = ~lo8, zh = ~hi8;                 // zero byte <=> 0xFF
+        const u64 tl = (zl - 0x0101010101010101ull) & ~zl & 0x8080808080808080ull;
+        const u64 th = (zh - 0x0101010101010101ull) & ~zh & 0x8080808080808080ull;
+        const int tpos = tl ? __builtin_ctzll(tl) >> 3 : (th ? 8 + (__builtin_ctzll(th) >> 3) : 16);
+        const int m = (8 - spare + b - 1) / b < w ? (8 - spare + b - 1) / b : w;     // full symbols reaching into the low byte
+        u32 acc = 0;
+        for (int i = w - m; i < w; i++) {
+            const u32 byte = (u32)((i < 8 ? lo8 >> (8 * i) : hi8 >> (8 * (i - 8))) & 0xFFu);
+            const u32 x = i > tpos ? 0u : byte;
+            acc = (acc << b) | (x == 0xFFu ? term_first : x);
+        }
+        if (spare > 0) {
+            const u32 byte = (u32)((w < 8 ? lo8 >> (8 * w) : hi8 >> (8 * (w - 8))) & 0xFFu);
+            const u32 x = w > tpos ? 0u : (byte == 0xFFu ? term_first : byte);
+            acc = (acc << spare) | (x >> (b - spare));
+        }
+        return acc & 255u;
+    }
 };
 
 template <class K> struct KeyNeqWindowIn {

@@ -31,21 +31,54 @@ template <class K> struct PairSrc {
     __device__ __forceinline__ u32 val(u32 i) const { return vals[i]; }
 };
 
+// digit of pair i at `shift`; a generator that can produce the first pass's digit without the whole
+// key (low_digit, shift == 0 there by construction) is asked for just that
+template <class Src>
+__device__ __forceinline__ auto radix_digit(const Src &src, u32 i, int shift, int) -> decltype(src.low_digit(i))
+{
+    return src.low_digit(i);
+}
+template <class Src>
+__device__ __forceinline__ u32 radix_digit(const Src &src, u32 i, int shift, long)
+{
+    return (u32)(src.key(i) >> shift) & 255u;
+}
+
 template <class K, class Src>
 __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(Src src, u32 n, int shift, u32 *__restrict__ hist,
                                                            u32 n_tiles)
 {
-    __shared__ u32 bins[RS_BINS];
-    bins[threadIdx.x] = 0;
+    __shared__ u32 bins[WAVES_PER_BLOCK][RS_BINS];     // one sub-histogram per wave: a quarter of the atomic contention
+#pragma unroll
+    for (int k = 0; k < WAVES_PER_BLOCK; k++) bins[k][threadIdx.x] = 0;
     __syncthreads();
+    u32 *mine = bins[wave_id()];
     const u32 base = blockIdx.x * RS_TILE;
+    if constexpr (std::is_same<Src, PairSrc<K>>::value && sizeof(K) == 4) {
+        if (base + RS_TILE <= n) {                      // a full tile of 32-bit keys: 16-byte loads
+#pragma unroll
+            for (int j = 0; j < RS_TILE / (BLOCK * 4); j++) {
+                const uint4 k4 = reinterpret_cast<const uint4 *>(src.keys + base)[j * BLOCK + threadIdx.x];
+                atomicAdd(&mine[(k4.x >> shift) & 255u], 1u);
+                atomicAdd(&mine[(k4.y >> shift) & 255u], 1u);
+                atomicAdd(&mine[(k4.z >> shift) & 255u], 1u);
+                atomicAdd(&mine[(k4.w >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] =
+                bins[0][threadIdx.x] + bins[1][threadIdx.x] + bins[2][threadIdx.x] + bins[3][threadIdx.x];
+            return;
+        }
+    }
 #pragma unroll 4
     for (int j = 0; j < RS_TILE / BLOCK; j++) {
         const u32 i = base + j * BLOCK + threadIdx.x;
-        if (i < n) atomicAdd(&bins[(u32)(src.key(i) >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&mine[radix_digit(src, i, shift, 0)], 1u);
     }
     __syncthreads();
-    hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = bins[threadIdx.x];       // tile-major: one coalesced row
+    static_assert(WAVES_PER_BLOCK == 4, "sub-histogram sum below assumes 4 waves");
+    hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] =          // tile-major: one coalesced row
+        bins[0][threadIdx.x] + bins[1][threadIdx.x] + bins[2][threadIdx.x] + bins[3][threadIdx.x];
 }
 
 // ---- scan of the histogram: base[t][d] = sum_{d' < d, all t'} h[t'][d'] + sum_{t' < t} h[t'][d] ----
