@@ -78,8 +78,7 @@ def kernel_bytes(name, info, n, n_q, n_docs):
         "lcp8_kernel": n * 24,
         # level-0 placement pass (no refinement rounds): 4 B element + 4 B key read, 4 B SA (+ 4 B LCP with one
         # document) written per suffix; the tied ones add two 8 B text gathers each
-        "dc3_refine_classify_kernel": (first * (16 if n_docs == 1 and info["window_sorted"] else 12)
-                                       if info["refine_rounds"] == 0 else None),
+        "lvl0_place_kernel": first * (16 if n_docs == 1 and info["window_sorted"] else 12),
         # 4 B LCP read + 4 B annotation write per rank
         "ann_kernel": n * 8,
         # 4 B sorted sample read + one random 4 B rank store per sample

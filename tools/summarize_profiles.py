@@ -36,7 +36,7 @@ GATHER = ("dc3_merge_tile_kernel", "dc3_merge_partition_kernel", "dc3_merge_lcp_
           "dc3_pair_keys_kernel", "dc3_gather_third_kernel", "ann_kernel", "child_kernel", "doc_keys_kernel",
           # mixed: a streaming pass (counted at 1/2) plus text gathers for the tied suffixes (counted in full);
           # with c = 1 the figure is a lower bound, short by the streamed half (4 B/suffix)
-          "dc3_refine_classify_kernel", "lvl0_lcp_keys_kernel", "dc3_refine_keys_kernel")
+          "dc3_refine_classify_kernel", "lvl0_place_kernel", "lvl0_lcp_keys_kernel", "dc3_refine_keys_kernel")
 
 
 def short(name):
@@ -46,7 +46,7 @@ def short(name):
     name = name.replace("> >", ">>")
     for k in ("u32", "u64"):
         name = name.replace(", PairSrc<%s>>" % k, ">").replace(", WindowSrc<%s>>" % k, ",gen>")
-    for plain in ("dc3_refine_classify_kernel", "dc3_refine_compact_kernel", "dc3_refine_restore_kernel",
+    for plain in ("dc3_refine_classify_kernel", "dc3_refine_compact_kernel", "dc3_refine_restore_kernel", "lvl0_place_kernel",
                   "lvl0_lcp_keys_kernel", "validate_n_strings_kernel", "score_walk_kernel"):
         if name.startswith(plain + "<"):
             name = plain
