@@ -303,6 +303,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_rank_kernel(const u32 *__restrict__
 
 static size_t g_rank_bucket_bytes = (size_t)192 << 20;      // east_hip_debug_set_rank_bucket_bytes (tests)
 static const bool g_trace = getenv("EAST_HIP_TRACE") != nullptr;   // per-round progress on stderr
+static bool g_force_wide_keys = false;                      // east_hip_debug_set_window_sort(3) (tests)
 static bool g_force_lean = false;                           // east_hip_debug_set_window_sort(2) (tests)
 static bool g_window_sort = true;                            // east_hip_debug_set_window_sort (tests)
 
@@ -1248,7 +1249,8 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
     const int bt = bit_width_u32(term_first);
     const int w = lvl0_window(n, bt, term_first);
     u32 n_names = 0;
-    const bool ok = w * bt <= 32 ? dc3_level0_bytes<u32>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped)
+    const bool ok = w * bt <= 32 && !g_force_wide_keys
+                        ? dc3_level0_bytes<u32>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped)
                      : dc3_level0_bytes<u64>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped);
     ar.release(mark);
     return ok;
@@ -1280,7 +1282,7 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         const size_t mark = ar.mark();
         const int bt = bit_width_u32(term_first);          // bits of the compressed level-0 alphabet
         const int w = lvl0_window(n, bt, term_first);
-        const bool final_order = w * bt <= 32
+        const bool final_order = w * bt <= 32 && !g_force_wide_keys
             ? dc3_level0_bytes<u32>(ctx, s8, n0, n02, w, bt, term_first, sa12, s12, n_names)
             : dc3_level0_bytes<u64>(ctx, s8, n0, n02, w, bt, term_first, sa12, s12, n_names);
         if (final_order) n_names = n02;

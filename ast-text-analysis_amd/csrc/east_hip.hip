@@ -1049,6 +1049,7 @@ int east_hip_debug_set_window_sort(int enabled)
 {
     g_window_sort = enabled != 0;
     g_force_lean = enabled == 2;
+    g_force_wide_keys = enabled == 3;
     return EAST_HIP_OK;
 }
 

@@ -205,7 +205,8 @@ int east_hip_debug_suffix_array(int device, const uint32_t *symbols, int64_t n, 
 int east_hip_debug_set_rank_bucket_bytes(int64_t bytes);
 /* Test knob: 0 skips the all-suffix window sort, so that every build goes through DC3 (the
  * fallback for repetitive inputs); 1 (default) restores it; 2 = window sort on, but built as if
- * the device were short of memory for the tie-refinement rounds ("lean"). */
+ * the device were short of memory for the tie-refinement rounds ("lean"); 3 = window sort on with
+ * 64-bit window keys even where 32 bits suffice (the code path of large inputs, on small ones). */
 int east_hip_debug_set_window_sort(int enabled);
 /* Host-only: bytes of device arena a build of n_total symbols / n_docs documents
  * reserves (worst case over inputs).  Needs no device. */

@@ -466,6 +466,32 @@ def test_build_from_resident_symbols_at_any_alignment(hip, oracle, shift):
         assert np.array_equal(t[name], getattr(o, name)), name
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_wide_window_keys_on_small_inputs(hip, oracle, seed):
+    """Inputs of several hundred million symbols sort 64-bit window keys (separate key and element
+    arrays, other kernel instantiations); forced here on small texts with few and with many ties, one
+    and several documents, so that placement, refinement rounds and LCP-from-keys run on 64-bit keys."""
+    from east import hip_backend, synthetic
+    assert hip.load().east_hip_debug_set_window_sort(3) == 0          # (the autouse fixture restores the default)
+    rng = np.random.default_rng(4100 + seed)
+    if seed % 2 == 0:
+        vocab = synthetic.zipf_vocabulary(rng, size=int(rng.choice([12, 300])), exponent=1.0)
+        docs = [synthetic.zipf_document(rng, int(rng.integers(30000, 200000)), vocab) for _ in range(1 + seed)]
+    else:
+        docs = [synthetic.word_stream_document(rng, int(rng.integers(30000, 200000)), want_text=False)[1:]
+                for _ in range(seed)]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    index = hip_backend.HipIndex()
+    index.build(sym, off, np.array([d[1] for d in docs]))
+    assert index.info()["radix_elements_u64"] > 0
+    for d in range(len(docs)):
+        o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+
+
 def test_lean_build_without_refinement_rounds(hip, oracle):
     """When the buffers of the tie-refinement rounds do not fit the device, the build runs without
     them: heavy ties go straight to the DC3 recursion.  Forced here on a small-vocabulary text."""
