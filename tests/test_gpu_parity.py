@@ -492,6 +492,31 @@ def test_wide_window_keys_on_small_inputs(hip, oracle, seed):
             assert np.array_equal(t[name], getattr(o, name)), (name, d)
 
 
+@pytest.mark.parametrize("case", ["one_document", "three_documents"])
+def test_long_repeats_in_large_groups_exhaust_the_rounds(hip, oracle, case):
+    """Twenty copies of a 400-symbol string: tie groups larger than the direct ordering takes, with
+    common prefixes longer than the refinement rounds reach.  The window sort must give up cleanly
+    (all-suffix mode: DC3 takes over; sample mode: the refined names feed the recursion)."""
+    from east import hip_backend
+    from east.asts import utils as ast_utils
+    rng = np.random.default_rng(8)
+    blob = "".join(rng.choice(list("ABCDEFG"), size=400))
+    filler = lambda k: "".join(rng.choice(list("ABCDEFG"), size=k))
+    doc = [blob + filler(int(rng.integers(1, 30))) for _ in range(20)] + [filler(5000)]
+    docs = [doc] if case == "one_document" else [doc, [filler(3000), blob * 3], doc[:7]]
+    parts = [ast_utils.strings_to_symbols(sc) for sc in docs]
+    index = hip_backend.HipIndex()
+    index.build(np.concatenate(parts), np.concatenate([[0], np.cumsum([p.size for p in parts])]),
+                np.array([len(sc) for sc in docs]))
+    info = index.info()
+    assert info["window_sorted"] == 0 and info["dc3_levels"] >= 2 and info["refine_rounds"] > 0, info
+    for d, sc in enumerate(docs):
+        o = oracle.OracleEASA(sc)
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+
+
 def test_lean_build_without_refinement_rounds(hip, oracle):
     """When the buffers of the tie-refinement rounds do not fit the device, the build runs without
     them: heavy ties go straight to the DC3 recursion.  Forced here on a small-vocabulary text."""
