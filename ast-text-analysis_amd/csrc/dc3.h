@@ -903,6 +903,16 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
                         bool whole;
                         lcp_g[j] = j > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, k[e + 1], k[e], whole) : 0u;
                     }
+                } else if (k[e] == k[e + 1] && k[e + 2] == k[e + 1] &&           // (tied on both sides: worth two more reads)
+                           ((j >= REFINE_SMALL_GROUP && f.keys[j - REFINE_SMALL_GROUP] == k[e + 1]) ||
+                            (j + REFINE_SMALL_GROUP < m && f.keys[j + REFINE_SMALL_GROUP] == k[e + 1]))) {
+                    // sorted keys: an equal key 8 places away means more than 8 equal keys around j -- a large
+                    // group (natural-language text: half of the suffixes), flagged without the exact bounds
+                    order_g[j] = v[e];
+                    if (names_g) names_g[j] = start[e];
+                    const u32 local = threadIdx.x * PLACE_IPT + e;
+                    atomicOr(&keep_bits[local >> 5], 1u << (local & 31u));
+                    atomicAdd(&n_keep, 1u);
                 } else {
                     work[atomicAdd(&n_work, 1u)] = j;    // phase 2
                 }
