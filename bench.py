@@ -245,10 +245,19 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, synthetic)
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line goes last: native libraries (the RCCL version banner) write through C stdio, whose
+        # buffer would otherwise be flushed behind it when stdout is a pipe
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(args, synthetic):
