@@ -688,17 +688,24 @@ static void ensure_kgram(east_hip_index *h, Ctx &ctx)
         h->kg = (u32 *)p;
         h->kg_cap = bytes;
     }
-    HIP_CHECK(hipMemsetAsync(h->kg, 0xFF, bytes, h->stream));
-    i64 longest = 0;
-    for (u32 d = 0; d < h->n_docs; d++) longest = std::max(longest, h->h_doc_off[d + 1] - h->h_doc_off[d]);
-    if (h->n_docs > 1)
-        LAUNCH_NAMED(ctx, "kgram_mark_kernel", kgram_mark_tiled_kernel, dim3(ceil_div_u32((u64)longest + 3, BLOCK * 4), h->n_docs),
-                     (const u32 *)h->lcp, (const u32 *)h->sa, (const uint8_t *)h->s8, (const u32 *)h->doc_off, h->n_docs,
-                     h->n, k, A, (u32)bins, h->kg);
-    else
-        LAUNCH(ctx, kgram_mark_kernel, dim3(ceil_div_u32((u64)longest, BLOCK), h->n_docs), (const u32 *)h->lcp,
-               (const u32 *)h->sa, (const uint8_t *)h->s8, (const u32 *)h->doc_off, h->n_docs, h->n, k, A, (u32)bins, h->kg);
-    LAUNCH(ctx, kgram_fill_kernel, h->n_docs, (const u32 *)h->doc_off, (u32)bins, h->kg);
+    if ((u64)h->n / h->n_docs >= 256 * bins) {
+        // long documents: every table entry by binary search on the suffix array
+        LAUNCH(ctx, kgram_search_kernel, dim3(ceil_div_u32(bins + 1, BLOCK), h->n_docs), (const u32 *)h->sa,
+               (const uint8_t *)h->s8, (const u32 *)h->doc_off, k, A, (u32)bins, h->kg);
+    } else {
+        HIP_CHECK(hipMemsetAsync(h->kg, 0xFF, bytes, h->stream));
+        i64 longest = 0;
+        for (u32 d = 0; d < h->n_docs; d++) longest = std::max(longest, h->h_doc_off[d + 1] - h->h_doc_off[d]);
+        if (h->n_docs > 1)
+            LAUNCH_NAMED(ctx, "kgram_mark_kernel", kgram_mark_tiled_kernel,
+                         dim3(ceil_div_u32((u64)longest + 3, BLOCK * 4), h->n_docs), (const u32 *)h->lcp, (const u32 *)h->sa,
+                         (const uint8_t *)h->s8, (const u32 *)h->doc_off, h->n_docs, h->n, k, A, (u32)bins, h->kg);
+        else
+            LAUNCH(ctx, kgram_mark_kernel, dim3(ceil_div_u32((u64)longest, BLOCK), h->n_docs), (const u32 *)h->lcp,
+                   (const u32 *)h->sa, (const uint8_t *)h->s8, (const u32 *)h->doc_off, h->n_docs, h->n, k, A, (u32)bins,
+                   h->kg);
+        LAUNCH(ctx, kgram_fill_kernel, h->n_docs, (const u32 *)h->doc_off, (u32)bins, h->kg);
+    }
     h->kg_k = k;
     h->kg_A = A;
     h->kg_bins = (u32)bins;

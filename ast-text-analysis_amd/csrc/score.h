@@ -101,6 +101,27 @@ __global__ __launch_bounds__(BLOCK) void kgram_mark_tiled_kernel(const u32 *__re
     }
 }
 
+// Long documents (hundreds of ranks per bucket or more): the table entries are found directly --
+// kgram_code is non-decreasing along a document's suffix array (terminators sort above every text
+// symbol and all fall into the top class), so kg[d][g] is a lower bound found by binary search,
+// one thread per entry: log2(n_d) probes each instead of a pass over all n_d LCP values plus the
+// suffix-minimum fill (64 MiB document: 0.22 -> 0.05 ms).
+__global__ __launch_bounds__(BLOCK) void kgram_search_kernel(const u32 *__restrict__ sa, const uint8_t *__restrict__ s8,
+                                                             const u32 *__restrict__ doc_off, int k, u32 A, u32 bins,
+                                                             u32 *__restrict__ kg)
+{
+    const u32 g = blockIdx.x * BLOCK + threadIdx.x, d = blockIdx.y;
+    if (g > bins) return;
+    const u32 first = doc_off[d], nd = doc_off[d + 1] - first;
+    u32 lo = 0, hi = nd;                          // first rank whose k-gram code is >= g
+    if (g == bins) lo = nd;
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (kgram_code(s8, sa[first + mid], k, A) < g) lo = mid + 1; else hi = mid;
+    }
+    kg[(size_t)d * (bins + 1) + g] = lo;
+}
+
 // one workgroup per document: kg[d][g] = min over g' >= g (suffix minimum), kg[d][bins] = n_d
 __global__ __launch_bounds__(BLOCK) void kgram_fill_kernel(const u32 *__restrict__ doc_off, u32 bins,
                                                            u32 *__restrict__ kg)
