@@ -156,6 +156,7 @@ struct east_hip_index {
     u32 *s = nullptr, *sa = nullptr, *lcp = nullptr, *ann = nullptr, *up = nullptr, *down = nullptr,
         *next = nullptr, *doc_off = nullptr, *n_strings = nullptr, *code_map = nullptr;
     Pyramid pyr;
+    u32 build_docs = 0;          // documents of the build in progress (h->n_docs is set when it has succeeded)
     // keyphrases + score scratch (own allocation, grown on demand)
     char *q_buf = nullptr;
     size_t q_cap = 0;
@@ -178,6 +179,18 @@ struct east_hip_index {
 };
 
 static void use_device(east_hip_index *h) { HIP_CHECK(hipSetDevice(h->device)); }
+
+// min pyramid over the LCP table, then the annotation table
+static void annotate(east_hip_index *h, Ctx &ctx)
+{
+    const Pyramid &pyr = h->pyr;
+    const u32 n = pyr.len[0];
+    for (int l = 1; l < pyr.levels; l++)
+        LAUNCH(ctx, pyramid_level_kernel, ceil_div_u32(pyr_padded(pyr.len[l]), BLOCK), pyr.ptr[l - 1], pyr.len[l],
+               pyr_padded(pyr.len[l]), (u32 *)pyr.ptr[l]);
+    LAUNCH(ctx, ann_kernel, ceil_div_u32(n, ANN_TILE), pyr, (const u32 *)h->doc_off, (const u32 *)h->n_strings,
+           h->build_docs, n, h->ann);
+}
 
 // The build proper.  With ctx.dry it only measures the arena high-water mark
 // (worst case: widest keys, recursion to the bottom).
@@ -210,6 +223,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         pyr.levels++;
     }
     h->pyr = pyr;
+    h->build_docs = n_docs;
 
     // ---- host-side small tables ---------------------------------------------
     std::vector<u32> off32((size_t)n_docs + 1), m32(n_docs);
@@ -339,35 +353,32 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         }
         if (n_docs > 1)
             LAUNCH(ctx, lcp_doc_starts_kernel, ceil_div_u32(n_docs, BLOCK), (const u32 *)h->doc_off, n_docs, h->lcp);
-        if (!ctx.dry) {
-            // a repetitive input: finish the capped ranks with the Kasai carry (rare; costs one sync)
-            u32 h_capped = 0;
-            if (n > LCP_DIRECT_CAP) {           // shorter inputs cannot reach the cap
-                HIP_CHECK(hipMemcpyAsync(&h_capped, capped, sizeof(u32), hipMemcpyDeviceToHost, ctx.stream));
-                HIP_CHECK(hipStreamSynchronize(ctx.stream));
-            }
-            if (h_capped) {
-                rank = ar.alloc<u32>(n);
-                LAUNCH(ctx, inverse_sa_kernel, gn, (const u32 *)h->sa, n, rank);
-                const u32 kb = ceil_div_u32(ceil_div_u32(n, KASAI_BLOCK), BLOCK);
-                if (h->use_s8)
-                    LAUNCH(ctx, (lcp_finish_kernel<true>), kb, (const void *)h->s8, (const u32 *)h->sa,
-                           (const u32 *)rank, n, h->lcp);
-                else
-                    LAUNCH(ctx, (lcp_finish_kernel<false>), kb, (const void *)h->s, (const u32 *)h->sa,
-                           (const u32 *)rank, n, h->lcp);
-            }
-        }
         (void)rank;
         ar.release(mark);
     }
-    for (int l = 1; l < pyr.levels; l++)
-        LAUNCH(ctx, pyramid_level_kernel, ceil_div_u32(pyr_padded(pyr.len[l]), BLOCK), pyr.ptr[l - 1], pyr.len[l],
-               pyr_padded(pyr.len[l]), (u32 *)pyr.ptr[l]);
-    LAUNCH(ctx, ann_kernel, ceil_div_u32(n, ANN_TILE), pyr, (const u32 *)h->doc_off, (const u32 *)h->n_strings,
-           n_docs, n, h->ann);
+    // (comparisons that hit the cap -- a repetitive input -- are found out about at the end of the build,
+    // together with the status word: build_common then finishes those ranks and redoes the two steps below)
+    annotate(h, ctx);
     h->kg_built = false;
     h->child_built = false;      // childtab_up / down / next_l_index: built on first east_hip_get_tables request
+}
+
+// A repetitive input: the ranks whose direct comparison was capped are finished with the Kasai carry
+// over the text (blocked, O(n + marked work)), then pyramid and annotation are built again.
+static void finish_capped_lcp(east_hip_index *h, Ctx &ctx)
+{
+    Arena &ar = *ctx.arena;
+    const u32 n = h->pyr.len[0];
+    const size_t mark = ar.mark();
+    u32 *rank = ar.alloc<u32>(n);
+    LAUNCH(ctx, inverse_sa_kernel, ceil_div_u32(n, BLOCK), (const u32 *)h->sa, n, rank);
+    const u32 kb = ceil_div_u32(ceil_div_u32(n, KASAI_BLOCK), BLOCK);
+    if (h->use_s8)
+        LAUNCH(ctx, (lcp_finish_kernel<true>), kb, (const void *)h->s8, (const u32 *)h->sa, (const u32 *)rank, n, h->lcp);
+    else
+        LAUNCH(ctx, (lcp_finish_kernel<false>), kb, (const void *)h->s, (const u32 *)h->sa, (const u32 *)rank, n, h->lcp);
+    ar.release(mark);
+    annotate(h, ctx);
 }
 
 static size_t plan_arena_bytes(u32 n, u32 n_docs, bool lean = false)
@@ -456,9 +467,15 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));
     build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings);
     HIP_CHECK(hipEventRecord(h->ev1, h->stream));
-    u32 status = 0;
-    HIP_CHECK(hipMemcpyAsync(&status, h->code_map + TEXT_SYMBOLS + 1, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    u32 flags[2] = {0, 0};                               // [0] LCP comparisons were capped, [1] status
+    HIP_CHECK(hipMemcpyAsync(flags, h->code_map + TEXT_SYMBOLS, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
+    const u32 status = flags[1];
+    if (flags[0] && !(status & 2u)) {
+        finish_capped_lcp(h, ctx);
+        HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
     if (status & 2u)
         east_throw(EAST_HIP_ERR_DOMAIN, "n_strings does not match the terminators found in a document "
                                         "(text symbols must be < U+0A00)");
