@@ -31,6 +31,7 @@
 #define PRESENT_WORDS (TEXT_SYMBOLS / 32)           // 80
 
 static thread_local std::string g_last_error;
+static u32 g_plan_epoch = 1;        // bumped by the test knobs that change what a build allocates
 
 // ------------------------------------------------------------ prep kernels --
 // (vec: the caller's symbol array is 16-byte aligned, as every allocation is; a misaligned view of a
@@ -157,6 +158,8 @@ struct east_hip_index {
         *next = nullptr, *doc_off = nullptr, *n_strings = nullptr, *code_map = nullptr;
     Pyramid pyr;
     u32 build_docs = 0;          // documents of the build in progress (h->n_docs is set when it has succeeded)
+    u32 plan_n = 0, plan_docs = 0, plan_epoch = 0;   // shape of the last sizing run (and test-knob epoch), its result
+    size_t plan_bytes = 0;
     // keyphrases + score scratch (own allocation, grown on demand)
     char *q_buf = nullptr;
     size_t q_cap = 0;
@@ -439,7 +442,13 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     h->built = false;
     const u32 n = (u32)n_total;
     const size_t staging_bytes = sym_on_host ? ((size_t)n * 4 + 255) & ~(size_t)255 : 0;
-    size_t need = plan_arena_bytes(n, (u32)n_docs) + staging_bytes;
+    if (h->plan_n != n || h->plan_docs != (u32)n_docs || h->plan_epoch != g_plan_epoch) {     // (the sizing run costs host time: remembered per shape)
+        h->plan_bytes = plan_arena_bytes(n, (u32)n_docs);
+        h->plan_n = n;
+        h->plan_docs = (u32)n_docs;
+        h->plan_epoch = g_plan_epoch;
+    }
+    size_t need = h->plan_bytes + staging_bytes;
     bool lean = g_force_lean;
     if (!lean && need > h->arena.cap) {
         // the tie-refinement rounds are the largest consumer: when they do not fit next to what else
@@ -1066,6 +1075,7 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes)
 {
     if (bytes < 0) return EAST_HIP_ERR_INVALID;
     g_rank_bucket_bytes = (size_t)bytes;
+    g_plan_epoch++;
     return EAST_HIP_OK;
 }
 
@@ -1074,6 +1084,7 @@ int east_hip_debug_set_window_sort(int enabled)
     g_window_sort = enabled != 0;
     g_force_lean = enabled == 2;
     g_force_wide_keys = enabled == 3;
+    g_plan_epoch++;
     return EAST_HIP_OK;
 }
 
