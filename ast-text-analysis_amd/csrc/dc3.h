@@ -741,11 +741,14 @@ static const u32 *dc3_sort_and_name(Ctx &ctx, SortBufs<K> &sb, u32 n02, int bits
 //   * the members of larger groups are keyed by (group, the NEXT window of symbols) and radix
 //     sorted -- the groups stay where they are, their members get ordered by the next symbols --
 //     and what is still tied afterwards forms the next, smaller domain.
-// A few rounds cover a whole 3-word string.  If ties survive all rounds (long repeats), the refined
-// names still are valid DC3 names (order-preserving over a window that covers the triple) and feed
+// A few rounds cover a whole 3-word string.  If ties survive (long repeats: the domain stops
+// shrinking), the refined names still are valid DC3 names (order-preserving over a window that covers the triple) and feed
 // the recursion; in all-suffix mode the caller falls back to DC3.
 #define REFINE_SMALL_GROUP 8
-#define REFINE_MAX_ROUNDS 8
+#define REFINE_MAX_ROUNDS 32
+#define REFINE_ENDGAME_DOMAIN 262144     // domains this small: groups up to REFINE_ENDGAME_GROUP are ordered directly,
+#define REFINE_ENDGAME_GROUP 128         // with comparisons of at most REFINE_ENDGAME_LEN symbols (longer: give up)
+#define REFINE_ENDGAME_LEN 256
 
 struct BitIn {                                  // one flag per element, 64 to a word (written by wave ballots)
     const u64 *bits;
@@ -796,14 +799,15 @@ __device__ __forceinline__ u32 lvl0_place_tied(u32 j, const u32 *__restrict__ el
                                                const u32 *__restrict__ slot, u32 m, const uint8_t *__restrict__ s8,
                                                u32 n0, u32 depth, u32 *__restrict__ order_g,
                                                u32 *__restrict__ names_g, u32 *__restrict__ lcp_g, LcpFirst lcp_first,
-                                               u32 *__restrict__ fail)
+                                               u32 *__restrict__ fail, u32 limit = REFINE_SMALL_GROUP,
+                                               u32 max_len = RESOLVE_MAX_LEN)
 {
     const bool first = slot == nullptr;
     const u32 e = elem[j];
     u32 a = j, bnd = j + 1;
-    while (a > 0 && !starts(a) && j - a <= REFINE_SMALL_GROUP) a--;
-    while (bnd < m && !starts(bnd) && bnd - j <= REFINE_SMALL_GROUP) bnd++;
-    if (bnd - a > REFINE_SMALL_GROUP) {
+    while (a > 0 && !starts(a) && j - a <= limit) a--;
+    while (bnd < m && !starts(bnd) && bnd - j <= limit) bnd++;
+    if (bnd - a > limit) {
         if (first) { order_g[j] = e; if (names_g) names_g[j] = starts(j); }
         return 1;
     }
@@ -814,7 +818,7 @@ __device__ __forceinline__ u32 lvl0_place_tied(u32 j, const u32 *__restrict__ el
         const u32 p2 = lvl0_pos(elem[x], n0);
         bool decided = false, less = false;             // less: suffix p2 < suffix p
         u32 h = depth;
-        for (; h < depth + RESOLVE_MAX_LEN && !decided; h += 8) {
+        for (; h < depth + max_len && !decided; h += 8) {
             const u64 u = load_u64_unaligned(s8 + p + h), v = load_u64_unaligned(s8 + p2 + h);
             const u64 d = u ^ v, z = ~u;
             const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
@@ -950,7 +954,8 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
                                                                     const u32 *__restrict__ slot, u32 m,
                                                                     const uint8_t *__restrict__ s8, u32 n0, u32 depth,
                                                                     u32 *__restrict__ order_g, u32 *__restrict__ names_g,
-                                                                    u64 *__restrict__ keep, u32 *__restrict__ fail)
+                                                                    u64 *__restrict__ keep, u32 *__restrict__ fail,
+                                                                    u32 limit, u32 max_len)
 {
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
     u32 my_keep = 0;
@@ -959,7 +964,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
         const bool right_same = j + 1 < m && !starts(j + 1);
         if (left_same || right_same)
             my_keep = lvl0_place_tied(j, elem, starts, slot, m, s8, n0, depth, order_g, names_g, (u32 *)nullptr, NoLcp(),
-                                      fail);
+                                      fail, limit, max_len);
     }
     // keep[]: one bit per element (entries m.. of the last word are 0: the exclusive scan over m + 1 yields the total)
     const u64 bal = __ballot(my_keep != 0);
@@ -1137,7 +1142,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     bool done = false;
     if (!ctx.lean && !h_fail) {
         const size_t mark_rounds = ar.mark();
-        const u32 cap = (u32)(0.6 * n02) + 1;          // a radix round is only tried below this share of the input
+        const u32 cap = n02 + 1;                        // natural-language text: most suffixes can be in large groups
         u32 *ebuf[3], *sbuf[2], *fbuf[2];
         for (auto &e : ebuf) e = ar.alloc<u32>(cap);
         for (auto &e : sbuf) e = ar.alloc<u32>(cap);
@@ -1153,9 +1158,13 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         const u32 *elem = sorted_vals, *slot = nullptr, *flag = nullptr;
         int e_dom = -1, s_dom = 0, f_dom = 0;           // which of the rotating buffers hold the domain
         bool have_idx = false;                          // idx = exclusive scan of keep over the domain
+        int stalled = 0;                                // rounds in a row that placed (almost) nothing
         for (int round = 0; !ctx.dry; round++) {
             if (m_next == 0) { done = true; break; }
-            if (round == REFINE_MAX_ROUNDS || m_next >= cap || (round > 0 && m_next > m - m / 4)) break;
+            // Strings of a few words dissolve within their own length, a round takes 6-12 symbols off.  A domain
+            // that stops shrinking is a long repeat (every round would cost the same again): give up on it.
+            stalled = (round > 0 && m_next > m - m / 32) ? stalled + 1 : 0;
+            if (round == REFINE_MAX_ROUNDS || stalled == 2) break;
             const u32 gm = ceil_div_u32((u64)m + 1, BLOCK);
             if (!have_idx) device_scan<BitIn, false>(ctx, BitIn{keep}, m + 1, idx);
             // compact the members of large groups, number their groups, sort by (group, next window)
@@ -1188,8 +1197,12 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             depth += (u32)w2;
             if (ctx.stats) ctx.stats->refine_rounds++;
             // the new, smaller domain: place what is untied or in small groups now, count the rest
+            // a small domain is finished by direct ordering of much larger groups (a round costs ~60 launches
+            // however few suffixes are left); the comparisons are kept short so that the work stays bounded
+            const bool endgame = m <= REFINE_ENDGAME_DOMAIN;
             LAUNCH(ctx, dc3_refine_classify_kernel, gt, elem, FlagArrIn{flag}, slot, m, s8, n0, depth, sa12, names_g, keep,
-                   fail);
+                   fail, endgame ? (u32)REFINE_ENDGAME_GROUP : (u32)REFINE_SMALL_GROUP,
+                   endgame ? (u32)REFINE_ENDGAME_LEN : (u32)RESOLVE_MAX_LEN);
             device_scan<BitIn, false>(ctx, BitIn{keep}, m + 1, idx);
             have_idx = true;
             HIP_CHECK(hipMemcpyAsync(&m_next, idx + m, 4, hipMemcpyDeviceToHost, ctx.stream));

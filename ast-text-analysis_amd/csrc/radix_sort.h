@@ -125,6 +125,26 @@ __global__ __launch_bounds__(BLOCK) void hist_apply_kernel(u32 *__restrict__ his
     }
 }
 
+// Few tiles (small sorts are bound by launch latency): the whole scan in one workgroup, one launch
+// instead of three.  Thread d owns digit column d: exclusive scan down the tiles, then the digit bases.
+#define HS_SMALL_TILES 128
+__global__ __launch_bounds__(BLOCK) void hist_scan_small_kernel(u32 *__restrict__ hist, u32 n_tiles)
+{
+    __shared__ u32 lds4[WAVES_PER_BLOCK];
+    const u32 d = threadIdx.x;
+    u32 run = 0;
+#pragma unroll 8
+    for (u32 t = 0; t < n_tiles; t++) run += hist[(size_t)t * RS_BINS + d];
+    u32 total;
+    u32 base = block_exclusive_sum(run, lds4, total);      // all smaller digits, all tiles
+#pragma unroll 8
+    for (u32 t = 0; t < n_tiles; t++) {
+        const u32 v = hist[(size_t)t * RS_BINS + d];
+        hist[(size_t)t * RS_BINS + d] = base;
+        base += v;
+    }
+}
+
 // THREADS = 64*WAVES threads move one 4096-pair tile.  Wave w owns the contiguous
 // 4096/WAVES pairs [w*64*IPT, (w+1)*64*IPT) and walks them in IPT rows of 64
 // (coalesced), so (wave, row, lane) is the input order and the pass is stable.
@@ -320,9 +340,13 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin
         if (!first)
             LAUNCH_NAMED(ctx, sizeof(K) == 8 ? "radix_hist_kernel<u64>" : "radix_hist_kernel<u32>",
                          (radix_hist_kernel<K, PairSrc<K>>), n_tiles, src, n, shift, hist, n_tiles);
-        LAUNCH(ctx, hist_chunk_sums_kernel, n_chunks, (const u32 *)hist, n_tiles, chunk_sums);
-        LAUNCH(ctx, hist_chunk_scan_kernel, 1, (const u32 *)chunk_sums, n_chunks, chunk_prefix);
-        LAUNCH(ctx, hist_apply_kernel, n_chunks, hist, n_tiles, (const u32 *)chunk_prefix, n_chunks);
+        if (n_tiles <= HS_SMALL_TILES) {
+            LAUNCH(ctx, hist_scan_small_kernel, 1, hist, n_tiles);
+        } else {
+            LAUNCH(ctx, hist_chunk_sums_kernel, n_chunks, (const u32 *)hist, n_tiles, chunk_sums);
+            LAUNCH(ctx, hist_chunk_scan_kernel, 1, (const u32 *)chunk_sums, n_chunks, chunk_prefix);
+            LAUNCH(ctx, hist_apply_kernel, n_chunks, hist, n_tiles, (const u32 *)chunk_prefix, n_chunks);
+        }
         if (!ctx.dry) {
             if constexpr (HAS_GEN) {
                 if (first) {

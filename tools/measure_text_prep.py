@@ -24,8 +24,9 @@ t_dev = time.perf_counter() - t0
 if os.environ.get("EAST_PROFILE"):
     index.profile_enable(True)
     index.build_texts([text])
+    report = index.profile_report()
     index.profile_enable(False)
-    for name, (count, ms) in sorted(index.profile_report().items(), key=lambda kv: -kv[1][1])[:24]:
+    for name, (count, ms) in sorted(report.items(), key=lambda kv: -kv[1][1])[:24]:
         print("  %-40s %3d launches %8.3f ms" % (name, count, ms))
 got, off, ms = index.prepared()
 assert ms[0] == m and np.array_equal(got, sym)
