@@ -800,7 +800,7 @@ __device__ __forceinline__ u32 lvl0_place_tied(u32 j, const u32 *__restrict__ el
                                                u32 n0, u32 depth, u32 *__restrict__ order_g,
                                                u32 *__restrict__ names_g, u32 *__restrict__ lcp_g, LcpFirst lcp_first,
                                                u32 *__restrict__ fail, u32 limit = REFINE_SMALL_GROUP,
-                                               u32 max_len = RESOLVE_MAX_LEN)
+                                               u32 max_len = RESOLVE_MAX_LEN, u32 *__restrict__ name_of = nullptr)
 {
     const bool first = slot == nullptr;
     const u32 e = elem[j];
@@ -831,8 +831,10 @@ __device__ __forceinline__ u32 lvl0_place_tied(u32 j, const u32 *__restrict__ el
         if (less) { r++; best = h > best ? h : best; }
     }
     const u32 at = a + r;                               // final place inside the domain
-    order_g[first ? at : slot[at]] = e;
+    const u32 at_g = first ? at : slot[at];
+    order_g[at_g] = e;
     if (names_g) names_g[first ? j : slot[j]] = 1;
+    if (name_of) name_of[p] = at_g;                     // (prefix doubling: a placed suffix is named by its exact position)
     if (lcp_g) lcp_g[at] = r > 0 ? best : lcp_first(at);
     return 0;
 }
@@ -955,7 +957,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
                                                                     const uint8_t *__restrict__ s8, u32 n0, u32 depth,
                                                                     u32 *__restrict__ order_g, u32 *__restrict__ names_g,
                                                                     u64 *__restrict__ keep, u32 *__restrict__ fail,
-                                                                    u32 limit, u32 max_len)
+                                                                    u32 limit, u32 max_len, u32 *__restrict__ name_of)
 {
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
     u32 my_keep = 0;
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
         const bool right_same = j + 1 < m && !starts(j + 1);
         if (left_same || right_same)
             my_keep = lvl0_place_tied(j, elem, starts, slot, m, s8, n0, depth, order_g, names_g, (u32 *)nullptr, NoLcp(),
-                                      fail, limit, max_len);
+                                      fail, limit, max_len, name_of);
     }
     // keep[]: one bit per element (entries m.. of the last word are 0: the exclusive scan over m + 1 yields the total)
     const u64 bal = __ballot(my_keep != 0);
@@ -1023,6 +1025,53 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_keys_kernel(const uint8_t *_
         key = (key << b) | (u64)(x == 0xFFu ? term_first : x);
     }
     keys[j] = key;
+    vals[j] = j;
+}
+
+// ---- prefix doubling for long repeats (all-suffix mode) ------------------------------------------
+// A domain that shrinks slowly holds long repeats (boilerplate, runs of one character): symbol
+// windows would take 6-12 symbols off per round.  Then every suffix gets a NAME -- the global
+// position where its group of equal prefixes starts, its own position once it is placed -- kept in
+// name_of[text position], and a round keys the members of a group by the name of the suffix `depth`
+// symbols further on (Manber-Myers / Larsson-Sadakane): names order suffixes by at least `depth`
+// symbols, so every round doubles the depth and the rounds are bounded by log2(n).
+__global__ __launch_bounds__(BLOCK) void dc3_names_init_kernel(const u32 *__restrict__ order_g, u32 n,
+                                                               u32 *__restrict__ name_of)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) name_of[order_g[i]] = i;
+}
+
+// start_slot[k] = global position of the first member of the domain's k-th group (inc = inclusive scan of flag)
+__global__ __launch_bounds__(BLOCK) void dc3_group_starts_kernel(const u32 *__restrict__ flag, const u32 *__restrict__ inc,
+                                                                 const u32 *__restrict__ slot, u32 m,
+                                                                 u32 *__restrict__ start_slot)
+{
+    const u32 r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r < m && flag[r]) start_slot[inc[r] - 1u] = slot[r];
+}
+
+// (only_kept: members of groups that were just placed for good keep their exact position as name)
+__global__ __launch_bounds__(BLOCK) void dc3_names_update_kernel(const u32 *__restrict__ elem, const u32 *__restrict__ inc,
+                                                                 const u32 *__restrict__ start_slot, u32 m,
+                                                                 const u64 *__restrict__ only_kept,
+                                                                 u32 *__restrict__ name_of)
+{
+    const u32 r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= m) return;
+    if (only_kept && !((only_kept[r >> 6] >> (r & 63u)) & 1u)) return;
+    name_of[elem[r]] = start_slot[inc[r] - 1u];
+}
+
+// key = (dense group number << 32) | name of the suffix `depth` symbols further on
+__global__ __launch_bounds__(BLOCK) void dc3_double_keys_kernel(const u32 *__restrict__ name_of,
+                                                                const u32 *__restrict__ elems,
+                                                                const u32 *__restrict__ group, u32 m, u32 depth,
+                                                                u64 *__restrict__ keys, u32 *__restrict__ vals)
+{
+    const u32 j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    keys[j] = ((u64)group[j] << 32) | (u64)name_of[elems[j] + depth];
     vals[j] = j;
 }
 
@@ -1154,6 +1203,8 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             device_scan<BitIn, false>(ctx, BitIn{keep}, n02 + 1, idx);
             (void)radix_sort_pairs<u64>(ctx, rb, cap, 8);
         }
+        u32 *name_of = n0 == 0 ? ar.alloc<u32>(n02) : nullptr;      // all-suffix mode: names for prefix doubling
+        bool doubling = false;
         u32 depth = (u32)w;
         const u32 *elem = sorted_vals, *slot = nullptr, *flag = nullptr;
         int e_dom = -1, s_dom = 0, f_dom = 0;           // which of the rotating buffers hold the domain
@@ -1164,8 +1215,18 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // Strings of a few words dissolve within their own length, a round takes 6-12 symbols off.  A domain
             // that stops shrinking is a long repeat (every round would cost the same again): give up on it.
             stalled = (round > 0 && m_next > m - m / 32) ? stalled + 1 : 0;
-            if (round == REFINE_MAX_ROUNDS || stalled == 2) break;
+            if (round == REFINE_MAX_ROUNDS || (stalled == 2 && !doubling && !name_of)) break;
             const u32 gm = ceil_div_u32((u64)m + 1, BLOCK);
+            if (name_of && !doubling && round > 0 && m_next > m / 2) {
+                // slow shrinking = long repeats: from here on the depth doubles every round (see above)
+                doubling = true;
+                LAUNCH(ctx, dc3_names_init_kernel, ceil_div_u32(n02, BLOCK), (const u32 *)sa12, n02, name_of);
+                device_scan<ArrIn, true>(ctx, ArrIn{flag}, m, group);
+                LAUNCH(ctx, dc3_group_starts_kernel, gm, flag, (const u32 *)group, slot, m, gstart);
+                LAUNCH(ctx, dc3_names_update_kernel, gm, elem, (const u32 *)group, (const u32 *)gstart, m, (const u64 *)keep,
+                       name_of);
+                if (g_trace) fprintf(stderr, "[east_hip]   switching to prefix doubling at depth %u\n", depth);
+            }
             if (!have_idx) device_scan<BitIn, false>(ctx, BitIn{keep}, m + 1, idx);
             // compact the members of large groups, number their groups, sort by (group, next window)
             const int e_c = (e_dom + 4) % 3, e_out = (e_dom + 5) % 3;      // the two buffers the domain is not in
@@ -1178,23 +1239,37 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                              FlagArrIn{flag}, slot, BitIn{keep}, (const u32 *)idx, m, slot_c, ebuf[e_c], gstart);
             m = m_next;
             device_scan<ArrIn, true>(ctx, ArrIn{gstart}, m, group);
-            u32 n_groups = 0;
-            HIP_CHECK(hipMemcpyAsync(&n_groups, group + (m - 1), 4, hipMemcpyDeviceToHost, ctx.stream));
-            HIP_CHECK(hipStreamSynchronize(ctx.stream));
-            const int gbits = bit_width_u32(n_groups);
-            const int w2 = std::min(12, (64 - gbits) / bt);
-            if (w2 < 1) break;
+            // (every group here has more than REFINE_SMALL_GROUP members: a bound on their number saves a read-back)
+            const int gbits = bit_width_u32(m / (REFINE_SMALL_GROUP + 1) + 1);
             const u32 gt = ceil_div_u32((u64)m + 1, BLOCK);
-            LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)ebuf[e_c], (const u32 *)group, m, n0, depth, w2, bt,
-                   term_first, rb.keys[0], rb.vals[0]);
-            const int rr = radix_sort_pairs<u64>(ctx, rb, m, gbits + w2 * bt);
-            const KeyNeqWindowIn<u64> f = KeyNeqWindowIn<u64>::make(nullptr, w2, bt, 0, term_first);
-            LAUNCH(ctx, dc3_refine_writeback_kernel, gt, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr],
-                   (const u32 *)slot_c, (const u32 *)ebuf[e_c], m, f.rep_t, f.ones, f.highs, sa12, names_g, ebuf[e_out],
-                   fbuf[f_dom ^ 1]);
+            if (doubling) {
+                LAUNCH(ctx, dc3_double_keys_kernel, gt, (const u32 *)name_of, (const u32 *)ebuf[e_c], (const u32 *)group, m,
+                       depth, rb.keys[0], rb.vals[0]);
+                const int rr = radix_sort_pairs<u64>(ctx, rb, m, 32 + gbits);
+                LAUNCH(ctx, dc3_refine_writeback_kernel, gt, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr],
+                       (const u32 *)slot_c, (const u32 *)ebuf[e_c], m, (u64)0, (u64)0, (u64)0, sa12, names_g, ebuf[e_out],
+                       fbuf[f_dom ^ 1]);
+                // the members' new names: where their (possibly split) group now starts
+                device_scan<ArrIn, true>(ctx, ArrIn{fbuf[f_dom ^ 1]}, m, group);
+                LAUNCH(ctx, dc3_group_starts_kernel, gt, (const u32 *)fbuf[f_dom ^ 1], (const u32 *)group, (const u32 *)slot_c, m,
+                       gstart);
+                LAUNCH(ctx, dc3_names_update_kernel, gt, (const u32 *)ebuf[e_out], (const u32 *)group, (const u32 *)gstart, m,
+                       (const u64 *)nullptr, name_of);
+                depth *= 2;
+            } else {
+                const int w2 = std::min(12, (64 - gbits) / bt);
+                if (w2 < 1) break;
+                LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)ebuf[e_c], (const u32 *)group, m, n0, depth, w2, bt,
+                       term_first, rb.keys[0], rb.vals[0]);
+                const int rr = radix_sort_pairs<u64>(ctx, rb, m, gbits + w2 * bt);
+                const KeyNeqWindowIn<u64> f = KeyNeqWindowIn<u64>::make(nullptr, w2, bt, 0, term_first);
+                LAUNCH(ctx, dc3_refine_writeback_kernel, gt, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr],
+                       (const u32 *)slot_c, (const u32 *)ebuf[e_c], m, f.rep_t, f.ones, f.highs, sa12, names_g, ebuf[e_out],
+                       fbuf[f_dom ^ 1]);
+                depth += (u32)w2;
+            }
             e_dom = e_out; s_dom ^= 1; f_dom ^= 1;
             elem = ebuf[e_dom]; slot = sbuf[s_dom]; flag = fbuf[f_dom];
-            depth += (u32)w2;
             if (ctx.stats) ctx.stats->refine_rounds++;
             // the new, smaller domain: place what is untied or in small groups now, count the rest
             // a small domain is finished by direct ordering of much larger groups (a round costs ~60 launches
@@ -1202,7 +1277,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             const bool endgame = m <= REFINE_ENDGAME_DOMAIN;
             LAUNCH(ctx, dc3_refine_classify_kernel, gt, elem, FlagArrIn{flag}, slot, m, s8, n0, depth, sa12, names_g, keep,
                    fail, endgame ? (u32)REFINE_ENDGAME_GROUP : (u32)REFINE_SMALL_GROUP,
-                   endgame ? (u32)REFINE_ENDGAME_LEN : (u32)RESOLVE_MAX_LEN);
+                   endgame ? (u32)REFINE_ENDGAME_LEN : (u32)RESOLVE_MAX_LEN, doubling ? name_of : (u32 *)nullptr);
             device_scan<BitIn, false>(ctx, BitIn{keep}, m + 1, idx);
             have_idx = true;
             HIP_CHECK(hipMemcpyAsync(&m_next, idx + m, 4, hipMemcpyDeviceToHost, ctx.stream));
