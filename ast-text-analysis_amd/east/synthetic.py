@@ -120,3 +120,48 @@ def zipf_document(rng, n_bytes, vocab):
     out[mask] = letters
     out[term_pos] = np.arange(m, dtype=np.uint32) + np.uint32(TERMINATOR_START)
     return out, int(m)
+
+
+# ---- real prose ---------------------------------------------------------------------------------
+_PROSE_DIRS = ("/usr/share/perl", "/usr/share/perl5", "/usr/share/doc", "/usr/share/common-licenses", "/usr/lib/python3",
+               "/usr/lib/python3.10", "/usr/local/lib/python3.10/dist-packages", "/opt/rocm/share/doc", "/usr/share/vim")
+_PROSE_EXT = (".pod", ".rst", ".md", ".txt")
+_PROSE_NAMES = ("README", "LICENSE", "COPYING", "NEWS", "copyright", "CHANGELOG", "CHANGES")
+
+
+def image_prose(max_bytes, keep_duplicates=False):
+    """Natural-language text that ships with the container image (POD / reST / Markdown / README /
+    licence files), for BASELINE config 5 -- enwik8 is not available offline.  Files with identical
+    content are taken once unless keep_duplicates (duplicates = long repeats); code points outside
+    the method's domain (>= U+0A00, SURVEY.md 2.1) become spaces.  Returns (bytes, number of files);
+    deterministic for a given image (sorted walk)."""
+    import hashlib
+    import os
+    seen, parts, total = set(), [], 0
+    for top in _PROSE_DIRS:
+        for base, dirs, files in os.walk(top):
+            dirs.sort()
+            if "/db" in base or "/torch/share" in base:
+                continue
+            for f in sorted(files):
+                if not (f.endswith(_PROSE_EXT) or f.startswith(_PROSE_NAMES)) or "fdb" in f or ".db." in f:
+                    continue
+                path = os.path.join(base, f)
+                try:
+                    if not 4096 <= os.path.getsize(path) <= 2000000:
+                        continue
+                    with open(path, "rb") as fh:
+                        data = fh.read()
+                except OSError:
+                    continue
+                text = data.decode("utf-8", errors="replace")
+                data = "".join(c if ord(c) < TERMINATOR_START else " " for c in text).encode("utf-8")
+                digest = hashlib.sha1(data).digest()
+                if digest in seen and not keep_duplicates:
+                    continue
+                seen.add(digest)
+                parts.append(data)
+                total += len(data)
+                if total >= max_bytes:
+                    return b"\n".join(parts)[:max_bytes], len(parts)
+    return b"\n".join(parts), len(parts)

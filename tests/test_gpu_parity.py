@@ -517,6 +517,35 @@ def test_long_repeats_in_large_groups_exhaust_the_rounds(hip, oracle, case):
             assert np.array_equal(t[name], getattr(o, name)), (name, d)
 
 
+def test_real_prose_from_the_image(hip, oracle):
+    """BASELINE config 5 on real natural language: the prose that ships with the container image
+    (mixed alphabet of ~100 symbols, most suffixes tied after the first window, boilerplate repeated
+    across files).  Device text preparation + build of 0.5 MiB documents; tables of two documents
+    bit-exact and the scores of 40 keyphrases bit-equal against the oracle."""
+    from east import hip_backend, synthetic
+    raw, n_files = synthetic.image_prose(3 << 20, keep_duplicates=True)
+    if len(raw) < (1 << 20):
+        pytest.skip("less than 1 MiB of prose found on this image")
+    step = 1 << 19
+    texts = [raw[i:i + step] for i in range(0, len(raw), step)]
+    hip_backend.unicode_tables()
+    index = hip_backend.HipIndex()
+    index.build_texts(texts)
+    info = index.info()
+    assert info["sigma_text"] > 40 and info["refine_rounds"] > 0, info
+    sym, off, ms = index.prepared()
+    rng = np.random.default_rng(5)
+    qs, qo = synthetic.keyphrases(rng, sym[off[0]:off[1]], 40)
+    table = index.score_table(qs, qo, True)
+    for d in (0, len(texts) - 1):
+        o = oracle.OracleEASA(symbols=sym[off[d]:off[d + 1]], n_strings=int(ms[d]))
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+        for k in range(40):
+            assert table[k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=True), (k, d)
+
+
 def test_lean_build_without_refinement_rounds(hip, oracle):
     """When the buffers of the tie-refinement rounds do not fit the device, the build runs without
     them: heavy ties go straight to the DC3 recursion.  Forced here on a small-vocabulary text."""

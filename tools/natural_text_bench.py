@@ -8,7 +8,6 @@ with the CPU oracle.
     python tools/natural_text_bench.py [--doc-mib 1] [--max-mib 24] [--keep-duplicates] [--check]
 """
 import argparse
-import hashlib
 import os
 import sys
 import time
@@ -19,28 +18,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ast-text-analysis_amd"))
 sys.path.insert(0, ROOT)
 
-DIRS = ("/usr/share/perl", "/usr/share/perl5", "/usr/share/doc", "/usr/share/common-licenses", "/usr/lib/python3",
-        "/usr/lib/python3.10", "/usr/local/lib/python3.10/dist-packages", "/opt/rocm/share/doc", "/usr/share/vim")
-EXT = (".pod", ".rst", ".md", ".txt")
-NAMES = ("README", "LICENSE", "COPYING", "NEWS", "copyright", "CHANGELOG", "CHANGES")
-
-
-def prose_files():
-    for top in DIRS:
-        for base, _, files in os.walk(top):
-            if "/db" in base or "/site-packages/torch/share" in base:
-                continue
-            for f in sorted(files):
-                if f.endswith(EXT) or f.startswith(NAMES):
-                    path = os.path.join(base, f)
-                    try:
-                        size = os.path.getsize(path)
-                    except OSError:
-                        continue
-                    if 4096 <= size <= 2_000_000 and "fdb" not in f and ".db." not in f:
-                        yield path
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--doc-mib", type=float, default=1.0)
@@ -50,27 +27,11 @@ def main():
     args = ap.parse_args()
     from east import hip_backend
 
-    seen, blob = set(), []
-    total = 0
-    for path in prose_files():
-        try:
-            data = open(path, "rb").read()
-        except OSError:
-            continue
-        # the method is defined for code points < U+0A00: anything above becomes a space
-        data = "".join(c if ord(c) < 0x0A00 else " " for c in data.decode("utf-8", errors="replace")).encode("utf-8")
-        digest = hashlib.sha1(data).digest()
-        if digest in seen and not args.keep_duplicates:
-            continue
-        seen.add(digest)
-        blob.append(data)
-        total += len(data)
-        if total >= args.max_mib * (1 << 20):
-            break
-    raw = b"\n".join(blob)
+    from east import synthetic
+    raw, n_files = synthetic.image_prose(int(args.max_mib * (1 << 20)), args.keep_duplicates)
     step = int(args.doc_mib * (1 << 20))
     texts = [raw[i:i + step] for i in range(0, len(raw), step)]
-    print("%d files, %.1f MiB of text in %d documents of %.2f MiB" % (len(blob), len(raw) / 2**20, len(texts), args.doc_mib))
+    print("%d files, %.1f MiB of text in %d documents of %.2f MiB" % (n_files, len(raw) / 2**20, len(texts), args.doc_mib))
 
     hip_backend.unicode_tables()
     index = hip_backend.HipIndex()
