@@ -949,6 +949,27 @@ int east_hip_score_table(east_hip_handle_t h, const uint32_t *q_symbols, const i
     });
 }
 
+int east_hip_reset(east_hip_handle_t h)
+{
+    return guarded([&] {
+        if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
+        use_device(h);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->built = false;
+        h->n = 0;
+        h->n_docs = 0;
+        h->n_kp = 0;
+        h->n_q = 0;
+        h->kg_built = false;
+        h->child_built = false;
+        h->prep_n = 0;
+        h->prep_doc_off.clear();
+        h->prep_n_strings.clear();
+        h->prof.enabled = false;
+        h->stats = Stats();
+    });
+}
+
 int east_hip_synchronize(east_hip_handle_t h)
 {
     return guarded([&] {

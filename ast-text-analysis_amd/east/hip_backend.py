@@ -5,6 +5,7 @@ Thin by design: numpy arrays in, numpy arrays out, every error code turned
 into HipBackendError.  There is no CPU fallback -- if the library or a HIP
 device is missing, every compute call raises.
 """
+import atexit
 import ctypes
 import os
 
@@ -27,6 +28,7 @@ SIGNATURES = {
     "east_hip_last_error": (ctypes.c_char_p, []),
     "east_hip_device_count": (ctypes.c_int, []),
     "east_hip_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
+    "east_hip_reset": (ctypes.c_int, [ctypes.c_void_p]),
     "east_hip_destroy": (None, [ctypes.c_void_p]),
     "east_hip_build": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, ctypes.c_int64, _c_i64p, _c_i32p, ctypes.c_int32]),
     "east_hip_build_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _c_i64p, _c_i32p,
@@ -149,6 +151,24 @@ def unicode_tables():
     return _unicode_tables
 
 
+POOL_HANDLES = 2                        # recycled handles kept per device ...
+POOL_MAX_ARENA_BYTES = 256 << 20        # ... if their device arena is at most this large
+_handle_pool = {}
+
+
+def _drain_pool():
+    lib = _lib
+    for handles in _handle_pool.values():
+        while handles:
+            if lib is not None:
+                lib.east_hip_destroy(handles.pop())
+            else:
+                handles.pop()
+
+
+atexit.register(_drain_pool)
+
+
 class HipIndex(object):
     """One device-resident batch of annotated suffix arrays (an AST shard)."""
 
@@ -156,14 +176,32 @@ class HipIndex(object):
         self._lib = load()
         self._h = ctypes.c_void_p()
         self.device = default_device() if device is None else int(device)
-        _check(self._lib.east_hip_create(self.device, int(reserve_symbols), ctypes.byref(self._h)))
+        pooled = _handle_pool.get(self.device)
+        if pooled and not reserve_symbols:
+            self._h = pooled.pop()               # a recycled handle (reset: behaves like a new one)
+        else:
+            _check(self._lib.east_hip_create(self.device, int(reserve_symbols), ctypes.byref(self._h)))
         self.n_docs = 0
         self.doc_offsets = None
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h:
-            self._lib.east_hip_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        """Release the handle.  Handles of small indexes go back to a per-device pool instead of being
+        destroyed: stream / event / memory set-up costs more than building a small collection."""
+        h = getattr(self, "_h", None)
+        if not h:
+            return
+        self._h = None
+        try:
+            pool = _handle_pool.setdefault(self.device, [])
+            buf = np.zeros(8, dtype=np.int64)
+            keep = (len(pool) < POOL_HANDLES and self._lib.east_hip_build_info(h, _ptr(buf, _c_i64p), buf.size) > 6
+                    and buf[6] <= POOL_MAX_ARENA_BYTES and self._lib.east_hip_reset(h) == 0)
+        except Exception:                        # interpreter shutdown: module globals may be gone
+            keep = False
+        if keep:
+            pool.append(h)
+        else:
+            self._lib.east_hip_destroy(h)
 
     __del__ = close
 
@@ -222,6 +260,8 @@ class HipIndex(object):
     def tables(self, doc=0, names=("suftab", "lcptab", "anntab", "childtab_up", "childtab_down",
                                    "childtab_next_l_index")):
         order = ("suftab", "lcptab", "anntab", "childtab_up", "childtab_down", "childtab_next_l_index")
+        if self.doc_offsets is None or not 0 <= doc < self.n_docs:
+            raise exceptions.HipBackendError(reason="no index has been built on this handle, or no such document")
         nd = int(self.doc_offsets[doc + 1] - self.doc_offsets[doc])
         bufs = {k: np.empty(nd, dtype=np.int32) for k in names}
         args = [_ptr(bufs[k], _c_i32p) if k in bufs else None for k in order]

@@ -28,16 +28,35 @@ class RelevanceMeasure(object):
         raise NotImplementedError()
 
 
+class _Shard(object):
+    """The device index of a measure plus a one-row score cache.  Shared by the measure and its
+    per-document views without a reference back to either, so that dropping the measure releases
+    the device handle at once (no reference cycle waiting for the garbage collector)."""
+
+    def __init__(self):
+        self.index = None
+        self.row_cache = (None, None, None)
+
+    def row(self, query, normalized):
+        q = query.replace(" ", "")
+        if self.row_cache[0] != q or self.row_cache[1] != bool(normalized):
+            if not q:
+                raise ZeroDivisionError("float division by zero")              # easa.py:134
+            qs, qo = hip_backend.pack_queries([q])
+            self.row_cache = (q, bool(normalized), self.index.score_table(qs, qo, normalized)[0])
+        return self.row_cache[2]
+
+
 class _DocumentAST(object):
     """What `measure.asts[i]` is in the reference: something with .score()."""
 
-    def __init__(self, measure, doc):
-        self._measure, self._doc = measure, doc
+    def __init__(self, shard, doc):
+        self._shard, self._doc = shard, doc
 
     def score(self, query, normalized=True, synonimizer=None, return_suffix_scores=False):
         if synonimizer or return_suffix_scores:
             raise NotImplementedError("use east.asts.base.AST.get_ast(...) for synonym / per-suffix scoring")
-        return self._measure._row(query, normalized)[self._doc]
+        return self._shard.row(query, normalized)[self._doc]
 
 
 class ASTRelevanceMeasure(RelevanceMeasure):
@@ -50,8 +69,15 @@ class ASTRelevanceMeasure(RelevanceMeasure):
         self.ast_algorithm = ast_algorithm
         self.normalized = normalized
         self.device = device
-        self.index = None
-        self._row_cache = (None, None, None)
+        self._shard = _Shard()
+
+    @property
+    def index(self):
+        return self._shard.index
+
+    @index.setter
+    def index(self, value):
+        self._shard.index = value
 
     # HOT LOOP A (relevance.py:34-49) as one batched build
     def set_text_collection(self, texts, language=consts.Language.ENGLISH):
@@ -68,8 +94,8 @@ class ASTRelevanceMeasure(RelevanceMeasure):
                     code = int(str(e).split("U+")[1].split()[0], 16)
                     raise exceptions.SymbolOutOfDomainException(code=code)
                 raise
-            self.asts = [_DocumentAST(self, d) for d in range(len(texts))]
-            self._row_cache = (None, None, None)
+            self.asts = [_DocumentAST(self._shard, d) for d in range(len(texts))]
+            self._shard.row_cache = (None, None, None)
             return
         collections = [utils.text_to_strings_collection(text) for text in texts]   # relevance.py:44-45
         self.set_strings_collections(collections)
@@ -84,17 +110,11 @@ class ASTRelevanceMeasure(RelevanceMeasure):
         if self.index is None:
             self.index = hip_backend.HipIndex(self.device)
         self.index.build(symbols, doc_offsets, n_strings)
-        self.asts = [_DocumentAST(self, d) for d in range(len(parts))]
-        self._row_cache = (None, None, None)
+        self.asts = [_DocumentAST(self._shard, d) for d in range(len(parts))]
+        self._shard.row_cache = (None, None, None)
 
     def _row(self, query, normalized):
-        q = query.replace(" ", "")
-        if self._row_cache[0] != q or self._row_cache[1] != bool(normalized):
-            if not q:
-                raise ZeroDivisionError("float division by zero")              # easa.py:134
-            qs, qo = hip_backend.pack_queries([q])
-            self._row_cache = (q, bool(normalized), self.index.score_table(qs, qo, normalized)[0])
-        return self._row_cache[2]
+        return self._shard.row(query, normalized)
 
     def relevance(self, keyphrase, text, synonimizer=None):
         """relevance.py:51-53: the score of a prepared keyphrase in text number `text`."""

@@ -58,6 +58,11 @@ int east_hip_device_count(void);       /* >= 0, or EAST_HIP_ERR_NO_DEVICE */
  */
 int east_hip_create(int device, int64_t reserve_symbols, east_hip_handle_t *out);
 void east_hip_destroy(east_hip_handle_t h);
+/* Forget the index, the keyphrases and the prepared texts but keep the stream and the device memory:
+ * the handle then behaves like a new one.  Creating and destroying a handle costs ~4 ms of driver
+ * calls -- more than a whole build of a small collection -- so callers that index one collection
+ * after the other recycle handles (east/hip_backend.py keeps a small pool). */
+int east_hip_reset(east_hip_handle_t h);
 
 /*
  * Batched EASA build: replaces EnhancedAnnotatedSuffixArray.__init__

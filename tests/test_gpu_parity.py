@@ -546,6 +546,35 @@ def test_real_prose_from_the_image(hip, oracle):
             assert table[k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=True), (k, d)
 
 
+def test_recycled_handles_behave_like_new_ones(hip):
+    """hip_backend keeps the handles of small indexes in a pool (create + destroy cost more than a small
+    build).  A recycled handle must have forgotten index, keyphrases and prepared texts."""
+    from east import exceptions, hip_backend
+    from east.asts import utils as ast_utils
+    a = hip_backend.HipIndex()
+    sym = ast_utils.strings_to_symbols(["XABXAC", "BABXAC"])
+    a.build(sym, np.array([0, sym.size]), np.array([2]))
+    q = ast_utils.query_to_symbols("ABX")
+    first = a.score_table(q, np.array([0, q.size]), True)[0, 0]
+    a.set_keyphrases(q, np.array([0, q.size]))
+    a.close()
+    a.close()                                            # idempotent
+    assert hip_backend._handle_pool[a.device], "a small handle should have been pooled"
+    b = hip_backend.HipIndex()
+    assert not hip_backend._handle_pool[b.device] or len(hip_backend._handle_pool[b.device]) < hip_backend.POOL_HANDLES
+    with pytest.raises(exceptions.HipBackendError):      # nothing built yet on the recycled handle
+        b.score_table(q, np.array([0, q.size]), True)
+    with pytest.raises(exceptions.HipBackendError):
+        b.tables(0)
+    b.build(sym, np.array([0, sym.size]), np.array([2]))
+    with pytest.raises(exceptions.HipBackendError):      # the keyphrases of the previous owner are gone
+        out = np.zeros((1, 1))
+        b.score_resident(True, out.ctypes.data)
+    assert b.score_table(q, np.array([0, q.size]), True)[0, 0] == first
+    with pytest.raises(exceptions.HipBackendError):      # a closed index refuses work
+        a.build(sym, np.array([0, sym.size]), np.array([2]))
+
+
 def test_lean_build_without_refinement_rounds(hip, oracle):
     """When the buffers of the tie-refinement rounds do not fit the device, the build runs without
     them: heavy ties go straight to the DC3 recursion.  Forced here on a small-vocabulary text."""
