@@ -546,6 +546,38 @@ def test_real_prose_from_the_image(hip, oracle):
             assert table[k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=True), (k, d)
 
 
+@pytest.mark.parametrize("sigma", [33, 64, 130, 254])
+def test_byte_stream_alphabet_sizes_vs_oracle(hip, oracle, sigma):
+    """The byte stream serves text alphabets of up to 254 symbols: 6-, 7- and 8-bit window fields, no spare
+    key bits at 8 bits per symbol, the terminator class as code 255 at sigma = 254.  Random and
+    repetitive strings over `sigma` code points; tables bit-exact, scores bit-equal."""
+    from east import hip_backend
+    from east.asts import utils as ast_utils
+    rng = np.random.default_rng(1000 + sigma)
+    alphabet = [chr(0x0100 + i) for i in range(sigma)]
+    docs = []
+    for d in range(3):
+        strings = ["".join(rng.choice(alphabet, size=int(rng.integers(1, 40)))) for _ in range(int(rng.integers(5, 400)))]
+        strings += [strings[0]] * 12 + [strings[-1] + strings[0]]          # repeats: large tie groups
+        docs.append(strings)
+    docs[0] = ["".join(alphabet)] + docs[0]                                 # every symbol occurs
+    parts = [ast_utils.strings_to_symbols(sc) for sc in docs]
+    index = hip_backend.HipIndex()
+    index.build(np.concatenate(parts), np.concatenate([[0], np.cumsum([p.size for p in parts])]),
+                np.array([len(sc) for sc in docs]))
+    assert index.info()["sigma_text"] == sigma
+    queries = [docs[0][1][:5], docs[1][0], alphabet[3] + alphabet[7], docs[2][-1][2:]]
+    qs, qo = hip_backend.pack_queries([q for q in queries if q])
+    table = index.score_table(qs, qo, True)
+    for d, sc in enumerate(docs):
+        o = oracle.OracleEASA(sc)
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+        for k, q in enumerate([q for q in queries if q]):
+            assert table[k, d] == o.score(q, fast=True), (d, k)
+
+
 def test_recycled_handles_behave_like_new_ones(hip):
     """hip_backend keeps the handles of small indexes in a pool (create + destroy cost more than a small
     build).  A recycled handle must have forgotten index, keyphrases and prepared texts."""
