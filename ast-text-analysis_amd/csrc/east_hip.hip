@@ -751,17 +751,18 @@ static void score_resident(east_hip_index *h, int normalized)
     ensure_kgram(h, ctx);
     LAUNCH(ctx, query_map_kernel, ceil_div_u32(h->n_q, BLOCK), (const u32 *)h->q_raw, h->n_q,
            (const u32 *)h->code_map, h->q_code);
-    const u32 walk_grid = ceil_div_u32((u64)h->n_q * h->n_docs, BLOCK);
+    const int xcd_order = h->n_docs >= 64;                // see score_walk_kernel
+    const u32 walk_grid = (xcd_order ? 8u * ceil_div_u32(h->n_docs, 8) : h->n_docs) * ceil_div_u32(h->n_q, BLOCK);
     if (h->use_s8)
         LAUNCH_NAMED(ctx, "score_walk_kernel", (score_walk_kernel<uint8_t>), walk_grid, (const uint8_t *)h->s8,
                      (const u32 *)h->sa, (const u32 *)h->doc_off, (const u32 *)h->n_strings, h->n_docs,
                      (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, (const u32 *)h->kg, h->kg_k,
-                     h->kg_A, h->kg_bins, h->suffix);
+                     h->kg_A, h->kg_bins, xcd_order, h->suffix);
     else
         LAUNCH_NAMED(ctx, "score_walk_kernel", (score_walk_kernel<u32>), walk_grid, (const u32 *)h->s,
                      (const u32 *)h->sa, (const u32 *)h->doc_off, (const u32 *)h->n_strings, h->n_docs,
                      (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, (const u32 *)h->kg, h->kg_k,
-                     h->kg_A, h->kg_bins, h->suffix);
+                     h->kg_A, h->kg_bins, xcd_order, h->suffix);
     LAUNCH(ctx, score_reduce_kernel, ceil_div_u32((u64)h->n_kp * h->n_docs, BLOCK), (const double *)h->suffix,
            (const u32 *)h->q_off, h->n_kp, h->n_docs, h->n_q, h->table);
     HIP_CHECK(hipEventRecord(h->ev1, h->stream));

@@ -170,12 +170,17 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
     const SYM *__restrict__ s, const u32 *__restrict__ sa, const u32 *__restrict__ doc_off,
     const u32 *__restrict__ n_strings, u32 n_docs, const u32 *__restrict__ q_code,
     const u32 *__restrict__ q_end, u32 n_q, int normalized, const u32 *__restrict__ kg, int kg_k, u32 kg_A,
-    u32 kg_bins, double *__restrict__ suffix_out)
+    u32 kg_bins, int xcd_order, double *__restrict__ suffix_out)
 {
-    const u64 gid = (u64)blockIdx.x * BLOCK + threadIdx.x;
-    if (gid >= (u64)n_docs * n_q) return;
-    const u32 d = (u32)(gid / n_q);
-    const u32 si = (u32)(gid - (u64)d * n_q);
+    // XCD-aware work order: workgroups go round-robin over the 8 XCDs, each with its own 4 MB L2.  All the
+    // keyphrase suffixes of ONE document are walked by ONE XCD (document d belongs to XCD d mod 8, which takes
+    // its documents one after the other), so the top of that document's binary searches stays in that L2.
+    // (Only with many documents -- xcd_order, host side: with a handful an XCD would sit idle.)
+    const u32 blocks_per_doc = (n_q + BLOCK - 1u) / BLOCK;
+    const u32 local = xcd_order ? blockIdx.x >> 3 : blockIdx.x;
+    const u32 d = xcd_order ? (local / blocks_per_doc) * 8u + (blockIdx.x & 7u) : local / blocks_per_doc;
+    const u32 si = (local % blocks_per_doc) * BLOCK + threadIdx.x;
+    if (d >= n_docs || si >= n_q) return;
     const u32 seg = doc_off[d];
     const u32 nd = doc_off[d + 1] - seg;
     const u32 root_ann = nd - n_strings[d];
