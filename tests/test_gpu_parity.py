@@ -502,7 +502,8 @@ def test_long_repeats_in_large_groups_exhaust_the_rounds(hip, oracle, case):
     rng = np.random.default_rng(8)
     blob = "".join(rng.choice(list("ABCDEFG"), size=400))
     filler = lambda k: "".join(rng.choice(list("ABCDEFG"), size=k))
-    doc = [blob + filler(int(rng.integers(1, 30))) for _ in range(20)] + [filler(5000)]
+    # (more than 65 536 sample suffixes: smaller inputs skip the rounds and order groups of up to 128 directly)
+    doc = [blob + filler(int(rng.integers(1, 30))) for _ in range(20)] + [filler(120000)]
     docs = [doc] if case == "one_document" else [doc, [filler(3000), blob * 3], doc[:7]]
     parts = [ast_utils.strings_to_symbols(sc) for sc in docs]
     index = hip_backend.HipIndex()

@@ -31,3 +31,23 @@ if os.environ.get("EAST_PROFILE"):
         applications.keyphrases_table(g["keyphrases"], texts, relevance.ASTRelevanceMeasure("easa", True))
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+if os.environ.get("EAST_BREAKDOWN"):
+    from east import hip_backend, utils
+    prepared = [utils.prepare_text(k) for k in g["keyphrases"]]
+    qs, qo = hip_backend.pack_queries([p.replace(" ", "") for p in prepared])
+    index = hip_backend.HipIndex()
+    tl = list(texts.values())
+    index.build_texts(tl)
+    t = {"build_texts": [], "score_table": []}
+    for _ in range(50):
+        t0 = time.perf_counter(); index.build_texts(tl); t1 = time.perf_counter()
+        index.score_table(qs, qo, True); t2 = time.perf_counter()
+        t["build_texts"].append(t1 - t0); t["score_table"].append(t2 - t1)
+    print("build_texts %.3f ms (device: prep %.3f + build %.3f), score_table %.3f ms (device %.3f)"
+          % (sorted(t["build_texts"])[25] * 1e3, index.last_prep_ms, index.last_build_ms,
+             sorted(t["score_table"])[25] * 1e3, index.last_score_ms))
+    index.profile_enable(True)
+    index.build_texts(tl)
+    rep = index.profile_report()
+    index.profile_enable(False)
+    print("launches per build_texts:", sum(c for c, _ in rep.values()), sorted(rep.items(), key=lambda kv: -kv[1][0])[:8])
