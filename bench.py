@@ -49,6 +49,8 @@ def parse():
                     help="text: 3-word strings as the CLI does; direct: get_ast([one string])")
     ap.add_argument("--corpus", choices=["words", "zipf"], default="words",
                     help="words: uniform A-Z word stream (configs 1-3); zipf: natural-language-like (config 5)")
+    ap.add_argument("--duplicate-docs", type=int, default=0,
+                    help="the last N documents are copies of the first N (long repeats across documents)")
     ap.add_argument("--denormalized", action="store_true", help="the CLI's -d")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=float, default=32.0,
@@ -126,6 +128,8 @@ def main():
             sym_d, m_d = synthetic.direct_document(rng, doc_bytes + 1)
         parts.append(sym_d)
         ms.append(m_d)
+    for i in range(min(args.duplicate_docs, len(parts) // 2)):
+        parts[len(parts) - 1 - i], ms[len(ms) - 1 - i] = parts[i], ms[i]
     symbols = np.concatenate(parts) if len(parts) > 1 else parts[0]
     m = int(sum(ms))
     n = int(symbols.size)
