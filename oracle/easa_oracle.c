@@ -118,7 +118,13 @@ int easa_suftab(const uint32_t *sym, i64 n, i64 *suftab)
     if (n == 1) { suftab[0] = 0; return 0; }   /* the reference raises IndexError here */
     i64 *s = (i64 *)malloc(((size_t)n + 3) * sizeof(i64));
     i64 K = 1;
-    for (i64 i = 0; i < n; i++) { s[i] = (i64)sym[i]; if (s[i] > K) K = s[i]; }
+    for (i64 i = 0; i < n; i++) {
+        s[i] = (i64)sym[i];
+        if (s[i] > K) K = s[i];
+        /* the reference pads with chr(1) (easa.py:149): a text symbol <= U+0001 is not smaller than the
+         * pad and its DC3 goes wrong (out-of-range suffix numbers) -- outside the reference's domain */
+        if (s[i] <= 1) { free(s); return -2; }
+    }
     s[n] = s[n + 1] = s[n + 2] = 1;
     kark_sort(s, suftab, n, K);
     free(s);

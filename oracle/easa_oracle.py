@@ -101,9 +101,11 @@ class OracleEASA(object):
                               _p(self.childtab_next_l_index, ctypes.c_int64),
                               _p(self.anntab, ctypes.c_int64))
             if rc:
-                raise RuntimeError("easa_build failed")
+                raise ValueError("easa_build failed (%d): empty input, or a symbol <= U+0001 -- the reference pads "
+                                 "with chr(1), easa.py:149, and is undefined for such text" % rc)
         else:  # SA + LCP only (enough for score_fast)
-            L.easa_suftab(_p(self.symbols, ctypes.c_uint32), n, _p(self.suftab, ctypes.c_int64))
+            if L.easa_suftab(_p(self.symbols, ctypes.c_uint32), n, _p(self.suftab, ctypes.c_int64)):
+                raise ValueError("easa_suftab failed: empty input, or a symbol <= U+0001")
             L.easa_lcptab(_p(self.symbols, ctypes.c_uint32), n,
                           _p(self.suftab, ctypes.c_int64), _p(self.lcptab, ctypes.c_int64))
             self.anntab = None
