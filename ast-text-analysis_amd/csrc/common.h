@@ -149,6 +149,18 @@ static inline int bit_width_u32(u32 x) { int b = 0; while (x) { b++; x >>= 1; } 
         }                                                                                  \
     } while (0)
 
+// (the same with a workgroup size other than BLOCK)
+#define LAUNCH_BLOCK(ctx, kernel, grid, block, ...)                                        \
+    do {                                                                                   \
+        if (!(ctx).dry) {                                                                  \
+            const bool _p = (ctx).prof && (ctx).prof->enabled;                             \
+            if (_p) (ctx).prof->begin(#kernel, (ctx).stream);                              \
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx).stream, __VA_ARGS__); \
+            HIP_CHECK(hipGetLastError());                                                  \
+            if (_p) (ctx).prof->end((ctx).stream);                                         \
+        }                                                                                  \
+    } while (0)
+
 // ---------------------------------------------------------- device utils ----
 __device__ __forceinline__ u64 load_u64_unaligned(const uint8_t *p)
 {

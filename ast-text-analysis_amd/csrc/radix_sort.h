@@ -94,22 +94,43 @@ __global__ __launch_bounds__(BLOCK) void hist_chunk_sums_kernel(const u32 *__res
     chunk_sums[(size_t)blockIdx.x * RS_BINS + d] = sum;
 }
 
-// one workgroup: per digit column, exclusive scan over the chunks; then the digit bases
-__global__ __launch_bounds__(BLOCK) void hist_chunk_scan_kernel(const u32 *__restrict__ chunk_sums,
-                                                                u32 n_chunks, u32 *__restrict__ chunk_prefix)
+// one workgroup of 1024 threads: per digit column, exclusive scan over the chunks -- the column is cut into
+// HSC_PARTS stretches scanned side by side (a single thread per column was 15 us of pure latency per pass) --
+// then the digit bases
+#define HSC_PARTS 4
+__global__ __launch_bounds__(BLOCK * HSC_PARTS) void hist_chunk_scan_kernel(const u32 *__restrict__ chunk_sums,
+                                                                            u32 n_chunks, u32 *__restrict__ chunk_prefix)
 {
+    __shared__ u32 part_total[HSC_PARTS][RS_BINS];
     __shared__ u32 lds4[WAVES_PER_BLOCK];
-    const u32 d = threadIdx.x;
+    const u32 d = threadIdx.x & (RS_BINS - 1u), g = threadIdx.x / RS_BINS;
+    const u32 per = (n_chunks + HSC_PARTS - 1u) / HSC_PARTS;
+    const u32 c0 = g * per < n_chunks ? g * per : n_chunks;
+    const u32 c1 = c0 + per < n_chunks ? c0 + per : n_chunks;
     u32 run = 0;
 #pragma unroll 8
-    for (u32 c = 0; c < n_chunks; c++) {       // separate in/out arrays: the loads pipeline
+    for (u32 c = c0; c < c1; c++) run += chunk_sums[(size_t)c * RS_BINS + d];
+    part_total[g][d] = run;
+    __syncthreads();
+    u32 before = 0, column = 0;                 // chunks of this column in earlier stretches / in all stretches
+#pragma unroll
+    for (u32 k = 0; k < HSC_PARTS; k++) {
+        const u32 v = part_total[k][d];
+        if (k < g) before += v;
+        column += v;
+    }
+    run = before;
+#pragma unroll 8
+    for (u32 c = c0; c < c1; c++) {             // separate in/out arrays: the loads pipeline
         const u32 v = chunk_sums[(size_t)c * RS_BINS + d];
         chunk_prefix[(size_t)c * RS_BINS + d] = run;
         run += v;
     }
-    u32 total;
-    const u32 digit_base = block_exclusive_sum(run, lds4, total);     // all smaller digits, all tiles
-    chunk_prefix[(size_t)n_chunks * RS_BINS + d] = digit_base;
+    if (g == 0) {                               // (the first 256 threads = 4 waves: the block-wide sum helper fits)
+        u32 total;
+        const u32 digit_base = block_exclusive_sum(column, lds4, total);     // all smaller digits, all tiles
+        chunk_prefix[(size_t)n_chunks * RS_BINS + d] = digit_base;
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void hist_apply_kernel(u32 *__restrict__ hist, u32 n_tiles,
@@ -344,7 +365,7 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin
             LAUNCH(ctx, hist_scan_small_kernel, 1, hist, n_tiles);
         } else {
             LAUNCH(ctx, hist_chunk_sums_kernel, n_chunks, (const u32 *)hist, n_tiles, chunk_sums);
-            LAUNCH(ctx, hist_chunk_scan_kernel, 1, (const u32 *)chunk_sums, n_chunks, chunk_prefix);
+            LAUNCH_BLOCK(ctx, hist_chunk_scan_kernel, 1, BLOCK * HSC_PARTS, (const u32 *)chunk_sums, n_chunks, chunk_prefix);
             LAUNCH(ctx, hist_apply_kernel, n_chunks, hist, n_tiles, (const u32 *)chunk_prefix, n_chunks);
         }
         if (!ctx.dry) {
