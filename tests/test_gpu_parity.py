@@ -640,6 +640,42 @@ def test_recycled_handles_behave_like_new_ones(hip):
         a.build(sym, np.array([0, sym.size]), np.array([2]))
 
 
+@pytest.mark.parametrize("wide_keys", [False, True])
+@pytest.mark.parametrize("corpus", ["word_stream", "small_vocabulary", "real_prose"])
+def test_resident_build_fits_the_planned_arena(hip, corpus, wide_keys):
+    """east_hip_build_device has no staging area behind the planned arena: the sizing run must cover the
+    real run exactly, also with 64-bit window keys, refinement rounds, prefix doubling and several
+    documents (a transient of the rounds was once priced below a buffer allocated after it)."""
+    import torch
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(17)
+    if corpus == "word_stream":
+        docs = [synthetic.word_stream_document(rng, 1 << 21, want_text=False)[1:] for _ in range(2)]
+    elif corpus == "small_vocabulary":
+        vocab = synthetic.zipf_vocabulary(rng, size=300, exponent=1.0)
+        docs = [synthetic.zipf_document(rng, 1 << 20, vocab) for _ in range(3)]
+    else:
+        raw, _ = synthetic.image_prose(3 << 20, keep_duplicates=True)
+        if len(raw) < (1 << 20):
+            pytest.skip("less than 1 MiB of prose found on this image")
+        prep = hip_backend.HipIndex()
+        prep.build_texts([raw[: len(raw) // 2], raw[len(raw) // 2:]])
+        sym, off, ms = prep.prepared()
+        docs = [(sym[off[d]:off[d + 1]], int(ms[d])) for d in range(2)]
+    if wide_keys:
+        assert hip.load().east_hip_debug_set_window_sort(3) == 0      # (the autouse fixture restores the default)
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    d_sym = torch.from_numpy(sym.astype(np.int32)).to("cuda:0")
+    index = hip_backend.HipIndex()
+    index.build_device(d_sym.data_ptr(), sym.size, off, np.array([d[1] for d in docs]))
+    info = index.info()
+    plan = hip.load().east_hip_plan_arena_bytes(sym.size, len(docs))
+    assert info["arena_high_water"] <= plan and info["arena_bytes"] >= info["arena_high_water"], info
+    t = index.tables(0, names=("suftab",))["suftab"]
+    assert int(t.sum()) == docs[0][0].size * (docs[0][0].size - 1) // 2       # a permutation of the document's positions
+
+
 def test_lean_build_without_refinement_rounds(hip, oracle):
     """When the buffers of the tie-refinement rounds do not fit the device, the build runs without
     them: heavy ties go straight to the DC3 recursion.  Forced here on a small-vocabulary text."""

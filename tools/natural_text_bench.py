@@ -24,11 +24,19 @@ def main():
     ap.add_argument("--max-mib", type=float, default=24.0)
     ap.add_argument("--keep-duplicates", action="store_true", help="keep files with identical content (long repeats)")
     ap.add_argument("--check", action="store_true", help="compare document 0 with the CPU oracle")
+    ap.add_argument("--resample-mib", type=float, default=0.0,
+                    help="scale the corpus up: draw lines of the prose at random (with replacement) until this size")
     args = ap.parse_args()
     from east import hip_backend
 
     from east import synthetic
     raw, n_files = synthetic.image_prose(int(args.max_mib * (1 << 20)), args.keep_duplicates)
+    if args.resample_mib > 0:
+        rng = np.random.default_rng(20245)
+        lines = [ln for ln in raw.split(b"\n") if len(ln) > 20]
+        lens = np.array([len(ln) + 1 for ln in lines])
+        picks = rng.integers(0, len(lines), size=int(args.resample_mib * (1 << 20) / lens.mean()) + 1)
+        raw = b"\n".join(lines[i] for i in picks)[:int(args.resample_mib * (1 << 20))]
     step = int(args.doc_mib * (1 << 20))
     texts = [raw[i:i + step] for i in range(0, len(raw), step)]
     print("%d files, %.1f MiB of text in %d documents of %.2f MiB" % (n_files, len(raw) / 2**20, len(texts), args.doc_mib))
