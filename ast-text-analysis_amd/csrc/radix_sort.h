@@ -44,6 +44,21 @@ __device__ __forceinline__ u32 radix_digit(const Src &src, u32 i, int shift, lon
     return (u32)(src.key(i) >> shift) & 255u;
 }
 
+// One more key for the wave's sub-histogram.  Keys that arrive sorted on their high bits (the group
+// numbers of the refinement rounds) put a whole wavefront on ONE bin, where 64 LDS atomics would queue
+// up: that case is a compare against the first active lane and a single add.
+__device__ __forceinline__ void radix_hist_add(u32 *mine, u32 digit)
+{
+    const u32 first = __builtin_amdgcn_readfirstlane(digit);
+    const u64 active = __ballot(1);
+    if (__ballot(digit == first) == active) {
+        if (digit == first && lane_id() == (u32)(__ffsll((unsigned long long)active) - 1))
+            atomicAdd(&mine[first], (u32)__popcll(active));
+    } else {
+        atomicAdd(&mine[digit], 1u);
+    }
+}
+
 template <class K, class Src>
 __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(Src src, u32 n, int shift, u32 *__restrict__ hist,
                                                            u32 n_tiles)
@@ -59,10 +74,10 @@ __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(Src src, u32 n, int s
 #pragma unroll
             for (int j = 0; j < RS_TILE / (BLOCK * 4); j++) {
                 const uint4 k4 = reinterpret_cast<const uint4 *>(src.keys + base)[j * BLOCK + threadIdx.x];
-                atomicAdd(&mine[(k4.x >> shift) & 255u], 1u);
-                atomicAdd(&mine[(k4.y >> shift) & 255u], 1u);
-                atomicAdd(&mine[(k4.z >> shift) & 255u], 1u);
-                atomicAdd(&mine[(k4.w >> shift) & 255u], 1u);
+                radix_hist_add(mine, (k4.x >> shift) & 255u);
+                radix_hist_add(mine, (k4.y >> shift) & 255u);
+                radix_hist_add(mine, (k4.z >> shift) & 255u);
+                radix_hist_add(mine, (k4.w >> shift) & 255u);
             }
             __syncthreads();
             hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] =
@@ -73,7 +88,7 @@ __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(Src src, u32 n, int s
 #pragma unroll 4
     for (int j = 0; j < RS_TILE / BLOCK; j++) {
         const u32 i = base + j * BLOCK + threadIdx.x;
-        if (i < n) atomicAdd(&mine[radix_digit(src, i, shift, 0)], 1u);
+        if (i < n) radix_hist_add(mine, radix_digit(src, i, shift, 0));
     }
     __syncthreads();
     static_assert(WAVES_PER_BLOCK == 4, "sub-histogram sum below assumes 4 waves");
