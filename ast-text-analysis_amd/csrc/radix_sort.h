@@ -69,6 +69,21 @@ __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(Src src, u32 n, int s
     __syncthreads();
     u32 *mine = bins[wave_id()];
     const u32 base = blockIdx.x * RS_TILE;
+    if constexpr (std::is_same<Src, PairSrc<K>>::value && sizeof(K) == 8) {
+        if (base + RS_TILE <= n) {                      // a full tile of 64-bit keys: 16-byte loads, two keys each
+#pragma unroll
+            for (int j = 0; j < RS_TILE / (BLOCK * 2); j++) {
+                const uint4 k2 = reinterpret_cast<const uint4 *>(src.keys + base)[j * BLOCK + threadIdx.x];
+                const u64 ka = ((u64)k2.y << 32) | k2.x, kb = ((u64)k2.w << 32) | k2.z;
+                radix_hist_add(mine, (u32)(ka >> shift) & 255u);
+                radix_hist_add(mine, (u32)(kb >> shift) & 255u);
+            }
+            __syncthreads();
+            hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] =
+                bins[0][threadIdx.x] + bins[1][threadIdx.x] + bins[2][threadIdx.x] + bins[3][threadIdx.x];
+            return;
+        }
+    }
     if constexpr (std::is_same<Src, PairSrc<K>>::value && sizeof(K) == 4) {
         if (base + RS_TILE <= n) {                      // a full tile of 32-bit keys: 16-byte loads
 #pragma unroll
