@@ -80,7 +80,9 @@ int east_hip_reset(east_hip_handle_t h);
  *   n_strings     D values m_d (strings per document = terminators per document)
  *
  * On success the suffix array, LCP table, child tables and annotation table of
- * every document are resident on the device.  east_hip_build_device takes a
+ * every document are resident on the device.  (How: a window sort over all
+ * suffixes with tie refinement, data-parallel DC3 as the fallback -- DESIGN.md 4;
+ * either way the tables are bit for bit what easa.py computes.)  east_hip_build_device takes a
  * DEVICE pointer for `symbols` (doc_offsets / n_strings stay host pointers);
  * the buffer is only read.
  */
