@@ -230,8 +230,10 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
 
     // ---- host-side small tables ---------------------------------------------
     std::vector<u32> off32((size_t)n_docs + 1), m32(n_docs);
+    u32 longest_doc = ctx.dry ? n : 0;                    // (sizing run: as if one document held everything)
     if (!ctx.dry) {
         for (u32 d = 0; d <= n_docs; d++) off32[d] = (u32)doc_offsets[d];
+        for (u32 d = 0; d < n_docs; d++) longest_doc = std::max(longest_doc, off32[d + 1] - off32[d]);
         for (u32 d = 0; d < n_docs; d++) m32[d] = (u32)n_strings[d];
         HIP_CHECK(hipMemcpyAsync(h->doc_off, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, ctx.stream));
         HIP_CHECK(hipMemcpyAsync(h->n_strings, m32.data(), m32.size() * 4, hipMemcpyHostToDevice, ctx.stream));
@@ -285,34 +287,35 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     u32 *capped = h->code_map + TEXT_SYMBOLS;            // flag words behind the code map
     u32 *status = capped + 1;
     if (!ctx.dry) HIP_CHECK(hipMemsetAsync(capped, 0, 2 * sizeof(u32), ctx.stream));
-    // text first goes through the window sort over all suffixes; DC3 is the bounded-work fallback
+    // Text first goes through the window sort over all suffixes -- with several documents the keys carry
+    // the document number on top, so that every document's tables come out side by side --; DC3 is the
+    // bounded-work fallback (several documents: one suffix sort of the whole shard, then a stable
+    // partition by document).
     bool window_sorted = false;
-    const size_t mark_sa = ar.mark();
-    // several documents: the suffix array of the whole shard lands in vals[0]; the partition by document
-    // is a stable radix sort of (document, suffix) pairs whose last pass writes into h->sa (pass i
-    // reads buffers [i % 2] and writes the other pair)
-    SortBufs<u32> sb;
     const int doc_bits = n_docs > 1 ? bit_width_u32(n_docs - 1) : 0;
-    if (n_docs > 1) {
-        const int last = ((doc_bits + 7) / 8) & 1;
-        for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>((size_t)n + 4); sb.vals[k] = k == last ? h->sa : ar.alloc<u32>((size_t)n + 4); }
+    if ((h->use_s8 || ctx.dry) && g_window_sort) {       // (the sizing run prices it with 64-bit keys)
+        DocKey docs;
+        if (n_docs > 1) { docs.doc_off = h->doc_off; docs.n_docs = n_docs; docs.bits = doc_bits; }
+        window_sorted = window_suffix_sort(ctx, h->s8, n, sigma_t + 1, h->sa, h->lcp, capped, docs, longest_doc);
     }
-    u32 *sa_whole = n_docs == 1 ? h->sa : sb.vals[0];
-    if ((h->use_s8 || ctx.dry) && g_window_sort)         // (the sizing run prices it with 64-bit keys)
-        window_sorted = window_suffix_sort(ctx, h->s8, n, sigma_t + 1, sa_whole, n_docs == 1 ? h->lcp : nullptr, capped);
     ctx.stats->window_sorted = window_sorted;
-    // one document on the byte stream: the LCP table comes with the suffix array (from the window
-    // keys, or out of the level-0 merge of DC3)
-    const bool fused_lcp = n_docs == 1 && h->use_s8;
+    // on the byte stream the LCP table comes with the suffix array: from the window keys, or (one
+    // document) out of the level-0 merge of DC3
+    const bool fused_lcp = h->use_s8 && (window_sorted || n_docs == 1);
     if (window_sorted) {
         ctx.stats->levels = 0;
     } else if (n_docs == 1) {
         ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr,
                                              fused_lcp ? h->lcp : nullptr, capped);
     } else {
+        // the suffix array of the whole shard lands in vals[0]; the partition is a stable radix sort of
+        // (document, suffix) pairs whose last pass writes into h->sa (pass i reads buffers [i % 2], writes the others)
+        const size_t mark_sa = ar.mark();
+        SortBufs<u32> sb;
+        const int last = ((doc_bits + 7) / 8) & 1;
+        for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>((size_t)n + 4); sb.vals[k] = k == last ? h->sa : ar.alloc<u32>((size_t)n + 4); }
+        u32 *sa_whole = sb.vals[0];
         ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sa_whole, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr);
-    }
-    if (n_docs > 1) {
         if (n_docs <= DOC_LDS_MAX) {
             LAUNCH(ctx, doc_keys_lds_kernel, ceil_div_u32(n, BLOCK * 4), (const u32 *)sa_whole, (const u32 *)h->doc_off, n_docs,
                    n, sb.keys[0]);
@@ -327,8 +330,8 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         }
         const int r = radix_sort_pairs<u32>(ctx, sb, n, doc_bits);
         if (sb.vals[r] != h->sa) east_throw(EAST_HIP_ERR_INTERNAL, "document partition ended in the wrong buffer");
+        ar.release(mark_sa);
     }
-    ar.release(mark_sa);
 
     // n_strings against the terminators actually present (read back at the end of the build)
     if (h->use_s8)

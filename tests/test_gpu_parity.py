@@ -602,8 +602,9 @@ def test_duplicated_passages_stay_on_the_window_sort(hip, oracle, case):
     index = hip_backend.HipIndex()
     index.build(sym, off, np.ones(len(docs), dtype=np.int32))
     info = index.info()
-    if hip.load() and info["dc3_levels"] == 0:
-        assert info["window_sorted"] == 1 and info["refine_rounds"] > 0, info
+    if info["dc3_levels"] == 0:
+        # (two documents alike: with the document number in the key their suffixes never meet -- no rounds at all)
+        assert info["window_sorted"] == 1 and (info["refine_rounds"] > 0 or case == "two_documents_alike"), info
     for d in range(len(docs)):
         o = oracle.OracleEASA(symbols=docs[d], n_strings=1)
         t = index.tables(d)
