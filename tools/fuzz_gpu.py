@@ -51,7 +51,7 @@ def random_collection(rng, max_symbols):
     # (code points >= 2: the reference -- and with it the oracle -- pads with chr(1) and is undefined below that)
     alphabet = (np.arange(sigma) + int(rng.choice([2, 33, 65, 0x100, 0x400]))).astype(np.uint32)
     alphabet = alphabet[alphabet < TERM]
-    n_docs = int(rng.choice([1, 1, 2, 3, 7]))
+    n_docs = int(rng.choice([1, 1, 2, 3, 7, 40]))
     budget = int(rng.integers(50, max_symbols)) // n_docs
     docs = []
     for _ in range(n_docs):
