@@ -172,6 +172,7 @@ struct east_hip_index {
     int kg_k = 0;
     u32 kg_A = 0, kg_bins = 0;
     bool kg_built = false;
+    bool kg_marked = false;      // the bucket starts were written by the build (off the window keys): only the fill is due
     float last_build_ms = -1.f, last_score_ms = -1.f, last_prep_ms = -1.f;
     // symbols prepared on the device by east_hip_build_texts (own allocation)
     u32 *prep_sym = nullptr;
@@ -182,6 +183,8 @@ struct east_hip_index {
 };
 
 static void use_device(east_hip_index *h) { HIP_CHECK(hipSetDevice(h->device)); }
+
+static bool kgram_reserve(east_hip_index *h, u64 bins, u32 n_docs);
 
 // min pyramid over the LCP table, then the annotation table
 static void annotate(east_hip_index *h, Ctx &ctx)
@@ -293,10 +296,37 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     // partition by document).
     bool window_sorted = false;
     const int doc_bits = n_docs > 1 ? bit_width_u32(n_docs - 1) : 0;
+    h->kg_marked = false;
     if ((h->use_s8 || ctx.dry) && g_window_sort) {       // (the sizing run prices it with 64-bit keys)
         DocKey docs;
         if (n_docs > 1) { docs.doc_off = h->doc_off; docs.n_docs = n_docs; docs.bits = doc_bits; }
-        window_sorted = window_suffix_sort(ctx, h->s8, n, sigma_t + 1, h->sa, h->lcp, capped, docs, longest_doc);
+        // the score walk's k-gram tables are marked off the sorted keys on the way (KgMark): as many levels
+        // as a table of at most twice a document's size (and 1 GiB in all) has room for
+        KgMark km;
+        if (!ctx.dry && n_docs <= 65535) {
+            km.A = sigma_t + 2;
+            u64 bins = 1;
+            while (km.k < KGRAM_KEYS_MAX_K && bins * km.A <= KGRAM_KEYS_MAX_BINS && bins * km.A <= 2 * ((u64)n / n_docs) + 4096 &&
+                   (bins * km.A + 1) * n_docs * 4 <= ((u64)1 << 30)) {
+                bins *= km.A;
+                km.k++;
+            }
+            if (km.k > 0 && kgram_reserve(h, bins, n_docs)) {
+                km.kg = h->kg;
+                km.doc_off = h->doc_off;
+                km.n_docs = n_docs;
+            } else {
+                km.k = 0;
+            }
+        }
+        window_sorted = window_suffix_sort(ctx, h->s8, n, sigma_t + 1, h->sa, h->lcp, capped, docs, longest_doc,
+                                           km.k > 0 ? &km : nullptr);
+        if (window_sorted && km.k > 0) {                 // (km.k is 0 if the sort did not mark: small inputs)
+            h->kg_marked = true;
+            h->kg_k = km.k;
+            h->kg_A = km.A;
+            h->kg_bins = km.bins;
+        }
     }
     ctx.stats->window_sorted = window_sorted;
     // on the byte stream the LCP table comes with the suffix array: from the window keys, or (one
@@ -690,10 +720,38 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
     h->n_q = n_q;
 }
 
+// device memory for n_docs rows of bins + 1 entries plus the fill's chunk scratch; false if it cannot be had
+static bool kgram_reserve(east_hip_index *h, u64 bins, u32 n_docs)
+{
+    const size_t chunks = (size_t)((bins + KGF_CHUNK - 1) / KGF_CHUNK);
+    const size_t bytes = ((size_t)(bins + 1) + 2 * chunks) * n_docs * 4 + 256;
+    if (bytes <= h->kg_cap) return true;
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->kg) HIP_CHECK(hipFree(h->kg));
+    h->kg = nullptr;
+    h->kg_cap = 0;
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    h->kg = (u32 *)p;
+    h->kg_cap = bytes;
+    return true;
+}
+
 // k-gram bucket tables of the current index (score.h); k = 0 when the alphabet is too wide
 static void ensure_kgram(east_hip_index *h, Ctx &ctx)
 {
     if (h->kg_built) return;
+    if (h->kg_marked) {
+        // the build left the bucket starts in the table: suffix minimum per document, in chunks
+        const u32 bins = h->kg_bins, n_chunks = ceil_div_u32(bins, KGF_CHUNK);
+        u32 *cmin = h->kg + (size_t)(bins + 1) * h->n_docs, *csuf = cmin + (size_t)n_chunks * h->n_docs;
+        LAUNCH(ctx, kgram_chunk_min_kernel, dim3(n_chunks, h->n_docs), (const u32 *)h->kg, bins, n_chunks, cmin);
+        LAUNCH(ctx, kgram_chunk_suffix_kernel, h->n_docs, (const u32 *)cmin, (const u32 *)h->doc_off, n_chunks, csuf);
+        LAUNCH(ctx, kgram_chunk_fill_kernel, dim3(n_chunks, h->n_docs), (const u32 *)csuf, (const u32 *)h->doc_off, bins,
+               n_chunks, h->kg);
+        h->kg_built = true;
+        return;
+    }
     h->kg_k = 0;
     h->kg_built = true;
     if (!h->use_s8 || h->n_docs > 65535) return;
@@ -707,16 +765,7 @@ static void ensure_kgram(east_hip_index *h, Ctx &ctx)
     }
     if (k == 0) return;
     const size_t bytes = (size_t)(bins + 1) * h->n_docs * 4;
-    if (bytes > h->kg_cap) {
-        HIP_CHECK(hipStreamSynchronize(h->stream));
-        if (h->kg) HIP_CHECK(hipFree(h->kg));
-        h->kg = nullptr;
-        h->kg_cap = 0;
-        void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) return;          // no table: plain binary search
-        h->kg = (u32 *)p;
-        h->kg_cap = bytes;
-    }
+    if (!kgram_reserve(h, bins, h->n_docs)) return;              // no table: plain binary search
     if ((u64)h->n / h->n_docs >= 256 * bins) {
         // long documents: every table entry by binary search on the suffix array
         LAUNCH(ctx, kgram_search_kernel, dim3(ceil_div_u32(bins + 1, BLOCK), h->n_docs), (const u32 *)h->sa,

@@ -17,8 +17,10 @@
 #include "common.h"
 
 #define Q_NOMATCH 0xFFFFFFFFu
-#define KGRAM_MAX_K 3
+#define KGRAM_MAX_K 3                    // tables built from the finished arrays (mark / search kernels)
 #define KGRAM_MAX_BINS 65536u
+#define KGRAM_KEYS_MAX_K 4               // tables marked off the sorted window keys (window_sort.h): one level more
+#define KGRAM_KEYS_MAX_BINS 1048576u
 
 // ---- k-gram bucket tables ---------------------------------------------------------
 // Most walks end within the first few symbols, where the
@@ -145,6 +147,98 @@ __global__ __launch_bounds__(BLOCK) void kgram_fill_kernel(const u32 *__restrict
         row[g - 1] = m;
     }
     if (tid == 0) row[bins] = nd;
+}
+
+// The same for long rows (tables marked off the window keys have up to a million entries per document), all
+// accesses coalesced: minima of 1024-entry chunks, their suffix minima per document, then a reverse
+// min-scan inside every chunk seeded with the minimum of everything behind it.
+#define KGF_CHUNK 1024
+__global__ __launch_bounds__(BLOCK) void kgram_chunk_min_kernel(const u32 *__restrict__ kg, u32 bins,
+                                                                u32 n_chunks, u32 *__restrict__ cmin)
+{
+    __shared__ u32 wmin[WAVES_PER_BLOCK];
+    const u32 c = blockIdx.x, d = blockIdx.y;
+    const u32 *row = kg + (size_t)d * (bins + 1);
+    u32 m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int e = 0; e < KGF_CHUNK / BLOCK; e++) {
+        const u32 g = c * KGF_CHUNK + e * BLOCK + threadIdx.x;
+        if (g < bins) { const u32 x = row[g]; m = x < m ? x : m; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { const u32 y = __shfl_xor(m, o, WAVE); m = y < m ? y : m; }
+    if (lane_id() == 0) wmin[wave_id()] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < WAVES_PER_BLOCK; k++) m = wmin[k] < m ? wmin[k] : m;
+        cmin[(size_t)d * n_chunks + c] = m;
+    }
+}
+
+// one workgroup per document: csuf[c] = min over the chunks behind c (n_d behind the last one); 256 chunks
+// at a time from the back, a reverse min-scan by wave shuffles with the carry of the tiles behind
+__global__ __launch_bounds__(BLOCK) void kgram_chunk_suffix_kernel(const u32 *__restrict__ cmin,
+                                                                   const u32 *__restrict__ doc_off, u32 n_chunks,
+                                                                   u32 *__restrict__ csuf)
+{
+    __shared__ u32 wmin[WAVES_PER_BLOCK];
+    const u32 d = blockIdx.x;
+    const u32 *in = cmin + (size_t)d * n_chunks;
+    u32 carry = doc_off[d + 1] - doc_off[d];
+    for (u32 hi = n_chunks; hi > 0; hi = hi > BLOCK ? hi - BLOCK : 0) {
+        const u32 lo = hi > BLOCK ? hi - BLOCK : 0;
+        const u32 c = lo + threadIdx.x;
+        const u32 x = c < hi ? in[c] : 0xFFFFFFFFu;
+        u32 m = x;                                          // inclusive suffix min over the lanes >= this one
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const u32 y = __shfl_down(m, o, WAVE);
+            if (lane_id() + o < WAVE) m = y < m ? y : m;
+        }
+        if (lane_id() == 0) wmin[wave_id()] = m;
+        __syncthreads();
+        u32 behind = carry;
+        for (u32 k = wave_id() + 1; k < WAVES_PER_BLOCK; k++) behind = wmin[k] < behind ? wmin[k] : behind;
+        const u32 next = __shfl_down(m, 1, WAVE);
+        const u32 after = lane_id() + 1 < WAVE ? (next < behind ? next : behind) : behind;
+        if (c < hi) csuf[(size_t)d * n_chunks + c] = after;         // exclusive: the chunks behind c
+        u32 all = carry;
+        for (u32 k = 0; k < WAVES_PER_BLOCK; k++) all = wmin[k] < all ? wmin[k] : all;
+        carry = all;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void kgram_chunk_fill_kernel(const u32 *__restrict__ csuf,
+                                                                 const u32 *__restrict__ doc_off, u32 bins,
+                                                                 u32 n_chunks, u32 *__restrict__ kg)
+{
+    __shared__ u32 wmin[WAVES_PER_BLOCK];
+    const u32 c = blockIdx.x, d = blockIdx.y;
+    u32 *row = kg + (size_t)d * (bins + 1);
+    const u32 g0 = c * KGF_CHUNK + threadIdx.x * 4u;       // four consecutive entries per thread
+    u32 x[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) x[e] = g0 + e < bins ? row[g0 + e] : 0xFFFFFFFFu;
+    // suffix minima inside the thread, then across the lanes behind it, then across the waves behind it
+    x[2] = x[3] < x[2] ? x[3] : x[2];
+    x[1] = x[2] < x[1] ? x[2] : x[1];
+    x[0] = x[1] < x[0] ? x[1] : x[0];
+    u32 m = x[0];                                           // inclusive suffix min over the lanes >= this one
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const u32 y = __shfl_down(m, o, WAVE);
+        if (lane_id() + o < WAVE) m = y < m ? y : m;
+    }
+    if (lane_id() == 0) wmin[wave_id()] = m;
+    __syncthreads();
+    u32 behind = csuf[(size_t)d * n_chunks + c];            // everything behind this chunk
+    for (u32 k = wave_id() + 1; k < WAVES_PER_BLOCK; k++) behind = wmin[k] < behind ? wmin[k] : behind;
+    const u32 next = __shfl_down(m, 1, WAVE);               // lanes behind this one (exclusive)
+    const u32 after = lane_id() + 1 < WAVE ? (next < behind ? next : behind) : behind;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const u32 v = x[e] < after ? x[e] : after;
+        if (g0 + e < bins) row[g0 + e] = v;
+    }
+    if (c == 0 && threadIdx.x == 0) row[bins] = doc_off[d + 1] - doc_off[d];
 }
 
 // raw query code points -> dense codes of the corpus alphabet

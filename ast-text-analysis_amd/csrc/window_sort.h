@@ -54,6 +54,19 @@ struct DocKey {
 };
 #define DOC_TILE_SHIFT 12
 
+// The score walk's k-gram bucket tables (score.h) can be read off the sorted window keys for free: rank j
+// opens a bucket of its document iff the leading k symbol fields (or the document number) of its key
+// differ from the key before -- exactly "k-gram class code differs", terminator class and the zeroes
+// behind it included.  The placement pass writes those entries (kg[d][code] = rank inside the document;
+// the table was preset to 0xFFFFFFFF), the score side only has to run the suffix-minimum fill.
+struct KgMark {
+    u32 *kg = nullptr;              // n_docs rows of bins + 1 entries
+    int k = 0;                      // on entry: the largest k the table has room for; on return: the k marked (<= w)
+    u32 A = 0, bins = 0;            // alphabet of the class codes (sigma_text + 2), A^k
+    const u32 *doc_off = nullptr;
+    u32 n_docs = 1;
+};
+
 __global__ __launch_bounds__(BLOCK) void doc_tiles_kernel(const u32 *__restrict__ doc_off, u32 n_docs, u32 n_tiles,
                                                           u32 *__restrict__ tile_doc)
 {
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
                                                           int spare, u32 *__restrict__ order_g,
                                                           u32 *__restrict__ names_g, u32 *__restrict__ lcp_g,
                                                           u64 *__restrict__ keep, u32 *__restrict__ block_keep,
-                                                          u32 *__restrict__ fail, LongRepeats lr_arg)
+                                                          u32 *__restrict__ fail, LongRepeats lr_arg, KgMark km)
 {
     const LongRepeats lr = OPTIMISTIC ? LongRepeats() : lr_arg;
     constexpr u32 limit = ENDGAME_LIMITS ? REFINE_ENDGAME_GROUP : REFINE_SMALL_GROUP;
@@ -340,6 +353,20 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
             const K x = k[e + 1] ^ f.rep_t;
             const bool has_term = ((x - f.ones) & ~x & f.highs) != 0;
             start[e] = j0 + e == 0 || j0 + e >= m || has_term || k[e + 1] != k[e];
+        }
+        if (OPTIMISTIC && km.kg) {                      // k-gram bucket starts, read off the keys (see KgMark)
+            const int top = spare + (w - km.k) * b;
+#pragma unroll
+            for (int e = 0; e < PLACE_IPT; e++) {
+                const u32 j = j0 + e;
+                if (j < m && (j == 0 || (K)(k[e + 1] >> top) != (K)(k[e] >> top))) {
+                    const u32 d = km.n_docs > 1 ? (u32)(k[e + 1] >> (w * b + spare)) : 0u;     // (one document: no bits above the window)
+                    u32 code = 0;
+                    for (int i = 0; i < km.k; i++)
+                        code = code * km.A + ((u32)(k[e + 1] >> (spare + (w - 1 - i) * b)) & ((1u << b) - 1u));
+                    km.kg[(size_t)d * (km.bins + 1) + code] = j - km.doc_off[d];
+                }
+            }
         }
         bool all_final = j0 + PLACE_IPT <= m;
 #pragma unroll
@@ -601,7 +628,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_lcp_keys_kernel(KeyNeqWindowIn<K> 
 template <class K>
 static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w, int bt, u32 term_first, u32 *sa12,
                              u32 *s12, u32 &n_names, u32 *lcp_out = nullptr, u32 *lcp_capped = nullptr,
-                             DocKey docs = DocKey())
+                             DocKey docs = DocKey(), KgMark *kg_mark = nullptr)
 {
     Arena &ar = *ctx.arena;
     const u32 g02 = ceil_div_u32((u64)n02 + 1, BLOCK);
@@ -638,18 +665,28 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
 
     // ---- the whole sorted input as the first domain --------------------------------------
     // (a small input is better off with the direct ordering of much larger groups than with a round of ~50 launches)
+    KgMark km;                                          // k-gram bucket starts ride along with the first placement pass
     const bool small_input = n02 <= REFINE_SMALL_INPUT;
+    if (kg_mark) kg_mark->k = kg_mark->kg && n0 == 0 && !ctx.dry && !small_input ? kg_mark->k : 0;
+    if (kg_mark && kg_mark->k > 0) {
+        km = *kg_mark;
+        km.k = std::min(km.k, w);
+        km.bins = 1;
+        for (int i = 0; i < km.k; i++) km.bins *= km.A;
+        HIP_CHECK(hipMemsetAsync(km.kg, 0xFF, (size_t)(km.bins + 1) * km.n_docs * sizeof(u32), ctx.stream));
+        *kg_mark = km;
+    }
     u32 m = n02, m_next = n02, h_fail = 0;              // (sizing run: as if everything were tied)
     auto place = [&](int mode) {
         if (small_input)
             LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, true, false>), gp, starts, sorted_vals, n02, s8, n0, w,
-                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode});
+                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
         else if (mode == 0)
             LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, false, true>), gp, starts, sorted_vals, n02, s8, n0, w,
-                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode});
+                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, km);
         else
             LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, false, false>), gp, starts, sorted_vals, n02, s8, n0, w,
-                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode});
+                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
         if (mode == 1 || ctx.dry) return;
         LAUNCH(ctx, (scan_reduce_kernel<ArrIn>), nb, ArrIn{block_keep}, gp, block_sums);
         std::vector<u32> h_sums(nb);
@@ -857,7 +894,7 @@ static int lvl0_window(u32 n, int bt, u32 term_first, int doc_bits = 0)
 // number on top, sa_out / lcp_out receive every document's tables side by side (lcp_out: the first
 // entry of each document still has to be reset, lcp_doc_starts_kernel).
 static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_first, u32 *sa_out, u32 *lcp_out,
-                               u32 *lcp_capped, DocKey docs = DocKey(), u32 longest = 0)
+                               u32 *lcp_capped, DocKey docs = DocKey(), u32 longest = 0, KgMark *kg_mark = nullptr)
 {
     Arena &ar = *ctx.arena;
     const size_t mark = ar.mark();
@@ -866,8 +903,10 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
     const int w = lvl0_window(docs.bits ? longest : n, bt, term_first, docs.bits);
     u32 n_names = 0;
     const bool ok = w * bt + docs.bits <= 32 && !g_force_wide_keys
-                        ? dc3_level0_bytes<u32>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs)
-                     : dc3_level0_bytes<u64>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs);
+                        ? dc3_level0_bytes<u32>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
+                                                kg_mark)
+                        : dc3_level0_bytes<u64>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
+                                                kg_mark);
     ar.release(mark);
     return ok;
 }
