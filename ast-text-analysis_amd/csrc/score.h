@@ -348,13 +348,15 @@ __global__ __launch_bounds__(BLOCK) void score_reduce_kernel(const double *__res
                                                              u32 n_kp, u32 n_docs, u32 n_q,
                                                              double *__restrict__ out)
 {
+    // neighbouring threads take neighbouring keyphrases of ONE document: their suffix results lie side by
+    // side in that document's row (the 8-byte stores into the K x D table are the strided side: 13x fewer)
     const u64 gid = (u64)blockIdx.x * BLOCK + threadIdx.x;
     if (gid >= (u64)n_kp * n_docs) return;
-    const u32 k = (u32)(gid / n_docs);
-    const u32 d = (u32)(gid - (u64)k * n_docs);
+    const u32 d = (u32)(gid / n_kp);
+    const u32 k = (u32)(gid - (u64)d * n_kp);
     const u32 b = q_off[k], e = q_off[k + 1];
     const double *row = suffix + (u64)d * n_q;
     double total = 0.0;
     for (u32 i = b; i < e; i++) total += row[i];          // easa.py:130
-    out[gid] = total / (double)(e - b);                   // easa.py:134
+    out[(u64)k * n_docs + d] = total / (double)(e - b);   // easa.py:134
 }
