@@ -30,8 +30,8 @@ def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=Non
         wanted = [kp for kp in dict.fromkeys(keyphrases) if kp]          # applications.py:44-45
         if wanted:
             scores = similarity_measure.relevance_table([keyphrases_prepared[kp] for kp in wanted])
-            for r, keyphrase in enumerate(wanted):
-                res[keyphrase] = {text_titles[j]: float(scores[r, j]) for j in range(len(text_titles))}
+            for keyphrase, row in zip(wanted, scores.tolist()):          # (one C-level conversion of the K x D table)
+                res[keyphrase] = dict(zip(text_titles, row))
         return res
 
     i = 0
