@@ -9,9 +9,10 @@
 //      ALL suffixes are keyed by their first w symbols (w*bits <= 32 or 64), generated inside the
 //      first pass of one stable LSD radix sort; one classify pass then places every suffix whose
 //      key is unique and orders small groups of equal keys directly on the text; members of
-//      larger groups are refined in rounds keyed by (group, next window).  With one document the
-//      LCP table falls out of the sorted keys.  No sample, no ranks, no merge -- but the work is
-//      only bounded for inputs whose repeats are short, so it gives up when ties persist and
+//      larger groups are refined in rounds keyed by (group, next window), long repeats by prefix
+//      doubling.  Several documents: the document number rides on top of the key.  The LCP table
+//      falls out of the sorted keys.  No sample, no ranks, no merge.  In the rare cases it gives up
+//      (round limit), for wide alphabets and when memory is short,
 //
 // B. dc3_suffix_array, data-parallel DC3 / skew (Karkkainen & Sanders 2003), takes over:
 //   1. sample positions i mod 3 != 0 become packed keys -- at level 0 on the byte stream the same

@@ -193,9 +193,10 @@ __global__ __launch_bounds__(BLOCK) void dc3_scatter_names_kernel(const u32 *__r
 //   * the members of larger groups are keyed by (group, the NEXT window of symbols) and radix
 //     sorted -- the groups stay where they are, their members get ordered by the next symbols --
 //     and what is still tied afterwards forms the next, smaller domain.
-// A few rounds cover a whole 3-word string.  If ties survive (long repeats: the domain stops
-// shrinking), the refined names still are valid DC3 names (order-preserving over a window that covers the triple) and feed
-// the recursion; in all-suffix mode the caller falls back to DC3.
+// A few rounds cover a whole 3-word string.  Long repeats (the domain shrinks slowly): in all-suffix
+// mode the rounds switch to prefix doubling (further down) and finish in O(log n) rounds; in DC3's
+// sample mode they stop when the domain stalls -- the refined names still are valid DC3 names
+// (order-preserving over a window that covers the triple) and feed the recursion.
 #define REFINE_SMALL_GROUP 8
 #define REFINE_MAX_ROUNDS 32
 #define REFINE_ENDGAME_DOMAIN 262144     // domains this small: groups up to REFINE_ENDGAME_GROUP are ordered directly,
@@ -745,7 +746,8 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         for (int round = 0; !ctx.dry; round++) {
             if (m_next == 0) { done = true; break; }
             // Strings of a few words dissolve within their own length, a round takes 6-12 symbols off.  A domain
-            // that stops shrinking is a long repeat (every round would cost the same again): give up on it.
+            // that stops shrinking is a long repeat: all-suffix mode goes over to prefix doubling (below), the
+            // sample mode of DC3 stops here (every round would cost the same again) and recurses on the names.
             stalled = (round > 0 && m_next > m - m / 32) ? stalled + 1 : 0;
             if (round == REFINE_MAX_ROUNDS || (stalled == 2 && !doubling && !name_of)) break;
             const u32 gm = ceil_div_u32((u64)m + 1, BLOCK);
@@ -887,9 +889,9 @@ static int lvl0_window(u32 n, int bt, u32 term_first, int doc_bits = 0)
 }
 
 // The fast path for text: ALL n suffixes keyed by their first w symbols, one stable sort, the tied
-// ones refined by further windows / ordered directly -- no sample, no ranks, no merge.  Ordinary text
-// (few and short repeats) ends here; returns false when the ties do not dissolve (long or many
-// repeats), and the caller runs DC3, whose work is bounded whatever the input.
+// ones ordered directly / refined by further windows / by prefix doubling -- no sample, no ranks, no
+// merge.  Returns false only in the rare cases it gives up (REFINE_MAX_ROUNDS, or no room for a
+// window next to the document number); the caller then runs DC3, whose work is bounded whatever the input.
 // Several documents (docs.bits > 0, longest = symbols of the longest one): the keys carry the document
 // number on top, sa_out / lcp_out receive every document's tables side by side (lcp_out: the first
 // entry of each document still has to be reset, lcp_doc_starts_kernel).
