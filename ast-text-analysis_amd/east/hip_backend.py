@@ -228,7 +228,7 @@ class HipIndex(object):
         """Text preparation + build on the device.  texts: list of bytes (UTF-8, decoded with
         errors='replace' semantics) or str."""
         raw = [t if isinstance(t, bytes) else t.encode("utf-8", errors="surrogatepass") for t in texts]
-        blob = b"\xff".join(raw) + b"\xff"
+        blob = b"\xff".join(raw + [b""])        # every text followed by one 0xFF, in a single copy
         offsets = np.zeros(len(raw) + 1, dtype=np.int64)
         np.cumsum([len(t) + 1 for t in raw], out=offsets[1:])
         cls, upper, word_hi, digit_hi, hi_from, hi_to = unicode_tables()
