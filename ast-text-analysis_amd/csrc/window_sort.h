@@ -515,7 +515,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_keys_kernel(const uint8_t *_
         key = (key << b) | (u64)(x == 0xFFu ? term_first : x);
     }
     keys[j] = key;
-    vals[j] = j;
+    vals[j] = elems[j];                 // (the suffix itself travels with its key: no look-up after the sort)
 }
 
 // ---- prefix doubling for long repeats (all-suffix mode) ------------------------------------------
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_double_keys_kernel(const u32 *__res
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
     if (j >= m) return;
     keys[j] = ((u64)group[j] << 32) | (u64)name_of[elems[j] + depth];
-    vals[j] = j;
+    vals[j] = elems[j];                 // (the suffix itself travels with its key: no look-up after the sort)
 }
 
 // after the sort: the slots of the domain receive their members in refined order (globally and as
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_writeback_kernel(const u64 *
     const u64 k = keys[r];
     const u64 x = k ^ rep_t;
     const bool has_term = ((x - ones) & ~x & highs) != 0;       // a terminator inside the window: unique
-    const u32 slot = slots[r], e = elems[vals[r]];
+    const u32 slot = slots[r], e = vals[r];
     const u32 f = (r == 0 || has_term || k != keys[r - 1]) ? 1u : 0u;
     order_g[slot] = e;
     if (names_g) names_g[slot] = f;
