@@ -535,12 +535,15 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
 #define TP_WORD_HI_WORDS ((0x110000u - TP_TEXT_LIMIT + 31u) / 32u)
 
 // bytes: the texts concatenated, each followed by one 0xFF byte (host pointer).
+// (texts != nullptr: the texts lie apart in host memory -- text d = texts[d], text_offsets as if they were
+// concatenated with their separators; they are uploaded one by one and never joined on the host)
 static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_bytes64, const i64 *text_offsets,
                              int32_t n_docs, const uint8_t *cp_class, const u32 *cp_upper, const u32 *word_hi,
-                             const u32 *digit_hi, const u32 *hi_upper_from, const u32 *hi_upper_to, int32_t n_hi_upper)
+                             const u32 *digit_hi, const u32 *hi_upper_from, const u32 *hi_upper_to, int32_t n_hi_upper,
+                             const uint8_t *const *texts = nullptr)
 {
     if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
-    if (!bytes || !text_offsets || !cp_class || !cp_upper || !word_hi || !digit_hi || n_docs < 1 || n_hi_upper < 0 ||
+    if ((!bytes && !texts) || !text_offsets || !cp_class || !cp_upper || !word_hi || !digit_hi || n_docs < 1 || n_hi_upper < 0 ||
         (n_hi_upper > 0 && (!hi_upper_from || !hi_upper_to)))
         east_throw(EAST_HIP_ERR_INVALID, "null argument or no documents");
     if (n_bytes64 < n_docs || n_bytes64 >= (i64)0x7FFFFFF0) east_throw(EAST_HIP_ERR_INVALID, "total bytes out of range");
@@ -548,8 +551,8 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
         east_throw(EAST_HIP_ERR_INVALID, "text_offsets must start at 0 and end at the total");
     for (int32_t d = 0; d < n_docs; d++) {
         if (text_offsets[d + 1] <= text_offsets[d]) east_throw(EAST_HIP_ERR_INVALID, "text_offsets must increase");
-        if (bytes[text_offsets[d + 1] - 1] != 0xFFu)
-            east_throw(EAST_HIP_ERR_INVALID, "every text must be followed by one 0xFF separator byte");
+        if (texts ? (text_offsets[d + 1] - text_offsets[d] > 1 && !texts[d]) : bytes[text_offsets[d + 1] - 1] != 0xFFu)
+            east_throw(EAST_HIP_ERR_INVALID, texts ? "null text" : "every text must be followed by one 0xFF separator byte");
     }
     use_device(h);
     h->built = false;
@@ -575,7 +578,15 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     u32 *d_bad = ar.alloc<u32>(1);
     std::vector<u32> off32((size_t)D + 1);
     for (u32 d = 0; d <= D; d++) off32[d] = (u32)text_offsets[d];
-    HIP_CHECK(hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, h->stream));
+    if (texts) {
+        HIP_CHECK(hipMemsetAsync(d_bytes, 0xFF, n_bytes, h->stream));              // the separators
+        for (u32 d = 0; d < D; d++) {
+            const size_t len = (size_t)(text_offsets[d + 1] - text_offsets[d] - 1);
+            if (len) HIP_CHECK(hipMemcpyAsync(d_bytes + text_offsets[d], texts[d], len, hipMemcpyHostToDevice, h->stream));
+        }
+    } else {
+        HIP_CHECK(hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, h->stream));
+    }
     HIP_CHECK(hipMemsetAsync(d_bytes + n_bytes, 0, 8, h->stream));
     HIP_CHECK(hipMemcpyAsync(d_text_off, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipMemcpyAsync(d_class, cp_class, TP_TEXT_LIMIT, hipMemcpyHostToDevice, h->stream));
@@ -913,6 +924,23 @@ int east_hip_build_texts(east_hip_handle_t h, const uint8_t *bytes, int64_t n_by
     return guarded([&] {
         build_from_texts(h, bytes, n_bytes, text_offsets, n_docs, cp_class, cp_upper, word_hi, digit_hi, hi_upper_from,
                          hi_upper_to, n_hi_upper);
+    });
+}
+
+int east_hip_build_texts_v(east_hip_handle_t h, const uint8_t *const *texts, const int64_t *lengths, int32_t n_docs,
+                           const uint8_t *cp_class, const uint32_t *cp_upper, const uint32_t *word_hi,
+                           const uint32_t *digit_hi, const uint32_t *hi_upper_from, const uint32_t *hi_upper_to,
+                           int32_t n_hi_upper)
+{
+    return guarded([&] {
+        if (!texts || !lengths || n_docs < 1) east_throw(EAST_HIP_ERR_INVALID, "null argument or no documents");
+        std::vector<i64> off((size_t)n_docs + 1, 0);
+        for (int32_t d = 0; d < n_docs; d++) {
+            if (lengths[d] < 0) east_throw(EAST_HIP_ERR_INVALID, "negative text length");
+            off[d + 1] = off[d] + lengths[d] + 1;                                   // + the separator
+        }
+        build_from_texts(h, nullptr, off[n_docs], off.data(), n_docs, cp_class, cp_upper, word_hi, digit_hi, hi_upper_from,
+                         hi_upper_to, n_hi_upper, texts);
     });
 }
 

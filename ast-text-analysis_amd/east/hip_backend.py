@@ -36,6 +36,9 @@ SIGNATURES = {
     "east_hip_build_texts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, _c_i64p, ctypes.c_int32,
                                             ctypes.POINTER(ctypes.c_uint8), _c_u32p, _c_u32p, _c_u32p, _c_u32p,
                                             _c_u32p, ctypes.c_int32]),
+    "east_hip_build_texts_v": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p), _c_i64p, ctypes.c_int32,
+                                              ctypes.POINTER(ctypes.c_uint8), _c_u32p, _c_u32p, _c_u32p, _c_u32p,
+                                              _c_u32p, ctypes.c_int32]),
     "east_hip_get_prepared": (ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_i64p, _c_i32p, _c_u32p]),
     "east_hip_last_prep_ms": (ctypes.c_double, [ctypes.c_void_p]),
     "east_hip_get_tables": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [_c_i32p] * 6),
@@ -151,6 +154,8 @@ def unicode_tables():
     return _unicode_tables
 
 
+JOIN_FREE_MAX_TEXTS = 512               # build_texts: up to this many texts of at least ...
+JOIN_FREE_MIN_BYTES = 1 << 20           # ... this many bytes in all go to the device one by one, unjoined
 POOL_HANDLES = 2                        # recycled handles kept per device ...
 POOL_MAX_ARENA_BYTES = 256 << 20        # ... if their device arena is at most this large
 _handle_pool = {}
@@ -228,14 +233,21 @@ class HipIndex(object):
         """Text preparation + build on the device.  texts: list of bytes (UTF-8, decoded with
         errors='replace' semantics) or str."""
         raw = [t if isinstance(t, bytes) else t.encode("utf-8", errors="surrogatepass") for t in texts]
-        blob = b"\xff".join(raw + [b""])        # every text followed by one 0xFF, in a single copy
-        offsets = np.zeros(len(raw) + 1, dtype=np.int64)
-        np.cumsum([len(t) + 1 for t in raw], out=offsets[1:])
         cls, upper, word_hi, digit_hi, hi_from, hi_to = unicode_tables()
-        _check(self._lib.east_hip_build_texts(self._h, blob, len(blob), _ptr(offsets, _c_i64p), len(raw),
-                                              _ptr(cls, ctypes.POINTER(ctypes.c_uint8)), _ptr(upper, _c_u32p),
-                                              _ptr(word_hi, _c_u32p), _ptr(digit_hi, _c_u32p),
-                                              _ptr(hi_from, _c_u32p), _ptr(hi_to, _c_u32p), hi_from.size))
+        tables = (_ptr(cls, ctypes.POINTER(ctypes.c_uint8)), _ptr(upper, _c_u32p), _ptr(word_hi, _c_u32p),
+                  _ptr(digit_hi, _c_u32p), _ptr(hi_from, _c_u32p), _ptr(hi_to, _c_u32p), hi_from.size)
+        total = sum(len(t) for t in raw)
+        if len(raw) <= JOIN_FREE_MAX_TEXTS and total >= JOIN_FREE_MIN_BYTES:
+            # a few large texts: uploaded one by one straight out of their bytes objects (joining 64 MiB costs
+            # more host time than the device needs for the whole build)
+            ptrs = (ctypes.c_char_p * len(raw))(*raw)
+            lengths = np.array([len(t) for t in raw], dtype=np.int64)
+            _check(self._lib.east_hip_build_texts_v(self._h, ptrs, _ptr(lengths, _c_i64p), len(raw), *tables))
+        else:
+            blob = b"\xff".join(raw + [b""])    # every text followed by one 0xFF, in a single copy
+            offsets = np.zeros(len(raw) + 1, dtype=np.int64)
+            np.cumsum([len(t) + 1 for t in raw], out=offsets[1:])
+            _check(self._lib.east_hip_build_texts(self._h, blob, len(blob), _ptr(offsets, _c_i64p), len(raw), *tables))
         self.n_docs = len(raw)
         doc_offsets = np.zeros(self.n_docs + 1, dtype=np.int64)
         n_total = ctypes.c_int64(0)

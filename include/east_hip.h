@@ -115,6 +115,13 @@ int east_hip_build_texts(east_hip_handle_t h, const uint8_t *bytes, int64_t n_by
                          const int64_t *text_offsets, int32_t n_docs, const uint8_t *cp_class,
                          const uint32_t *cp_upper, const uint32_t *word_hi, const uint32_t *digit_hi,
                          const uint32_t *hi_upper_from, const uint32_t *hi_upper_to, int32_t n_hi_upper);
+/* The same for texts that lie apart in host memory (text d = lengths[d] bytes at texts[d], no
+ * separators): they are uploaded one by one, the caller does not have to join them (for a few large
+ * texts the join costs more than the build). */
+int east_hip_build_texts_v(east_hip_handle_t h, const uint8_t *const *texts, const int64_t *lengths,
+                           int32_t n_docs, const uint8_t *cp_class, const uint32_t *cp_upper,
+                           const uint32_t *word_hi, const uint32_t *digit_hi,
+                           const uint32_t *hi_upper_from, const uint32_t *hi_upper_to, int32_t n_hi_upper);
 int east_hip_get_prepared(east_hip_handle_t h, int64_t *n_total, int64_t *doc_offsets,
                           int32_t *n_strings, uint32_t *symbols);
 double east_hip_last_prep_ms(east_hip_handle_t h);
