@@ -657,10 +657,15 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
         h->prep_sym = (u32 *)p;
         h->prep_cap = (size_t)n_sym * 4;
     }
-    if (n_tok)
+    if (n_tok) {
+        u32 *tok_out = keep, *tok_term = klen;           // (keep / klen are dead once their scans exist)
+        LAUNCH(ctx, tp_token_out_kernel, ceil_div_u32(n_tok, BLOCK), (const u32 *)tstart, (const u32 *)keep_ex,
+               (const u32 *)klen_ex, (const u32 *)doc_cp_off, (const u32 *)first_tok, (const u32 *)doc_sym_off, D, n_tok,
+               tok_out, tok_term);
         LAUNCH(ctx, tp_emit_kernel, ceil_div_u32(n_cp, BLOCK), (const u32 *)cpu, (const uint8_t *)cw, (const u32 *)tok_inc,
-               (const u32 *)tstart, (const u32 *)tend, (const u32 *)keep_ex, (const u32 *)klen_ex,
-               (const u32 *)doc_cp_off, (const u32 *)first_tok, (const u32 *)doc_sym_off, D, n_cp, h->prep_sym, d_bad);
+               (const u32 *)tstart, (const u32 *)tend, (const u32 *)tok_out, (const u32 *)tok_term, n_cp, h->prep_sym,
+               d_bad);
+    }
     LAUNCH(ctx, tp_empty_docs_kernel, ceil_div_u32(D, BLOCK), (const u32 *)first_tok, (const u32 *)keep_ex,
            (const u32 *)doc_sym_off, D, h->prep_sym);
     HIP_CHECK(hipEventRecord(h->ev1, h->stream));

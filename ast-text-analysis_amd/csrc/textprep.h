@@ -204,31 +204,48 @@ __device__ __forceinline__ u32 tp_doc_of_cp(const u32 *__restrict__ doc_cp_off, 
     return lo;
 }
 
+// per kept token: where its first symbol goes, and the terminator that follows its last one (0 = none) --
+// the document look-up and the group arithmetic happen once per token, not once per code point
+#define TP_DROPPED 0xFFFFFFFFu
+__global__ __launch_bounds__(BLOCK) void tp_token_out_kernel(const u32 *__restrict__ tstart,
+                                                             const u32 *__restrict__ keep_ex,
+                                                             const u32 *__restrict__ klen_ex,
+                                                             const u32 *__restrict__ doc_cp_off,
+                                                             const u32 *__restrict__ first_tok,
+                                                             const u32 *__restrict__ doc_sym_off, u32 n_docs, u32 n_tok,
+                                                             u32 *__restrict__ tok_out, u32 *__restrict__ tok_term)
+{
+    const u32 k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n_tok) return;
+    if (keep_ex[k + 1u] == keep_ex[k]) { tok_out[k] = TP_DROPPED; tok_term[k] = 0; return; }
+    const u32 d = tp_doc_of_cp(doc_cp_off, n_docs, tstart[k]);
+    const u32 ft = first_tok[d], ft1 = first_tok[d + 1];
+    const u32 kidx = keep_ex[k] - keep_ex[ft];               // index among the document's kept tokens
+    const u32 kd = keep_ex[ft1] - keep_ex[ft];
+    const u32 g = kidx / 3u;
+    tok_out[k] = doc_sym_off[d] + (klen_ex[k] - klen_ex[ft]) + g;
+    tok_term[k] = (kidx % 3u == 2u || kidx + 1u == kd) ? TP_TEXT_LIMIT + g : 0u;
+}
+
 // every code point of a kept token goes to its place; the last one of a group writes the terminator
 __global__ __launch_bounds__(BLOCK) void tp_emit_kernel(const u32 *__restrict__ cpu, const uint8_t *__restrict__ cw,
                                                         const u32 *__restrict__ tok_inc,
                                                         const u32 *__restrict__ tstart, const u32 *__restrict__ tend,
-                                                        const u32 *__restrict__ keep_ex,
-                                                        const u32 *__restrict__ klen_ex,
-                                                        const u32 *__restrict__ doc_cp_off,
-                                                        const u32 *__restrict__ first_tok,
-                                                        const u32 *__restrict__ doc_sym_off, u32 n_docs, u32 n_cp,
+                                                        const u32 *__restrict__ tok_out,
+                                                        const u32 *__restrict__ tok_term, u32 n_cp,
                                                         u32 *__restrict__ sym, u32 *__restrict__ bad_cp)
 {
     const u32 p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= n_cp || !(cw[p] & TP_CLASS_WORD)) return;
     const u32 k = tok_inc[p] - 1u;
-    if (keep_ex[k + 1u] == keep_ex[k]) return;              // token dropped
-    const u32 d = tp_doc_of_cp(doc_cp_off, n_docs, p);
-    const u32 ft = first_tok[d], ft1 = first_tok[d + 1];
-    const u32 kidx = keep_ex[k] - keep_ex[ft];               // index among the document's kept tokens
-    const u32 kd = keep_ex[ft1] - keep_ex[ft];
-    const u32 g = kidx / 3u;
-    const u32 out = doc_sym_off[d] + (klen_ex[k] - klen_ex[ft]) + (p - tstart[k]) + g;
+    const u32 base = tok_out[k];
+    if (base == TP_DROPPED) return;                         // token dropped
+    const u32 out = base + (p - tstart[k]);
     const u32 cp = cpu[p];
     if (cp >= TP_TEXT_LIMIT) atomicMin(bad_cp, cp);         // a kept word character outside the method's domain
     sym[out] = cp;
-    if (p == tend[k] && (kidx % 3u == 2u || kidx + 1u == kd)) sym[out + 1u] = TP_TEXT_LIMIT + g;
+    const u32 term = tok_term[k];
+    if (term && p == tend[k]) sym[out + 1u] = term;
 }
 
 __global__ __launch_bounds__(BLOCK) void tp_empty_docs_kernel(const u32 *__restrict__ first_tok,
