@@ -147,12 +147,15 @@ def _random_collections(rng, n_docs, alphabet, max_strings=8, max_len=14):
     return docs
 
 
-@pytest.mark.parametrize("alphabet", ["AB", "ABC", "ABCDEFGH", "AB C", "АБВГДЕЖЗ"])
+FUZZ_SEEDS = {"AB": 101, "ABC": 202, "ABCDEFGH": 303, "AB C": 404, "АБВГДЕЖЗ": 505}
+
+
+@pytest.mark.parametrize("alphabet", list(FUZZ_SEEDS))
 def test_fuzz_multidoc_vs_oracle(hip, oracle, alphabet):
     """Random small corpora: every table of every document and the K x D scores vs the oracle's
     faithful port (sibling-chain walk), normalized and denormalized."""
     from east import relevance
-    rng = np.random.default_rng(abs(hash(alphabet)) % 1000)
+    rng = np.random.default_rng(FUZZ_SEEDS[alphabet])         # (fixed: hash() is randomized per process)
     for it in range(6):
         docs = _random_collections(rng, int(rng.integers(1, 9)), alphabet)
         measure = relevance.ASTRelevanceMeasure()
@@ -281,7 +284,7 @@ def test_16mib_document_vs_oracle(hip, oracle):
             assert table[k, 0] == o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=True)
 
 
-def _check_easa_properties(sym, m, t):
+def _check_easa_properties(sym, m, t, spot=4000):
     """Size-independent properties that pin SA and LCP completely: sa is a permutation; for every
     rank r the two neighbouring suffixes agree on exactly lcp[r] symbols and the next symbol of the
     left one is smaller (=> sorted, and lcp exact).  anntab: root n-m, interval widths."""
@@ -299,7 +302,7 @@ def _check_easa_properties(sym, m, t):
     first = np.flatnonzero(ann[1:] > 0) + 1
     assert (lcp[first] > 0).all()
     rng = np.random.default_rng(1)
-    for i in rng.integers(1, n, size=4000).tolist():             # spot-check against plain scans
+    for i in rng.integers(1, n, size=spot).tolist():             # spot-check against plain scans
         v = lcp[i]
         p = i - 1
         while lcp[p] > v:
@@ -351,6 +354,40 @@ def test_256_documents_batched_equals_individual(hip):
         for name in TABLES:
             assert np.array_equal(tb[name], ts[name]), (name, d)
         assert np.array_equal(single.score_table(qs, qo, True)[:, 0], table[:, d])
+
+
+def test_config2_256_documents_10000_keyphrases_vs_oracle(hip, oracle):
+    """BASELINE configs[2] at its full size: 256 word-stream documents of 1 MiB (text mode) and
+    10 000 keyphrases in ONE batched build + ONE score call.  Every document: the properties that
+    pin SA / LCP / annotation completely; 8 sampled documents: all six tables array_equal to the
+    oracle and all 10 000 scores bit-equal, normalized and denormalized (applications.py:43-52)."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(20240 + 3)
+    docs = [synthetic.word_stream_document(rng, 1 << 20, want_text=False)[1:] for _ in range(256)]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])]).astype(np.int64)
+    ms = np.array([d[1] for d in docs], dtype=np.int32)
+    index = hip_backend.HipIndex()
+    index.build(sym, off, ms)
+    assert index.info()["n_docs"] == 256 and index.info()["n_total"] == sym.size
+    qs, qo = synthetic.keyphrases(rng, sym, 10000)
+    tables = {norm: index.score_table(qs, qo, norm) for norm in (True, False)}
+    assert tables[True].shape == (10000, 256)
+    assert (tables[True] >= 0).all() and (tables[True] <= 1).all()
+    for d in range(256):
+        t = index.tables(d, names=("suftab", "lcptab", "anntab"))
+        _check_easa_properties(docs[d][0], docs[d][1], t, spot=150)
+    sampled = [0, 1, 37, 100, 128, 199, 254, 255]
+    for d in sampled:
+        o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+        for norm in (True, False):
+            want = np.array([o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=True) for k in range(10000)])
+            assert np.array_equal(tables[norm][:, d], want), (d, norm)
+    # every keyphrase copied from a document scores > 0 there (keyphrases() takes the even ones from the corpus)
+    assert (tables[True].max(axis=1)[0::2] > 0).all()
 
 
 def test_keyphrases_graph_fixture(hip):
