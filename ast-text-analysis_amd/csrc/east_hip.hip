@@ -164,8 +164,8 @@ struct east_hip_index {
     char *q_buf = nullptr;
     size_t q_cap = 0;
     u32 n_kp = 0, n_q = 0;
-    u32 *q_raw = nullptr, *q_code = nullptr, *q_end = nullptr, *q_off = nullptr;
-    double *suffix = nullptr, *table = nullptr;
+    u32 *q_raw = nullptr, *q_code = nullptr, *q_end = nullptr, *q_off = nullptr, *group_off = nullptr;
+    double *suffix = nullptr, *table = nullptr, *table_g = nullptr;
     // k-gram bucket tables for the score walk (own allocation, rebuilt after every build)
     u32 *kg = nullptr;
     size_t kg_cap = 0;
@@ -703,8 +703,8 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
     use_device(h);
     const u32 n_q = (u32)S;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t bytes = al((size_t)n_q * 4) * 3 + al(((size_t)n_kp + 1) * 4) +
-                         al((size_t)n_q * h->n_docs * 8) + al((size_t)n_kp * h->n_docs * 8);
+    const size_t bytes = al((size_t)n_q * 4) * 3 + al(((size_t)n_kp + 1) * 4) * 2 +
+                         al((size_t)n_q * h->n_docs * 8) + al((size_t)n_kp * h->n_docs * 8) * 2;
     if (bytes > h->q_cap) {
         HIP_CHECK(hipStreamSynchronize(h->stream));
         if (h->q_buf) HIP_CHECK(hipFree(h->q_buf));
@@ -720,8 +720,10 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
     h->q_code = (u32 *)p; p += al((size_t)n_q * 4);
     h->q_end = (u32 *)p;  p += al((size_t)n_q * 4);
     h->q_off = (u32 *)p;  p += al(((size_t)n_kp + 1) * 4);
+    h->group_off = (u32 *)p; p += al(((size_t)n_kp + 1) * 4);      // synonym-expanded scoring: variants per keyphrase
     h->suffix = (double *)p; p += al((size_t)n_q * h->n_docs * 8);
-    h->table = (double *)p;
+    h->table = (double *)p; p += al((size_t)n_kp * h->n_docs * 8);
+    h->table_g = (double *)p;
     std::vector<u32> end(n_q), off((size_t)n_kp + 1);
     for (int32_t k = 0; k < n_kp; k++) {
         off[k] = (u32)q_offsets[k];
@@ -1032,6 +1034,53 @@ int east_hip_score_table(east_hip_handle_t h, const uint32_t *q_symbols, const i
                                      h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
         HIP_CHECK(hipEventElapsedTime(&h->last_score_ms, h->ev0, h->ev1));
+    });
+}
+
+int east_hip_score_table_grouped(east_hip_handle_t h, const uint32_t *q_symbols, const int64_t *q_offsets,
+                                 int32_t n_queries, const int64_t *group_offsets, int32_t n_groups, int normalized,
+                                 double *out)
+{
+    return guarded([&] {
+        if (!out || !group_offsets || n_groups < 1) east_throw(EAST_HIP_ERR_INVALID, "null output table or no groups");
+        if (group_offsets[0] != 0 || group_offsets[n_groups] != n_queries)
+            east_throw(EAST_HIP_ERR_INVALID, "group_offsets must start at 0 and end at n_queries");
+        for (int32_t g = 0; g < n_groups; g++)
+            if (group_offsets[g + 1] <= group_offsets[g]) east_throw(EAST_HIP_ERR_INVALID, "empty group");
+        set_keyphrases(h, q_symbols, q_offsets, n_queries);
+        std::vector<u32> goff((size_t)n_groups + 1);
+        for (int32_t g = 0; g <= n_groups; g++) goff[g] = (u32)group_offsets[g];
+        HIP_CHECK(hipMemcpyAsync(h->group_off, goff.data(), goff.size() * 4, hipMemcpyHostToDevice, h->stream));
+        score_resident(h, normalized);
+        Ctx ctx;
+        ctx.stream = h->stream;
+        ctx.prof = &h->prof;
+        LAUNCH(ctx, score_group_max_kernel, ceil_div_u32((u64)n_groups * h->n_docs, BLOCK), (const double *)h->table,
+               (const u32 *)h->group_off, (u32)n_groups, h->n_docs, h->table_g);
+        HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+        HIP_CHECK(hipMemcpyAsync(out, h->table_g, (size_t)n_groups * h->n_docs * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));       // (also covers goff)
+        HIP_CHECK(hipEventElapsedTime(&h->last_score_ms, h->ev0, h->ev1));
+    });
+}
+
+int east_hip_get_lcp_intervals(east_hip_handle_t h, int32_t doc, int32_t *left)
+{
+    return guarded([&] {
+        if (!h || !left) east_throw(EAST_HIP_ERR_INVALID, "null handle or output");
+        if (!h->built) east_throw(EAST_HIP_ERR_NOT_BUILT, "no index has been built on this handle");
+        if (doc < 0 || (u32)doc >= h->n_docs) east_throw(EAST_HIP_ERR_INVALID, "document index out of range");
+        use_device(h);
+        Ctx ctx;
+        ctx.stream = h->stream;
+        ctx.prof = &h->prof;
+        const u32 seg = (u32)h->h_doc_off[doc], nd = (u32)(h->h_doc_off[doc + 1] - h->h_doc_off[doc]);
+        // (h->up is rewritten by child_kernel on the next east_hip_get_tables request that wants it)
+        u32 *scratch = h->up;
+        h->child_built = false;
+        LAUNCH(ctx, interval_left_kernel, ceil_div_u32(nd, BLOCK), h->pyr, (const u32 *)h->ann, seg, nd, scratch);
+        HIP_CHECK(hipMemcpyAsync(left, scratch, (size_t)nd * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
     });
 }
 

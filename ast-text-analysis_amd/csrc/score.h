@@ -360,3 +360,22 @@ __global__ __launch_bounds__(BLOCK) void score_reduce_kernel(const double *__res
     for (u32 i = b; i < e; i++) total += row[i];          // easa.py:130
     out[(u64)k * n_docs + d] = total / (double)(e - b);   // easa.py:134
 }
+
+// Synonym-expanded scoring (easa.py:27-34): every keyphrase was expanded into its variants (the product of the
+// per-word alternatives), all variants were scored as ordinary queries (table_v: V x D); the score of a keyphrase
+// is the maximum over its variants -- a segmented max, variants of keyphrase k = [group_off[k], group_off[k+1]).
+__global__ __launch_bounds__(BLOCK) void score_group_max_kernel(const double *__restrict__ table_v,
+                                                                const u32 *__restrict__ group_off, u32 n_groups,
+                                                                u32 n_docs, double *__restrict__ out)
+{
+    const u64 gid = (u64)blockIdx.x * BLOCK + threadIdx.x;
+    if (gid >= (u64)n_groups * n_docs) return;
+    const u32 k = (u32)(gid / n_docs), d = (u32)(gid - (u64)k * n_docs);
+    const u32 b = group_off[k], e = group_off[k + 1];
+    double best = table_v[(u64)b * n_docs + d];
+    for (u32 v = b + 1; v < e; v++) {
+        const double x = table_v[(u64)v * n_docs + d];
+        best = x > best ? x : best;                         // (Python's max: the first maximal element; same value)
+    }
+    out[gid] = best;
+}

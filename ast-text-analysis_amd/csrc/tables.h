@@ -479,3 +479,21 @@ __global__ __launch_bounds__(BLOCK) void child_kernel(Pyramid P, const u32 *__re
     up[k] = u;
     down[k] = dn;
 }
+
+// Left boundaries of the lcp-intervals (easa.py:38-85, the traversals): an lcp-interval l-[i..j], l > 0, is
+// named by its first l-index k (the rank with anntab[k] > 0): i = PSV(k), j = i + anntab[k] - 1, l = lcptab[k]
+// (SURVEY.md Appendix A.2).  left[k] = PSV(k) local to the document for those ranks, NONE_U32 for every other.
+// The host turns the intervals into the reference's pre-/post-order visits (east/asts/easa_hip.py).
+__global__ __launch_bounds__(BLOCK) void interval_left_kernel(Pyramid P, const u32 *__restrict__ ann, u32 seg, u32 nd,
+                                                              u32 *__restrict__ left)
+{
+    const u32 r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= nd) return;
+    const u32 k = seg + r;
+    u32 out = NONE_U32;
+    if (r > 0 && ann[k] > 0) {
+        const u32 v = P.ptr[0][k];                          // > 0: the document's first rank (lcp 0) bounds the search
+        out = pyr_find_left<true>(P, k, v) - seg;
+    }
+    left[r] = out;
+}

@@ -26,10 +26,12 @@ def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=Non
     res = {}
 
     # batched path: one score call for the whole table
-    if synonimizer is None and hasattr(similarity_measure, "relevance_table"):
+    if hasattr(similarity_measure, "relevance_table"):
         wanted = [kp for kp in dict.fromkeys(keyphrases) if kp]          # applications.py:44-45
         if wanted:
-            scores = similarity_measure.relevance_table([keyphrases_prepared[kp] for kp in wanted])
+            prepared = [keyphrases_prepared[kp] for kp in wanted]
+            scores = (similarity_measure.relevance_table(prepared, synonimizer) if synonimizer
+                      else similarity_measure.relevance_table(prepared))
             for keyphrase, row in zip(wanted, scores.tolist()):          # (one C-level conversion of the K x D table)
                 res[keyphrase] = dict(zip(text_titles, row))
         return res

@@ -50,7 +50,7 @@ def strings_to_symbols(strings_collection):
     return out
 
 
-def query_to_symbols(query):
+def query_to_symbols(query, keep_spaces=False):
     """score() removes U+0020 only (easa.py:36)."""
-    q = query.replace(" ", "")
+    q = query if keep_spaces else query.replace(" ", "")
     return np.frombuffer(q.encode("utf-32-le", errors="surrogatepass"), dtype="<u4").astype(np.uint32)

@@ -44,6 +44,9 @@ SIGNATURES = {
     "east_hip_get_tables": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [_c_i32p] * 6),
     "east_hip_score_table": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, _c_i64p, ctypes.c_int32, ctypes.c_int,
                                             _c_dblp, _c_dblp]),
+    "east_hip_score_table_grouped": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, _c_i64p, ctypes.c_int32, _c_i64p,
+                                                    ctypes.c_int32, ctypes.c_int, _c_dblp]),
+    "east_hip_get_lcp_intervals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_i32p]),
     "east_hip_set_keyphrases": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, _c_i64p, ctypes.c_int32]),
     "east_hip_score_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "east_hip_score_resident_async": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
@@ -188,6 +191,7 @@ class HipIndex(object):
             _check(self._lib.east_hip_create(self.device, int(reserve_symbols), ctypes.byref(self._h)))
         self.n_docs = 0
         self.doc_offsets = None
+        self._host_symbols = None
 
     def close(self):
         """Release the handle.  Handles of small indexes go back to a per-device pool instead of being
@@ -219,6 +223,7 @@ class HipIndex(object):
                                         _ptr(n_strings, _c_i32p), n_strings.size))
         self.n_docs = int(n_strings.size)
         self.doc_offsets = doc_offsets.copy()
+        self._host_symbols = symbols
 
     def build_device(self, d_symbols_ptr, n_total, doc_offsets, n_strings):
         """d_symbols_ptr: integer address of a uint32 device buffer (e.g. tensor.data_ptr())."""
@@ -228,6 +233,7 @@ class HipIndex(object):
                                                _ptr(doc_offsets, _c_i64p), _ptr(n_strings, _c_i32p), n_strings.size))
         self.n_docs = int(n_strings.size)
         self.doc_offsets = doc_offsets.copy()
+        self._host_symbols = None
 
     def build_texts(self, texts):
         """Text preparation + build on the device.  texts: list of bytes (UTF-8, decoded with
@@ -249,6 +255,7 @@ class HipIndex(object):
             np.cumsum([len(t) + 1 for t in raw], out=offsets[1:])
             _check(self._lib.east_hip_build_texts(self._h, blob, len(blob), _ptr(offsets, _c_i64p), len(raw), *tables))
         self.n_docs = len(raw)
+        self._host_symbols = None
         doc_offsets = np.zeros(self.n_docs + 1, dtype=np.int64)
         n_total = ctypes.c_int64(0)
         _check(self._lib.east_hip_get_prepared(self._h, ctypes.byref(n_total), _ptr(doc_offsets, _c_i64p), None, None))
@@ -264,6 +271,13 @@ class HipIndex(object):
         _check(self._lib.east_hip_get_prepared(self._h, ctypes.byref(n_total), _ptr(doc_offsets, _c_i64p),
                                                _ptr(n_strings, _c_i32p), _ptr(symbols, _c_u32p)))
         return symbols, doc_offsets, n_strings
+
+    def symbols(self):
+        """The symbols of the index as the host last saw them: kept by build(), fetched from the device
+        after build_texts()."""
+        if self._host_symbols is None:
+            self._host_symbols = self.prepared()[0]
+        return self._host_symbols
 
     @property
     def last_prep_ms(self):
@@ -291,6 +305,26 @@ class HipIndex(object):
                                               int(bool(normalized)), _ptr(out, _c_dblp),
                                               _ptr(suf, _c_dblp) if want_suffix else None))
         return (out, suf) if want_suffix else out
+
+    def score_table_grouped(self, q_symbols, q_offsets, group_offsets, normalized=True):
+        """Scores of groups of queries: out[g, d] = max over the queries of group g (synonym variants)."""
+        q_symbols = np.ascontiguousarray(q_symbols, dtype=np.uint32)
+        q_offsets = np.ascontiguousarray(q_offsets, dtype=np.int64)
+        group_offsets = np.ascontiguousarray(group_offsets, dtype=np.int64)
+        G = group_offsets.size - 1
+        out = np.empty((G, self.n_docs), dtype=np.float64)
+        _check(self._lib.east_hip_score_table_grouped(self._h, _ptr(q_symbols, _c_u32p), _ptr(q_offsets, _c_i64p),
+                                                      q_offsets.size - 1, _ptr(group_offsets, _c_i64p), G,
+                                                      int(bool(normalized)), _ptr(out, _c_dblp)))
+        return out
+
+    def lcp_interval_lefts(self, doc=0):
+        """left[k] = left boundary of the lcp-interval whose first l-index is rank k, -1 for other ranks."""
+        if self.doc_offsets is None or not 0 <= doc < self.n_docs:
+            raise exceptions.HipBackendError(reason="no index has been built on this handle, or no such document")
+        left = np.empty(int(self.doc_offsets[doc + 1] - self.doc_offsets[doc]), dtype=np.int32)
+        _check(self._lib.east_hip_get_lcp_intervals(self._h, int(doc), _ptr(left, _c_i32p)))
+        return left.astype(np.int64)
 
     def set_keyphrases(self, q_symbols, q_offsets):
         q_symbols = np.ascontiguousarray(q_symbols, dtype=np.uint32)
@@ -336,10 +370,11 @@ class HipIndex(object):
         return float(self._lib.east_hip_last_score_ms(self._h))
 
 
-def pack_queries(queries):
-    """[unicode query with spaces already removed] -> (q_symbols uint32, q_offsets int64)."""
+def pack_queries(queries, keep_spaces=False):
+    """[unicode query] -> (q_symbols uint32, q_offsets int64); U+0020 is removed as score() does
+    (easa.py:36) unless keep_spaces (synonym variants go to _score as they are, easa.py:34)."""
     from east.asts import utils as ast_utils
-    parts = [ast_utils.query_to_symbols(q) for q in queries]
+    parts = [ast_utils.query_to_symbols(q, keep_spaces) for q in queries]
     offsets = np.zeros(len(parts) + 1, dtype=np.int64)
     for i, p in enumerate(parts):
         offsets[i + 1] = offsets[i] + p.size

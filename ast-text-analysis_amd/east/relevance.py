@@ -7,6 +7,7 @@ text collection (the documents become one device-resident shard of annotated
 suffix arrays) and `relevance_table`, ONE score call for all keyphrases.
 CosineRelevanceMeasure is a different method and out of scope.
 """
+import itertools
 import os
 
 import numpy as np
@@ -28,6 +29,20 @@ class RelevanceMeasure(object):
         raise NotImplementedError()
 
 
+def synonym_variants(query, synonimizer):
+    """The queries easa.py:27-33 scores for a keyphrase under a synonimizer: every word of the
+    (prepared) keyphrase may be replaced by one of its synonyms -- the product of the per-word
+    alternatives, synonyms first, each variant the concatenation of its words.  `synonimizer`
+    is anything with get_synonyms() -> {word: [synonyms]}; a word missing from the mapping
+    raises KeyError exactly as the reference's dictionary look-up does."""
+    synonyms = synonimizer.get_synonyms()
+    alternatives = [list(synonyms[word]) + [word] for word in utils.tokenize(query)]
+    variants = ["".join(words) for words in itertools.product(*alternatives)]
+    if not all(variants):
+        raise ZeroDivisionError("float division by zero")              # easa.py:134 on an empty variant
+    return variants
+
+
 class _Shard(object):
     """The device index of a measure plus a one-row score cache.  Shared by the measure and its
     per-document views without a reference back to either, so that dropping the measure releases
@@ -36,15 +51,39 @@ class _Shard(object):
     def __init__(self):
         self.index = None
         self.row_cache = (None, None, None)
+        self.host_symbols = None
 
-    def row(self, query, normalized):
+    def row(self, query, normalized, synonimizer=None):
         q = query.replace(" ", "")
-        if self.row_cache[0] != q or self.row_cache[1] != bool(normalized):
-            if not q:
-                raise ZeroDivisionError("float division by zero")              # easa.py:134
-            qs, qo = hip_backend.pack_queries([q])
-            self.row_cache = (q, bool(normalized), self.index.score_table(qs, qo, normalized)[0])
+        key = (q, bool(normalized)) if synonimizer is None else (query, id(synonimizer))
+        if self.row_cache[0] != key:
+            if synonimizer is not None:
+                # easa.py:27-34: max over the variants, scored with normalized=True whatever was asked for
+                variants = synonym_variants(query, synonimizer)
+                qs, qo = hip_backend.pack_queries(variants, keep_spaces=True)
+                row = self.index.score_table_grouped(qs, qo, [0, len(variants)], True)[0]
+            else:
+                if not q:
+                    raise ZeroDivisionError("float division by zero")          # easa.py:134
+                qs, qo = hip_backend.pack_queries([q])
+                row = self.index.score_table(qs, qo, normalized)[0]
+            self.row_cache = (key, None, row)
         return self.row_cache[2]
+
+    def symbols(self, doc):
+        """The EASA string of one document as code points (host copy, fetched once per build)."""
+        if self.host_symbols is None:
+            self.host_symbols = self.index.symbols()
+        off = self.index.doc_offsets
+        return self.host_symbols[int(off[doc]):int(off[doc + 1])]
+
+    def suffix_scores(self, query, normalized, doc):
+        q = query.replace(" ", "")
+        if not q:
+            raise ZeroDivisionError("float division by zero")                  # easa.py:134
+        qs, qo = hip_backend.pack_queries([q])
+        table, suf = self.index.score_table(qs, qo, normalized, want_suffix=True)
+        return float(table[0, doc]), {q[i:]: float(suf[doc, i]) for i in range(len(q))}
 
 
 class _DocumentAST(object):
@@ -54,9 +93,27 @@ class _DocumentAST(object):
         self._shard, self._doc = shard, doc
 
     def score(self, query, normalized=True, synonimizer=None, return_suffix_scores=False):
-        if synonimizer or return_suffix_scores:
-            raise NotImplementedError("use east.asts.base.AST.get_ast(...) for synonym / per-suffix scoring")
+        if synonimizer:                                                         # easa.py:27-34
+            return float(self._shard.row(query, normalized, synonimizer)[self._doc])
+        if return_suffix_scores:                                                # easa.py:132-137
+            return self._shard.suffix_scores(query, normalized, self._doc)
         return self._shard.row(query, normalized)[self._doc]
+
+    # the rest of the AST surface (base.py:28-34), from this document's tables in the shard
+    def traverse(self, callback, order=consts.TraversalOrder.DEPTH_FIRST_PRE_ORDER):
+        from east.asts import intervals
+        index, d = self._shard.index, self._doc
+        t = index.tables(d, names=("suftab", "lcptab", "anntab", "childtab_down"))
+        left = index.lcp_interval_lefts(d)
+        if order == consts.TraversalOrder.DEPTH_FIRST_POST_ORDER:
+            visits = intervals.post_order(t["lcptab"], t["anntab"], left)
+        elif order == consts.TraversalOrder.DEPTH_FIRST_PRE_ORDER:
+            visits = intervals.pre_order(t["lcptab"], t["anntab"], left, t["childtab_down"], t["suftab"],
+                                         self._shard.symbols(d))
+        else:
+            raise NotImplementedError                                           # easa.py:87-89
+        for visit in visits:
+            callback(visit)
 
 
 class ASTRelevanceMeasure(RelevanceMeasure):
@@ -96,6 +153,7 @@ class ASTRelevanceMeasure(RelevanceMeasure):
                 raise
             self.asts = [_DocumentAST(self._shard, d) for d in range(len(texts))]
             self._shard.row_cache = (None, None, None)
+            self._shard.host_symbols = None
             return
         collections = [utils.text_to_strings_collection(text) for text in texts]   # relevance.py:44-45
         self.set_strings_collections(collections)
@@ -112,19 +170,23 @@ class ASTRelevanceMeasure(RelevanceMeasure):
         self.index.build(symbols, doc_offsets, n_strings)
         self.asts = [_DocumentAST(self._shard, d) for d in range(len(parts))]
         self._shard.row_cache = (None, None, None)
-
-    def _row(self, query, normalized):
-        return self._shard.row(query, normalized)
+        self._shard.host_symbols = symbols
 
     def relevance(self, keyphrase, text, synonimizer=None):
         """relevance.py:51-53: the score of a prepared keyphrase in text number `text`."""
-        if synonimizer:
-            raise NotImplementedError("synonym-expanded scoring is not part of the HIP hot path")
-        return float(self._row(keyphrase, self.normalized)[text])
+        return float(self._shard.row(keyphrase, self.normalized, synonimizer or None)[text])
 
     # HOT LOOP B (applications.py:43-52) as one batched call
-    def relevance_table(self, prepared_keyphrases):
-        """K prepared keyphrases -> K x D float64 array of scores."""
+    def relevance_table(self, prepared_keyphrases, synonimizer=None):
+        """K prepared keyphrases -> K x D float64 array of scores.  With a synonimizer every
+        keyphrase is expanded into its variants (synonym_variants), all variants of all keyphrases
+        are scored in the one call and a segmented max on the device folds them back (easa.py:27-34)."""
+        if synonimizer:
+            groups = [synonym_variants(kp, synonimizer) for kp in prepared_keyphrases]
+            offsets = np.zeros(len(groups) + 1, dtype=np.int64)
+            np.cumsum([len(g) for g in groups], out=offsets[1:])
+            qs, qo = hip_backend.pack_queries([v for g in groups for v in g], keep_spaces=True)
+            return self.index.score_table_grouped(qs, qo, offsets, True)
         queries = [kp.replace(" ", "") for kp in prepared_keyphrases]
         if not all(queries):
             raise ZeroDivisionError("float division by zero")

@@ -169,6 +169,27 @@ int east_hip_set_keyphrases(east_hip_handle_t h, const uint32_t *q_symbols,
 int east_hip_score_resident(east_hip_handle_t h, int normalized, double *d_out);
 int east_hip_score_resident_async(east_hip_handle_t h, int normalized);
 
+/*
+ * Synonym-expanded scoring (east/asts/easa.py:27-34 behind relevance.py:51-53 with a synonimizer):
+ * the caller expands every keyphrase into its variants (itertools.product of the per-word
+ * alternatives), the variants are scored as n_queries ordinary queries and the score of keyphrase g
+ * is the maximum over its variants [group_offsets[g], group_offsets[g+1]) -- a segmented max on the
+ * device.  out: n_groups x D doubles.  (The reference scores the variants with normalized=True
+ * whatever its caller asked for; the Python side passes 1 to reproduce that.)
+ */
+int east_hip_score_table_grouped(east_hip_handle_t h, const uint32_t *q_symbols,
+                                 const int64_t *q_offsets, int32_t n_queries,
+                                 const int64_t *group_offsets, int32_t n_groups, int normalized,
+                                 double *out);
+
+/*
+ * The lcp-intervals of one document for the traversal API (easa.py:38-85, base.py:28-34): for every
+ * rank k that is the first l-index of an lcp-interval (anntab[k] > 0, k > 0) left[k] = its left
+ * boundary i (the interval is lcptab[k]-[i .. i + anntab[k] - 1]), -1 for every
+ * other rank.  n_d int32 values, positions local to the document.
+ */
+int east_hip_get_lcp_intervals(east_hip_handle_t h, int32_t doc, int32_t *left);
+
 /* Block until everything queued on the handle's stream has finished. */
 int east_hip_synchronize(east_hip_handle_t h);
 /* The handle's hipStream_t (as void*) so callers can record events on it. */

@@ -16,6 +16,8 @@ Files written (tests/golden/):
   hse_graph.json        keyphrases_graph + gml/edges output on the HSE corpus (17 keyphrases)
   fuzz_small.json       random small collections: every table + scores (easa == ast_linear)
   zipf_docs.json        natural-language-like docs scored by ast_linear and easa (config 5 sub-sample)
+  traversal_synonyms.json  pre-/post-order lcp-interval traversals (easa.py:38-85) and synonym-expanded
+                        scores (easa.py:27-34, relevance.py:51-53, applications.py:43-52) with a stub synonimizer
 """
 import glob
 import json
@@ -28,7 +30,7 @@ sys.path.insert(0, HERE)
 import ref_shim  # noqa: E402
 
 ref_shim.install()
-from east import applications, formatting, relevance, utils  # noqa: E402
+from east import applications, consts, formatting, relevance, utils  # noqa: E402
 from east.asts import base  # noqa: E402
 from east.asts import utils as ast_utils  # noqa: E402
 
@@ -245,6 +247,78 @@ def gen_zipf():
     write("zipf_docs.json", d)
 
 
+class StubSynonimizer(object):
+    """What score() needs of a SynonymExtractor (synonyms/synonyms.py): get_synonyms() -> {word: [synonyms]}."""
+
+    def __init__(self, mapping):
+        self.mapping = mapping
+
+    def get_synonyms(self):
+        return self.mapping
+
+
+def nested(interval):
+    return [int(interval[0]), int(interval[1]), int(interval[2]), [nested(c) for c in interval[3]]]
+
+
+def traversal_dump(strings):
+    ast = base.AST.get_ast(strings, "easa")
+    pre, post = [], []
+    ast.traverse(lambda iv: pre.append([int(iv[0]), int(iv[1]), int(iv[2]), ord(iv[3]) if iv[3] else -1]),
+                 consts.TraversalOrder.DEPTH_FIRST_PRE_ORDER)
+    ast.traverse(lambda iv: post.append([int(iv[0]), int(iv[1]), int(iv[2]),
+                                         [[int(c[0]), int(c[1]), int(c[2])] for c in iv[3]]]),
+                 consts.TraversalOrder.DEPTH_FIRST_POST_ORDER)
+    last = []
+    ast.traverse_depth_first_post_order(lambda iv: last.append(iv))
+    return {"strings": strings, "pre_order": pre, "post_order": post, "root_nested": nested(last[-1])}
+
+
+def gen_traversal_synonyms():
+    rng = random.Random(20246)
+    d = {"traversals": [], "synonym_scores": [], "synonym_tables": []}
+    collections = [["XABXAC", "HI"], ["abcd efg ops", "xyzq", "test"], ["A"], ["", "A"], ["AAAAAAAA"],
+                   ["ABABABAB", "ABABABAB"], ["A", "A", "A"], [" "], ["ZZZZ", "ZZZ", "ZZ", "Z"], ["AB", "", "AB"]]
+    for alpha in ["AB", "ABC", "ABCDEFGH", "АБВГД"]:
+        for _ in range(6):
+            collections.append(["".join(rng.choice(alpha) for _ in range(rng.randint(0, 14)))
+                                for _ in range(rng.randint(1, 6))])
+    for strings in collections:
+        if sum(len(s) for s in strings) + len(strings) < 2:
+            continue                                    # (the reference crashes on a one-symbol string)
+        d["traversals"].append(traversal_dump(strings))
+    # synonym-expanded score(): max over the product of the per-word alternatives, always normalized (easa.py:27-34)
+    syn_cases = [
+        (["XABXAC", "HI"], {"XAB": ["XAC", "HI"], "AC": ["AB"], "HI": []}, ["XAB AC", "HI", "AC HI XAB"]),
+        (["QUICK BROWN FOX", "LAZY DOG JUMPS", "FAST RED FOX"],
+         {"QUICK": ["FAST", "RAPID"], "FOX": ["DOG", "WOLF"], "LAZY": [], "BROWN": ["RED"]},
+         ["QUICK FOX", "QUICK BROWN FOX", "LAZY FOX", "BROWN"]),
+        (["ABAB", "BABA", "AABB"], {"AB": ["BA", "AA", "BB"], "BA": ["AB"]}, ["AB BA", "BA", "AB AB AB"]),
+    ]
+    for strings, mapping, queries in syn_cases:
+        ast = base.AST.get_ast(strings, "easa")
+        lin = base.AST.get_ast(strings, "ast_linear")
+        syn = StubSynonimizer(mapping)
+        for q in queries:
+            sn = ast.score(q, normalized=True, synonimizer=syn)
+            sd = ast.score(q, normalized=False, synonimizer=syn)
+            assert sn == sd                              # the quirk: `normalized` is ignored under a synonimizer
+            d["synonym_scores"].append({"strings": strings, "synonyms": mapping, "query": q,
+                                        "score": float(sn), "ast_linear_agrees": bool(lin.score(q, synonimizer=syn) == sn)})
+    # the table path with a synonimizer (applications.py:43-52 -> relevance.py:51-53)
+    texts = {"fox": b"The quick brown fox jumps over the lazy dog", "dog": b"A fast red dog sleeps near the rapid river",
+             "none": b"12 34 zz"}
+    mapping = {"QUICK": ["FAST", "RAPID"], "FOX": ["DOG"], "RIVER": [], "LAZY": ["SLEEPY"], "BROWN": ["RED"]}
+    keyphrases = ["quick fox", "lazy brown fox", "river", "quick"]
+    for norm in (True, False):
+        measure = relevance.ASTRelevanceMeasure("easa", norm)
+        table = applications.keyphrases_table(keyphrases, texts, measure, StubSynonimizer(mapping))
+        d["synonym_tables"].append({"normalized": norm, "keyphrases": keyphrases,
+                                    "texts": {k: v.decode("utf-8") for k, v in texts.items()}, "synonyms": mapping,
+                                    "table": {k: {t: float(v) for t, v in row.items()} for k, row in table.items()}})
+    write("traversal_synonyms.json", d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_readme()
@@ -254,3 +328,4 @@ if __name__ == "__main__":
     gen_hse()
     gen_fuzz()
     gen_zipf()
+    gen_traversal_synonyms()

@@ -390,6 +390,112 @@ def test_config2_256_documents_10000_keyphrases_vs_oracle(hip, oracle):
     assert (tables[True].max(axis=1)[0::2] > 0).all()
 
 
+class _Synonimizer(object):
+    def __init__(self, mapping):
+        self.mapping = mapping
+
+    def get_synonyms(self):
+        return self.mapping
+
+
+def test_traversals_vs_reference_fixture(hip):
+    """AST.traverse() (base.py:28-34 -> easa.py:38-85): the visits in pre- and post-order, leaves and
+    the nested children lists included, as recorded from the reference."""
+    from east import consts
+    from east.asts import base
+    for case in load_golden("traversal_synonyms.json")["traversals"]:
+        ast = base.AST.get_ast(case["strings"])
+        pre, post = [], []
+        ast.traverse(pre.append, consts.TraversalOrder.DEPTH_FIRST_PRE_ORDER)
+        ast.traverse(post.append, consts.TraversalOrder.DEPTH_FIRST_POST_ORDER)
+        assert [[v[0], v[1], v[2], ord(v[3]) if v[3] else -1] for v in pre] == case["pre_order"], case["strings"]
+        assert type(pre[0]) is list and all(type(v) is tuple for v in pre[1:])     # easa.py:45, 363-376
+        assert [[v[0], v[1], v[2], [c[:3] for c in v[3]]] for v in post] == case["post_order"], case["strings"]
+        assert post[-1] == case["root_nested"]
+        ast.traverse(pre.append)                                                    # default order: pre-order
+        assert len(pre) == 2 * len(case["pre_order"])
+        with pytest.raises(NotImplementedError):
+            ast.traverse(post.append, consts.TraversalOrder.BREADTH_FIRST)
+
+
+def test_traversals_of_the_documents_of_a_measure(hip):
+    """measure.asts[d] (relevance.py:41-47) offers the same traverse() as a stand-alone AST: all fixture
+    collections as the documents of ONE batched build, built from strings and from raw texts."""
+    from east import consts, relevance
+    cases = load_golden("traversal_synonyms.json")["traversals"]
+    measure = relevance.ASTRelevanceMeasure()
+    measure.set_strings_collections([c["strings"] for c in cases])
+    for d, case in enumerate(cases):
+        pre, post = [], []
+        measure.asts[d].traverse(pre.append)
+        measure.asts[d].traverse(post.append, consts.TraversalOrder.DEPTH_FIRST_POST_ORDER)
+        assert [[v[0], v[1], v[2], ord(v[3]) if v[3] else -1] for v in pre] == case["pre_order"], case["strings"]
+        assert post[-1] == case["root_nested"]
+    measure.set_text_collection([b"xabxac hi", b"abcd efg ops xyzq test"])
+    post = []
+    measure.asts[0].traverse(post.append, consts.TraversalOrder.DEPTH_FIRST_POST_ORDER)
+    pre = []
+    measure.asts[0].traverse(pre.append)
+    assert post[-1][:3] == [0, 0, len([v for v in pre if v[1] == v[2]]) - 1]
+    assert "".join(v[3] for v in pre if v[1] == v[2] and ord(v[3] or " ") < 0x0A00) != ""
+
+
+def test_traversal_of_a_large_document_vs_lcp_scan(hip, oracle):
+    """64 KiB word-stream document: the post-order visits equal a plain stack scan over the oracle's
+    LCP table (Kasai et al. 2001), the pre-order visits cover every rank exactly once as a leaf."""
+    from east import utils
+    from east.asts import base
+    rng = np.random.default_rng(31)
+    strings = utils.text_to_strings_collection(word_stream(rng, 64 << 10))
+    ast = base.AST.get_ast(strings)
+    lcp = oracle.OracleEASA(strings).lcptab
+    want, stack = [], [(0, 0)]
+    for r in range(1, len(lcp)):
+        lb = r - 1
+        while lcp[r] < stack[-1][0]:
+            l, lb = stack.pop()
+            want.append((l, lb, r - 1))
+        if lcp[r] > stack[-1][0]:
+            stack.append((int(lcp[r]), lb))
+    want.append((0, 0, len(lcp) - 1))
+    post, pre = [], []
+    ast.traverse_depth_first_post_order(lambda v: post.append((v[0], v[1], v[2])))
+    assert post == want
+    ast.traverse_depth_first_pre_order(pre.append)
+    assert sorted(v[1] for v in pre if v[1] == v[2]) == list(range(len(lcp)))
+    assert sorted((v[0], v[1], v[2]) for v in pre if v[1] != v[2]) == sorted(want)
+
+
+def test_synonym_expanded_scores_vs_reference_fixture(hip):
+    """easa.py:27-34 on the AST surface and on the measure / table path (relevance.py:51-53,
+    applications.py:43-52): extra queries + a segmented max on the device; `normalized` is ignored
+    under a synonimizer, as in the reference."""
+    from east import applications, relevance, utils
+    from east.asts import base
+    g = load_golden("traversal_synonyms.json")
+    for case in g["synonym_scores"]:
+        ast = base.AST.get_ast(case["strings"])
+        syn = _Synonimizer(case["synonyms"])
+        for norm in (True, False):
+            got = ast.score(case["query"], normalized=norm, synonimizer=syn)
+            assert got == case["score"] and abs(got - case["score"]) <= TOL, (case["strings"], case["query"])
+    for case in g["synonym_tables"]:
+        texts = {k: v.encode("utf-8") for k, v in case["texts"].items()}
+        syn = _Synonimizer(case["synonyms"])
+        measure = relevance.ASTRelevanceMeasure("easa", case["normalized"])
+        table = applications.keyphrases_table(case["keyphrases"], texts, measure, syn)
+        _table_equal(table, case["table"])
+        names = list(texts)
+        for kp in case["keyphrases"]:                      # the per-pair surface and the per-document AST views
+            for j, name in enumerate(names):
+                assert measure.relevance(utils.prepare_text(kp), j, synonimizer=syn) == case["table"][kp][name]
+                assert measure.asts[j].score(utils.prepare_text(kp), synonimizer=syn) == case["table"][kp][name]
+        total, suffixes = measure.asts[0].score("QUICK FOX", normalized=case["normalized"], return_suffix_scores=True)
+        assert total == measure.relevance("QUICK FOX", 0) and set(suffixes) == {"QUICKFOX"[i:] for i in range(8)}
+        with pytest.raises(KeyError):
+            measure.relevance("UNKNOWN WORD", 0, synonimizer=syn)
+
+
 def test_keyphrases_graph_fixture(hip):
     """applications.keyphrases_graph + graph2gml / graph2edges on the HSE corpus (17 keyphrases)."""
     from east import applications, formatting, relevance

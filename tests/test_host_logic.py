@@ -169,3 +169,50 @@ def test_shard_documents():
         shards = parallel.shard_documents(sizes, world)
         assert len(shards) == world and shards[0][0] == 0 and shards[-1][1] == len(sizes)
         assert all(shards[r][1] == shards[r + 1][0] for r in range(world - 1))
+
+
+def _brute_force_lefts(lcp, ann):
+    """left[k] = PSV(k) for the first l-indices (anntab > 0, k > 0), -1 elsewhere -- what
+    east_hip_get_lcp_intervals returns, by plain scans."""
+    left = np.full(len(lcp), -1, dtype=np.int64)
+    for k in range(1, len(lcp)):
+        if ann[k] > 0:
+            p = k - 1
+            while lcp[p] >= lcp[k]:
+                p -= 1
+            left[k] = p
+    return left
+
+
+def test_interval_traversals_from_closed_forms(oracle):
+    """east/asts/intervals.py (the host half of the traversal API, easa.py:38-85) on the oracle's
+    tables, against the visits recorded from the reference's traverse()."""
+    from east.asts import intervals
+    for case in load_golden("traversal_synonyms.json")["traversals"]:
+        o = oracle.OracleEASA(case["strings"])
+        left = _brute_force_lefts(o.lcptab, o.anntab)
+        post = [[v[0], v[1], v[2], [c[:3] for c in v[3]]] for v in intervals.post_order(o.lcptab, o.anntab, left)]
+        assert post == case["post_order"], case["strings"]
+        last = None
+        for last in intervals.post_order(o.lcptab, o.anntab, left):
+            pass
+        assert last == case["root_nested"]
+        pre = [[v[0], v[1], v[2], ord(v[3]) if v[3] else -1]
+               for v in intervals.pre_order(o.lcptab, o.anntab, left, o.childtab_down, o.suftab, o.symbols)]
+        assert pre == case["pre_order"], case["strings"]
+
+
+def test_synonym_variants():
+    """The variants easa.py:27-33 scores: product of (synonyms + the word itself) per word."""
+    from east import relevance
+
+    class Syn(object):
+        def get_synonyms(self):
+            return {"QUICK": ["FAST", "RAPID"], "FOX": ["DOG"], "X": []}
+    assert relevance.synonym_variants("QUICK FOX", Syn()) == ["FASTDOG", "FASTFOX", "RAPIDDOG", "RAPIDFOX", "QUICKDOG",
+                                                             "QUICKFOX"]
+    assert relevance.synonym_variants("X", Syn()) == ["X"]
+    with pytest.raises(KeyError):
+        relevance.synonym_variants("QUICK WOLF", Syn())
+    with pytest.raises(ZeroDivisionError):
+        relevance.synonym_variants(" ", Syn())
