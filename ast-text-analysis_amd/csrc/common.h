@@ -172,6 +172,16 @@ __device__ __forceinline__ u64 load_u64_unaligned(const uint8_t *p)
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
 
+// __syncthreads() behind LDS atomics that return nothing (ds_add_u32), for use at the top of a loop:
+// hipcc (ROCm 7.2, gfx950) was seen to leave out the s_waitcnt lgkmcnt(0) in front of the s_barrier on the
+// loop's back edge, so other waves read the counters before this wave's adds had landed.  The wait is
+// written as inline asm, which the compiler's wait-count pass neither sees nor removes.
+__device__ __forceinline__ void syncthreads_after_lds_atomics()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // Inclusive prefix sum across the 64 lanes of a wavefront.
 __device__ __forceinline__ u32 wave_inclusive_sum(u32 x)
 {

@@ -342,7 +342,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         // (document, suffix) pairs whose last pass writes into h->sa (pass i reads buffers [i % 2], writes the others)
         const size_t mark_sa = ar.mark();
         SortBufs<u32> sb;
-        const int last = ((doc_bits + 7) / 8) & 1;
+        const int last = radix_pass_count(doc_bits) & 1;
         for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>((size_t)n + 4); sb.vals[k] = k == last ? h->sa : ar.alloc<u32>((size_t)n + 4); }
         u32 *sa_whole = sb.vals[0];
         ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sa_whole, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr);
@@ -1214,7 +1214,7 @@ template <class K> static void debug_sort(int device, K *keys, u32 *vals, i64 n,
     if (n < 0 || n >= (i64)0x7FFFFFF0 || !keys || !vals || bits < 1 || bits > (int)sizeof(K) * 8)
         east_throw(EAST_HIP_ERR_INVALID, "bad radix sort arguments");
     if (n == 0) return;
-    DebugScope sc(device, (size_t)n * (sizeof(K) + 4) * 2 + (size_t)ceil_div_u32(n, RS_TILE) * 1200 + (8u << 20));
+    DebugScope sc(device, (size_t)n * (sizeof(K) + 4) * 2 + (40u << 20));
     SortBufs<K> sb;
     for (int k = 0; k < 2; k++) { sb.keys[k] = sc.arena.alloc<K>(n); sb.vals[k] = sc.arena.alloc<u32>(n); }
     HIP_CHECK(hipMemcpyAsync(sb.keys[0], keys, (size_t)n * sizeof(K), hipMemcpyHostToDevice, sc.stream));

@@ -1,48 +1,44 @@
 // radix_sort.h -- stable LSD radix sort of (key, value) pairs, 8-bit digits.
 //
-// One pass:
-//   radix_hist_kernel     per-tile 256-bin histogram (LDS atomics)      -> hist[tile][digit]
-//   hist_chunk_sums / hist_chunk_scan / hist_apply
-//                         exclusive scan in digit-major ORDER over the tile-major
-//                         LAYOUT: one thread per digit column, rows of 256
-//                         counters are read and written coalesced       -> global bases
-//   radix_scatter_kernel  wave64 ballot multisplit for the stable rank inside
-//                         the tile, tile re-ordered by digit in LDS, then
-//                         written out as contiguous per-digit runs.
-//
-// Tile = 4096 pairs per workgroup (see radix_scatter_kernel for the geometry).
+// One pass = three launches (no inter-workgroup communication inside a launch):
+//   radix_hist_kernel     a workgroup counts a GROUP of RS_GROUP consecutive tiles, every wave whole tiles
+//                         into per-tile histograms in LDS, and writes them as running sums -- hist[tile][digit]
+//                         = the tile's exclusive prefix inside its group -- plus the group's sums; the digit
+//                         totals over all groups are accumulated on the way (global atomics, one row per group)
+//   radix_spine_kernel    exclusive scan down the groups for every digit column + the digit bases
+//   radix_scatter_kernel  one tile per workgroup: wave64 ballot multisplit for the stable rank inside the
+//                         tile, tile re-ordered by digit in LDS, written out as contiguous per-digit runs
+//                         at  group_prefix[group][digit] + hist[tile][digit].
+// (Round 1 scanned the per-tile histograms with three more streaming launches per pass; the group
+// structure leaves a scan over 1/8 of the rows.  Wider digits -- 10 bits, 3 passes for a 30-bit key --
+// were built and measured: the pass is bound by the number of write requests a CU can keep in flight
+// towards the L2, a request carries one 64-byte-aligned piece of a run, and runs of 8 pairs make a
+// 3-pass sort as slow as the 4-pass one; see DESIGN.md.)
 #pragma once
 #include "common.h"
 #include "scan.h"
 
-#ifndef RS_THREADS
 #define RS_THREADS 1024                // threads per scatter workgroup (16 waves)
-#endif
-#define RS_TILE 4096                   // pairs per workgroup, both kernels
+#define RS_IPT 4
+#define RS_TILE (RS_THREADS * RS_IPT)  // 4096 pairs per workgroup
+#define RS_DB 8
 #define RS_BINS 256
+#ifndef RS_GROUP
+#define RS_GROUP 8                     // tiles per histogram group
+#endif
+#define RS_HIST_THREADS 256
 
 // Where a pass reads its pairs from: the buffers of the previous pass, or -- first pass only -- a
-// generator that computes pair i on the fly (the keys then never make a round trip through HBM
-// before the first scatter).
+// generator (MODE 1: computes pair i on the fly, key(i) / val(i); MODE 2: fills a whole tile of keys in
+// LDS, see TextWindowGen in window_sort.h; the value of element i is i).  The keys then never make a
+// round trip through HBM before the first scatter.
 template <class K> struct PairSrc {
+    static constexpr int MODE = 0;
     const K *keys;
     const u32 *vals;
     __device__ __forceinline__ K key(u32 i) const { return keys[i]; }
     __device__ __forceinline__ u32 val(u32 i) const { return vals[i]; }
 };
-
-// digit of pair i at `shift`; a generator that can produce the first pass's digit without the whole
-// key (low_digit, shift == 0 there by construction) is asked for just that
-template <class Src>
-__device__ __forceinline__ auto radix_digit(const Src &src, u32 i, int shift, int) -> decltype(src.low_digit(i))
-{
-    return src.low_digit(i);
-}
-template <class Src>
-__device__ __forceinline__ u32 radix_digit(const Src &src, u32 i, int shift, long)
-{
-    return (u32)(src.key(i) >> shift) & 255u;
-}
 
 // One more key for the wave's sub-histogram.  Keys that arrive sorted on their high bits (the group
 // numbers of the refinement rounds) put a whole wavefront on ONE bin, where 64 LDS atomics would queue
@@ -59,243 +55,243 @@ __device__ __forceinline__ void radix_hist_add(u32 *mine, u32 digit)
     }
 }
 
+// ---- histogram: per-tile counts of a group of tiles, written as running sums ------------------------------
+// Wave w of the workgroup counts the tiles w, w + 4, ... of its group into that tile's OWN histogram in
+// LDS: no wave ever touches another wave's counters, so there is no barrier inside the loop, and a wave
+// keeps a batch of 16-byte loads in flight while it counts the batch before.  At the end thread d turns
+// digit d's column into running sums: hist[tile][d] = the pairs with digit d in the group's earlier tiles.
+#ifndef RS_HIST_BATCH
+#define RS_HIST_BATCH 8                // 16-byte loads a wave keeps in flight (8 KiB)
+#endif
 template <class K, class Src>
-__global__ __launch_bounds__(BLOCK) void radix_hist_kernel(Src src, u32 n, int shift, u32 *__restrict__ hist,
-                                                           u32 n_tiles)
+__global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u32 n, int shift, u32 mask, u32 n_tiles,
+                                                                     u32 *__restrict__ hist, u32 *__restrict__ group_sum,
+                                                                     u32 *__restrict__ digit_total)
 {
-    __shared__ u32 bins[WAVES_PER_BLOCK][RS_BINS];     // one sub-histogram per wave: a quarter of the atomic contention
+    constexpr int UW = RS_HIST_THREADS / WAVE;
+    static_assert(RS_HIST_THREADS == RS_BINS, "thread d owns digit d");
+    __shared__ u32 bins[RS_GROUP][RS_BINS];
 #pragma unroll
-    for (int k = 0; k < WAVES_PER_BLOCK; k++) bins[k][threadIdx.x] = 0;
+    for (int k = 0; k < RS_GROUP; k++) bins[k][threadIdx.x] = 0;
     __syncthreads();
-    u32 *mine = bins[wave_id()];
-    const u32 base = blockIdx.x * RS_TILE;
-    if constexpr (std::is_same<Src, PairSrc<K>>::value && sizeof(K) == 8) {
-        if (base + RS_TILE <= n) {                      // a full tile of 64-bit keys: 16-byte loads, two keys each
+    const u32 g = blockIdx.x, lane = lane_id();
+    const u32 t0 = g * RS_GROUP, t1 = t0 + RS_GROUP < n_tiles ? t0 + RS_GROUP : n_tiles;
+    for (u32 tile = t0 + wave_id(); tile < t1; tile += UW) {
+        u32 *mine = bins[tile - t0];
+        const u32 base = tile * RS_TILE;
+        const u32 count = n - base < (u32)RS_TILE ? n - base : (u32)RS_TILE;
+        if constexpr (Src::MODE == 0) {
+            constexpr u32 PER = 16 / sizeof(K);         // keys per 16-byte load
+            constexpr int LOADS = RS_TILE / (WAVE * PER);
+            static_assert(LOADS % RS_HIST_BATCH == 0, "batches of loads");
+            if (count == (u32)RS_TILE) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(src.keys + base) + lane;
+                for (int j0 = 0; j0 < LOADS; j0 += RS_HIST_BATCH) {
+                    uint4 q[RS_HIST_BATCH];
 #pragma unroll
-            for (int j = 0; j < RS_TILE / (BLOCK * 2); j++) {
-                const uint4 k2 = reinterpret_cast<const uint4 *>(src.keys + base)[j * BLOCK + threadIdx.x];
-                const u64 ka = ((u64)k2.y << 32) | k2.x, kb = ((u64)k2.w << 32) | k2.z;
-                radix_hist_add(mine, (u32)(ka >> shift) & 255u);
-                radix_hist_add(mine, (u32)(kb >> shift) & 255u);
+                    for (int j = 0; j < RS_HIST_BATCH; j++) q[j] = p[(j0 + j) * WAVE];
+#pragma unroll
+                    for (int j = 0; j < RS_HIST_BATCH; j++) {
+                        if constexpr (sizeof(K) == 8) {
+                            const u64 ka = ((u64)q[j].y << 32) | q[j].x, kb = ((u64)q[j].w << 32) | q[j].z;
+                            radix_hist_add(mine, (u32)(ka >> shift) & mask);
+                            radix_hist_add(mine, (u32)(kb >> shift) & mask);
+                        } else {
+                            radix_hist_add(mine, (u32)(q[j].x >> shift) & mask);
+                            radix_hist_add(mine, (u32)(q[j].y >> shift) & mask);
+                            radix_hist_add(mine, (u32)(q[j].z >> shift) & mask);
+                            radix_hist_add(mine, (u32)(q[j].w >> shift) & mask);
+                        }
+                    }
+                }
+            } else {
+                for (u32 i = lane; i < count; i += WAVE) radix_hist_add(mine, (u32)(src.keys[base + i] >> shift) & mask);
             }
-            __syncthreads();
-            hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] =
-                bins[0][threadIdx.x] + bins[1][threadIdx.x] + bins[2][threadIdx.x] + bins[3][threadIdx.x];
-            return;
+        } else if constexpr (Src::MODE == 1) {
+            for (u32 i = lane; i < count; i += WAVE) radix_hist_add(mine, (u32)(src.key(base + i) >> shift) & mask);
+        } else {
+            src.hist_tile(mine, base, base + count, shift, mask);
         }
     }
-    if constexpr (std::is_same<Src, PairSrc<K>>::value && sizeof(K) == 4) {
-        if (base + RS_TILE <= n) {                      // a full tile of 32-bit keys: 16-byte loads
+    syncthreads_after_lds_atomics();
+    u32 run = 0;
 #pragma unroll
-            for (int j = 0; j < RS_TILE / (BLOCK * 4); j++) {
-                const uint4 k4 = reinterpret_cast<const uint4 *>(src.keys + base)[j * BLOCK + threadIdx.x];
-                radix_hist_add(mine, (k4.x >> shift) & 255u);
-                radix_hist_add(mine, (k4.y >> shift) & 255u);
-                radix_hist_add(mine, (k4.z >> shift) & 255u);
-                radix_hist_add(mine, (k4.w >> shift) & 255u);
-            }
-            __syncthreads();
-            hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] =
-                bins[0][threadIdx.x] + bins[1][threadIdx.x] + bins[2][threadIdx.x] + bins[3][threadIdx.x];
-            return;
-        }
+    for (int k = 0; k < RS_GROUP; k++) {
+        if (t0 + k < t1) hist[(size_t)(t0 + k) * RS_BINS + threadIdx.x] = run;
+        run += bins[k][threadIdx.x];
     }
-#pragma unroll 4
-    for (int j = 0; j < RS_TILE / BLOCK; j++) {
-        const u32 i = base + j * BLOCK + threadIdx.x;
-        if (i < n) radix_hist_add(mine, radix_digit(src, i, shift, 0));
-    }
-    __syncthreads();
-    static_assert(WAVES_PER_BLOCK == 4, "sub-histogram sum below assumes 4 waves");
-    hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] =          // tile-major: one coalesced row
-        bins[0][threadIdx.x] + bins[1][threadIdx.x] + bins[2][threadIdx.x] + bins[3][threadIdx.x];
+    group_sum[(size_t)g * RS_BINS + threadIdx.x] = run;     // one coalesced row per group
+    if (run) atomicAdd(&digit_total[threadIdx.x], run);
 }
 
-// ---- scan of the histogram: base[t][d] = sum_{d' < d, all t'} h[t'][d'] + sum_{t' < t} h[t'][d] ----
-#define HS_CHUNK 64                    // tiles per chunk
-
-__global__ __launch_bounds__(BLOCK) void hist_chunk_sums_kernel(const u32 *__restrict__ hist, u32 n_tiles,
-                                                                u32 *__restrict__ chunk_sums)
+// ---- spine: exclusive scan down the groups, per digit column, plus the digit bases --------------------
+// A workgroup owns 16 digit columns; its 256 threads cut the column into 16 stretches scanned side by
+// side (all of it lives in the L2: the rows were written by the kernel before).  digit_total is read
+// by every workgroup (its exclusive scan = the digit bases); workgroup 0 clears the OTHER total buffer
+// for the next pass's histogram.
+#define RS_SPINE_COLS 16
+#define RS_SPINE_PARTS 16
+__global__ __launch_bounds__(BLOCK) void radix_spine_kernel(const u32 *__restrict__ group_sum, u32 n_groups,
+                                                            const u32 *__restrict__ digit_total,
+                                                            u32 *__restrict__ next_total, u32 *__restrict__ group_prefix)
 {
-    const u32 d = threadIdx.x, t0 = blockIdx.x * HS_CHUNK;
-    const u32 t1 = t0 + HS_CHUNK < n_tiles ? t0 + HS_CHUNK : n_tiles;
-    u32 sum = 0;
-    for (u32 t = t0; t < t1; t++) sum += hist[(size_t)t * RS_BINS + d];
-    chunk_sums[(size_t)blockIdx.x * RS_BINS + d] = sum;
-}
-
-// one workgroup of 1024 threads: per digit column, exclusive scan over the chunks -- the column is cut into
-// HSC_PARTS stretches scanned side by side (a single thread per column was 15 us of pure latency per pass) --
-// then the digit bases
-#define HSC_PARTS 4
-__global__ __launch_bounds__(BLOCK * HSC_PARTS) void hist_chunk_scan_kernel(const u32 *__restrict__ chunk_sums,
-                                                                            u32 n_chunks, u32 *__restrict__ chunk_prefix)
-{
-    __shared__ u32 part_total[HSC_PARTS][RS_BINS];
+    static_assert(RS_BINS == BLOCK, "one digit per thread in the scan of the totals");
+    __shared__ u32 base_of[RS_BINS];
+    __shared__ u32 part_total[RS_SPINE_PARTS][RS_SPINE_COLS];
     __shared__ u32 lds4[WAVES_PER_BLOCK];
-    const u32 d = threadIdx.x & (RS_BINS - 1u), g = threadIdx.x / RS_BINS;
-    const u32 per = (n_chunks + HSC_PARTS - 1u) / HSC_PARTS;
-    const u32 c0 = g * per < n_chunks ? g * per : n_chunks;
-    const u32 c1 = c0 + per < n_chunks ? c0 + per : n_chunks;
+    {
+        const u32 t = digit_total[threadIdx.x];
+        u32 total;
+        base_of[threadIdx.x] = block_exclusive_sum(t, lds4, total);
+        if (blockIdx.x == 0) next_total[threadIdx.x] = 0;
+    }
+    const u32 c = threadIdx.x & (RS_SPINE_COLS - 1u), part = threadIdx.x / RS_SPINE_COLS;
+    const u32 col = blockIdx.x * RS_SPINE_COLS + c;
+    const u32 per = (n_groups + RS_SPINE_PARTS - 1u) / RS_SPINE_PARTS;
+    const u32 r0 = part * per < n_groups ? part * per : n_groups;
+    const u32 r1 = r0 + per < n_groups ? r0 + per : n_groups;
     u32 run = 0;
 #pragma unroll 8
-    for (u32 c = c0; c < c1; c++) run += chunk_sums[(size_t)c * RS_BINS + d];
-    part_total[g][d] = run;
+    for (u32 r = r0; r < r1; r++) run += group_sum[(size_t)r * RS_BINS + col];
+    part_total[part][c] = run;
     __syncthreads();
-    u32 before = 0, column = 0;                 // chunks of this column in earlier stretches / in all stretches
-#pragma unroll
-    for (u32 k = 0; k < HSC_PARTS; k++) {
-        const u32 v = part_total[k][d];
-        if (k < g) before += v;
-        column += v;
-    }
+    u32 before = base_of[col];
+    for (u32 k = 0; k < part; k++) before += part_total[k][c];
     run = before;
 #pragma unroll 8
-    for (u32 c = c0; c < c1; c++) {             // separate in/out arrays: the loads pipeline
-        const u32 v = chunk_sums[(size_t)c * RS_BINS + d];
-        chunk_prefix[(size_t)c * RS_BINS + d] = run;
-        run += v;
-    }
-    if (g == 0) {                               // (the first 256 threads = 4 waves: the block-wide sum helper fits)
-        u32 total;
-        const u32 digit_base = block_exclusive_sum(column, lds4, total);     // all smaller digits, all tiles
-        chunk_prefix[(size_t)n_chunks * RS_BINS + d] = digit_base;
-    }
-}
-
-__global__ __launch_bounds__(BLOCK) void hist_apply_kernel(u32 *__restrict__ hist, u32 n_tiles,
-                                                           const u32 *__restrict__ chunk_sums, u32 n_chunks)
-{
-    const u32 d = threadIdx.x, t0 = blockIdx.x * HS_CHUNK;
-    const u32 t1 = t0 + HS_CHUNK < n_tiles ? t0 + HS_CHUNK : n_tiles;
-    u32 run = chunk_sums[(size_t)n_chunks * RS_BINS + d] + chunk_sums[(size_t)blockIdx.x * RS_BINS + d];
-    for (u32 t = t0; t < t1; t++) {
-        const u32 v = hist[(size_t)t * RS_BINS + d];
-        hist[(size_t)t * RS_BINS + d] = run;
+    for (u32 r = r0; r < r1; r++) {                     // separate in/out arrays: the loads pipeline
+        const u32 v = group_sum[(size_t)r * RS_BINS + col];
+        group_prefix[(size_t)r * RS_BINS + col] = run;
         run += v;
     }
 }
 
-// Few tiles (small sorts are bound by launch latency): the whole scan in one workgroup, one launch
-// instead of three.  Thread d owns digit column d: exclusive scan down the tiles, then the digit bases.
-#define HS_SMALL_TILES 128
-__global__ __launch_bounds__(BLOCK) void hist_scan_small_kernel(u32 *__restrict__ hist, u32 n_tiles)
-{
-    __shared__ u32 lds4[WAVES_PER_BLOCK];
-    const u32 d = threadIdx.x;
-    u32 run = 0;
-#pragma unroll 8
-    for (u32 t = 0; t < n_tiles; t++) run += hist[(size_t)t * RS_BINS + d];
-    u32 total;
-    u32 base = block_exclusive_sum(run, lds4, total);      // all smaller digits, all tiles
-#pragma unroll 8
-    for (u32 t = 0; t < n_tiles; t++) {
-        const u32 v = hist[(size_t)t * RS_BINS + d];
-        hist[(size_t)t * RS_BINS + d] = base;
-        base += v;
-    }
-}
-
-// THREADS = 64*WAVES threads move one 4096-pair tile.  Wave w owns the contiguous
-// 4096/WAVES pairs [w*64*IPT, (w+1)*64*IPT) and walks them in IPT rows of 64
-// (coalesced), so (wave, row, lane) is the input order and the pass is stable.
-// Keys and values are staged through the SAME LDS buffer one after the other
-// (the per-pair destination is kept in registers), which keeps the workgroup at
-// 4096*sizeof(K) + 4*WAVES*256 + 2 KiB of LDS: two 16-wave workgroups (32 waves,
-// the hardware maximum) fit a CU.
-template <class K, int WAVES> struct ScatterLds {      // (declared once in the kernel: both tile paths share it)
+// ---- scatter -----------------------------------------------------------------------------------------
+// RS_THREADS = 64*WAVES threads move one 4096-pair tile.  Wave w owns the contiguous 4096/WAVES pairs
+// [w*64*IPT, (w+1)*64*IPT) and walks them in IPT rows of 64 (coalesced), so (wave, row, lane) is the
+// input order and the pass is stable.  Keys and values are staged through the SAME LDS buffer one after
+// the other (the per-pair destination is kept in registers), which keeps the workgroup at
+// 4096*sizeof(K) + 2*WAVES*256 + 2 KiB of LDS: two 16-wave workgroups (32 waves, the hardware maximum)
+// fit a CU.  The per-wave digit counters are 16 bits wide, two to a word (a wave holds 256 pairs).
+template <class K> struct ScatterLds {
     K s_keys[RS_TILE];
-    u32 wave_cnt[WAVES][RS_BINS];           // per-wave digit counts, then wave bases
-    u32 digit_start[RS_BINS];               // first slot of the digit inside the tile
-    u32 global_base[RS_BINS];               // output index of slot 0 of the digit
-    u32 lds4[4];
+    u32 wave_cnt[RS_THREADS / WAVE][RS_BINS / 2];   // per-wave digit counts (packed pairs), then wave bases
+    u32 digit_start[RS_BINS];                       // first slot of the digit inside the tile
+    u32 global_base[RS_BINS];                       // output index of slot 0 of the digit
+    u32 wsum[RS_THREADS / WAVE];
 };
 
-template <class K, int THREADS, class Src, bool FULL>
-__device__ __forceinline__ void radix_scatter_tile(
-    ScatterLds<K, THREADS / WAVE> &lds, const Src &src, K *__restrict__ keys_out, u32 *__restrict__ vals_out, int shift,
-    const u32 *__restrict__ scanned_hist, u32 tile, u32 tile_count)
+template <class K, class Src, bool FULL>
+__device__ __forceinline__ void radix_scatter_tile(ScatterLds<K> &lds, const Src &src, K *__restrict__ keys_out,
+                                                   u32 *__restrict__ vals_out, int shift, u32 mask,
+                                                   const u32 *__restrict__ hist, const u32 *__restrict__ group_prefix,
+                                                   u32 tile, u32 tile_count)
 {
-    constexpr int WAVES = THREADS / WAVE;
-    constexpr int IPT = RS_TILE / THREADS;
+    constexpr int WAVES = RS_THREADS / WAVE, IPT = RS_IPT, THREADS = RS_THREADS, BINS = RS_BINS, DB = RS_DB;
     constexpr int WAVE_ITEMS = WAVE * IPT;
-    static_assert(THREADS >= RS_BINS && RS_TILE % THREADS == 0, "bad scatter geometry");
-    K (&s_keys)[RS_TILE] = lds.s_keys;
-    u32 (&wave_cnt)[WAVES][RS_BINS] = lds.wave_cnt;
-    u32 (&digit_start)[RS_BINS] = lds.digit_start;
-    u32 (&global_base)[RS_BINS] = lds.global_base;
-    u32 (&lds4)[4] = lds.lds4;
-    u32 *s_vals = reinterpret_cast<u32 *>(s_keys);
-
+    u32 *s_vals = reinterpret_cast<u32 *>(lds.s_keys);
     const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    const u32 tile_base = tile * RS_TILE;
-
-    for (u32 i = tid; i < WAVES * RS_BINS; i += THREADS) (&wave_cnt[0][0])[i] = 0;
-    __syncthreads();
+    const u32 tile_base = tile * (u32)RS_TILE;
 
     K key[IPT];
     u32 val[IPT];
-    u32 slot[IPT];             // rank among equal digits inside this wave's pairs, later the tile slot
+    if constexpr (Src::MODE != 2) {
+#pragma unroll
+        for (int j = 0; j < IPT; j++) {
+            const u32 local = w * WAVE_ITEMS + j * WAVE + lane;
+            const bool valid = FULL || local < tile_count;
+            key[j] = valid ? src.key(tile_base + local) : (K)0;
+            val[j] = valid ? src.val(tile_base + local) : 0u;
+        }
+    }
+    // where the tile's digits go: requested now, needed after the ranking (digit pair 2*tid, 2*tid + 1)
+    uint2 out_base = {0u, 0u};
+    if (tid < BINS / 2) {
+        const uint2 a = reinterpret_cast<const uint2 *>(hist + (size_t)tile * BINS)[tid];
+        const uint2 b = reinterpret_cast<const uint2 *>(group_prefix + (size_t)(tile / RS_GROUP) * BINS)[tid];
+        out_base = uint2{a.x + b.x, a.y + b.y};
+    }
+    if constexpr (Src::MODE == 2) {
+        // the generator fills s_keys with the tile's keys in input order
+        src.fill_tile(lds.s_keys, tile_base, tile_count);
+        __syncthreads();
+    }
+    for (u32 i = tid; i < WAVES * (BINS / 2); i += THREADS) (&lds.wave_cnt[0][0])[i] = 0;
+    __syncthreads();
 
+    u32 slot[IPT];             // rank among equal digits inside this wave's pairs, later the tile slot
+    if constexpr (Src::MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < IPT; j++) {
+            const u32 local = w * WAVE_ITEMS + j * WAVE + lane;
+            key[j] = lds.s_keys[local];
+            val[j] = tile_base + local;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < IPT; j++) {
         const u32 local = w * WAVE_ITEMS + j * WAVE + lane;
         const bool valid = FULL || local < tile_count;
-        key[j] = valid ? src.key(tile_base + local) : (K)0;
-        val[j] = valid ? src.val(tile_base + local) : 0u;
-        const u32 digit = (u32)(key[j] >> shift) & 255u;
+        const u32 digit = (u32)(key[j] >> shift) & mask;
         // wave64 multisplit: lanes holding the same digit find each other with 8 ballots.  Per bit:
         // s = the bit spread over a word (one v_bfe_i32), the ballot of it, and the lanes that
         // differ from this one in that bit accumulate in `diff` (xor + or per half).  (The kernel is
-        // bound by instruction issue, not by HBM: 9 -> 5 VALU per bit here was worth 10 % of a pass;
-        // interleaving the rows' chains to fill the ballot hazards was measured and is slower --
-        // the rows then cannot start before all four loads have landed.)
+        // bound by its write requests, then by instruction issue: 9 -> 5 VALU per bit here was worth
+        // 10 % of a pass; interleaving the rows' chains to fill the ballot hazards was measured and is
+        // slower -- the rows then cannot start before all four loads have landed.)
         u32 diff_lo = 0, diff_hi = 0;
 #pragma unroll
-        for (int bit = 0; bit < 8; bit++) {
+        for (int bit = 0; bit < DB; bit++) {
             const u32 sbit = (u32)__builtin_amdgcn_sbfe((int)digit, (u32)bit, 1u);      // 0 or ~0
             const u64 bal = __ballot((int)sbit < 0);
             diff_lo |= (u32)bal ^ sbit;
             diff_hi |= (u32)(bal >> 32) ^ sbit;
         }
-        u64 mask = ~(((u64)diff_hi << 32) | diff_lo);
+        u64 same = ~(((u64)diff_hi << 32) | diff_lo);
         if (!FULL) {
-            mask &= __ballot(valid);
-            if (!valid) mask = 1ull << lane;
+            same &= __ballot(valid);
+            if (!valid) same = 1ull << lane;
         }
-        const u32 cnt = (u32)__popcll(mask);
-        // set bits of `mask` below this lane (v_mbcnt_lo/hi take a per-lane mask)
-        const u32 before = __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
-        const int leader = __ffsll((unsigned long long)mask) - 1;
+        const u32 cnt = (u32)__popcll(same);
+        // set bits of `same` below this lane (v_mbcnt_lo/hi take a per-lane mask)
+        const u32 before = __builtin_amdgcn_mbcnt_hi((u32)(same >> 32), __builtin_amdgcn_mbcnt_lo((u32)same, 0u));
+        const int leader = __ffsll((unsigned long long)same) - 1;
+        const u32 half = (digit & 1u) * 16u;
         u32 prior = 0;
-        if (valid && before == 0) prior = atomicAdd(&wave_cnt[w][digit], cnt);
-        prior = __shfl(prior, leader, WAVE);
+        if (valid && before == 0) prior = atomicAdd(&lds.wave_cnt[w][digit >> 1], cnt << half);
+        prior = (__shfl(prior, leader, WAVE) >> half) & 0xFFFFu;
         slot[j] = prior + before;
     }
     __syncthreads();
 
-    // thread d (< 256) owns digit d: wave bases, then the exclusive scan over digits inside the tile
-    u32 total_d = 0, inc = 0;
-    if (tid < RS_BINS) {
-        u32 run = 0;
+    // digit pair e (< 128): wave bases, then the exclusive scan over digits inside the tile
+    constexpr int PAIRS = BINS / 2;
+    u32 tot_lo = 0, tot_hi = 0;
+    if (tid < (u32)PAIRS) {
+        u32 run = 0;                                    // both halves at once: the sums stay below 2^16
 #pragma unroll
         for (int k = 0; k < WAVES; k++) {
-            const u32 c = wave_cnt[k][tid];
-            wave_cnt[k][tid] = run;
+            const u32 c = lds.wave_cnt[k][tid];
+            lds.wave_cnt[k][tid] = run;
             run += c;
         }
-        total_d = run;
-        inc = wave_inclusive_sum(total_d);
-        if (lane == 63) lds4[w] = inc;
+        tot_lo = run & 0xFFFFu;
+        tot_hi = run >> 16;
     }
+    const u32 tsum = tot_lo + tot_hi;
+    const u32 inc = wave_inclusive_sum(tsum);
+    if (lane == 63 && w < (u32)(PAIRS / WAVE)) lds.wsum[w] = inc;
     __syncthreads();
-    if (tid < RS_BINS) {
-        u32 start = inc - total_d;
-        if (w > 0) start += lds4[0];
-        if (w > 1) start += lds4[1];
-        if (w > 2) start += lds4[2];
-        digit_start[tid] = start;
-        global_base[tid] = scanned_hist[(size_t)tile * RS_BINS + tid] - start;
+    if (tid < (u32)PAIRS) {
+        u32 start = inc - tsum;
+#pragma unroll
+        for (int k = 0; k < PAIRS / WAVE; k++)
+            if ((u32)k < w) start += lds.wsum[k];
+        lds.digit_start[2 * tid] = start;
+        lds.global_base[2 * tid] = out_base.x - start;
+        start += tot_lo;
+        lds.digit_start[2 * tid + 1] = start;
+        lds.global_base[2 * tid + 1] = out_base.y - start;
     }
     __syncthreads();
 
@@ -304,9 +300,9 @@ __device__ __forceinline__ void radix_scatter_tile(
     for (int j = 0; j < IPT; j++) {
         const u32 local = w * WAVE_ITEMS + j * WAVE + lane;
         if (FULL || local < tile_count) {
-            const u32 digit = (u32)(key[j] >> shift) & 255u;
-            slot[j] = digit_start[digit] + wave_cnt[w][digit] + slot[j];
-            s_keys[slot[j]] = key[j];
+            const u32 digit = (u32)(key[j] >> shift) & mask;
+            slot[j] = lds.digit_start[digit] + ((lds.wave_cnt[w][digit >> 1] >> ((digit & 1u) * 16u)) & 0xFFFFu) + slot[j];
+            lds.s_keys[slot[j]] = key[j];
         }
     }
     __syncthreads();
@@ -315,8 +311,8 @@ __device__ __forceinline__ void radix_scatter_tile(
     for (int j = 0; j < IPT; j++) {
         const u32 pos = j * THREADS + tid;
         if (FULL || pos < tile_count) {
-            const K k = s_keys[pos];
-            dst[j] = global_base[(u32)(k >> shift) & 255u] + pos;
+            const K k = lds.s_keys[pos];
+            dst[j] = lds.global_base[(u32)(k >> shift) & mask] + pos;
             keys_out[dst[j]] = k;
         }
     }
@@ -335,10 +331,10 @@ __device__ __forceinline__ void radix_scatter_tile(
     }
 }
 
-template <class K, int THREADS, class Src>
-__global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
-    Src src, K *__restrict__ keys_out, u32 *__restrict__ vals_out, u32 n, int shift,
-    const u32 *__restrict__ scanned_hist, u32 n_tiles)
+template <class K, class Src>
+__global__ __launch_bounds__(RS_THREADS, 8) void radix_scatter_kernel(
+    Src src, K *__restrict__ keys_out, u32 *__restrict__ vals_out, u32 n, int shift, u32 mask,
+    const u32 *__restrict__ hist, const u32 *__restrict__ group_prefix, u32 n_tiles)
 {
     // XCD-aware tile order: workgroups go round-robin over the 8 XCDs, each with its own L2.  The
     // per-digit runs of NEIGHBOURING tiles are neighbours in the output, so neighbouring tiles are
@@ -349,11 +345,11 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     if (tile >= n_tiles) return;
     const u32 tile_count = (n - tile * RS_TILE) < (u32)RS_TILE ? (n - tile * RS_TILE) : (u32)RS_TILE;
     // every tile but the last is full: no bounds tests in its code path
-    __shared__ ScatterLds<K, THREADS / WAVE> lds;
+    __shared__ ScatterLds<K> lds;
     if (tile_count == (u32)RS_TILE)
-        radix_scatter_tile<K, THREADS, Src, true>(lds, src, keys_out, vals_out, shift, scanned_hist, tile, tile_count);
+        radix_scatter_tile<K, Src, true>(lds, src, keys_out, vals_out, shift, mask, hist, group_prefix, tile, tile_count);
     else
-        radix_scatter_tile<K, THREADS, Src, false>(lds, src, keys_out, vals_out, shift, scanned_hist, tile, tile_count);
+        radix_scatter_tile<K, Src, false>(lds, src, keys_out, vals_out, shift, mask, hist, group_prefix, tile, tile_count);
 }
 
 template <class K> struct SortBufs {
@@ -361,70 +357,85 @@ template <class K> struct SortBufs {
     u32 *vals[2];
 };
 
-struct NoGen {};
+struct NoGen {
+    static constexpr int MODE = 0;
+};
 
-// Sorts on key bits [begin_bit, bits).  Input in buffers [0] -- or, with a generator (a Src with
-// key(i) / val(i)), produced on the fly by the first pass, which then writes into buffers [0].
-// Returns the index (0/1) of the buffers that hold the sorted pairs.
+static inline int radix_pass_count(int bits) { return (bits + RS_DB - 1) / RS_DB; }
+
+// element count and pass bookkeeping for bench.py's byte model
+static inline void radix_account(Ctx &ctx, size_t key_bytes, u32 n, bool generated)
+{
+    if (!ctx.stats) return;
+    ctx.stats->radix_passes++;
+    if (!generated) {                           // (generator passes are accounted under their own kernel names)
+        ctx.stats->radix_elems += n;
+        if (key_bytes == 8) { ctx.stats->radix_elems_u64 += n; ctx.stats->radix_passes_u64++; }
+        else { ctx.stats->radix_elems_u32 += n; ctx.stats->radix_passes_u32++; }
+    }
+    if ((i64)(key_bytes + 4) > ctx.stats->radix_elem_bytes) ctx.stats->radix_elem_bytes = key_bytes + 4;
+}
+
+// Sorts on key bits [begin_bit, bits).  Input in buffers [0] -- or, with a generator, produced on the
+// fly by the first pass, which then writes into buffers [0].  Returns the index (0/1) of the buffers
+// that hold the sorted pairs.
 template <class K, class Gen = NoGen>
 static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin_bit = 0, Gen gen = Gen())
 {
     constexpr bool HAS_GEN = !std::is_same<Gen, NoGen>::value;
-    if (n == 0) return 0;
+    if (n == 0 || bits <= begin_bit) return 0;
     const u32 n_tiles = ceil_div_u32(n, RS_TILE);
+    const u32 n_groups = ceil_div_u32(n_tiles, RS_GROUP);
     const size_t mark = ctx.arena->mark();
     u32 *hist = ctx.arena->alloc<u32>((size_t)RS_BINS * n_tiles);
-    const u32 n_chunks = ceil_div_u32(n_tiles, HS_CHUNK);
-    u32 *chunk_sums = ctx.arena->alloc<u32>((size_t)RS_BINS * n_chunks);
-    u32 *chunk_prefix = ctx.arena->alloc<u32>((size_t)RS_BINS * (n_chunks + 1));
+    u32 *group_sum = ctx.arena->alloc<u32>((size_t)RS_BINS * n_groups);
+    u32 *group_prefix = ctx.arena->alloc<u32>((size_t)RS_BINS * n_groups);
+    u32 *totals = ctx.arena->alloc<u32>(2 * RS_BINS);
+    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(totals, 0, 2 * RS_BINS * sizeof(u32), ctx.stream));
     const bool prof = ctx.prof && ctx.prof->enabled;
-    int cur = 0;
+    int cur = 0, pass = 0;
     bool first = HAS_GEN;                       // the generator pass reads no buffers and writes [0]
-    for (int shift = begin_bit; shift < bits; shift += 8) {
+    for (int shift = begin_bit; shift < bits; shift += RS_DB, pass++) {
+        const u32 mask = (1u << std::min(RS_DB, bits - shift)) - 1u;
         const PairSrc<K> src{b.keys[cur], b.vals[cur]};
         const int out = first ? 0 : cur ^ 1;
-        if constexpr (HAS_GEN) {
-            if (first)
-                LAUNCH_NAMED(ctx, sizeof(K) == 8 ? "radix_hist_kernel<u64,gen>" : "radix_hist_kernel<u32,gen>",
-                             (radix_hist_kernel<K, Gen>), n_tiles, gen, n, shift, hist, n_tiles);
-        }
-        if (!first)
-            LAUNCH_NAMED(ctx, sizeof(K) == 8 ? "radix_hist_kernel<u64>" : "radix_hist_kernel<u32>",
-                         (radix_hist_kernel<K, PairSrc<K>>), n_tiles, src, n, shift, hist, n_tiles);
-        if (n_tiles <= HS_SMALL_TILES) {
-            LAUNCH(ctx, hist_scan_small_kernel, 1, hist, n_tiles);
-        } else {
-            LAUNCH(ctx, hist_chunk_sums_kernel, n_chunks, (const u32 *)hist, n_tiles, chunk_sums);
-            LAUNCH_BLOCK(ctx, hist_chunk_scan_kernel, 1, BLOCK * HSC_PARTS, (const u32 *)chunk_sums, n_chunks, chunk_prefix);
-            LAUNCH(ctx, hist_apply_kernel, n_chunks, hist, n_tiles, (const u32 *)chunk_prefix, n_chunks);
-        }
+        u32 *tot = totals + (pass & 1) * RS_BINS, *tot_next = totals + ((pass & 1) ^ 1) * RS_BINS;
+        // (static strings: the profiler keeps the pointers)
+        const char *name_hist = sizeof(K) == 8 ? (first ? "radix_hist_kernel<u64,gen>" : "radix_hist_kernel<u64>")
+                                               : (first ? "radix_hist_kernel<u32,gen>" : "radix_hist_kernel<u32>");
+        const char *name_scatter = sizeof(K) == 8 ? (first ? "radix_scatter_kernel<u64,gen>" : "radix_scatter_kernel<u64>")
+                                                  : (first ? "radix_scatter_kernel<u32,gen>" : "radix_scatter_kernel<u32>");
         if (!ctx.dry) {
+            if (prof) ctx.prof->begin(name_hist, ctx.stream);
             if constexpr (HAS_GEN) {
-                if (first) {
-                    if (prof) ctx.prof->begin(sizeof(K) == 8 ? "radix_scatter_kernel<u64,gen>" : "radix_scatter_kernel<u32,gen>", ctx.stream);
-                    hipLaunchKernelGGL((radix_scatter_kernel<K, RS_THREADS, Gen>), dim3(8 * ((n_tiles + 7) / 8)), dim3(RS_THREADS), 0,
-                                       ctx.stream, gen, b.keys[out], b.vals[out], n, shift, (const u32 *)hist, n_tiles);
-                }
+                if (first)
+                    hipLaunchKernelGGL((radix_hist_kernel<K, Gen>), dim3(n_groups), dim3(RS_HIST_THREADS), 0, ctx.stream, gen, n,
+                                       shift, mask, n_tiles, hist, group_sum, tot);
             }
-            if (!first) {
-                if (prof) ctx.prof->begin(sizeof(K) == 8 ? "radix_scatter_kernel<u64>" : "radix_scatter_kernel<u32>", ctx.stream);
-                hipLaunchKernelGGL((radix_scatter_kernel<K, RS_THREADS, PairSrc<K>>), dim3(8 * ((n_tiles + 7) / 8)), dim3(RS_THREADS), 0,
-                                   ctx.stream, src, b.keys[out], b.vals[out], n, shift, (const u32 *)hist, n_tiles);
+            if (!first)
+                hipLaunchKernelGGL((radix_hist_kernel<K, PairSrc<K>>), dim3(n_groups), dim3(RS_HIST_THREADS), 0, ctx.stream, src,
+                                   n, shift, mask, n_tiles, hist, group_sum, tot);
+            HIP_CHECK(hipGetLastError());
+            if (prof) ctx.prof->end(ctx.stream);
+        }
+        LAUNCH(ctx, radix_spine_kernel, RS_BINS / RS_SPINE_COLS, (const u32 *)group_sum, n_groups, (const u32 *)tot, tot_next,
+               group_prefix);
+        if (!ctx.dry) {
+            if (prof) ctx.prof->begin(name_scatter, ctx.stream);
+            const dim3 grid(8 * ((n_tiles + 7) / 8));
+            if constexpr (HAS_GEN) {
+                if (first)
+                    hipLaunchKernelGGL((radix_scatter_kernel<K, Gen>), grid, dim3(RS_THREADS), 0, ctx.stream, gen, b.keys[out],
+                                       b.vals[out], n, shift, mask, (const u32 *)hist, (const u32 *)group_prefix, n_tiles);
             }
+            if (!first)
+                hipLaunchKernelGGL((radix_scatter_kernel<K, PairSrc<K>>), grid, dim3(RS_THREADS), 0, ctx.stream, src, b.keys[out],
+                                   b.vals[out], n, shift, mask, (const u32 *)hist, (const u32 *)group_prefix, n_tiles);
             HIP_CHECK(hipGetLastError());
             if (prof) ctx.prof->end(ctx.stream);
         }
         cur = out;
-        if (ctx.stats) {
-            ctx.stats->radix_passes++;
-            if (!first) {                       // (generator passes are accounted under their own kernel names)
-                ctx.stats->radix_elems += n;
-                if (sizeof(K) == 8) { ctx.stats->radix_elems_u64 += n; ctx.stats->radix_passes_u64++; }
-                else { ctx.stats->radix_elems_u32 += n; ctx.stats->radix_passes_u32++; }
-            }
-            if ((i64)(sizeof(K) + 4) > ctx.stats->radix_elem_bytes)
-                ctx.stats->radix_elem_bytes = sizeof(K) + 4;
-        }
+        radix_account(ctx, sizeof(K), n, first);
         first = false;
     }
     ctx.arena->release(mark);

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(BLOCK) void doc_tiles_kernel(const u32 *__restrict_
 }
 
 template <class K> struct WindowSrc {          // the (window key, element) pairs, generated by the first radix pass
+    static constexpr int MODE = 1;             // (element by element: DC3's sample, n0 > 0)
     const uint8_t *s8;
     u32 n0;
     int w, b, spare;
@@ -149,6 +150,96 @@ template <class K> struct WindowSrc {          // the (window key, element) pair
         return acc & 255u;
     }
 };
+
+// The same keys for ALL suffixes in text order (n0 == 0, element u = text position u), a tile at a time:
+// a thread takes 8 consecutive positions, loads their 21 bytes once (three aligned 8-byte loads) and
+// rolls the keys out from right to left --
+//     key(q) = code(x[q]) on top of [ the fields of key(q + 1) moved down one place ],   all zero behind a terminator
+// -- so that a key costs a dozen integer operations instead of its own two unaligned loads and a loop
+// over its symbols, and the truncation at the first terminator comes with the recurrence.  The radix
+// sort's first pass calls fill_tile (keys into LDS, no round trip through HBM) and hist_tile (digit
+// histogram of a tile).
+#define TW_RUN 8
+template <class K> struct TextWindowGen {
+    static constexpr int MODE = 2;
+    const uint8_t *s8;                          // byte stream; readable (any content) up to 24 bytes behind the last symbol
+    u32 n;
+    int w, b, spare;
+    u32 term_first;
+    DocKey docs;
+
+    // keys of the positions p0 .. p0 + 7 (p0 a multiple of 8) from x = the bytes s8[p0 .. p0 + 24)
+    __device__ __forceinline__ void keys_of_run(const u32 (&x)[6], K (&out)[TW_RUN]) const
+    {
+        const int top = spare + (w - 1) * b;
+        const K fmask = ((K)1 << b) - 1;
+        K key = 0;
+#pragma unroll
+        for (int q = TW_RUN + 12; q >= 0; q--) {
+            if (q > TW_RUN + w) continue;       // (uniform: the run starts w + 1 symbols to the right, from zero)
+            const u32 c = (x[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+            const bool term = c == 0xFFu;
+            const K body = key >> spare;        // the w full fields of key(q + 1)
+            const K rest = (K)((body >> b) << spare) | (K)((body & fmask) >> (b - spare));
+            key = ((K)(term ? term_first : c) << top) | (term ? (K)0 : rest);
+            if (q < TW_RUN) out[q] = key;
+        }
+    }
+    __device__ __forceinline__ void load_run(u32 p0, u32 (&x)[6]) const
+    {
+        const uint2 *src = reinterpret_cast<const uint2 *>(s8 + p0);
+        const uint2 a = src[0], c = src[1], e = src[2];
+        x[0] = a.x; x[1] = a.y; x[2] = c.x; x[3] = c.y; x[4] = e.x; x[5] = e.y;
+    }
+    // the document number on top of the keys of a run (several documents per shard)
+    __device__ __forceinline__ void add_docs(u32 p0, K (&out)[TW_RUN]) const
+    {
+        u32 lo = docs.tile_doc[p0 >> DOC_TILE_SHIFT];
+        const int at = w * b + spare;
+#pragma unroll
+        for (int q = 0; q < TW_RUN; q++) {
+            while (lo + 1 < docs.n_docs && docs.doc_off[lo + 1] <= p0 + q) lo++;
+            out[q] |= (K)lo << at;
+        }
+    }
+    __device__ __forceinline__ void fill_tile(K *s_keys, u32 tile_base, u32 tile_count) const
+    {
+        for (u32 r = threadIdx.x; r < (u32)RS_TILE / TW_RUN; r += RS_THREADS) {
+            if (r * TW_RUN >= tile_count) break;
+            u32 x[6];
+            K k[TW_RUN];
+            load_run(tile_base + r * TW_RUN, x);
+            keys_of_run(x, k);
+            if (docs.bits) add_docs(tile_base + r * TW_RUN, k);
+#pragma unroll
+            for (int q = 0; q < TW_RUN; q++) s_keys[r * TW_RUN + q] = k[q];
+        }
+    }
+    // digit histogram of the positions [e0, e1) of a tile, by ONE wave
+    __device__ __forceinline__ void hist_tile(u32 *mine, u32 e0, u32 e1, int shift, u32 mask) const
+    {
+        const bool need_docs = docs.bits && w * b + spare < shift + 12;     // (a digit only sees the document number of short windows)
+        for (u32 p0 = e0 + lane_id() * TW_RUN; p0 < e1; p0 += WAVE * TW_RUN) {
+            u32 x[6];
+            K k[TW_RUN];
+            load_run(p0, x);
+            keys_of_run(x, k);
+            if (need_docs) add_docs(p0, k);
+#pragma unroll
+            for (int q = 0; q < TW_RUN; q++)
+                if (p0 + q < e1) radix_hist_add(mine, (u32)(k[q] >> shift) & mask);
+        }
+    }
+};
+
+// Layout of a window key of `used` = w * bits + document bits: whole radix passes are paid for anyway, so
+// the key is filled up to a whole number of digits (of the width the sort will pick) with the top bits of
+// one more symbol.  Returns the spare bits taken from symbol w + 1.
+static int lvl0_spare_bits(int used, int key_bits, int bt, int w)
+{
+    const int total = std::min(radix_pass_count(used) * RS_DB, key_bits);
+    return w < 12 ? std::min(total - used, bt - 1) : 0;
+}
 
 template <class K> struct KeyNeqWindowIn {
     const K *keys;
@@ -635,9 +726,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     const u32 g02 = ceil_div_u32((u64)n02 + 1, BLOCK);
     // whole passes are paid for anyway: fill the last digit with the top bits of the next symbol
     // (the document number, if any, sits above window and spare bits)
-    const int used = w * bt + docs.bits;
-    const int total = std::min(((used + 7) / 8) * 8, (int)sizeof(K) * 8);
-    const int spare = w < 12 ? std::min(total - used, bt - 1) : 0;
+    const int spare = lvl0_spare_bits(w * bt + docs.bits, (int)sizeof(K) * 8, bt, w);
     SortBufs<K> sb;
     // (one spare element each: the idle half serves as scratch after the sort)
     // (8 spare entries: the placement pass reads whole 16-byte groups; >= 64 so that the idle half can hold its scratch)
@@ -649,8 +738,10 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         LAUNCH(ctx, doc_tiles_kernel, ceil_div_u32(n_dt, BLOCK), docs.doc_off, docs.n_docs, n_dt, tile_doc);
         docs.tile_doc = tile_doc;
     }
-    const int r = radix_sort_pairs<K, WindowSrc<K>>(ctx, sb, n02, w * bt + spare + docs.bits, 0,
-                                                    WindowSrc<K>{s8, n0, w, bt, spare, term_first, docs});
+    const int r = n0 ? radix_sort_pairs<K, WindowSrc<K>>(ctx, sb, n02, w * bt + spare + docs.bits, 0,
+                                                         WindowSrc<K>{s8, n0, w, bt, spare, term_first, docs})
+                     : radix_sort_pairs<K, TextWindowGen<K>>(ctx, sb, n02, w * bt + spare + docs.bits, 0,
+                                                             TextWindowGen<K>{s8, n02, w, bt, spare, term_first, docs});
     const KeyNeqWindowIn<K> starts = KeyNeqWindowIn<K>::make(sb.keys[r], w, bt, spare, term_first);
     const u32 *sorted_vals = sb.vals[r];
     u64 *keep = (u64 *)sb.keys[r ^ 1];                   // n02 + 1 bits, in the keys idle since the sort
@@ -880,8 +971,7 @@ static int lvl0_window(u32 n, int bt, u32 term_first, int doc_bits = 0)
     const int w32 = (32 - doc_bits) / bt;
     if (w32 >= 3 && w32 < w) {
         // the spare bits of the last digit hold the top bits of one more symbol: that many more buckets
-        const int used32 = w32 * bt + doc_bits;
-        const int spare32 = std::min(std::min(((used32 + 7) / 8) * 8, 32) - used32, bt - 1);
+        const int spare32 = lvl0_spare_bits(w32 * bt + doc_bits, 32, bt, w32);
         const double buckets = spare32 > 0 ? (double)((term_first >> (bt - spare32)) + 1u) : 1.0;
         if (pow((double)term_first, w32) * buckets >= 4.0 * (double)n) w = w32;
     }
