@@ -186,16 +186,27 @@ static void use_device(east_hip_index *h) { HIP_CHECK(hipSetDevice(h->device)); 
 
 static bool kgram_reserve(east_hip_index *h, u64 bins, u32 n_docs);
 
-// min pyramid over the LCP table, then the annotation table
+// min pyramid over the LCP table and the annotation table: the streaming pass decides all but the widest
+// intervals and writes pyramid level 1 on the way, the upper levels follow, then the listed wide ones
 static void annotate(east_hip_index *h, Ctx &ctx)
 {
     const Pyramid &pyr = h->pyr;
     const u32 n = pyr.len[0];
-    for (int l = 1; l < pyr.levels; l++)
+    Arena &ar = *ctx.arena;
+    const size_t mark = ar.mark();
+    const u32 n_tiles = ceil_div_u32(n, ANN_TILE);
+    u32 *wide_list = ar.alloc<u32>((size_t)n_tiles * ANN_TILE);       // every tile has its own stretch
+    u32 *wide_count = ar.alloc<u32>(n_tiles);
+    const bool has_lvl1 = pyr.levels > 1;                // (a table of at most 16 entries has no level 1)
+    LAUNCH(ctx, ann_stream_kernel, n_tiles, pyr.ptr[0], (const u32 *)h->doc_off, (const u32 *)h->n_strings,
+           h->build_docs, n, h->ann, has_lvl1 ? (u32 *)pyr.ptr[1] : (u32 *)nullptr, has_lvl1 ? pyr.len[1] : 0u,
+           has_lvl1 ? pyr_padded(pyr.len[1]) : 0u, wide_list, wide_count);
+    for (int l = 2; l < pyr.levels; l++)
         LAUNCH(ctx, pyramid_level_kernel, ceil_div_u32(pyr_padded(pyr.len[l]), BLOCK), pyr.ptr[l - 1], pyr.len[l],
                pyr_padded(pyr.len[l]), (u32 *)pyr.ptr[l]);
-    LAUNCH(ctx, ann_kernel, ceil_div_u32(n, ANN_TILE), pyr, (const u32 *)h->doc_off, (const u32 *)h->n_strings,
-           h->build_docs, n, h->ann);
+    LAUNCH(ctx, ann_wide_kernel, ceil_div_u32(n_tiles, BLOCK / ANN_WIDE_SLOTS), pyr, n, n_tiles, (const u32 *)wide_list,
+           (const u32 *)wide_count, h->ann);
+    ar.release(mark);
 }
 
 // The build proper.  With ctx.dry it only measures the arena high-water mark

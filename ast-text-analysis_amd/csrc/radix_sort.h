@@ -19,7 +19,9 @@
 #include "scan.h"
 
 #define RS_THREADS 1024                // threads per scatter workgroup (16 waves)
+#ifndef RS_IPT
 #define RS_IPT 4
+#endif
 #define RS_TILE (RS_THREADS * RS_IPT)  // 4096 pairs per workgroup
 #define RS_DB 8
 #define RS_BINS 256
@@ -27,6 +29,9 @@
 #define RS_GROUP 8                     // tiles per histogram group
 #endif
 #define RS_HIST_THREADS 256
+#ifndef RS_TOTAL_SHARDS
+#define RS_TOTAL_SHARDS 8
+#endif
 
 // Where a pass reads its pairs from: the buffers of the previous pass, or -- first pass only -- a
 // generator (MODE 1: computes pair i on the fly, key(i) / val(i); MODE 2: fills a whole tile of keys in
@@ -121,7 +126,8 @@ __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u3
         run += bins[k][threadIdx.x];
     }
     group_sum[(size_t)g * RS_BINS + threadIdx.x] = run;     // one coalesced row per group
-    if (run) atomicAdd(&digit_total[threadIdx.x], run);
+    // (RS_TOTAL_SHARDS copies of the totals: thousands of workgroups adding into one 1 KiB row queue up behind one another)
+    if (run) atomicAdd(&digit_total[(blockIdx.x % RS_TOTAL_SHARDS) * RS_BINS + threadIdx.x], run);
 }
 
 // ---- spine: exclusive scan down the groups, per digit column, plus the digit bases --------------------
@@ -140,10 +146,15 @@ __global__ __launch_bounds__(BLOCK) void radix_spine_kernel(const u32 *__restric
     __shared__ u32 part_total[RS_SPINE_PARTS][RS_SPINE_COLS];
     __shared__ u32 lds4[WAVES_PER_BLOCK];
     {
-        const u32 t = digit_total[threadIdx.x];
+        u32 t = 0;
+#pragma unroll
+        for (int k = 0; k < RS_TOTAL_SHARDS; k++) t += digit_total[k * RS_BINS + threadIdx.x];
         u32 total;
         base_of[threadIdx.x] = block_exclusive_sum(t, lds4, total);
-        if (blockIdx.x == 0) next_total[threadIdx.x] = 0;
+        if (blockIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < RS_TOTAL_SHARDS; k++) next_total[k * RS_BINS + threadIdx.x] = 0;
+        }
     }
     const u32 c = threadIdx.x & (RS_SPINE_COLS - 1u), part = threadIdx.x / RS_SPINE_COLS;
     const u32 col = blockIdx.x * RS_SPINE_COLS + c;
@@ -332,7 +343,7 @@ __device__ __forceinline__ void radix_scatter_tile(ScatterLds<K> &lds, const Src
 }
 
 template <class K, class Src>
-__global__ __launch_bounds__(RS_THREADS, 8) void radix_scatter_kernel(
+__global__ __launch_bounds__(RS_THREADS, (RS_IPT <= 4 ? 8 : 4)) void radix_scatter_kernel(
     Src src, K *__restrict__ keys_out, u32 *__restrict__ vals_out, u32 n, int shift, u32 mask,
     const u32 *__restrict__ hist, const u32 *__restrict__ group_prefix, u32 n_tiles)
 {
@@ -390,8 +401,8 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin
     u32 *hist = ctx.arena->alloc<u32>((size_t)RS_BINS * n_tiles);
     u32 *group_sum = ctx.arena->alloc<u32>((size_t)RS_BINS * n_groups);
     u32 *group_prefix = ctx.arena->alloc<u32>((size_t)RS_BINS * n_groups);
-    u32 *totals = ctx.arena->alloc<u32>(2 * RS_BINS);
-    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(totals, 0, 2 * RS_BINS * sizeof(u32), ctx.stream));
+    u32 *totals = ctx.arena->alloc<u32>(2 * RS_TOTAL_SHARDS * RS_BINS);
+    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(totals, 0, 2 * RS_TOTAL_SHARDS * RS_BINS * sizeof(u32), ctx.stream));
     const bool prof = ctx.prof && ctx.prof->enabled;
     int cur = 0, pass = 0;
     bool first = HAS_GEN;                       // the generator pass reads no buffers and writes [0]
@@ -399,7 +410,7 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin
         const u32 mask = (1u << std::min(RS_DB, bits - shift)) - 1u;
         const PairSrc<K> src{b.keys[cur], b.vals[cur]};
         const int out = first ? 0 : cur ^ 1;
-        u32 *tot = totals + (pass & 1) * RS_BINS, *tot_next = totals + ((pass & 1) ^ 1) * RS_BINS;
+        u32 *tot = totals + (pass & 1) * RS_TOTAL_SHARDS * RS_BINS, *tot_next = totals + ((pass & 1) ^ 1) * RS_TOTAL_SHARDS * RS_BINS;
         // (static strings: the profiler keeps the pointers)
         const char *name_hist = sizeof(K) == 8 ? (first ? "radix_hist_kernel<u64,gen>" : "radix_hist_kernel<u64>")
                                                : (first ? "radix_hist_kernel<u32,gen>" : "radix_hist_kernel<u32>");

@@ -326,6 +326,55 @@ __device__ __forceinline__ u32 pyr_find_right(const Pyramid &P, u32 k, u32 v)
     }
 }
 
+// pyr_find_left<false> and pyr_find_right<true> of one rank at once, level by level: first both searches
+// climb together (one group each per level, the two fetches in flight side by side), then both descend
+// together.  Written for wavefronts whose lanes search intervals of very different widths: with the two
+// plain searches above the lanes that find their group at different levels run their descents one after
+// the other (SIMT), 40-60 dependent fetches per wavefront instead of about a dozen.
+__device__ __forceinline__ void pyr_find_both(const Pyramid &P, u32 k, u32 v, u32 &pse, u32 &nsv)
+{
+    u32 lpos = k, rpos = k + 1, lq = NONE_U32, rq = NONE_U32;
+    int llvl = -1, rlvl = -1;                       // level at which the search found its group (-1: nothing found)
+    bool ldone = false, rdone = false;
+    for (int lvl = 0; lvl < P.levels && !(ldone && rdone); lvl++) {
+        const u32 *M = P.ptr[lvl];
+        if (!ldone) {
+            const u32 start = lpos & ~(PYR_FAN - 1u);
+            u32 m = 0;
+            if (lpos > start) m = pyr_group_mask<false>(M, start, v) & ((1u << (lpos - start)) - 1u);
+            if (m) { lq = start + 31u - (u32)__clz((int)m); llvl = lvl; ldone = true; }
+            else if (start == 0) ldone = true;
+            else lpos = start >> PYR_SHIFT;
+        }
+        if (!rdone) {
+            const u32 len = P.len[lvl];
+            if (rpos >= len) rdone = true;
+            else {
+                const u32 start = rpos & ~(PYR_FAN - 1u);
+                const u32 m = pyr_group_mask<true>(M, start, v) & ~((1u << (rpos - start)) - 1u);
+                if (m) { rq = start + (u32)__ffs((int)m) - 1u; rlvl = lvl; rdone = true; }
+                else if (start + PYR_FAN >= len) rdone = true;
+                else rpos = (start + PYR_FAN) >> PYR_SHIFT;
+            }
+        }
+    }
+    for (int lvl = P.levels - 1; lvl > 0; lvl--) {
+        const u32 *M = P.ptr[lvl - 1];
+        if (llvl == lvl) {
+            const u32 base = lq << PYR_SHIFT;
+            lq = base + 31u - (u32)__clz((int)pyr_group_mask<false>(M, base, v));
+            llvl--;
+        }
+        if (rlvl == lvl) {
+            const u32 base = rq << PYR_SHIFT;
+            rq = base + (u32)__ffs((int)pyr_group_mask<true>(M, base, v)) - 1u;
+            rlvl--;
+        }
+    }
+    pse = lq;
+    nsv = rq;
+}
+
 // leftmost position of the minimum of level0 over the open interval (a, b),
 // a + 1 < b.  Walks whole groups through the pyramid.
 __device__ __forceinline__ u32 pyr_leftmost_argmin(const Pyramid &P, u32 a, u32 b)
@@ -354,41 +403,91 @@ __device__ __forceinline__ u32 pyr_leftmost_argmin(const Pyramid &P, u32 a, u32 
     return pyr_find_right<false>(P, lo, best);
 }
 
-// anntab (easa.py:306-331).  Most ranks are decided by their nearest neighbours: phase 1
-// looks at most ANN_NEAR ranks to either side (coalesced, L1-resident) and parks the rest
-// -- the first l-indices of wide intervals, a few per cent -- in an LDS work list, which
-// phase 2 processes densely through the pyramid.  (With the pyramid search inlined,
-// nearly every wavefront paid for it because one lane in 64 needed it.)  doc segment
-// starts carry lcp == 0, which bounds every search inside the document.
+// anntab (easa.py:306-331) in two launches.
+//
+// ann_stream_kernel: a workgroup stages 1024 consecutive LCP values plus 32 to either side in LDS.
+//   phase 1  every thread decides its 4 ranks from the 8 neighbours to either side (five 16-byte LDS
+//            reads); most ranks end here and the thread writes one 16-byte store;
+//   phase 2  the rest -- first l-indices of intervals wider than that, a few per cent -- go to an LDS
+//            work list and are walked one per thread over the staged values, at most ANN_LOCAL ranks
+//            to either side (a wave per rank with 64 neighbours per ballot was measured: twice as slow,
+//            the ranks then queue up behind one another);
+//   what is wider still (the top levels of the tree, about one rank in a hundred) is appended to a
+//   global list for ann_wide_kernel.
+//   The kernel also writes level 1 of the min pyramid (it has the values in LDS): the LCP table is read
+//   once for both.
+// ann_wide_kernel: the listed ranks, one per thread, through the pyramid (O(log16 n) groups each).
+// Document starts carry lcp == 0, which bounds every search inside the document; ranks outside
+// [0, n) read as 0.
 #define ANN_NEAR 8
 #define ANN_IPT 4                       // consecutive ranks per thread: 16-byte loads and stores
 #define ANN_TILE (BLOCK * ANN_IPT)
+#define ANN_HALO 32
+#define ANN_LOCAL 24                    // phase 2 walks at most this far; what is wider goes to ann_wide_kernel
 
-__global__ __launch_bounds__(BLOCK) void ann_kernel(Pyramid P, const u32 *__restrict__ doc_off,
-                                                    const u32 *__restrict__ n_strings, u32 n_docs, u32 n,
-                                                    u32 *__restrict__ ann)
+__global__ __launch_bounds__(BLOCK) void ann_stream_kernel(const u32 *__restrict__ lcp, const u32 *__restrict__ doc_off,
+                                                           const u32 *__restrict__ n_strings, u32 n_docs, u32 n,
+                                                           u32 *__restrict__ ann, u32 *__restrict__ lvl1, u32 len1,
+                                                           u32 len1_padded, u32 *__restrict__ wide_list,
+                                                           u32 *__restrict__ wide_count)      // per tile: its own stretch / count
 {
+    __shared__ __attribute__((aligned(16))) u32 tile[ANN_TILE + 2 * ANN_HALO];
     __shared__ u32 work[ANN_TILE];
-    __shared__ u32 work_count;
-    const u32 *lcp = P.ptr[0];
-    if (threadIdx.x == 0) work_count = 0;
+    __shared__ u32 work_count, far_count;
+    if (threadIdx.x == 0) { work_count = 0; far_count = 0; }
+    const u32 tile_base = blockIdx.x * ANN_TILE;
+    const u32 k0 = tile_base + threadIdx.x * ANN_IPT;
+    {
+        // own four values (the table is padded to a multiple of 16 entries, so whole groups can be loaded up
+        // to there); ranks outside [0, n) read as 0, which stops every scan
+        uint4 x = {0u, 0u, 0u, 0u};
+        if (k0 < ((n + PYR_FAN - 1u) & ~(PYR_FAN - 1u))) x = *reinterpret_cast<const uint4 *>(lcp + k0);
+        if (k0 + 0 >= n) x.x = 0u;
+        if (k0 + 1 >= n) x.y = 0u;
+        if (k0 + 2 >= n) x.z = 0u;
+        if (k0 + 3 >= n) x.w = 0u;
+        *reinterpret_cast<uint4 *>(&tile[ANN_HALO + threadIdx.x * ANN_IPT]) = x;
+        if (threadIdx.x < 2 * ANN_HALO / 4) {   // ANN_HALO ranks to the left (first threads) and to the right (the next ones)
+            const bool left = threadIdx.x < ANN_HALO / 4;
+            const u32 q = left ? threadIdx.x : threadIdx.x - ANN_HALO / 4;
+            const i64 g = left ? (i64)tile_base - ANN_HALO + 4 * q : (i64)tile_base + ANN_TILE + 4 * q;
+            uint4 h = {0u, 0u, 0u, 0u};
+            if (g >= 0 && g < (i64)((n + PYR_FAN - 1u) & ~(PYR_FAN - 1u))) h = *reinterpret_cast<const uint4 *>(lcp + g);
+            if (g + 0 >= (i64)n) h.x = 0u;
+            if (g + 1 >= (i64)n) h.y = 0u;
+            if (g + 2 >= (i64)n) h.z = 0u;
+            if (g + 3 >= (i64)n) h.w = 0u;
+            *reinterpret_cast<uint4 *>(&tile[left ? 4 * q : ANN_HALO + ANN_TILE + 4 * q]) = h;
+        }
+    }
     __syncthreads();
-    const u32 k0 = (blockIdx.x * BLOCK + threadIdx.x) * ANN_IPT;
+    // level 1 of the min pyramid: entry e = min of the 16 ranks 16e .. 16e+15 (entries past the table: NONE)
+    if (threadIdx.x < ANN_TILE / PYR_FAN) {
+        const u32 e = tile_base / PYR_FAN + threadIdx.x;
+        if (e < len1_padded) {
+            u32 m = NONE_U32;
+            if (e < len1) {
+                const uint4 *g = reinterpret_cast<const uint4 *>(&tile[ANN_HALO + threadIdx.x * PYR_FAN]);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint4 y = g[q];
+                    const u32 r = e * PYR_FAN + 4u * q;          // (ranks past n hold 0 in the tile: not part of the minimum)
+                    if (r + 0 < n) m = min(m, y.x);
+                    if (r + 1 < n) m = min(m, y.y);
+                    if (r + 2 < n) m = min(m, y.z);
+                    if (r + 3 < n) m = min(m, y.w);
+                }
+            }
+            lvl1[e] = m;
+        }
+    }
     if (k0 < n) {
-        // c[i] = lcp[k0 - ANN_NEAR + i] for the thread's 4 ranks and ANN_NEAR ranks to either side, five 16-byte
-        // loads (the neighbours' loads hit the same lines); ranks outside [0, n) read as 0, which stops every scan
+        // c[i] = lcp[k0 - ANN_NEAR + i]: the thread's 4 ranks and ANN_NEAR ranks to either side
         u32 c[ANN_IPT + 2 * ANN_NEAR];
 #pragma unroll
         for (int q = 0; q < (ANN_IPT + 2 * ANN_NEAR) / 4; q++) {
-            const u32 g = k0 + 4u * q;                  // global rank + ANN_NEAR
-            uint4 x = {0u, 0u, 0u, 0u};
-            if (g >= ANN_NEAR && g - ANN_NEAR < n) x = *reinterpret_cast<const uint4 *>(lcp + (g - ANN_NEAR));
+            const uint4 x = *reinterpret_cast<const uint4 *>(&tile[ANN_HALO + threadIdx.x * ANN_IPT - ANN_NEAR + 4 * q]);
             c[4 * q] = x.x; c[4 * q + 1] = x.y; c[4 * q + 2] = x.z; c[4 * q + 3] = x.w;
-            if (g - ANN_NEAR + 4u > n) {                // (pyramid padding behind n holds 0xFFFFFFFF)
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (g >= ANN_NEAR && g - ANN_NEAR + e >= n) c[4 * q + e] = 0u;
-            }
         }
         u32 out[ANN_IPT];
         bool direct[ANN_IPT];
@@ -428,22 +527,54 @@ __global__ __launch_bounds__(BLOCK) void ann_kernel(Pyramid P, const u32 *__rest
             for (int e = 0; e < ANN_IPT; e++) {
                 if (k0 + e >= n) break;
                 if (direct[e]) ann[k0 + e] = out[e];
-                else work[atomicAdd(&work_count, 1u)] = k0 + e;
+                else work[atomicAdd(&work_count, 1u)] = threadIdx.x * ANN_IPT + e;
             }
         }
     }
     __syncthreads();
+    // phase 2: one rank per thread, a short walk over the staged values to either side
     const u32 count = work_count;
-    for (u32 w = threadIdx.x; w < count; w += BLOCK) {
-        const u32 k = work[w];
-        const u32 v = lcp[k];
-        const u32 pse = pyr_find_left<false>(P, k, v);          // exists: the segment start holds 0
+    for (u32 wi = threadIdx.x; wi < count; wi += BLOCK) {
+        const u32 local = work[wi], at = ANN_HALO + local;
+        const u32 v = tile[at];
+        u32 d, x = 0;
+        bool far = false;
         u32 a = 0;
-        if (lcp[pse] < v) {
-            u32 nsv = pyr_find_right<true>(P, k, v);            // stops at the next segment start
-            if (nsv == NONE_U32) nsv = n;
-            a = nsv - pse;                                      // pse == PSV here
+        for (d = 1; d <= ANN_LOCAL; d++) {
+            x = tile[at - d];
+            if (x <= v) break;
         }
+        if (d > ANN_LOCAL) far = true;
+        else if (x < v) {                                   // first l-index: width = NSV - PSV
+            u32 e;
+            for (e = 1; e <= ANN_LOCAL; e++)
+                if (tile[at + e] < v) break;
+            if (e > ANN_LOCAL) far = true;
+            else a = d + e;
+        }
+        // (the tile's own stretch of the list: a single counter for all workgroups would serialise them)
+        if (far) wide_list[tile_base + atomicAdd(&far_count, 1u)] = tile_base + local;
+        else ann[tile_base + local] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) wide_count[blockIdx.x] = far_count;
+}
+
+#define ANN_WIDE_SLOTS 16                // threads per tile in ann_wide_kernel
+__global__ __launch_bounds__(BLOCK) void ann_wide_kernel(Pyramid P, u32 n, u32 n_tiles, const u32 *__restrict__ wide_list,
+                                                         const u32 *__restrict__ wide_count, u32 *__restrict__ ann)
+{
+    const u32 *lcp = P.ptr[0];
+    const u32 tile = blockIdx.x * (BLOCK / ANN_WIDE_SLOTS) + threadIdx.x / ANN_WIDE_SLOTS;
+    if (tile >= n_tiles) return;
+    const u32 count = wide_count[tile];
+    for (u32 i = threadIdx.x % ANN_WIDE_SLOTS; i < count; i += ANN_WIDE_SLOTS) {
+        const u32 k = wide_list[tile * ANN_TILE + i];
+        const u32 v = lcp[k];
+        u32 pse, nsv;                                           // pse exists: the segment start holds 0;
+        pyr_find_both(P, k, v, pse, nsv);                       // the search to the right stops at the next segment start
+        u32 a = 0;
+        if (lcp[pse] < v) a = (nsv == NONE_U32 ? n : nsv) - pse;    // first l-index: pse == PSV, width = NSV - PSV
         ann[k] = a;
     }
 }

@@ -39,6 +39,10 @@ def oracle():
 @pytest.fixture(scope="session")
 def hip():
     """The ctypes binding; GPU tests fail (not skip) if the library or device is missing."""
+    try:
+        import torch  # noqa: F401  (first: torch brings its own HIP runtime and finds no GPU if the system's was loaded before it)
+    except ImportError:
+        pass
     from east import hip_backend
     if not os.path.exists(hip_backend.LIB_PATH):      # a fresh checkout: compile the library first
         import __graft_entry__
