@@ -75,6 +75,7 @@ struct Arena {
 struct Stats {
     i64 levels = 0, levels_resolved = 0, refine_rounds = 0, window_sorted = 0, merge_elems = 0, radix_passes = 0, radix_elems = 0, radix_elem_bytes = 0;
     i64 radix_elems_u32 = 0, radix_elems_u64 = 0, radix_passes_u32 = 0, radix_passes_u64 = 0;
+    i64 long_repeats = 0;       // the placement pass had to be repeated as mark + commit (duplicated passages)
 };
 
 // Optional per-kernel timing with HIP events on the handle's own stream (the
@@ -129,6 +130,12 @@ struct Ctx {
     Arena *arena = nullptr;
     bool dry = false;
     bool lean = false;          // no tie-refinement rounds (their buffers did not fit the device)
+    // Speculative build (east_hip.hip, build_common): the host does not wait for the device where the previous
+    // build on the handle tells it what to expect -- the size of the text alphabet, "no suffix is left in a
+    // large tie group after the placement pass".  The device checks both and the one read-back at the
+    // end of the build finds out; a wrong guess costs a second, non-speculative build.
+    bool spec = false;
+    u32 *spec_out = nullptr;    // [0] suffixes left in large groups, [1] placement gave up on a long repeat
     Stats *stats = nullptr;
     Profiler *prof = nullptr;
 };

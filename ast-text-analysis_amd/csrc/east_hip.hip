@@ -31,6 +31,7 @@
 #define PRESENT_WORDS (TEXT_SYMBOLS / 32)           // 80
 
 static thread_local std::string g_last_error;
+static bool g_speculate = getenv("EAST_HIP_NO_SPECULATION") == nullptr;     // east_hip_debug_set_speculation (tests)
 static u32 g_plan_epoch = 1;        // bumped by the test knobs that change what a build allocates
 
 // ------------------------------------------------------------ prep kernels --
@@ -57,6 +58,44 @@ __global__ __launch_bounds__(BLOCK) void presence_kernel(const u32 *__restrict__
     for (u32 i = (n4 << 2) + blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) mark(sym[i]);
     __syncthreads();
     if (threadIdx.x < PRESENT_WORDS && bits[threadIdx.x]) atomicOr(&present[threadIdx.x], bits[threadIdx.x]);
+}
+
+// Dense codes of the text alphabet from the presence bitmap: code point c -> its rank (1 ..) among the code
+// points present, 0 if absent; flags[FLAG_SIGMA] = their number.  One workgroup, ten code points per thread.
+// `assumed` != NONE: the host went ahead with that alphabet size (speculative build); a different one, or a
+// document that does not end in a terminator (doc_status), is recorded in flags[FLAG_STATUS].
+#define FLAG_CAPPED 0
+#define FLAG_STATUS 1
+#define FLAG_SIGMA 2
+#define FLAG_KEEP 3
+#define FLAG_FAIL 4
+#define FLAG_WORDS 8
+#define STATUS_NO_TERMINATOR 1u
+#define STATUS_N_STRINGS 2u
+#define STATUS_SIGMA_GUESS 4u
+__global__ __launch_bounds__(BLOCK) void codemap_kernel(const u32 *__restrict__ present, u32 assumed,
+                                                        u32 *__restrict__ code_map, u32 *__restrict__ flags)
+{
+    static_assert(TEXT_SYMBOLS == BLOCK * 10, "ten code points per thread");
+    __shared__ u32 lds4[WAVES_PER_BLOCK];
+    const u32 c0 = threadIdx.x * 10u;
+    u32 bits = 0, cnt = 0;
+#pragma unroll
+    for (u32 i = 0; i < 10; i++) {
+        const u32 b = (present[(c0 + i) >> 5] >> ((c0 + i) & 31u)) & 1u;
+        bits |= b << i;
+        cnt += b;
+    }
+    u32 total;
+    u32 run = block_exclusive_sum(cnt, lds4, total);
+#pragma unroll
+    for (u32 i = 0; i < 10; i++) code_map[c0 + i] = ((bits >> i) & 1u) ? ++run : 0u;
+    if (threadIdx.x == 0) {
+        flags[FLAG_SIGMA] = total;
+        u32 st = present[PRESENT_WORDS] & STATUS_NO_TERMINATOR;
+        if (assumed != 0xFFFFFFFFu && assumed != total) st |= STATUS_SIGMA_GUESS;
+        if (st) atomicOr(&flags[FLAG_STATUS], st);
+    }
 }
 
 struct TermIn {                                 // 1 at terminators; defined on [0, n]
@@ -96,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) void validate_last_symbol_kernel(const u32 *
                                                                      u32 *__restrict__ status)
 {
     const u32 d = blockIdx.x * BLOCK + threadIdx.x;
-    if (d < n_docs && sym[doc_off[d + 1] - 1] < TEXT_SYMBOLS) atomicOr(status, 1u);
+    if (d < n_docs && sym[doc_off[d + 1] - 1] < TEXT_SYMBOLS) atomicOr(status, STATUS_NO_TERMINATOR);
 }
 
 // n_strings[d] must equal the terminators of document d.  Terminators sort above every text
@@ -112,12 +151,13 @@ __global__ __launch_bounds__(BLOCK) void validate_n_strings_kernel(const SYM *__
     const u32 d = blockIdx.x * BLOCK + threadIdx.x;
     if (d >= n_docs) return;
     u32 lo = doc_off[d], hi = doc_off[d + 1];
-    const u32 end = hi;
+    const u32 end = hi, last = doc_off[n_docs] - 1u;
     while (lo < hi) {                       // first rank whose suffix starts with a terminator
         const u32 mid = (lo + hi) >> 1;
-        if ((u32)s[sa[mid]] >= term_first) hi = mid; else lo = mid + 1;
+        const u32 p = sa[mid] < last ? sa[mid] : last;      // (a speculative build that guessed wrong leaves stale entries)
+        if ((u32)s[p] >= term_first) hi = mid; else lo = mid + 1;
     }
-    if (end - lo != n_strings[d]) atomicOr(status, 2u);
+    if (end - lo != n_strings[d]) atomicOr(status, STATUS_N_STRINGS);
 }
 
 __global__ __launch_bounds__(BLOCK) void remap_kernel(const u32 *__restrict__ sym,
@@ -158,6 +198,9 @@ struct east_hip_index {
         *next = nullptr, *doc_off = nullptr, *n_strings = nullptr, *code_map = nullptr;
     Pyramid pyr;
     u32 build_docs = 0;          // documents of the build in progress (h->n_docs is set when it has succeeded)
+    // what the last successful build found, the guesses of the next (speculative) one
+    bool hint_valid = false, hint_no_rounds = false;
+    u32 hint_sigma = 0;
     u32 plan_n = 0, plan_docs = 0, plan_epoch = 0;   // shape of the last sizing run (and test-knob epoch), its result
     size_t plan_bytes = 0;
     // keyphrases + score scratch (own allocation, grown on demand)
@@ -181,6 +224,8 @@ struct east_hip_index {
     std::vector<i64> prep_doc_off;
     std::vector<int32_t> prep_n_strings;
 };
+
+struct SpecAbort {};             // a speculative build cannot go on: build_common starts over with the read-backs in place
 
 static void use_device(east_hip_index *h) { HIP_CHECK(hipSetDevice(h->device)); }
 
@@ -212,7 +257,7 @@ static void annotate(east_hip_index *h, Ctx &ctx)
 // The build proper.  With ctx.dry it only measures the arena high-water mark
 // (worst case: widest keys, recursion to the bottom).
 static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32 n_docs,
-                       const i64 *doc_offsets, const int32_t *n_strings)
+                       const i64 *doc_offsets, const int32_t *n_strings, u32 spec_sigma = 0)
 {
     Arena &ar = *ctx.arena;
     ar.release(0);
@@ -227,7 +272,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     h->next = ar.alloc<u32>(n);
     h->doc_off = ar.alloc<u32>((size_t)n_docs + 1);
     h->n_strings = ar.alloc<u32>(n_docs);
-    h->code_map = ar.alloc<u32>(TEXT_SYMBOLS + 2);        // + the "LCP capped" flag and the validation status
+    h->code_map = ar.alloc<u32>(TEXT_SYMBOLS + FLAG_WORDS);   // + the flag words (FLAG_*)
     Pyramid pyr;
     pyr.levels = 1;
     pyr.ptr[0] = h->lcp;
@@ -255,6 +300,10 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
 
     const u32 gn = ceil_div_u32(n, BLOCK);
     u32 sigma_t = TEXT_SYMBOLS - 1, m_total = n;          // dry-run worst case
+    u32 *flags = h->code_map + TEXT_SYMBOLS;              // flag words behind the code map
+    u32 *capped = flags + FLAG_CAPPED, *status = flags + FLAG_STATUS;
+    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(flags, 0, FLAG_WORDS * sizeof(u32), ctx.stream));
+    ctx.spec_out = flags + FLAG_KEEP;
     {
         // ---- alphabet, dense remap ---------------------------------------------
         const size_t mark = ar.mark();
@@ -265,18 +314,18 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         LAUNCH(ctx, presence_kernel, std::min<u32>(gn, 2048), d_sym, n, vec, present);
         LAUNCH(ctx, validate_last_symbol_kernel, ceil_div_u32(n_docs, BLOCK), d_sym, (const u32 *)h->doc_off, n_docs,
                present + PRESENT_WORDS);
+        LAUNCH(ctx, codemap_kernel, 1, (const u32 *)present, ctx.spec ? spec_sigma : 0xFFFFFFFFu, h->code_map, flags);
         if (!ctx.dry) {
-            u32 hp[PRESENT_WORDS + 1];
-            HIP_CHECK(hipMemcpyAsync(hp, present, sizeof(hp), hipMemcpyDeviceToHost, ctx.stream));
-            HIP_CHECK(hipStreamSynchronize(ctx.stream));
-            if (hp[PRESENT_WORDS] & 1u)
-                east_throw(EAST_HIP_ERR_DOMAIN, "a document does not end in a string terminator (>= U+0A00)");
-            std::vector<u32> map(TEXT_SYMBOLS, 0u);
-            sigma_t = 0;
-            for (u32 c = 0; c < TEXT_SYMBOLS; c++)
-                if (hp[c >> 5] & (1u << (c & 31u))) map[c] = ++sigma_t;
-            HIP_CHECK(hipMemcpyAsync(h->code_map, map.data(), TEXT_SYMBOLS * 4, hipMemcpyHostToDevice, ctx.stream));
-            HIP_CHECK(hipStreamSynchronize(ctx.stream));   // `map` is a stack-lifetime source
+            if (ctx.spec) {
+                sigma_t = spec_sigma;                        // (checked on the device; found out at the end of the build)
+            } else {
+                u32 hf[FLAG_WORDS];
+                HIP_CHECK(hipMemcpyAsync(hf, flags, sizeof(hf), hipMemcpyDeviceToHost, ctx.stream));
+                HIP_CHECK(hipStreamSynchronize(ctx.stream));
+                if (hf[FLAG_STATUS] & STATUS_NO_TERMINATOR)
+                    east_throw(EAST_HIP_ERR_DOMAIN, "a document does not end in a string terminator (>= U+0A00)");
+                sigma_t = hf[FLAG_SIGMA];
+            }
             m_total = 0;
             for (u32 d = 0; d < n_docs; d++) m_total += (u32)n_strings[d];     // checked after the build
             h->use_s8 = sigma_t <= 254;
@@ -298,9 +347,6 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     h->bits0 = bit_width_u32(sigma);
 
     // ---- suffix array of the whole shard, then partition by document -------------
-    u32 *capped = h->code_map + TEXT_SYMBOLS;            // flag words behind the code map
-    u32 *status = capped + 1;
-    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(capped, 0, 2 * sizeof(u32), ctx.stream));
     // Text first goes through the window sort over all suffixes -- with several documents the keys carry
     // the document number on top, so that every document's tables come out side by side --; DC3 is the
     // bounded-work fallback (several documents: one suffix sort of the whole shard, then a stable
@@ -340,6 +386,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         }
     }
     ctx.stats->window_sorted = window_sorted;
+    if (ctx.spec && !window_sorted) throw SpecAbort();   // (DC3 is not written to survive a wrong guess of the alphabet)
     // on the byte stream the LCP table comes with the suffix array: from the window keys, or (one
     // document) out of the level-0 merge of DC3
     const bool fused_lcp = h->use_s8 && (window_sorted || n_docs == 1);
@@ -517,21 +564,45 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     ctx.stats = &h->stats;
     ctx.prof = &h->prof;
     ctx.lean = lean;
+    // The build is queued WITHOUT waiting for the device wherever the previous build on this handle says what
+    // to expect (alphabet size, no large tie groups): one read-back at the end finds out whether it was
+    // right.  If not -- or on a handle's first build -- the build runs with its read-backs in place.
+    u32 flags[FLAG_WORDS] = {0};
+    auto run = [&](bool spec) -> bool {
+        ctx.spec = spec;
+        try {
+            build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings, h->hint_sigma);
+        } catch (const SpecAbort &) {
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+            return false;
+        }
+        HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+        HIP_CHECK(hipMemcpyAsync(flags, h->code_map + TEXT_SYMBOLS, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        return true;
+    };
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));
-    build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings);
-    HIP_CHECK(hipEventRecord(h->ev1, h->stream));
-    u32 flags[2] = {0, 0};                               // [0] LCP comparisons were capped, [1] status
-    HIP_CHECK(hipMemcpyAsync(flags, h->code_map + TEXT_SYMBOLS, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
-    const u32 status = flags[1];
-    if (flags[0] && !(status & 2u)) {
+    const bool speculate = g_speculate && g_window_sort && h->hint_valid && h->hint_no_rounds && h->hint_sigma <= 254;
+    const bool went_through = run(speculate);
+    if (speculate && (!went_through || (flags[FLAG_STATUS] & STATUS_SIGMA_GUESS) || flags[FLAG_KEEP] || flags[FLAG_FAIL])) {
+        if (g_trace) fprintf(stderr, "[east_hip] speculative build guessed wrong: building again\n");
+        h->stats = Stats();
+        run(false);
+    }
+    const u32 status = flags[FLAG_STATUS];
+    if (status & STATUS_NO_TERMINATOR)
+        east_throw(EAST_HIP_ERR_DOMAIN, "a document does not end in a string terminator (>= U+0A00)");
+    if (flags[FLAG_CAPPED] && !(status & STATUS_N_STRINGS)) {
         finish_capped_lcp(h, ctx);
         HIP_CHECK(hipEventRecord(h->ev1, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
     }
-    if (status & 2u)
+    if (status & STATUS_N_STRINGS)
         east_throw(EAST_HIP_ERR_DOMAIN, "n_strings does not match the terminators found in a document "
                                         "(text symbols must be < U+0A00)");
+    h->hint_valid = true;
+    h->hint_sigma = h->sigma_t;
+    h->hint_no_rounds = h->stats.window_sorted && h->stats.refine_rounds == 0 && !h->stats.long_repeats;
     h->prof.collect();
     HIP_CHECK(hipEventElapsedTime(&h->last_build_ms, h->ev0, h->ev1));
     h->n = n;
@@ -1252,6 +1323,12 @@ int east_hip_debug_set_window_sort(int enabled)
     g_force_lean = enabled == 2;
     g_force_wide_keys = enabled == 3;
     g_plan_epoch++;
+    return EAST_HIP_OK;
+}
+
+int east_hip_debug_set_speculation(int enabled)
+{
+    g_speculate = enabled != 0;
     return EAST_HIP_OK;
 }
 

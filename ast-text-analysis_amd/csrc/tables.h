@@ -574,7 +574,8 @@ __global__ __launch_bounds__(BLOCK) void ann_wide_kernel(Pyramid P, u32 n, u32 n
         u32 pse, nsv;                                           // pse exists: the segment start holds 0;
         pyr_find_both(P, k, v, pse, nsv);                       // the search to the right stops at the next segment start
         u32 a = 0;
-        if (lcp[pse] < v) a = (nsv == NONE_U32 ? n : nsv) - pse;    // first l-index: pse == PSV, width = NSV - PSV
+        // (pse is only missing when the table is not an LCP table: a speculative build that guessed wrong)
+        if (pse != NONE_U32 && lcp[pse] < v) a = (nsv == NONE_U32 ? n : nsv) - pse;    // first l-index: pse == PSV, width = NSV - PSV
         ann[k] = a;
     }
 }

@@ -456,7 +456,8 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
                     u32 code = 0;
                     for (int i = 0; i < km.k; i++)
                         code = code * km.A + ((u32)(k[e + 1] >> (spare + (w - 1 - i) * b)) & ((1u << b) - 1u));
-                    km.kg[(size_t)d * (km.bins + 1) + code] = j - km.doc_off[d];
+                    // (code < bins always, except in a speculative build that assumed the wrong alphabet)
+                    if (code < km.bins) km.kg[(size_t)d * (km.bins + 1) + code] = j - km.doc_off[d];
                 }
             }
         }
@@ -712,6 +713,18 @@ __global__ __launch_bounds__(BLOCK) void lvl0_lcp_keys_kernel(KeyNeqWindowIn<K> 
     lcp[r] = h;
 }
 
+// what the placement pass left undone, next to the other flags (speculative build: read at the very end)
+__global__ void spec_counts_kernel(const u32 *__restrict__ block_sums, u32 nb, const u32 *__restrict__ fail,
+                                   u32 *__restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        u32 total = 0;
+        for (u32 i = 0; i < nb; i++) total += block_sums[i];
+        out[0] = total;
+        out[1] = *fail;
+    }
+}
+
 // Level 0 on the byte stream: the window keys are sorted, then one classify pass places everything
 // that is untied or tied in a small group (ordered directly on the text); large groups go through
 // refinement rounds (step 2c).  Returns true when sa12 is final (no name string is ever written);
@@ -781,6 +794,17 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                          bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
         if (mode == 1 || ctx.dry) return;
         LAUNCH(ctx, (scan_reduce_kernel<ArrIn>), nb, ArrIn{block_keep}, gp, block_sums);
+        if (ctx.spec && mode == 0 && n0 == 0) {
+            // speculative build: the host goes on as if nothing were left in large groups; the counts are
+            // put next to the build's other flags and read at the end (build_common repeats the build if
+            // they are not zero)
+            hipLaunchKernelGGL(spec_counts_kernel, dim3(1), dim3(WAVE), 0, ctx.stream, (const u32 *)block_sums, nb,
+                               (const u32 *)fail, ctx.spec_out);
+            HIP_CHECK(hipGetLastError());
+            m_next = 0;
+            h_fail = 0;
+            return;
+        }
         std::vector<u32> h_sums(nb);
         HIP_CHECK(hipMemcpyAsync(h_sums.data(), block_sums, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx.stream));
         HIP_CHECK(hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, ctx.stream));
@@ -796,6 +820,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     bool long_repeats = false;                          // small groups were handed to the rounds
     if (h_fail) {
         long_repeats = true;
+        if (ctx.stats) ctx.stats->long_repeats++;
         // duplicated passages inside small groups: put the domain back, mark those groups, place the others
         LAUNCH(ctx, (dc3_refine_restore_kernel<KeyNeqWindowIn<K>>), g02, sorted_vals, starts, (const u32 *)nullptr, n02, sa12,
                names_g);

@@ -243,6 +243,10 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes);
  * the device were short of memory for the tie-refinement rounds ("lean"); 3 = window sort on with
  * 64-bit window keys even where 32 bits suffice (the code path of large inputs, on small ones). */
 int east_hip_debug_set_window_sort(int enabled);
+/* Test knob: 0 = every build waits for the device's answers (alphabet size, tie groups) as a handle's
+ * first build does; 1 (default) = later builds on a handle are queued without waiting, on the strength
+ * of what the build before found, and checked by the one read-back at their end. */
+int east_hip_debug_set_speculation(int enabled);
 /* Host-only: bytes of device arena a build of n_total symbols / n_docs documents
  * reserves (worst case over inputs).  Needs no device. */
 int64_t east_hip_plan_arena_bytes(int64_t n_total, int32_t n_docs);

@@ -820,6 +820,42 @@ def test_resident_build_fits_the_planned_arena(hip, corpus, wide_keys):
     assert int(t.sum()) == docs[0][0].size * (docs[0][0].size - 1) // 2       # a permutation of the document's positions
 
 
+def test_speculative_builds_on_one_handle(hip, oracle):
+    """Builds after the first on a handle are queued without waiting for the device (alphabet size, "no large
+    tie groups" taken from the build before) and checked by one read-back at the end: a right guess and
+    every kind of wrong guess must give the same tables as the oracle."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(77)
+    vocab = synthetic.zipf_vocabulary(rng, size=200, exponent=1.0)
+    inputs = []
+    inputs.append(synthetic.word_stream_document(rng, 300000, want_text=False)[1:])        # first build: no guess
+    inputs.append(synthetic.word_stream_document(rng, 300000, want_text=False)[1:])        # right guess
+    inputs.append(synthetic.zipf_document(rng, 300000, vocab))                             # wrong: tie groups need rounds
+    inputs.append(synthetic.word_stream_document(rng, 200000, want_text=False)[1:])        # (after rounds: no guess)
+    sym5 = rng.integers(65, 70, size=150001, dtype=np.uint32)                              # wrong: 5-letter alphabet
+    sym5[-1] = 0x0A00
+    inputs.append((sym5, 1))
+    inputs.append(synthetic.word_stream_document(rng, 100000, want_text=False)[1:])
+    rep = np.tile(np.array([65, 66, 67], dtype=np.uint32), 40000)                          # wrong: long repeats
+    inputs.append((np.concatenate([rep, [0x0A00]]).astype(np.uint32), 1))
+    index = hip_backend.HipIndex()
+    for i, (sym, m) in enumerate(inputs):
+        index.build(sym, np.array([0, sym.size]), np.array([m]))
+        o = oracle.OracleEASA(symbols=sym, n_strings=m)
+        t = index.tables(0)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (i, name)
+    # the same sequence with the read-backs in place gives the same build facts
+    lib = hip.load()
+    assert lib.east_hip_debug_set_speculation(0) == 0
+    try:
+        sym, m = inputs[1]
+        index.build(sym, np.array([0, sym.size]), np.array([m]))
+        assert np.array_equal(index.tables(0)["suftab"], oracle.OracleEASA(symbols=sym, n_strings=m).suftab)
+    finally:
+        assert lib.east_hip_debug_set_speculation(1) == 0
+
+
 def test_lean_build_without_refinement_rounds(hip, oracle):
     """When the buffers of the tie-refinement rounds do not fit the device, the build runs without
     them: heavy ties go straight to the DC3 recursion.  Forced here on a small-vocabulary text."""
