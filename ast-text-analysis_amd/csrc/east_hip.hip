@@ -50,8 +50,17 @@ __global__ __launch_bounds__(BLOCK) void presence_kernel(const u32 *__restrict__
             atomicOr(&bits[c >> 5], 1u << (c & 31u));
     };
     const u32 stride = gridDim.x * BLOCK;
-    const u32 n4 = vec ? n >> 2 : 0u;                      // four symbols per 16-byte load
-    for (u32 i = blockIdx.x * BLOCK + threadIdx.x; i < n4; i += stride) {
+    const u32 n4 = vec ? n >> 2 : 0u;                      // four symbols per 16-byte load, four loads in flight
+    u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    for (; i + 3u * stride < n4; i += 4u * stride) {
+        const uint4 a = reinterpret_cast<const uint4 *>(sym)[i], b = reinterpret_cast<const uint4 *>(sym)[i + stride];
+        const uint4 c = reinterpret_cast<const uint4 *>(sym)[i + 2u * stride], d = reinterpret_cast<const uint4 *>(sym)[i + 3u * stride];
+        mark(a.x); mark(a.y); mark(a.z); mark(a.w);
+        mark(b.x); mark(b.y); mark(b.z); mark(b.w);
+        mark(c.x); mark(c.y); mark(c.z); mark(c.w);
+        mark(d.x); mark(d.y); mark(d.z); mark(d.w);
+    }
+    for (; i < n4; i += stride) {
         const uint4 c = reinterpret_cast<const uint4 *>(sym)[i];
         mark(c.x); mark(c.y); mark(c.z); mark(c.w);
     }
@@ -113,15 +122,22 @@ __global__ __launch_bounds__(BLOCK) void remap_bytes_kernel(const u32 *__restric
                                                             const u32 *__restrict__ code_map, u32 n, int vec,
                                                             uint8_t *__restrict__ s8)
 {
-    // four symbols per thread: one 16-byte load, one 4-byte store (the grid covers n + 16 bytes)
-    const u32 i = (blockIdx.x * BLOCK + threadIdx.x) * 4u;
-    if (vec && i + 4u <= n) {
-        const uint4 c = *reinterpret_cast<const uint4 *>(sym + i);
-        const u32 b0 = c.x < TEXT_SYMBOLS ? code_map[c.x] & 0xFFu : 0xFFu, b1 = c.y < TEXT_SYMBOLS ? code_map[c.y] & 0xFFu : 0xFFu;
-        const u32 b2 = c.z < TEXT_SYMBOLS ? code_map[c.z] & 0xFFu : 0xFFu, b3 = c.w < TEXT_SYMBOLS ? code_map[c.w] & 0xFFu : 0xFFu;
-        *reinterpret_cast<u32 *>(s8 + i) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    // sixteen symbols per thread: four 16-byte loads in flight, one 16-byte store (the grid covers n + 16 bytes)
+    const u32 i = (blockIdx.x * BLOCK + threadIdx.x) * 16u;
+    if (vec && i + 16u <= n) {
+        uint4 c[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) c[q] = reinterpret_cast<const uint4 *>(sym + i)[q];
+        u32 out[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 b0 = c[q].x < TEXT_SYMBOLS ? code_map[c[q].x] & 0xFFu : 0xFFu, b1 = c[q].y < TEXT_SYMBOLS ? code_map[c[q].y] & 0xFFu : 0xFFu;
+            const u32 b2 = c[q].z < TEXT_SYMBOLS ? code_map[c[q].z] & 0xFFu : 0xFFu, b3 = c[q].w < TEXT_SYMBOLS ? code_map[c[q].w] & 0xFFu : 0xFFu;
+            out[q] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+        *reinterpret_cast<uint4 *>(s8 + i) = uint4{out[0], out[1], out[2], out[3]};
     } else {
-        for (u32 j = i; j < i + 4u && j < n + 16u; j++) {
+        for (u32 j = i; j < i + 16u && j < n + 16u; j++) {
             uint8_t v = 0;
             if (j < n) { const u32 c = sym[j]; v = c < TEXT_SYMBOLS ? (uint8_t)code_map[c] : (uint8_t)0xFF; }
             s8[j] = v;
@@ -331,7 +347,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
             h->use_s8 = sigma_t <= 254;
         }
         if (h->use_s8 && !ctx.dry) {
-            LAUNCH(ctx, remap_bytes_kernel, ceil_div_u32((u64)n + 16, BLOCK * 4), d_sym, (const u32 *)h->code_map, n,
+            LAUNCH(ctx, remap_bytes_kernel, ceil_div_u32((u64)n + 16, BLOCK * 16), d_sym, (const u32 *)h->code_map, n,
                    vec, h->s8);
         } else {
             // wide alphabets: dense u32 codes, terminators numbered globally by a scan
