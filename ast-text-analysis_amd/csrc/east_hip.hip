@@ -801,7 +801,7 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
     use_device(h);
     const u32 n_q = (u32)S;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t bytes = al((size_t)n_q * 4) * 3 + al(((size_t)n_kp + 1) * 4) * 2 +
+    const size_t bytes = 256 + al((size_t)n_q * 4) * 3 + al(((size_t)n_kp + 1) * 4) * 2 +
                          al((size_t)n_q * h->n_docs * 8) + al((size_t)n_kp * h->n_docs * 8) * 2;
     if (bytes > h->q_cap) {
         HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -813,7 +813,7 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
         h->q_buf = (char *)p;
         h->q_cap = bytes;
     }
-    char *p = h->q_buf;
+    char *p = h->q_buf + 256;                            // (the first bytes hold the probe counter of east_hip_score_probes)
     h->q_raw = (u32 *)p;  p += al((size_t)n_q * 4);
     h->q_code = (u32 *)p; p += al((size_t)n_q * 4);
     h->q_end = (u32 *)p;  p += al((size_t)n_q * 4);
@@ -906,7 +906,7 @@ static void ensure_kgram(east_hip_index *h, Ctx &ctx)
 }
 
 // queues the score kernels; result in h->table (K x D) / h->suffix (D x S)
-static void score_resident(east_hip_index *h, int normalized)
+static void score_resident(east_hip_index *h, int normalized, unsigned long long *probe_count = nullptr)
 {
     if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
     if (!h->built) east_throw(EAST_HIP_ERR_NOT_BUILT, "no index has been built on this handle");
@@ -925,12 +925,12 @@ static void score_resident(east_hip_index *h, int normalized)
         LAUNCH_NAMED(ctx, "score_walk_kernel", (score_walk_kernel<uint8_t>), walk_grid, (const uint8_t *)h->s8,
                      (const u32 *)h->sa, (const u32 *)h->doc_off, (const u32 *)h->n_strings, h->n_docs,
                      (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, (const u32 *)h->kg, h->kg_k,
-                     h->kg_A, h->kg_bins, xcd_order, h->suffix);
+                     h->kg_A, h->kg_bins, xcd_order, h->suffix, probe_count);
     else
         LAUNCH_NAMED(ctx, "score_walk_kernel", (score_walk_kernel<u32>), walk_grid, (const u32 *)h->s,
                      (const u32 *)h->sa, (const u32 *)h->doc_off, (const u32 *)h->n_strings, h->n_docs,
                      (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, (const u32 *)h->kg, h->kg_k,
-                     h->kg_A, h->kg_bins, xcd_order, h->suffix);
+                     h->kg_A, h->kg_bins, xcd_order, h->suffix, probe_count);
     LAUNCH(ctx, score_reduce_kernel, ceil_div_u32((u64)h->n_kp * h->n_docs, BLOCK), (const double *)h->suffix,
            (const u32 *)h->q_off, h->n_kp, h->n_docs, h->n_q, h->table);
     HIP_CHECK(hipEventRecord(h->ev1, h->stream));
@@ -1111,6 +1111,22 @@ int east_hip_score_resident(east_hip_handle_t h, int normalized, double *d_out)
                                      h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
         HIP_CHECK(hipEventElapsedTime(&h->last_score_ms, h->ev0, h->ev1));
+    });
+}
+
+int east_hip_score_probes(east_hip_handle_t h, int normalized, int64_t *probes)
+{
+    return guarded([&] {
+        if (!h || !probes) east_throw(EAST_HIP_ERR_INVALID, "null handle or output");
+        if (!h->n_kp) east_throw(EAST_HIP_ERR_INVALID, "no keyphrases set");
+        use_device(h);
+        unsigned long long *d_count = (unsigned long long *)h->q_buf;
+        HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), h->stream));
+        score_resident(h, normalized, d_count);
+        unsigned long long c = 0;
+        HIP_CHECK(hipMemcpyAsync(&c, d_count, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        *probes = (int64_t)c;
     });
 }
 

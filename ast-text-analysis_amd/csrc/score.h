@@ -264,7 +264,7 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
     const SYM *__restrict__ s, const u32 *__restrict__ sa, const u32 *__restrict__ doc_off,
     const u32 *__restrict__ n_strings, u32 n_docs, const u32 *__restrict__ q_code,
     const u32 *__restrict__ q_end, u32 n_q, int normalized, const u32 *__restrict__ kg, int kg_k, u32 kg_A,
-    u32 kg_bins, int xcd_order, double *__restrict__ suffix_out)
+    u32 kg_bins, int xcd_order, double *__restrict__ suffix_out, unsigned long long *__restrict__ probe_count)
 {
     // XCD-aware work order: workgroups go round-robin over the 8 XCDs, each with its own 4 MB L2.  All the
     // keyphrase suffixes of ONE document are walked by ONE XCD (document d belongs to XCD d mod 8, which takes
@@ -275,6 +275,7 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
     const u32 d = xcd_order ? (local / blocks_per_doc) * 8u + (blockIdx.x & 7u) : local / blocks_per_doc;
     const u32 si = (local % blocks_per_doc) * BLOCK + threadIdx.x;
     if (d >= n_docs || si >= n_q) return;
+    u32 probes = 0;                     // table reads and binary-search probes of this walk (roofline accounting)
     const u32 seg = doc_off[d];
     const u32 nd = doc_off[d + 1] - seg;
     const u32 root_ann = nd - n_strings[d];
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
             stride /= kg_A;
             code = code * kg_A + c;
             const u32 a = row[code * stride], b1 = row[(code + 1u) * stride];
+            probes += 2;
             if (b1 <= a) break;                           // no suffix continues with c
             const u32 b = b1 - 1u;
             if (b - a < hi - lo) {
@@ -310,18 +312,21 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
         if (c == Q_NOMATCH) break;
         u32 a, b;
         if (lo == hi) {
+            probes++;
             if (s[sad[lo] + depth] != c) break;
             a = b = lo;
         } else {
             u32 x = lo, y = hi + 1;                       // lower bound of c at this depth
             while (x < y) {
                 const u32 mid = (x + y) >> 1;
+                probes++;
                 if (s[sad[mid] + depth] < c) x = mid + 1; else y = mid;
             }
             a = x;
             y = hi + 1;                                   // upper bound, from a
             while (x < y) {
                 const u32 mid = (x + y) >> 1;
+                probes++;
                 if (s[sad[mid] + depth] <= c) x = mid + 1; else y = mid;
             }
             if (x == a) break;                            // no suffix continues with c
@@ -340,6 +345,7 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
         if (normalized) r /= (double)depth;               // easa.py:128-129
     }
     suffix_out[(u64)d * n_q + si] = r;
+    if (probe_count) atomicAdd(probe_count, (unsigned long long)probes);   // (counting runs only: east_hip_score_probes)
 }
 
 // out[k*D + d] = (sum of the keyphrase's suffix results, in suffix order) / |q|

@@ -49,6 +49,7 @@ SIGNATURES = {
     "east_hip_get_lcp_intervals": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_i32p]),
     "east_hip_set_keyphrases": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, _c_i64p, ctypes.c_int32]),
     "east_hip_score_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "east_hip_score_probes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_i64p]),
     "east_hip_score_resident_async": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "east_hip_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
     "east_hip_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
@@ -336,6 +337,12 @@ class HipIndex(object):
     def score_resident(self, normalized=True, d_out_ptr=None):
         _check(self._lib.east_hip_score_resident(self._h, int(bool(normalized)),
                                                  ctypes.c_void_p(int(d_out_ptr)) if d_out_ptr else None))
+
+    def score_probes(self, normalized=True):
+        """Table reads + binary-search probes of one pass of the score walk over the resident keyphrases."""
+        c = ctypes.c_int64(0)
+        _check(self._lib.east_hip_score_probes(self._h, int(bool(normalized)), ctypes.byref(c)))
+        return int(c.value)
 
     def synchronize(self):
         _check(self._lib.east_hip_synchronize(self._h))

@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- the EAST hot path on N MI355X GPUs (one process per GPU).
 
-Workload (BASELINE.json configs[1], one copy per GPU = weak scaling):
-  one synthetic 64 MiB random-ASCII word-stream document per GPU, turned into
-  3-word strings exactly as `east keyphrases table` does (text mode), and 1 000
-  keyphrases.  The corpus shards at document granularity: rank r owns one AST
-  shard; the K x N score table is assembled with one RCCL all-gather.
+Workloads (BASELINE.json):
+  N = 1   configs[1]: one synthetic 64 MiB random-ASCII word-stream document, turned into 3-word strings
+          exactly as `east keyphrases table` does (text mode), and 1 000 keyphrases -- the headline.  The
+          same JSON line carries a second leg, `config2` = configs[2] (256 x 1 MiB documents, 10 000
+          keyphrases: the keyphrase x document score kernel), which is also the per-GPU shape of configs[3].
+  N > 1   configs[3] (2 048 documents of 1 MiB over 8 GPUs): every rank owns 256 x 1 MiB documents (one AST
+          shard per GPU, weak scaling), 10 000 keyphrases; the K x D_local score blocks (20.5 MB per rank)
+          are assembled with one RCCL all-gather.  `--docs/--doc-mib/--keyphrases` override either shape.
 
-A "step" is one pass of the whole hot path over that batch, with the symbol
-stream already resident in HBM:
-    EASA build (dense remap, DC3 suffix array, LCP, annotation + child tables)
+A "step" is one pass of the whole hot path over that batch, with the symbol stream already resident in HBM:
+    EASA build (dense remap, window sort / DC3 suffix array, LCP, annotation table; the child tables are
+    built on the first east_hip_get_tables request that asks for them -- `child_tables_ms` reports that kernel)
     + score table (K keyphrases x local documents) [+ all-gather of the blocks]
 value = input document bytes of all ranks / step time.
 
 The JSON line also carries
-  roofline      -- the dominant kernel of the timed region (by summed HIP-event
-                   time on the library's own stream): algorithmic bytes / time
-  cpu_baseline  -- the CPU oracle (C port of the reference's easa.py) timed on
-                   this box's host cores on a bounded sample (rank 0, N=1 only)
+  roofline       the dominant kernel of the timed region (by summed HIP-event time on the library's own
+                 stream): algorithmic bytes / time, PMC traffic from profiles/traffic.json;
+                 roofline.rocprof_hbm_fraction = the whole build: sum over its kernels of (PMC bytes per
+                 launch x launches) / sum of their HIP-event times, against the 8 TB/s peak
+  roofline_score the score walk: 8 B per table read / binary-search probe (counted by the kernel in an
+                 extra, untimed run) + 8 B per suffix result written and read + 8 B per score, / its time
+  build_from_host_ms  east_hip_build from host-resident symbols (H2D included), wall clock
+  cpu_baseline   the CPU oracle (C port of the reference's easa.py) timed on this box's host cores on the
+                 same 64 MiB document (one core) and over the documents of configs[2] (all cores)
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -35,6 +43,8 @@ sys.path.insert(0, os.path.join(ROOT, "ast-text-analysis_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured)
+BUILD_KERNEL_PREFIXES = ("radix_", "lvl0_", "ann_", "pyramid_", "presence_", "remap_", "codemap_", "validate_", "scan_",
+                         "dc3_", "lcp", "doc_", "inverse_sa", "spec_counts")
 
 
 def parse():
@@ -42,9 +52,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--doc-mib", type=float, default=64.0, help="size of one document in MiB")
-    ap.add_argument("--docs", type=int, default=1, help="documents per GPU (BASELINE configs[2]: 256 x 1 MiB)")
-    ap.add_argument("--keyphrases", type=int, default=1000)
+    ap.add_argument("--doc-mib", type=float, default=None, help="size of one document in MiB (default: 64 at N=1, 1 at N>1)")
+    ap.add_argument("--docs", type=int, default=None, help="documents per GPU (default: 1 at N=1, 256 at N>1)")
+    ap.add_argument("--keyphrases", type=int, default=None, help="default: 1000 at N=1, 10000 at N>1")
     ap.add_argument("--mode", choices=["text", "direct"], default="text",
                     help="text: 3-word strings as the CLI does; direct: get_ast([one string])")
     ap.add_argument("--corpus", choices=["words", "zipf"], default="words",
@@ -53,12 +63,14 @@ def parse():
                     help="the last N documents are copies of the first N (long repeats across documents)")
     ap.add_argument("--denormalized", action="store_true", help="the CLI's -d")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mib", type=float, default=32.0,
-                    help="size of the CPU-baseline sample document (about 10-30 s of single-core work)")
+    ap.add_argument("--no-config2", action="store_true", help="skip the configs[2] leg of the N=1 line")
+    ap.add_argument("--no-extras", action="store_true", help="skip build_from_host / child tables / probe count")
+    ap.add_argument("--cpu-sample-mib", type=float, default=64.0,
+                    help="size of the CPU-baseline document (64 = the bench document itself, about 15 s of one core)")
     return ap.parse_args()
 
 
-def kernel_bytes(name, info, n, n_q, n_docs):
+def kernel_bytes(name, info, n, n_docs):
     """Algorithmic HBM bytes of ALL launches of one kernel in one step."""
     e32, e64 = info["radix_elements_u32"], info["radix_elements_u64"]
     first = n if info["window_sorted"] else 2 * n // 3      # elements of the level-0 window sort
@@ -81,14 +93,81 @@ def kernel_bytes(name, info, n, n_q, n_docs):
         # level-0 placement pass (no refinement rounds): 4 B element + 4 B key read, 4 B SA (+ 4 B LCP with one
         # document) written per suffix; the tied ones add two 8 B text gathers each
         "lvl0_place_kernel": first * (16 if n_docs == 1 and info["window_sorted"] else 12),
-        # 4 B LCP read + 4 B annotation write per rank
-        "ann_kernel": n * 8,
+        # 4 B LCP read + 4 B annotation write per rank + pyramid level 1 (4 B per 16 ranks)
+        "ann_stream_kernel": n * 8 + n // 4,
+        # 4 B read per symbol
+        "presence_kernel": n * 4,
+        # 4 B read + 1 B written per symbol
+        "remap_bytes_kernel": n * 5,
         # 4 B sorted sample read + one random 4 B rank store per sample
         "dc3_rank_kernel": info["merge_elements"] * 2 // 3 * 8,
         # 8 symbols + 2 ranks read, one 16 B record written per symbol
         "dc3_records_kernel": n * 26,
     }
     return table.get(name)
+
+
+def make_corpus(args, synthetic, rng, n_docs, doc_bytes):
+    parts, ms = [], []
+    vocab = synthetic.zipf_vocabulary(np.random.default_rng(20245)) if args.corpus == "zipf" else None
+    for _ in range(n_docs):
+        if vocab is not None:
+            sym_d, m_d = synthetic.zipf_document(rng, doc_bytes, vocab)
+        elif args.mode == "text":
+            _, sym_d, m_d = synthetic.word_stream_document(rng, doc_bytes, want_text=False)
+        else:
+            sym_d, m_d = synthetic.direct_document(rng, doc_bytes + 1)
+        parts.append(sym_d)
+        ms.append(m_d)
+    for i in range(min(args.duplicate_docs, len(parts) // 2)):
+        parts[len(parts) - 1 - i], ms[len(ms) - 1 - i] = parts[i], ms[i]
+    symbols = np.concatenate(parts) if len(parts) > 1 else parts[0]
+    doc_offsets = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.int64)
+    return symbols, doc_offsets, np.array(ms, dtype=np.int32), vocab is not None
+
+
+def roofline_of(prof, info, n, n_docs, steps, traffic):
+    """(dominant-kernel roofline, per-kernel list, kernel ms per step) from a profile report."""
+    total_kernel_ms = sum(ms for _, ms in prof.values())
+    dom_name, (dom_launches, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1])
+    bytes_per_step = kernel_bytes(dom_name, info, n, n_docs)
+    roofline = {"kernel": dom_name, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "launches_per_step": dom_launches // steps, "avg_launch_ms": dom_ms / dom_launches,
+                "share_of_kernel_time": dom_ms / total_kernel_ms, "traffic": traffic.get(dom_name)}
+    if bytes_per_step is not None:
+        achieved = bytes_per_step * steps / (dom_ms * 1e-3) / 1e9
+        roofline.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": bytes_per_step / max(dom_launches // steps, 1)})
+    else:
+        roofline.update({"achieved": None, "frac": None})
+    by_kernel = []
+    for name, (launches, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:10]:
+        b = kernel_bytes(name, info, n, n_docs)
+        entry = {"kernel": name, "ms_per_step": ms / steps, "share_of_kernel_time": ms / total_kernel_ms}
+        if b is not None:
+            gbs = b * steps / (ms * 1e-3) / 1e9
+            entry.update({"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(name)})
+        by_kernel.append(entry)
+    per_step = {k: round(v[1] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+    return roofline, by_kernel, per_step
+
+
+def hbm_fraction(prof, traffic):
+    """The whole build: sum of (PMC bytes per launch x launches) / sum of HIP-event time over the build's kernels
+    (those profiles/traffic.json has a figure for), as a fraction of the 8 TB/s peak."""
+    num = den = 0.0
+    covered = []
+    for name, (launches, ms) in prof.items():
+        if not name.startswith(BUILD_KERNEL_PREFIXES) or name not in traffic:
+            continue
+        num += traffic[name] * launches
+        den += ms * 1e-3
+        covered.append(name)
+    if den == 0:
+        return None
+    build_ms = sum(ms for name, (_, ms) in prof.items() if name.startswith(BUILD_KERNEL_PREFIXES))
+    return {"GBps": num / den / 1e9, "frac": num / den / 1e9 / HBM_PEAK_GBS, "kernels": len(covered),
+            "share_of_build_kernel_time": den * 1e3 / build_ms if build_ms else None}
 
 
 def main():
@@ -113,29 +192,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    # the shape: configs[1] on one GPU, the per-GPU shape of configs[3] on several
+    scaling_shape = world > 1
+    D = args.docs if args.docs is not None else (256 if scaling_shape else 1)
+    doc_mib = args.doc_mib if args.doc_mib is not None else (1.0 if scaling_shape else 64.0)
+    K = args.keyphrases if args.keyphrases is not None else (10000 if scaling_shape else 1000)
+
     # ---- synthetic inputs (seed = 20240 + config# + rank), outside the timed region ----
-    doc_bytes = int(args.doc_mib * (1 << 20))
-    n_bytes = doc_bytes * args.docs                       # input bytes per GPU
+    doc_bytes = int(doc_mib * (1 << 20))
+    n_bytes = doc_bytes * D                               # input bytes per GPU
     rng = np.random.default_rng(20240 + 2 + 1000 * rank)
-    parts, ms = [], []
-    vocab = synthetic.zipf_vocabulary(np.random.default_rng(20245)) if args.corpus == "zipf" else None
-    for _ in range(args.docs):
-        if vocab is not None:
-            sym_d, m_d = synthetic.zipf_document(rng, doc_bytes, vocab)
-        elif args.mode == "text":
-            _, sym_d, m_d = synthetic.word_stream_document(rng, doc_bytes, want_text=False)
-        else:
-            sym_d, m_d = synthetic.direct_document(rng, doc_bytes + 1)
-        parts.append(sym_d)
-        ms.append(m_d)
-    for i in range(min(args.duplicate_docs, len(parts) // 2)):
-        parts[len(parts) - 1 - i], ms[len(ms) - 1 - i] = parts[i], ms[i]
-    symbols = np.concatenate(parts) if len(parts) > 1 else parts[0]
-    m = int(sum(ms))
+    symbols, doc_offsets, n_strings, is_zipf = make_corpus(args, synthetic, rng, D, doc_bytes)
+    m = int(n_strings.sum())
     n = int(symbols.size)
-    D = args.docs
-    K = args.keyphrases
-    # keyphrases: every rank contributes K/world sampled from its own document, the set is replicated
+    # keyphrases: every rank contributes K/world sampled from its own documents, the set is replicated
     share = [K // world + (1 if r < K % world else 0) for r in range(world)]
     q_local = synthetic.keyphrases(rng, symbols, share[rank])
     if use_dist:
@@ -150,8 +220,6 @@ def main():
     q_symbols, q_offsets = np.concatenate(q_parts), np.array(q_off, dtype=np.int64)
 
     d_symbols = torch.from_numpy(symbols.view(np.int32)).to(dev)          # resident in HBM
-    doc_offsets = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.int64)
-    n_strings = np.array(ms, dtype=np.int32)
     local_block = torch.empty((K, D), dtype=torch.float64, device=dev)    # K x D_local
     full_table = torch.empty((world * K, D), dtype=torch.float64, device=dev) if use_dist else None
 
@@ -194,59 +262,41 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * n_bytes / (elapsed / args.steps)
-        # ---- roofline of the dominant kernel (HIP events on the library's stream) ----
-        total_kernel_ms = sum(ms for _, ms in prof.values())
-        dom = max(prof.items(), key=lambda kv: kv[1][1])
-        dom_name, (dom_launches, dom_ms) = dom
-        bytes_per_step = kernel_bytes(dom_name, info, n, int(q_offsets[-1]), D)
-        roofline = {"kernel": dom_name, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "launches_per_step": dom_launches // args.steps,
-                    "avg_launch_ms": dom_ms / dom_launches,
-                    "share_of_kernel_time": dom_ms / total_kernel_ms, "traffic": None}
-        if bytes_per_step is not None:
-            achieved = bytes_per_step * args.steps / (dom_ms * 1e-3) / 1e9
-            roofline.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_launch": bytes_per_step / (dom_launches // args.steps)})
-        else:
-            roofline.update({"achieved": None, "frac": None})
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         traffic = {}
-        if os.path.exists(traffic_file):
+        default_shape = (D, doc_mib, K, args.mode, args.corpus) == (1, 64.0, 1000, "text", "words") and not args.duplicate_docs
+        if os.path.exists(traffic_file) and default_shape:       # (the counters were collected on the default workload)
             with open(traffic_file) as f:
-                traffic = json.load(f)
-        roofline["traffic"] = traffic.get(dom_name)
-        # the same accounting for every kernel with a byte model, largest first (the time is spread
-        # over several kernels of two kinds: streaming sort passes and random-sector gathers)
-        by_kernel = []
-        for name, (launches, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:8]:
-            b = kernel_bytes(name, info, n, int(q_offsets[-1]), D)
-            entry = {"kernel": name, "ms_per_step": ms / args.steps, "share_of_kernel_time": ms / total_kernel_ms}
-            if b is not None:
-                gbs = b * args.steps / (ms * 1e-3) / 1e9
-                entry.update({"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(name)})
-            by_kernel.append(entry)
+                traffic = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        roofline, by_kernel, per_step = roofline_of(prof, info, n, D, args.steps, traffic)
+        roofline["rocprof_hbm_fraction"] = hbm_fraction(prof, traffic)
         out = {
             "metric": "corpus chars/sec (SA+annotation build + keyphrase score table)",
             "value": value, "unit": "chars/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (symbols/indices) + f64 (scores)", "data": "synthetic",
             "config": {"workload": "%d synthetic %g MiB %s doc(s) per GPU (%s mode), "
-                                   "%d keyphrases, %s scores, easa-HIP"
-                                   % (D, args.doc_mib, "random-ASCII word-stream" if vocab is None else
+                                   "%d keyphrases, %s scores, easa-HIP%s"
+                                   % (D, doc_mib, "random-ASCII word-stream" if not is_zipf else
                                       "Zipf natural-language-like", args.mode, K,
-                                      "denormalized" if args.denormalized else "normalized"),
-                       "symbols_per_gpu": n, "strings_per_gpu": m, "parallelism": "doc-shard x%d" % world},
+                                      "denormalized" if args.denormalized else "normalized",
+                                      " [BASELINE configs[3] per-GPU shape]" if scaling_shape else ""),
+                       "symbols_per_gpu": n, "strings_per_gpu": m, "parallelism": "doc-shard x%d" % world,
+                       "all_gather_bytes_per_rank": K * D * 8 if use_dist else 0},
             "build_ms": float(np.mean(build_ms)), "score_ms": float(np.mean(score_ms)),
             "build_symbols_per_s": n / (float(np.mean(build_ms)) * 1e-3),
             "build_chars_per_s": n_bytes / (float(np.mean(build_ms)) * 1e-3),
             "keyphrase_scores_per_s": K * D / (float(np.mean(score_ms)) * 1e-3),
             "build_algorithmic_GBps": 16.0 * n / (float(np.mean(build_ms)) * 1e-3) / 1e9,
-            "dc3_levels": info["dc3_levels"], "dc3_levels_resolved": info["dc3_levels_resolved"], "dc3_refine_rounds": info["refine_rounds"], "window_sorted": info["window_sorted"],
+            "dc3_levels": info["dc3_levels"], "dc3_levels_resolved": info["dc3_levels_resolved"],
+            "dc3_refine_rounds": info["refine_rounds"], "window_sorted": info["window_sorted"],
             "radix_passes": info["radix_passes"],
-            "roofline": roofline, "roofline_by_kernel": by_kernel,
-            "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in
-                                    sorted(prof.items(), key=lambda kv: -kv[1][1])},
+            "roofline": roofline, "roofline_by_kernel": by_kernel, "kernels_ms_per_step": per_step,
         }
+        if not args.no_extras:
+            out.update(extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D))
+        if world == 1 and not args.no_config2 and default_shape:
+            out["config2"] = config2_leg(args, hip_backend, synthetic, torch, dev, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, synthetic)
     if use_dist:
@@ -264,12 +314,96 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+def extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D):
+    """Untimed extras of the same index: score roofline from a counted run, the child-table kernel, the build
+    from host-resident symbols."""
+    res = {}
+    n_q = int(q_offsets[-1])
+    walk = prof.get("score_walk_kernel")
+    if walk:
+        probes = index.score_probes(not args.denormalized)
+        # 8 B per table read / probe (suffix-array entry + symbol), the per-suffix results written by the walk
+        # and read by the reduction (8 B each way), 8 B per score
+        b = 8 * probes + 16 * n_q * D + 8 * K * D
+        ms = walk[1] / walk[0]
+        res["roofline_score"] = {"kernel": "score_walk_kernel", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "probes": probes, "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms,
+                                 "achieved": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "note": "random 4-byte reads in 64-byte sectors: latency-bound, not bandwidth-bound"}
+    # child tables: built by the first east_hip_get_tables request that asks for them
+    index.profile_enable(True)
+    index.tables(0, names=("childtab_up",))
+    child = index.profile_report().get("child_kernel")
+    index.profile_enable(False)
+    if child:
+        res["child_tables_ms"] = child[1] / child[0]
+    # the build from host-resident symbols (east_hip_build: one 4 B/symbol H2D copy in front), wall clock
+    walls = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        index.build(symbols, doc_offsets, n_strings)
+        walls.append((time.perf_counter() - t0) * 1e3)
+    res["build_from_host_ms"] = {"wall_ms_min": min(walls), "wall_ms_median": sorted(walls)[1],
+                                 "device_build_ms": index.last_build_ms, "h2d_bytes": int(symbols.size) * 4,
+                                 "note": "pageable host memory; the H2D copy precedes the build on the same stream"}
+    return res
+
+
+def config2_leg(args, hip_backend, synthetic, torch, dev, local_rank):
+    """BASELINE configs[2]: 256 x 1 MiB documents, 10 000 keyphrases, one GPU -- the score-kernel configuration."""
+    D, K, steps = 256, 10000, 3
+    rng = np.random.default_rng(20240 + 3)
+    symbols, doc_offsets, n_strings, _ = make_corpus(args, synthetic, rng, D, 1 << 20)
+    n = int(symbols.size)
+    qs, qo = synthetic.keyphrases(rng, symbols, K)
+    d_symbols = torch.from_numpy(symbols.view(np.int32)).to(dev)
+    block = torch.empty((K, D), dtype=torch.float64, device=dev)
+    index = hip_backend.HipIndex(local_rank, reserve_symbols=n)
+    index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)
+    index.set_keyphrases(qs, qo)
+    index.score_resident(True, block.data_ptr())
+    index.profile_enable(True)
+    build_ms, score_ms = [], []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)
+        index.score_resident(True, block.data_ptr())
+        build_ms.append(index.last_build_ms)
+        score_ms.append(index.last_score_ms)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = index.profile_report()
+    index.profile_enable(False)
+    info = index.info()
+    roofline, by_kernel, per_step = roofline_of(prof, info, n, D, steps, {})
+    res = {"workload": "256 synthetic 1 MiB random-ASCII word-stream docs (text mode), 10000 keyphrases, normalized",
+           "steps": steps, "ms_per_step": elapsed * 1e3 / steps, "value": D * (1 << 20) / (elapsed / steps),
+           "unit": "chars/s", "symbols": n, "build_ms": float(np.mean(build_ms)), "score_ms": float(np.mean(score_ms)),
+           "build_chars_per_s": D * (1 << 20) / (float(np.mean(build_ms)) * 1e-3),
+           "keyphrase_scores_per_s": K * D / (float(np.mean(score_ms)) * 1e-3),
+           "roofline": roofline, "kernels_ms_per_step": dict(list(per_step.items())[:12])}
+    walk = prof.get("score_walk_kernel")
+    if walk and not args.no_extras:
+        probes = index.score_probes(True)
+        b = 8 * probes + 16 * int(qo[-1]) * D + 8 * K * D
+        ms = walk[1] / walk[0]
+        res["roofline_score"] = {"kernel": "score_walk_kernel", "probes": probes, "algorithmic_bytes_per_launch": b,
+                                 "avg_launch_ms": ms, "achieved": b / (ms * 1e-3) / 1e9, "unit": "GB/s",
+                                 "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    index.close()
+    return res
+
+
 def cpu_baseline(args, synthetic):
-    """The oracle (C port of the reference algorithm, single thread) on a bounded sample."""
+    """The oracle (C port of the reference algorithm): one core on the bench document itself, and all host
+    cores over the documents of configs[2] (one oracle build per document, a thread each -- the C calls
+    release the interpreter lock)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import easa_oracle
     easa_oracle.build()
     n_bytes = int(args.cpu_sample_mib * (1 << 20))
-    rng = np.random.default_rng(20240 + 2)
+    rng = np.random.default_rng(20240 + 2)                 # (rank 0's seed: the bench document itself at 64 MiB)
     if args.mode == "text":
         _, symbols, m = synthetic.word_stream_document(rng, n_bytes, want_text=False)
     else:
@@ -282,12 +416,24 @@ def cpu_baseline(args, synthetic):
     for k in range(100):
         orc.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=False)     # the reference's own walk (sibling chains)
     t_score = time.perf_counter() - t0
-    return {"value": n_bytes / t_build, "unit": "chars/s", "cores": 1, "kind": "port",
-            "sample": "oracle/easa_oracle.c full EASA build (DC3+Kasai+childtab+anntab) of one %g MiB "
-                      "word-stream doc (%d symbols, %d strings), %.1f s; host has %d cores"
-                      % (args.cpu_sample_mib, symbols.size, m, t_build, os.cpu_count()),
-            "build_symbols_per_s": symbols.size / t_build,
-            "keyphrase_scores_per_s": 100 / t_score}
+    del orc
+    res = {"value": n_bytes / t_build, "unit": "chars/s", "cores": 1, "kind": "port",
+           "sample": "oracle/easa_oracle.c full EASA build (DC3+Kasai+childtab+anntab) of the %g MiB bench document "
+                     "(%d symbols, %d strings), %.1f s on one core; host has %d cores"
+                     % (args.cpu_sample_mib, symbols.size, m, t_build, os.cpu_count()),
+           "build_symbols_per_s": symbols.size / t_build, "keyphrase_scores_per_s": 100 / t_score}
+    # all cores over documents (configs[2]: 256 x 1 MiB)
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(20240 + 3)
+    docs = [synthetic.word_stream_document(rng, 1 << 20, want_text=False)[1:] for _ in range(256)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        list(pool.map(lambda d: easa_oracle.OracleEASA(symbols=d[0], n_strings=d[1]).n, docs))
+    t_all = time.perf_counter() - t0
+    res["over_documents"] = {"value": 256 * (1 << 20) / t_all, "unit": "chars/s", "cores": cores,
+                             "sample": "256 documents of 1 MiB (configs[2]), one oracle build per document on a pool of "
+                                       "%d threads, %.1f s" % (cores, t_all)}
+    return res
 
 
 if __name__ == "__main__":

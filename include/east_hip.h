@@ -190,6 +190,11 @@ int east_hip_score_table_grouped(east_hip_handle_t h, const uint32_t *q_symbols,
  */
 int east_hip_get_lcp_intervals(east_hip_handle_t h, int32_t doc, int32_t *left);
 
+/* Roofline accounting for bench.py: runs the score kernels on the resident index and keyphrases once more
+ * and counts what the walks read -- k-gram table entries and binary-search probes (one suffix-array entry +
+ * one symbol each), the "probes" of SURVEY.md 8(d).  Not a timed path. */
+int east_hip_score_probes(east_hip_handle_t h, int normalized, int64_t *probes);
+
 /* Block until everything queued on the handle's stream has finished. */
 int east_hip_synchronize(east_hip_handle_t h);
 /* The handle's hipStream_t (as void*) so callers can record events on it. */

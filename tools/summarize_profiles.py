@@ -25,7 +25,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
 
 
 # kernels whose reads are dominated by random gathers / whose writes by random scatters
@@ -33,7 +33,7 @@ GATHER = ("dc3_merge_tile_kernel", "dc3_merge_partition_kernel", "dc3_merge_lcp_
           "dc3_merge_partition_rec_kernel", "dc3_lcp_heads_kernel", "lcp8_kernel", "lcp_kernel",
           "dc3_compact_s0_bytes_kernel", "dc3_compact_s0_kernel", "dc3_rank_kernel", "dc3_scatter_names_kernel",
           "dc3_resolve_ties_text_kernel", "dc3_resolve_ties_kernel", "kgram_mark_kernel", "score_walk_kernel",
-          "dc3_pair_keys_kernel", "dc3_gather_third_kernel", "ann_kernel", "child_kernel", "doc_keys_kernel",
+          "dc3_pair_keys_kernel", "dc3_gather_third_kernel", "ann_wide_kernel", "child_kernel", "doc_keys_kernel",
           # mixed: a streaming pass (counted at 1/2) plus text gathers for the tied suffixes (counted in full);
           # with c = 1 the figure is a lower bound, short by the streamed half (4 B/suffix)
           "dc3_refine_classify_kernel", "lvl0_place_kernel", "lvl0_lcp_keys_kernel", "dc3_refine_keys_kernel")
@@ -46,6 +46,7 @@ def short(name):
     name = name.replace("> >", ">>")
     for k in ("u32", "u64"):
         name = name.replace(", PairSrc<%s>>" % k, ">").replace(", WindowSrc<%s>>" % k, ",gen>")
+        name = name.replace(", TextWindowGen<%s>>" % k, ",gen>")
     for plain in ("dc3_refine_classify_kernel", "dc3_refine_compact_kernel", "dc3_refine_restore_kernel", "lvl0_place_kernel",
                   "lvl0_lcp_keys_kernel", "validate_n_strings_kernel", "score_walk_kernel"):
         if name.startswith(plain + "<"):
