@@ -12,6 +12,7 @@ in the CPU tests).  A single document's suffix sort does not shard.
 import numpy as np
 
 from east import consts
+from east import hip_backend
 from east import relevance
 from east import utils
 
@@ -56,21 +57,34 @@ def all_gather_table(local_block, counts, group=None):
 class DistributedASTRelevanceMeasure(relevance.ASTRelevanceMeasure):
     """ASTRelevanceMeasure whose text collection is sharded over the ranks of a
     torch.distributed process group.  Every rank calls the same methods with the
-    same arguments; relevance_table returns the full K x D table on every rank."""
+    same arguments; relevance_table returns the full K x D table on every rank.
+
+    With the nccl (= RCCL) backend the rank's K x D_local block never leaves the device before the
+    collective: the score kernels write it into a torch tensor (east_hip_score_resident's d_out),
+    which goes straight into all_gather_into_tensor; the assembled table is copied to the host once."""
 
     def __init__(self, ast_algorithm=consts.ASTAlgorithm.EASA, normalized=True, device=None, group=None,
                  measure_factory=None):
         super(DistributedASTRelevanceMeasure, self).__init__(ast_algorithm, normalized, device)
         self.group = group
+        # ONE device for the index and for the collective: the explicit one, else EAST_HIP_DEVICE / LOCAL_RANK
+        self.gpu = hip_backend.default_device() if device is None else int(device)
         # the local shard's measure; the factory hook exists so that the collective
         # logic can be exercised on CPU (gloo) with a stand-in scorer
-        self._factory = measure_factory or (lambda: relevance.ASTRelevanceMeasure(ast_algorithm, normalized, device))
+        self._factory = measure_factory or (lambda: relevance.ASTRelevanceMeasure(ast_algorithm, normalized, self.gpu))
+
+    def _on_gpu(self):
+        import torch.distributed as dist
+        return dist.get_backend(self.group) == "nccl"
 
     def set_text_collection(self, texts, language=consts.Language.ENGLISH):
         import torch.distributed as dist
         self.texts = texts
         self.language = language
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        if self._on_gpu():
+            import torch
+            torch.cuda.set_device(self.gpu)          # also for a rank whose shard is empty and never calls the library
         self.shards = shard_documents([len(t) for t in texts], world)
         self.counts = [e - b for b, e in self.shards]
         b, e = self.shards[rank]
@@ -79,20 +93,36 @@ class DistributedASTRelevanceMeasure(relevance.ASTRelevanceMeasure):
         if e > b:
             self.local.set_text_collection(list(texts[b:e]), language)
 
-    def relevance_table(self, prepared_keyphrases):
+    def _local_block(self, prepared_keyphrases, synonimizer):
+        """K x D_local block of this rank as a torch tensor on the collective's device."""
         import torch
         import torch.distributed as dist
         rank = dist.get_rank(self.group)
-        K = len(prepared_keyphrases)
+        K, D = len(prepared_keyphrases), self.counts[rank]
         self.local.normalized = self.normalized
-        if self.counts[rank]:
-            block = np.asarray(self.local.relevance_table(prepared_keyphrases), dtype=np.float64)
-        else:
-            block = np.zeros((K, 0), dtype=np.float64)
-        backend = dist.get_backend(self.group)
-        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-        table = all_gather_table(torch.from_numpy(block).to(dev), self.counts, self.group)
+        if self._on_gpu():
+            dev = torch.device("cuda", self.gpu)
+            block = torch.zeros((K, D), dtype=torch.float64, device=dev)
+            if D and not synonimizer and getattr(self.local, "index", None) is not None:
+                queries = [kp.replace(" ", "") for kp in prepared_keyphrases]
+                if not all(queries):
+                    raise ZeroDivisionError("float division by zero")
+                qs, qo = hip_backend.pack_queries(queries)
+                self.local.index.set_keyphrases(qs, qo)
+                self.local.index.score_resident(self.normalized, block.data_ptr())    # device to device, synchronised
+                return block
+            if D:
+                args = (prepared_keyphrases, synonimizer) if synonimizer else (prepared_keyphrases,)
+                block.copy_(torch.from_numpy(np.ascontiguousarray(self.local.relevance_table(*args))))
+            return block
+        if D:
+            args = (prepared_keyphrases, synonimizer) if synonimizer else (prepared_keyphrases,)
+            return torch.from_numpy(np.asarray(self.local.relevance_table(*args), dtype=np.float64))
+        return torch.zeros((K, 0), dtype=torch.float64)
+
+    def relevance_table(self, prepared_keyphrases, synonimizer=None):
+        table = all_gather_table(self._local_block(prepared_keyphrases, synonimizer), self.counts, self.group)
         return table.cpu().numpy()
 
     def relevance(self, keyphrase, text, synonimizer=None):
-        return float(self.relevance_table([keyphrase])[0, text])
+        return float(self.relevance_table([keyphrase], synonimizer)[0, text])
