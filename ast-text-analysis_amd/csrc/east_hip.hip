@@ -222,7 +222,7 @@ struct east_hip_index {
     // keyphrases + score scratch (own allocation, grown on demand)
     char *q_buf = nullptr;
     size_t q_cap = 0;
-    u32 n_kp = 0, n_q = 0;
+    u32 n_kp = 0, n_q = 0, score_chunk = 0;     // score_chunk: documents per stretch the scratch was sized for
     u32 *q_raw = nullptr, *q_code = nullptr, *q_end = nullptr, *q_off = nullptr, *group_off = nullptr;
     double *suffix = nullptr, *table = nullptr, *table_g = nullptr;
     // k-gram bucket tables for the score walk (own allocation, rebuilt after every build)
@@ -243,7 +243,20 @@ struct east_hip_index {
 
 struct SpecAbort {};             // a speculative build cannot go on: build_common starts over with the read-backs in place
 
-static void use_device(east_hip_index *h) { HIP_CHECK(hipSetDevice(h->device)); }
+// Every entry point runs on the handle's device and puts the calling thread's current device back on the way
+// out (a caller that also drives torch or other HIP code on another GPU must not find its device changed).
+static thread_local int g_saved_device = -1;
+static void use_device_ordinal(int device)
+{
+    int cur = -1;
+    if (g_saved_device < 0 && hipGetDevice(&cur) == hipSuccess && cur != device) g_saved_device = cur;
+    HIP_CHECK(hipSetDevice(device));
+}
+static void use_device(east_hip_index *h) { use_device_ordinal(h->device); }
+static void restore_device()
+{
+    if (g_saved_device >= 0) { (void)hipSetDevice(g_saved_device); g_saved_device = -1; }
+}
 
 static bool kgram_reserve(east_hip_index *h, u64 bins, u32 n_docs);
 
@@ -673,7 +686,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     u32 *d_word_hi = ar.alloc<u32>(TP_WORD_HI_WORDS);
     u32 *d_digit_hi = ar.alloc<u32>(TP_WORD_HI_WORDS);
     u32 *d_hi_from = ar.alloc<u32>((size_t)n_hi_upper + 1), *d_hi_to = ar.alloc<u32>((size_t)n_hi_upper + 1);
-    u32 *d_bad = ar.alloc<u32>(1);
+    unsigned long long *d_bad = ar.alloc<unsigned long long>(1);
     std::vector<u32> off32((size_t)D + 1);
     for (u32 d = 0; d <= D; d++) off32[d] = (u32)text_offsets[d];
     if (texts) {
@@ -695,7 +708,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
         HIP_CHECK(hipMemcpyAsync(d_hi_from, hi_upper_from, (size_t)n_hi_upper * 4, hipMemcpyHostToDevice, h->stream));
         HIP_CHECK(hipMemcpyAsync(d_hi_to, hi_upper_to, (size_t)n_hi_upper * 4, hipMemcpyHostToDevice, h->stream));
     }
-    HIP_CHECK(hipMemsetAsync(d_bad, 0xFF, 4, h->stream));
+    HIP_CHECK(hipMemsetAsync(d_bad, 0xFF, 8, h->stream));
     const TpTables tables{d_class, d_upper, d_word_hi, d_digit_hi, d_hi_from, d_hi_to, (u32)n_hi_upper};
 
     // bytes -> code points
@@ -717,7 +730,8 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     u32 *nd_ex = ar.alloc<u32>((size_t)n_cp + 1);
     device_scan<TpTokStartIn, true>(ctx, TpTokStartIn{cw, n_cp}, n_cp, tok_inc);
     device_scan<TpNonDigitIn, false>(ctx, TpNonDigitIn{cw, n_cp}, n_cp + 1, nd_ex);
-    u32 n_tok = 0, bad = 0;
+    u32 n_tok = 0;
+    unsigned long long bad = 0;
     HIP_CHECK(hipMemcpyAsync(&n_tok, tok_inc + (n_cp - 1), 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
     u32 *tstart = ar.alloc<u32>((size_t)n_tok + 1), *tend = ar.alloc<u32>((size_t)n_tok + 1);
@@ -761,19 +775,20 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
                (const u32 *)klen_ex, (const u32 *)doc_cp_off, (const u32 *)first_tok, (const u32 *)doc_sym_off, D, n_tok,
                tok_out, tok_term);
         LAUNCH(ctx, tp_emit_kernel, ceil_div_u32(n_cp, BLOCK), (const u32 *)cpu, (const uint8_t *)cw, (const u32 *)tok_inc,
-               (const u32 *)tstart, (const u32 *)tend, (const u32 *)tok_out, (const u32 *)tok_term, n_cp, h->prep_sym,
-               d_bad);
+               (const u32 *)tstart, (const u32 *)tend, (const u32 *)tok_out, (const u32 *)tok_term, n_cp,
+               (const u32 *)doc_cp_off, D, h->prep_sym, d_bad);
     }
     LAUNCH(ctx, tp_empty_docs_kernel, ceil_div_u32(D, BLOCK), (const u32 *)first_tok, (const u32 *)keep_ex,
            (const u32 *)doc_sym_off, D, h->prep_sym);
     HIP_CHECK(hipEventRecord(h->ev1, h->stream));
-    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipEventElapsedTime(&h->last_prep_ms, h->ev0, h->ev1));
-    if (bad != 0xFFFFFFFFu) {
+    if (bad != ~0ull) {
         h->prep_doc_off.clear();
-        char msg[160];
-        snprintf(msg, sizeof(msg), "text contains the word character U+%04X >= U+0A00 (outside the method's domain)", bad);
+        char msg[200];
+        snprintf(msg, sizeof(msg), "text %u contains the word character U+%04X >= U+0A00 (outside the method's domain)",
+                 (unsigned)(bad >> 32), (unsigned)(bad & 0xFFFFFFFFu));
         east_throw(EAST_HIP_ERR_DOMAIN, msg);
     }
 
@@ -786,6 +801,17 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
 }
 
 // ------------------------------------------------------------------ score --
+// The walk writes one fp64 per (keyphrase suffix, document); that scratch is bounded -- a table over a million
+// one-line documents would need hundreds of GB -- and the documents are scored a stretch at a time.
+#define SCORE_SCRATCH_BYTES ((size_t)1 << 30)
+static size_t g_score_scratch_bytes = SCORE_SCRATCH_BYTES;     // east_hip_debug_set_score_scratch (tests)
+static u32 score_doc_chunk(u32 n_q, u32 n_docs)
+{
+    const size_t per_doc = (size_t)n_q * 8;
+    const size_t fit = per_doc ? g_score_scratch_bytes / per_doc : n_docs;
+    return (u32)std::min<size_t>(n_docs, std::max<size_t>(fit, 1));
+}
+
 static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q_offsets, int32_t n_kp)
 {
     if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
@@ -801,8 +827,9 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
     use_device(h);
     const u32 n_q = (u32)S;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const u32 chunk = score_doc_chunk(n_q, h->n_docs);
     const size_t bytes = 256 + al((size_t)n_q * 4) * 3 + al(((size_t)n_kp + 1) * 4) * 2 +
-                         al((size_t)n_q * h->n_docs * 8) + al((size_t)n_kp * h->n_docs * 8) * 2;
+                         al((size_t)n_q * chunk * 8) + al((size_t)n_kp * h->n_docs * 8) * 2;
     if (bytes > h->q_cap) {
         HIP_CHECK(hipStreamSynchronize(h->stream));
         if (h->q_buf) HIP_CHECK(hipFree(h->q_buf));
@@ -819,7 +846,7 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
     h->q_end = (u32 *)p;  p += al((size_t)n_q * 4);
     h->q_off = (u32 *)p;  p += al(((size_t)n_kp + 1) * 4);
     h->group_off = (u32 *)p; p += al(((size_t)n_kp + 1) * 4);      // synonym-expanded scoring: variants per keyphrase
-    h->suffix = (double *)p; p += al((size_t)n_q * h->n_docs * 8);
+    h->suffix = (double *)p; p += al((size_t)n_q * chunk * 8);
     h->table = (double *)p; p += al((size_t)n_kp * h->n_docs * 8);
     h->table_g = (double *)p;
     std::vector<u32> end(n_q), off((size_t)n_kp + 1);
@@ -834,6 +861,7 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->n_kp = (u32)n_kp;
     h->n_q = n_q;
+    h->score_chunk = chunk;
 }
 
 // device memory for n_docs rows of bins + 1 entries plus the fill's chunk scratch; false if it cannot be had
@@ -906,7 +934,8 @@ static void ensure_kgram(east_hip_index *h, Ctx &ctx)
 }
 
 // queues the score kernels; result in h->table (K x D) / h->suffix (D x S)
-static void score_resident(east_hip_index *h, int normalized, unsigned long long *probe_count = nullptr)
+static void score_resident(east_hip_index *h, int normalized, unsigned long long *probe_count = nullptr,
+                           double *suffix_host = nullptr)
 {
     if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
     if (!h->built) east_throw(EAST_HIP_ERR_NOT_BUILT, "no index has been built on this handle");
@@ -919,36 +948,45 @@ static void score_resident(east_hip_index *h, int normalized, unsigned long long
     ensure_kgram(h, ctx);
     LAUNCH(ctx, query_map_kernel, ceil_div_u32(h->n_q, BLOCK), (const u32 *)h->q_raw, h->n_q,
            (const u32 *)h->code_map, h->q_code);
-    const int xcd_order = h->n_docs >= 64;                // see score_walk_kernel
-    const u32 walk_grid = (xcd_order ? 8u * ceil_div_u32(h->n_docs, 8) : h->n_docs) * ceil_div_u32(h->n_q, BLOCK);
-    if (h->use_s8)
-        LAUNCH_NAMED(ctx, "score_walk_kernel", (score_walk_kernel<uint8_t>), walk_grid, (const uint8_t *)h->s8,
-                     (const u32 *)h->sa, (const u32 *)h->doc_off, (const u32 *)h->n_strings, h->n_docs,
-                     (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, (const u32 *)h->kg, h->kg_k,
-                     h->kg_A, h->kg_bins, xcd_order, h->suffix, probe_count);
-    else
-        LAUNCH_NAMED(ctx, "score_walk_kernel", (score_walk_kernel<u32>), walk_grid, (const u32 *)h->s,
-                     (const u32 *)h->sa, (const u32 *)h->doc_off, (const u32 *)h->n_strings, h->n_docs,
-                     (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, (const u32 *)h->kg, h->kg_k,
-                     h->kg_A, h->kg_bins, xcd_order, h->suffix, probe_count);
-    LAUNCH(ctx, score_reduce_kernel, ceil_div_u32((u64)h->n_kp * h->n_docs, BLOCK), (const double *)h->suffix,
-           (const u32 *)h->q_off, h->n_kp, h->n_docs, h->n_q, h->table);
+    const u32 chunk = h->score_chunk;
+    for (u32 first = 0; first < h->n_docs; first += chunk) {
+        const u32 count = std::min(chunk, h->n_docs - first);
+        const int xcd_order = count >= 64;                // see score_walk_kernel
+        const u32 walk_grid = (xcd_order ? 8u * ceil_div_u32(count, 8) : count) * ceil_div_u32(h->n_q, BLOCK);
+        if (h->use_s8)
+            LAUNCH_NAMED(ctx, "score_walk_kernel", (score_walk_kernel<uint8_t>), walk_grid, (const uint8_t *)h->s8,
+                         (const u32 *)h->sa, (const u32 *)h->doc_off, (const u32 *)h->n_strings, h->n_docs,
+                         (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, (const u32 *)h->kg, h->kg_k,
+                         h->kg_A, h->kg_bins, xcd_order, first, count, h->suffix, probe_count);
+        else
+            LAUNCH_NAMED(ctx, "score_walk_kernel", (score_walk_kernel<u32>), walk_grid, (const u32 *)h->s,
+                         (const u32 *)h->sa, (const u32 *)h->doc_off, (const u32 *)h->n_strings, h->n_docs,
+                         (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, (const u32 *)h->kg, h->kg_k,
+                         h->kg_A, h->kg_bins, xcd_order, first, count, h->suffix, probe_count);
+        LAUNCH(ctx, score_reduce_kernel, ceil_div_u32((u64)h->n_kp * count, BLOCK), (const double *)h->suffix,
+               (const u32 *)h->q_off, h->n_kp, h->n_docs, h->n_q, first, count, h->table);
+        if (suffix_host)                                  // the per-suffix results of this stretch of documents (D x S, row-major)
+            HIP_CHECK(hipMemcpyAsync(suffix_host + (size_t)first * h->n_q, h->suffix, (size_t)count * h->n_q * 8,
+                                     hipMemcpyDeviceToHost, h->stream));
+    }
     HIP_CHECK(hipEventRecord(h->ev1, h->stream));
 }
 
 // ------------------------------------------------------------------ C ABI --
 template <class F> static int guarded(F f)
 {
+    int rc = EAST_HIP_OK;
     try {
         f();
-        return EAST_HIP_OK;
     } catch (const EastError &e) {
         g_last_error = e.msg;
-        return e.code;
+        rc = e.code;
     } catch (const std::exception &e) {
         g_last_error = e.what();
-        return EAST_HIP_ERR_INTERNAL;
+        rc = EAST_HIP_ERR_INTERNAL;
     }
+    restore_device();
+    return rc;
 }
 
 extern "C" {
@@ -980,7 +1018,7 @@ int east_hip_create(int device, int64_t reserve_symbols, east_hip_handle_t *out)
         east_hip_index *h = new east_hip_index();
         h->device = device;
         try {
-            HIP_CHECK(hipSetDevice(device));
+            use_device_ordinal(device);
             HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreate(&h->ev0));
             HIP_CHECK(hipEventCreate(&h->ev1));
@@ -997,6 +1035,8 @@ int east_hip_create(int device, int64_t reserve_symbols, east_hip_handle_t *out)
 void east_hip_destroy(east_hip_handle_t h)
 {
     if (!h) return;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->arena.base) (void)hipFree(h->arena.base);
@@ -1006,6 +1046,7 @@ void east_hip_destroy(east_hip_handle_t h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (cur >= 0 && cur != h->device) (void)hipSetDevice(cur);
     delete h;
 }
 
@@ -1141,11 +1182,8 @@ int east_hip_score_table(east_hip_handle_t h, const uint32_t *q_symbols, const i
     return guarded([&] {
         if (!out) east_throw(EAST_HIP_ERR_INVALID, "null output table");
         set_keyphrases(h, q_symbols, q_offsets, n_keyphrases);
-        score_resident(h, normalized);
+        score_resident(h, normalized, nullptr, suffix_out);
         HIP_CHECK(hipMemcpyAsync(out, h->table, (size_t)h->n_kp * h->n_docs * 8, hipMemcpyDeviceToHost, h->stream));
-        if (suffix_out)
-            HIP_CHECK(hipMemcpyAsync(suffix_out, h->suffix, (size_t)h->n_q * h->n_docs * 8, hipMemcpyDeviceToHost,
-                                     h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
         HIP_CHECK(hipEventElapsedTime(&h->last_score_ms, h->ev0, h->ev1));
     });
@@ -1216,6 +1254,11 @@ int east_hip_reset(east_hip_handle_t h)
         h->prep_n_strings.clear();
         h->prof.enabled = false;
         h->stats = Stats();
+        // a recycled handle keeps its stream and a small arena, not gigabytes of side allocations
+        const size_t keep = (size_t)64 << 20;
+        if (h->q_cap > keep) { (void)hipFree(h->q_buf); h->q_buf = nullptr; h->q_cap = 0; }
+        if (h->kg_cap > keep) { (void)hipFree(h->kg); h->kg = nullptr; h->kg_cap = 0; }
+        if (h->prep_cap > keep) { (void)hipFree(h->prep_sym); h->prep_sym = nullptr; h->prep_cap = 0; }
     });
 }
 
@@ -1257,9 +1300,12 @@ int east_hip_profile_enable(east_hip_handle_t h, int on)
 int64_t east_hip_profile_report(east_hip_handle_t h, char *buf, int64_t cap)
 {
     if (!h || !buf || cap < 1) return EAST_HIP_ERR_INVALID;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     h->prof.collect();
+    if (cur >= 0 && cur != h->device) (void)hipSetDevice(cur);
     std::string out;
     for (auto &s : h->prof.sums) {
         char line[256];
@@ -1305,7 +1351,7 @@ struct DebugScope {
         if (hipGetDeviceCount(&c) != hipSuccess || c <= 0)
             east_throw(EAST_HIP_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
         if (device < 0 || device >= c) east_throw(EAST_HIP_ERR_NO_DEVICE, "device ordinal out of range");
-        HIP_CHECK(hipSetDevice(device));
+        use_device_ordinal(device);
         HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         void *p = nullptr;
         HIP_CHECK(hipMalloc(&p, bytes));
@@ -1355,6 +1401,12 @@ int east_hip_debug_set_window_sort(int enabled)
     g_force_lean = enabled == 2;
     g_force_wide_keys = enabled == 3;
     g_plan_epoch++;
+    return EAST_HIP_OK;
+}
+
+int east_hip_debug_set_score_scratch(int64_t bytes)
+{
+    g_score_scratch_bytes = bytes > 0 ? (size_t)bytes : SCORE_SCRATCH_BYTES;
     return EAST_HIP_OK;
 }
 

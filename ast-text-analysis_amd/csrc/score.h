@@ -264,7 +264,8 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
     const SYM *__restrict__ s, const u32 *__restrict__ sa, const u32 *__restrict__ doc_off,
     const u32 *__restrict__ n_strings, u32 n_docs, const u32 *__restrict__ q_code,
     const u32 *__restrict__ q_end, u32 n_q, int normalized, const u32 *__restrict__ kg, int kg_k, u32 kg_A,
-    u32 kg_bins, int xcd_order, double *__restrict__ suffix_out, unsigned long long *__restrict__ probe_count)
+    u32 kg_bins, int xcd_order, u32 doc_first, u32 doc_count, double *__restrict__ suffix_out,
+    unsigned long long *__restrict__ probe_count)
 {
     // XCD-aware work order: workgroups go round-robin over the 8 XCDs, each with its own 4 MB L2.  All the
     // keyphrase suffixes of ONE document are walked by ONE XCD (document d belongs to XCD d mod 8, which takes
@@ -272,9 +273,11 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
     // (Only with many documents -- xcd_order, host side: with a handful an XCD would sit idle.)
     const u32 blocks_per_doc = (n_q + BLOCK - 1u) / BLOCK;
     const u32 local = xcd_order ? blockIdx.x >> 3 : blockIdx.x;
-    const u32 d = xcd_order ? (local / blocks_per_doc) * 8u + (blockIdx.x & 7u) : local / blocks_per_doc;
+    // (the documents [doc_first, doc_first + doc_count) of this launch: the per-suffix scratch is bounded, see score_resident)
+    const u32 dl = xcd_order ? (local / blocks_per_doc) * 8u + (blockIdx.x & 7u) : local / blocks_per_doc;
     const u32 si = (local % blocks_per_doc) * BLOCK + threadIdx.x;
-    if (d >= n_docs || si >= n_q) return;
+    if (dl >= doc_count || si >= n_q) return;
+    const u32 d = doc_first + dl;
     u32 probes = 0;                     // table reads and binary-search probes of this walk (roofline accounting)
     const u32 seg = doc_off[d];
     const u32 nd = doc_off[d + 1] - seg;
@@ -344,27 +347,27 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
         r = (acc + (double)depth) - (double)nodes;        // easa.py:127
         if (normalized) r /= (double)depth;               // easa.py:128-129
     }
-    suffix_out[(u64)d * n_q + si] = r;
+    suffix_out[(u64)dl * n_q + si] = r;
     if (probe_count) atomicAdd(probe_count, (unsigned long long)probes);   // (counting runs only: east_hip_score_probes)
 }
 
 // out[k*D + d] = (sum of the keyphrase's suffix results, in suffix order) / |q|
 __global__ __launch_bounds__(BLOCK) void score_reduce_kernel(const double *__restrict__ suffix,
                                                              const u32 *__restrict__ q_off,
-                                                             u32 n_kp, u32 n_docs, u32 n_q,
+                                                             u32 n_kp, u32 n_docs, u32 n_q, u32 doc_first, u32 doc_count,
                                                              double *__restrict__ out)
 {
     // neighbouring threads take neighbouring keyphrases of ONE document: their suffix results lie side by
     // side in that document's row (the 8-byte stores into the K x D table are the strided side: 13x fewer)
     const u64 gid = (u64)blockIdx.x * BLOCK + threadIdx.x;
-    if (gid >= (u64)n_kp * n_docs) return;
-    const u32 d = (u32)(gid / n_kp);
+    if (gid >= (u64)n_kp * doc_count) return;
+    const u32 d = (u32)(gid / n_kp);                      // (local to this launch's documents)
     const u32 k = (u32)(gid - (u64)d * n_kp);
     const u32 b = q_off[k], e = q_off[k + 1];
     const double *row = suffix + (u64)d * n_q;
     double total = 0.0;
     for (u32 i = b; i < e; i++) total += row[i];          // easa.py:130
-    out[(u64)k * n_docs + d] = total / (double)(e - b);   // easa.py:134
+    out[(u64)k * n_docs + doc_first + d] = total / (double)(e - b);   // easa.py:134
 }
 
 // Synonym-expanded scoring (easa.py:27-34): every keyphrase was expanded into its variants (the product of the

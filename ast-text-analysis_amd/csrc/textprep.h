@@ -233,7 +233,8 @@ __global__ __launch_bounds__(BLOCK) void tp_emit_kernel(const u32 *__restrict__ 
                                                         const u32 *__restrict__ tstart, const u32 *__restrict__ tend,
                                                         const u32 *__restrict__ tok_out,
                                                         const u32 *__restrict__ tok_term, u32 n_cp,
-                                                        u32 *__restrict__ sym, u32 *__restrict__ bad_cp)
+                                                        const u32 *__restrict__ doc_cp_off, u32 n_docs,
+                                                        u32 *__restrict__ sym, unsigned long long *__restrict__ bad)
 {
     const u32 p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= n_cp || !(cw[p] & TP_CLASS_WORD)) return;
@@ -242,7 +243,14 @@ __global__ __launch_bounds__(BLOCK) void tp_emit_kernel(const u32 *__restrict__ 
     if (base == TP_DROPPED) return;                         // token dropped
     const u32 out = base + (p - tstart[k]);
     const u32 cp = cpu[p];
-    if (cp >= TP_TEXT_LIMIT) atomicMin(bad_cp, cp);         // a kept word character outside the method's domain
+    if (cp >= TP_TEXT_LIMIT) {                              // a kept word character outside the method's domain:
+        u32 lo = 0, hi = n_docs;                            // remember the first document it occurs in, and the character
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (doc_cp_off[mid] <= p) lo = mid; else hi = mid;
+        }
+        atomicMin(bad, ((unsigned long long)lo << 32) | cp);
+    }
     sym[out] = cp;
     const u32 term = tok_term[k];
     if (term && p == tend[k]) sym[out + 1u] = term;

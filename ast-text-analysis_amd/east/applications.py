@@ -2,6 +2,7 @@
 """keyphrases_table / keyphrases_graph (reference east/applications.py:11-149)."""
 
 from east import consts
+from east import exceptions
 from east import logging
 from east import relevance
 from east import utils
@@ -20,7 +21,12 @@ def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=Non
 
     text_titles = list(texts.keys())
     text_collection = list(texts.values())
-    similarity_measure.set_text_collection(text_collection, language)
+    try:
+        similarity_measure.set_text_collection(text_collection, language)
+    except exceptions.SymbolOutOfDomainException as e:        # name the text instead of numbering it
+        if isinstance(e.document, int) and 0 <= e.document < len(text_titles):
+            raise exceptions.SymbolOutOfDomainException(code=e.code, document=str(text_titles[e.document]))
+        raise
 
     keyphrases_prepared = {keyphrase: utils.prepare_text(keyphrase) for keyphrase in keyphrases}
     res = {}

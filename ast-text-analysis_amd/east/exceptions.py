@@ -35,8 +35,14 @@ class SymbolOutOfDomainException(EastException):
     """New: the reference is only defined for text code points below U+0A00
     (its string terminators start there, east/asts/utils.py:25-40); it crashes or
     gives algorithm-dependent scores beyond.  The HIP backend rejects such input."""
-    msg_fmt = ("Text contains the code point U+%(code)04X >= U+0A00, which collides with the "
+    msg_fmt = ("Text%(where)s contains the code point U+%(code)04X >= U+0A00, which collides with the "
                "string terminators of the annotated suffix tree (outside the method's domain).")
+
+    def __init__(self, code, document=None):
+        """document: index (or name) of the first text the character was found in, if known."""
+        self.code, self.document = code, document
+        super(SymbolOutOfDomainException, self).__init__(
+            code=code, where="" if document is None else " %s" % (repr(document) if isinstance(document, str) else "number %d" % document))
 
 
 class HipBackendError(EastException):

@@ -66,6 +66,7 @@ SIGNATURES = {
     "east_hip_debug_set_rank_bucket_bytes": (ctypes.c_int, [ctypes.c_int64]),
     "east_hip_debug_set_window_sort": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_debug_set_speculation": (ctypes.c_int, [ctypes.c_int]),
+    "east_hip_debug_set_score_scratch": (ctypes.c_int, [ctypes.c_int64]),
     "east_hip_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "east_hip_profile_report": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
 }

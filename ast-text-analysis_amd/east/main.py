@@ -12,6 +12,7 @@ import sys
 
 from east import applications
 from east import consts
+from east import exceptions
 from east import formatting
 from east import relevance
 
@@ -77,6 +78,14 @@ def main(argv=None):
         print("Synonym extraction (-y) needs the external Tomita parser and is not available.")
         return 1
 
+    try:
+        return _run(subcommand, keyphrases, texts, similarity_measure, opts)
+    except exceptions.EastException as e:       # (input outside the method's domain, no device, ...): a message, not a traceback
+        print(e)
+        return 1
+
+
+def _run(subcommand, keyphrases, texts, similarity_measure, opts):
     if subcommand == "table":
         table = applications.keyphrases_table(keyphrases, texts, similarity_measure, None, opts["-l"])
         table_format = opts.get("-f", "xml").lower()

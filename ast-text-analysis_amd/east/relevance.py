@@ -9,6 +9,7 @@ CosineRelevanceMeasure is a different method and out of scope.
 """
 import itertools
 import os
+import re
 
 import numpy as np
 
@@ -148,8 +149,9 @@ class ASTRelevanceMeasure(RelevanceMeasure):
                 self.index.build_texts(list(texts))
             except exceptions.HipBackendError as e:
                 if "outside the method's domain" in str(e):
-                    code = int(str(e).split("U+")[1].split()[0], 16)
-                    raise exceptions.SymbolOutOfDomainException(code=code)
+                    found = re.search(r"text (\d+) contains the word character U\+([0-9A-Fa-f]+)", str(e))
+                    if found:
+                        raise exceptions.SymbolOutOfDomainException(code=int(found.group(2), 16), document=int(found.group(1)))
                 raise
             self.asts = [_DocumentAST(self._shard, d) for d in range(len(texts))]
             self._shard.row_cache = (None, None, None)
@@ -160,7 +162,15 @@ class ASTRelevanceMeasure(RelevanceMeasure):
 
     def set_strings_collections(self, collections):
         """collections[d] = the strings collection of document d (one AST each)."""
-        parts = [ast_utils.strings_to_symbols(sc) for sc in collections]
+        parts = []
+        for d, sc in enumerate(collections):
+            try:
+                parts.append(ast_utils.strings_to_symbols(sc))
+            except exceptions.SymbolOutOfDomainException as e:
+                raise exceptions.SymbolOutOfDomainException(code=e.code, document=d)
+        self._build_from_parts(parts, collections)
+
+    def _build_from_parts(self, parts, collections):
         doc_offsets = np.zeros(len(parts) + 1, dtype=np.int64)
         np.cumsum([p.size for p in parts], out=doc_offsets[1:])
         n_strings = np.array([len(sc) for sc in collections], dtype=np.int32)

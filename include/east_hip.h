@@ -15,7 +15,8 @@
  *   - plain pointers and sizes only; the caller owns every host buffer
  *     (C-contiguous), the library owns device memory behind the opaque handle
  *   - calls are blocking unless the name ends in _async; a handle is not
- *     thread-safe, distinct handles are; one HIP stream per handle
+ *     thread-safe, distinct handles are; one HIP stream per handle; every call runs on
+ *     the handle's device and restores the calling thread's current HIP device before it returns
  *   - indices are int32 on the device (n_total < 2^31 - 8); the Python side
  *     widens to int64 to match the reference's np.int tables
  *   - symbols are Unicode code points; a symbol >= 0x0A00 is a string
@@ -252,6 +253,10 @@ int east_hip_debug_set_window_sort(int enabled);
  * first build does; 1 (default) = later builds on a handle are queued without waiting, on the strength
  * of what the build before found, and checked by the one read-back at their end. */
 int east_hip_debug_set_speculation(int enabled);
+/* Test knob: bytes of per-suffix scratch a score call may use (default 1 GiB; 0 restores it); a table over
+ * more documents than fit is scored a stretch of documents at a time.  Takes effect at the next
+ * east_hip_set_keyphrases / east_hip_score_table. */
+int east_hip_debug_set_score_scratch(int64_t bytes);
 /* Host-only: bytes of device arena a build of n_total symbols / n_docs documents
  * reserves (worst case over inputs).  Needs no device. */
 int64_t east_hip_plan_arena_bytes(int64_t n_total, int32_t n_docs);

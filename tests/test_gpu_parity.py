@@ -6,6 +6,8 @@ Bar: suffix array, LCP, annotation and child tables bit-exact; scores are
 compared with == (bit-equal) where the fixtures hold them and the required
 tolerance 1e-6 is asserted as well.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1069,6 +1071,61 @@ def test_many_small_documents(hip, oracle):
             assert np.array_equal(t[name], getattr(o, name)), (name, d)
         for k, kp in enumerate(kps):
             assert table[k, d] == o.score(kp, fast=True), (d, kp)
+
+
+def test_out_of_domain_text_is_reported_with_its_document(hip, tmp_path, capsys):
+    """A kept word character >= U+0A00 is outside the method's domain: the error names the first
+    text it occurs in -- on the device and on the host text preparation -- and the CLI prints it and returns 1."""
+    from east import applications, exceptions, main as east_main, relevance
+    texts = {"plain": b"alpha beta gamma delta", "cjk": "alpha \u4e2d\u6587\u5b57\u5178 beta".encode("utf-8"), "later": "\u0e01\u0e02\u0e03\u0e04".encode("utf-8")}
+    for prep in ("device", "host"):
+        os.environ["EAST_HIP_TEXT_PREP"] = prep
+        try:
+            with pytest.raises(exceptions.SymbolOutOfDomainException) as e:
+                applications.keyphrases_table(["alpha"], texts, relevance.ASTRelevanceMeasure())
+            assert e.value.document == "cjk" and e.value.code == 0x4E2D and "'cjk'" in str(e.value)
+            with pytest.raises(exceptions.SymbolOutOfDomainException) as e:
+                relevance.ASTRelevanceMeasure().set_text_collection(list(texts.values()))
+            assert e.value.document == 1
+        finally:
+            os.environ.pop("EAST_HIP_TEXT_PREP", None)
+    tdir = tmp_path / "texts"
+    tdir.mkdir()
+    for name, raw in texts.items():
+        (tdir / (name + ".txt")).write_bytes(raw)
+    (tmp_path / "kp.txt").write_text("alpha\n")
+    assert east_main.main(["keyphrases", "table", str(tmp_path / "kp.txt"), str(tdir)]) == 1
+    assert "U+4E2D" in capsys.readouterr().out
+    # texts without such characters next to it are fine
+    del texts["cjk"], texts["later"]
+    assert applications.keyphrases_table(["alpha"], texts, relevance.ASTRelevanceMeasure())["alpha"]["plain"] > 0
+
+
+def test_score_in_stretches_of_documents(hip, oracle):
+    """The per-suffix scratch of a score call is bounded: with a small bound the table and the per-suffix results
+    come out a stretch of documents at a time, identical to the one-piece result."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(61)
+    docs = [synthetic.word_stream_document(rng, int(rng.integers(200, 3000)), want_text=False)[1:] for _ in range(137)]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    index = hip_backend.HipIndex()
+    index.build(sym, off, np.array([d[1] for d in docs]))
+    qs, qo = synthetic.keyphrases(rng, sym, 40)
+    want, want_suf = index.score_table(qs, qo, True, want_suffix=True)
+    lib = hip.load()
+    assert lib.east_hip_debug_set_score_scratch(int(qo[-1]) * 8 * 10) == 0          # ten documents at a time
+    try:
+        got, got_suf = index.score_table(qs, qo, True, want_suffix=True)
+        assert np.array_equal(got, want) and np.array_equal(got_suf, want_suf)
+        index.set_keyphrases(qs, qo)
+        index.score_resident(True)
+        assert np.array_equal(index.score_table(qs, qo, False), index.score_table(qs, qo, False))
+    finally:
+        assert lib.east_hip_debug_set_score_scratch(0) == 0
+    o = oracle.OracleEASA(symbols=docs[77][0], n_strings=docs[77][1])
+    for k in range(40):
+        assert want[k, 77] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=True)
 
 
 def test_half_gib_symbols(hip):
