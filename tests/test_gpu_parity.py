@@ -822,6 +822,34 @@ def test_resident_build_fits_the_planned_arena(hip, corpus, wide_keys):
     assert int(t.sum()) == docs[0][0].size * (docs[0][0].size - 1) // 2       # a permutation of the document's positions
 
 
+def test_config5_zipf_100_documents_full_size(hip, oracle):
+    """BASELINE config 5 stand-in at its full size (enwik8 is not available offline): 100 natural-language-like
+    documents of 1 MiB (Zipf vocabulary, 94 M symbols, tie-refinement rounds), one batched build.  Every document:
+    the properties that pin SA / LCP / annotation; 6 sampled documents: tables and 400 scores, normalized and
+    -d denormalized, bit-equal to the oracle (the oracle itself is pinned to ast_linear on the zipf_docs fixture)."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(20240 + 5)
+    vocab = synthetic.zipf_vocabulary(np.random.default_rng(20245))
+    docs = [synthetic.zipf_document(rng, 1 << 20, vocab) for _ in range(100)]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])]).astype(np.int64)
+    index = hip_backend.HipIndex()
+    index.build(sym, off, np.array([d[1] for d in docs], dtype=np.int32))
+    qs, qo = synthetic.keyphrases(rng, sym, 400)
+    tables = {norm: index.score_table(qs, qo, norm) for norm in (True, False)}
+    for d in range(100):
+        t = index.tables(d, names=("suftab", "lcptab", "anntab"))
+        _check_easa_properties(docs[d][0], docs[d][1], t, spot=150)
+    for d in (0, 17, 42, 63, 98, 99):
+        o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+        for norm in (True, False):
+            want = np.array([o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=True) for k in range(400)])
+            assert np.array_equal(tables[norm][:, d], want) and np.abs(tables[norm][:, d] - want).max() <= TOL, (d, norm)
+
+
 def test_speculative_builds_on_one_handle(hip, oracle):
     """Builds after the first on a handle are queued without waiting for the device (alphabet size, "no large
     tie groups" taken from the build before) and checked by one read-back at the end: a right guess and
