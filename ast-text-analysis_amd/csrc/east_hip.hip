@@ -1121,8 +1121,17 @@ int east_hip_get_tables(east_hip_handle_t h, int32_t doc, int32_t *suftab, int32
             Ctx ctx;
             ctx.stream = h->stream;
             ctx.prof = &h->prof;
-            LAUNCH(ctx, child_kernel, ceil_div_u32(h->n, BLOCK), h->pyr, (const u32 *)h->doc_off, h->n_docs, h->n,
-                   h->up, h->down, h->next);
+            // (the lists of the ranks the streaming pass leaves to the pyramid live in the arena's temporary region)
+            ctx.arena = &h->arena;
+            const size_t mark = h->arena.mark();
+            const u32 n_tiles = ceil_div_u32(h->n, CH_TILE);
+            u32 *wide_list = h->arena.alloc<u32>((size_t)n_tiles * CH_TILE);
+            u32 *wide_count = h->arena.alloc<u32>(n_tiles);
+            LAUNCH(ctx, child_stream_kernel, n_tiles, h->pyr, (const u32 *)h->doc_off, h->n_docs, h->n, h->up, h->down,
+                   h->next, wide_list, wide_count);
+            LAUNCH(ctx, child_wide_kernel, ceil_div_u32(n_tiles, BLOCK / CH_WIDE_SLOTS), h->pyr, (const u32 *)h->doc_off,
+                   h->n_docs, h->n, n_tiles, (const u32 *)wide_list, (const u32 *)wide_count, h->up, h->down, h->next);
+            h->arena.release(mark);
             h->child_built = true;
         }
         const size_t b = (size_t)h->h_doc_off[doc], nd = (size_t)(h->h_doc_off[doc + 1] - h->h_doc_off[doc]);

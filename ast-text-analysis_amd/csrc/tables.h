@@ -580,22 +580,21 @@ __global__ __launch_bounds__(BLOCK) void ann_wide_kernel(Pyramid P, u32 n, u32 n
     }
 }
 
-// The three child tables of one rank, positions local to the document, 0 = none
-// (easa.py:268-304).  Not needed by the score walk: computed on first request.
-__global__ __launch_bounds__(BLOCK) void child_kernel(Pyramid P, const u32 *__restrict__ doc_off, u32 n_docs,
-                                                      u32 n, u32 *__restrict__ up, u32 *__restrict__ down,
-                                                      u32 *__restrict__ next)
+// The three child tables, positions local to the document, 0 = none (easa.py:268-304), in two launches like the
+// annotation table.  child_stream_kernel stages 1024 LCP values + CH_HALO to either side in LDS; a thread walks from
+// each of its 4 ranks to the left until it meets a value <= its own (PSE) and to the right (NSE), at most CH_LOCAL
+// steps, keeping the leftmost minimum of what it passes -- that is up[] and down[] --; next[] is NSE where the
+// values are equal.  Ranks whose walk does not end inside CH_LOCAL steps (the top of the tree, about one in a
+// hundred) go to the tile's list for child_wide_kernel, which uses the pyramid.
+#define CH_HALO 32
+#define CH_LOCAL 24
+#define CH_IPT 4
+#define CH_TILE (BLOCK * CH_IPT)
+
+__device__ __forceinline__ void child_of_rank(const Pyramid &P, u32 k, u32 seg, u32 seg_end, u32 &u, u32 &dn, u32 &nx)
 {
-    const u32 k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= n) return;
     const u32 *lcp = P.ptr[0];
     const u32 v = lcp[k];
-    u32 seg = 0, seg_end = n;
-    if (n_docs > 1) {
-        const u32 d = doc_of(doc_off, n_docs, k);
-        seg = doc_off[d];
-        seg_end = doc_off[d + 1];
-    }
     // previous / next position with a value <= v, inside the document
     u32 pse = NONE_U32, nse = NONE_U32;
     if (k > seg) {
@@ -604,12 +603,133 @@ __global__ __launch_bounds__(BLOCK) void child_kernel(Pyramid P, const u32 *__re
     }
     nse = pyr_find_right<false>(P, k, v);
     if (nse != NONE_U32 && nse >= seg_end) nse = NONE_U32;
-    next[k] = (nse != NONE_U32 && lcp[nse] == v) ? nse - seg : 0u;
-    u32 u = 0, dn = 0;
+    nx = (nse != NONE_U32 && lcp[nse] == v) ? nse - seg : 0u;
+    u = dn = 0;
     if (pse != NONE_U32 && k - pse > 1) u = pyr_leftmost_argmin(P, pse, k) - seg;
     if (nse != NONE_U32 && nse - k > 1) dn = pyr_leftmost_argmin(P, k, nse) - seg;
-    up[k] = u;
-    down[k] = dn;
+}
+
+__global__ __launch_bounds__(BLOCK) void child_stream_kernel(Pyramid P, const u32 *__restrict__ doc_off, u32 n_docs, u32 n,
+                                                             u32 *__restrict__ up, u32 *__restrict__ down,
+                                                             u32 *__restrict__ next, u32 *__restrict__ wide_list,
+                                                             u32 *__restrict__ wide_count)
+{
+    __shared__ __attribute__((aligned(16))) u32 tile[CH_TILE + 2 * CH_HALO];
+    __shared__ u32 far_count;
+    const u32 *lcp = P.ptr[0];
+    if (threadIdx.x == 0) far_count = 0;
+    const u32 tile_base = blockIdx.x * CH_TILE;
+    const u32 k0 = tile_base + threadIdx.x * CH_IPT;
+    const u32 padded = (n + PYR_FAN - 1u) & ~(PYR_FAN - 1u);
+    {   // ranks outside [0, n) read as 0, which ends every walk
+        uint4 x = {0u, 0u, 0u, 0u};
+        if (k0 < padded) x = *reinterpret_cast<const uint4 *>(lcp + k0);
+        if (k0 + 0 >= n) x.x = 0u;
+        if (k0 + 1 >= n) x.y = 0u;
+        if (k0 + 2 >= n) x.z = 0u;
+        if (k0 + 3 >= n) x.w = 0u;
+        *reinterpret_cast<uint4 *>(&tile[CH_HALO + threadIdx.x * CH_IPT]) = x;
+        if (threadIdx.x < 2 * CH_HALO / 4) {
+            const bool left = threadIdx.x < CH_HALO / 4;
+            const u32 q = left ? threadIdx.x : threadIdx.x - CH_HALO / 4;
+            const i64 g = left ? (i64)tile_base - CH_HALO + 4 * q : (i64)tile_base + CH_TILE + 4 * q;
+            uint4 h = {0u, 0u, 0u, 0u};
+            if (g >= 0 && g < (i64)padded) h = *reinterpret_cast<const uint4 *>(lcp + g);
+            if (g + 0 >= (i64)n) h.x = 0u;
+            if (g + 1 >= (i64)n) h.y = 0u;
+            if (g + 2 >= (i64)n) h.z = 0u;
+            if (g + 3 >= (i64)n) h.w = 0u;
+            *reinterpret_cast<uint4 *>(&tile[left ? 4 * q : CH_HALO + CH_TILE + 4 * q]) = h;
+        }
+    }
+    __syncthreads();
+    if (k0 < n) {
+        // the document of the thread's first rank (the others step forward from it)
+        u32 d = n_docs > 1 ? doc_of(doc_off, n_docs, k0) : 0u;
+        u32 seg = n_docs > 1 ? doc_off[d] : 0u, seg_end = n_docs > 1 ? doc_off[d + 1] : n;
+        u32 o_up[CH_IPT], o_dn[CH_IPT], o_nx[CH_IPT];
+        bool all_local = k0 + CH_IPT <= n;
+#pragma unroll
+        for (int e = 0; e < CH_IPT; e++) {
+            const u32 k = k0 + e;
+            o_up[e] = o_dn[e] = o_nx[e] = 0;
+            if (k >= n) break;
+            while (k >= seg_end) { d++; seg = seg_end; seg_end = doc_off[d + 1]; }
+            const u32 at = CH_HALO + threadIdx.x * CH_IPT + e;
+            const u32 v = tile[at];
+            // to the left: nearest value <= v (PSE) and the leftmost minimum of the run before it
+            bool far = false;
+            u32 j, best = NONE_U32, best_at = 0;
+            if (k > seg) {
+                for (j = 1; j <= CH_LOCAL; j++) {
+                    const u32 x = tile[at - j];
+                    if (x <= v) break;
+                    if (x <= best) { best = x; best_at = k - j; }        // (<=: the leftmost of equal minima)
+                }
+                if (j > CH_LOCAL) far = true;
+                else if (j > 1) o_up[e] = best_at - seg;                // (pse = k - j >= seg: the document's first rank holds 0)
+            }
+            // to the right: nearest value <= v (NSE), inside the document, and the leftmost minimum before it
+            if (!far) {
+                best = NONE_U32;
+                for (j = 1; j <= CH_LOCAL; j++) {
+                    const u32 x = tile[at + j];
+                    if (x <= v) break;
+                    if (x < best) { best = x; best_at = k + j; }
+                }
+                if (j > CH_LOCAL) far = true;
+                else if (k + j < seg_end) {                              // (a rank of the next document, or past the end: no NSE)
+                    if (tile[at + j] == v) o_nx[e] = k + j - seg;
+                    if (j > 1) o_dn[e] = best_at - seg;
+                }
+            }
+            if (far) {
+                all_local = false;
+                wide_list[tile_base + atomicAdd(&far_count, 1u)] = k;
+                o_up[e] = NONE_U32;                                      // (marks the rank for the scalar path below)
+            }
+        }
+        if (all_local) {
+            *reinterpret_cast<uint4 *>(up + k0) = uint4{o_up[0], o_up[1], o_up[2], o_up[3]};
+            *reinterpret_cast<uint4 *>(down + k0) = uint4{o_dn[0], o_dn[1], o_dn[2], o_dn[3]};
+            *reinterpret_cast<uint4 *>(next + k0) = uint4{o_nx[0], o_nx[1], o_nx[2], o_nx[3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < CH_IPT; e++) {
+                if (k0 + e >= n || o_up[e] == NONE_U32) continue;
+                up[k0 + e] = o_up[e];
+                down[k0 + e] = o_dn[e];
+                next[k0 + e] = o_nx[e];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) wide_count[blockIdx.x] = far_count;
+}
+
+#define CH_WIDE_SLOTS 16
+__global__ __launch_bounds__(BLOCK) void child_wide_kernel(Pyramid P, const u32 *__restrict__ doc_off, u32 n_docs, u32 n,
+                                                           u32 n_tiles, const u32 *__restrict__ wide_list,
+                                                           const u32 *__restrict__ wide_count, u32 *__restrict__ up,
+                                                           u32 *__restrict__ down, u32 *__restrict__ next)
+{
+    const u32 tile = blockIdx.x * (BLOCK / CH_WIDE_SLOTS) + threadIdx.x / CH_WIDE_SLOTS;
+    if (tile >= n_tiles) return;
+    const u32 count = wide_count[tile];
+    for (u32 i = threadIdx.x % CH_WIDE_SLOTS; i < count; i += CH_WIDE_SLOTS) {
+        const u32 k = wide_list[tile * CH_TILE + i];
+        u32 seg = 0, seg_end = n;
+        if (n_docs > 1) {
+            const u32 d = doc_of(doc_off, n_docs, k);
+            seg = doc_off[d];
+            seg_end = doc_off[d + 1];
+        }
+        u32 u, dn, nx;
+        child_of_rank(P, k, seg, seg_end, u, dn, nx);
+        up[k] = u;
+        down[k] = dn;
+        next[k] = nx;
+    }
 }
 
 // Left boundaries of the lcp-intervals (easa.py:38-85, the traversals): an lcp-interval l-[i..j], l > 0, is

@@ -350,14 +350,47 @@ struct LongRepeats {
     int mode = 0;
 };
 
-template <class Starts, class LcpFirst>
-__device__ __forceinline__ u32 lvl0_place_tied(u32 j, const u32 *__restrict__ elem, const Starts &starts,
+// The first 8 symbols behind the common depth of the tied elements of a workgroup's stretch, gathered ONCE per
+// element into LDS: a member of a group of g then ranks itself with g - 1 LDS reads instead of 2 (g - 1) text gathers
+// (only pairs that agree on all 8 symbols go on reading the text).
+struct NextSymbols {
+    const u64 *k2 = nullptr;        // k2[x - first] for the domain positions first .. first + count - 1 (valid for tied ones)
+    u32 first = 0, count = 0;
+};
+
+// The keys and elements of a workgroup's stretch of the sorted domain (plus PLACE_HALO to either side), staged in
+// LDS by the placement pass: the tied elements look for the bounds of their groups and for the other members
+// there instead of through a dozen scattered global loads each (phase 2 of the pass was bound by those).
+// Outside the staged range both fall back to the arrays.
+#define PLACE_HALO 8
+template <class K> struct TileStarts {
+    KeyNeqWindowIn<K> f;
+    const K *kt;                    // kt[i - first] = keys[i] for first <= i < first + count
+    u32 first, count;
+    __device__ __forceinline__ K key(u32 i) const { return i - first < count ? kt[i - first] : f.keys[i]; }
+    __device__ __forceinline__ u32 operator()(u32 i) const
+    {
+        if (i == 0) return 1u;
+        const K k = key(i);
+        const K x = k ^ f.rep_t;
+        const bool has_term = ((x - f.ones) & ~x & f.highs) != 0;
+        return (has_term || k != key(i - 1)) ? 1u : 0u;
+    }
+};
+struct TileElems {
+    const u32 *g, *t;               // t[i - first] = g[i] for first <= i < first + count
+    u32 first, count;
+    __device__ __forceinline__ u32 operator[](u32 i) const { return i - first < count ? t[i - first] : g[i]; }
+};
+
+template <class Starts, class LcpFirst, class Elem = const u32 *>
+__device__ __forceinline__ u32 lvl0_place_tied(u32 j, const Elem &elem, const Starts &starts,
                                                const u32 *__restrict__ slot, u32 m, const uint8_t *__restrict__ s8,
                                                u32 n0, u32 depth, u32 *__restrict__ order_g,
                                                u32 *__restrict__ names_g, u32 *__restrict__ lcp_g, LcpFirst lcp_first,
                                                u32 *__restrict__ fail, u32 limit = REFINE_SMALL_GROUP,
                                                u32 max_len = RESOLVE_MAX_LEN, u32 *__restrict__ name_of = nullptr,
-                                               LongRepeats lr = LongRepeats())
+                                               LongRepeats lr = LongRepeats(), NextSymbols ns = NextSymbols())
 {
     const bool first = slot == nullptr;
     const u32 e = elem[j];
@@ -369,6 +402,8 @@ __device__ __forceinline__ u32 lvl0_place_tied(u32 j, const u32 *__restrict__ el
         return 1;
     }
     const u32 p = lvl0_pos(e, n0);
+    const bool cached = ns.k2 && j - ns.first < ns.count;
+    const u64 u0 = cached ? ns.k2[j - ns.first] : 0;
     u32 r = 0, best = 0;                                // best: longest common prefix with a smaller member
     for (u32 x = a; x < bnd; x++) {
         if (x == j) continue;
@@ -376,7 +411,9 @@ __device__ __forceinline__ u32 lvl0_place_tied(u32 j, const u32 *__restrict__ el
         bool decided = false, less = false;             // less: suffix p2 < suffix p
         u32 h = depth;
         for (; h < depth + max_len && !decided; h += 8) {
-            const u64 u = load_u64_unaligned(s8 + p + h), v = load_u64_unaligned(s8 + p2 + h);
+            const bool first_step = h == depth && cached && x - ns.first < ns.count;
+            const u64 u = first_step ? u0 : load_u64_unaligned(s8 + p + h);
+            const u64 v = first_step ? ns.k2[x - ns.first] : load_u64_unaligned(s8 + p2 + h);
             const u64 d = u ^ v, z = ~u;
             const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
             const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
@@ -424,11 +461,26 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     constexpr u32 max_len = ENDGAME_LIMITS ? REFINE_ENDGAME_LEN : RESOLVE_MAX_LEN;
     __shared__ u32 keep_bits[BLOCK * PLACE_IPT / 32];
     __shared__ u32 work[BLOCK * PLACE_IPT];             // the tied elements of this workgroup's stretch
+    __shared__ u64 next8[BLOCK * PLACE_IPT];            // their next 8 symbols (NextSymbols)
+    __shared__ __attribute__((aligned(16))) K key_tile[BLOCK * PLACE_IPT + 2 * PLACE_HALO];   // TileStarts
+    __shared__ __attribute__((aligned(16))) u32 val_tile[BLOCK * PLACE_IPT + 2 * PLACE_HALO];  // TileElems
     __shared__ u32 n_keep, n_work;
     if (threadIdx.x < BLOCK * PLACE_IPT / 32) keep_bits[threadIdx.x] = 0;
     if (threadIdx.x == 0) { n_keep = 0; n_work = 0; }
     __syncthreads();
     const u32 j0 = (blockIdx.x * BLOCK + threadIdx.x) * PLACE_IPT;
+    {   // PLACE_HALO entries to either side of the stretch (threads 0 .. 2*PLACE_HALO-1, one each)
+        const u32 stretch0 = blockIdx.x * (BLOCK * PLACE_IPT);
+        if (threadIdx.x < 2 * PLACE_HALO) {
+            const bool left = threadIdx.x < PLACE_HALO;
+            const u32 q = left ? threadIdx.x : threadIdx.x - PLACE_HALO;
+            const u64 g = left ? (u64)stretch0 + q - PLACE_HALO : (u64)stretch0 + BLOCK * PLACE_IPT + q;    // (wraps below 0: skipped)
+            if ((!left || stretch0 >= PLACE_HALO) && g < (u64)m + 8) {
+                key_tile[left ? q : PLACE_HALO + BLOCK * PLACE_IPT + q] = f.keys[g];
+                val_tile[left ? q : PLACE_HALO + BLOCK * PLACE_IPT + q] = vals[g];
+            }
+        }
+    }
     if (j0 < m) {
         // keys j0-1 .. j0+4 (the arrays carry 8 spare entries behind m), elements j0 .. j0+3
         K k[PLACE_IPT + 2];
@@ -439,6 +491,11 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
         u32 v[PLACE_IPT];
 #pragma unroll
         for (int e = 0; e < PLACE_IPT; e++) v[e] = vals[j0 + e];
+#pragma unroll
+        for (int e = 0; e < PLACE_IPT; e++) {            // (the arrays carry 8 spare entries behind m: whole groups of 4)
+            key_tile[PLACE_HALO + threadIdx.x * PLACE_IPT + e] = k[e + 1];
+            val_tile[PLACE_HALO + threadIdx.x * PLACE_IPT + e] = v[e];
+        }
         bool start[PLACE_IPT + 1];
 #pragma unroll
         for (int e = 0; e <= PLACE_IPT; e++) {
@@ -507,16 +564,35 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     }
     __syncthreads();
     // phase 2: the tied elements, one per thread, so that their text gathers run side by side
-    // instead of one after the other inside the thread that met them
+    // instead of one after the other inside the thread that met them.  First every one of them fetches the 8
+    // symbols behind the window once (NextSymbols), then they rank themselves inside their groups.
+#ifdef PLACE_SKIP_PHASE2
+    const u32 todo = 0;             // (timing experiment only: wrong tables)
+#else
     const u32 todo = n_work;
+#endif
+    const u32 stretch = blockIdx.x * (BLOCK * PLACE_IPT);
+    for (u32 i = threadIdx.x; i < todo; i += BLOCK) {
+        const u32 j = work[i];
+        next8[j - stretch] = load_u64_unaligned(s8 + lvl0_pos(val_tile[PLACE_HALO + j - stretch], n0) + (u32)w);
+    }
+    __syncthreads();
+    const NextSymbols ns{next8, stretch, (u32)(BLOCK * PLACE_IPT)};
+    // the staged range: the stretch and PLACE_HALO to either side, as far as it exists
+    const u32 t_first = stretch >= PLACE_HALO ? stretch - PLACE_HALO : stretch;
+    const u32 t_skip = stretch >= PLACE_HALO ? 0u : (u32)PLACE_HALO;               // (no left halo in the first stretch)
+    const u64 t_end = std::min<u64>((u64)stretch + BLOCK * PLACE_IPT + PLACE_HALO, (u64)m + 8);
+    const u32 t_count = (u32)(t_end - t_first);
+    const TileStarts<K> tstarts{f, key_tile + t_skip, t_first, t_count};
+    const TileElems telems{vals, val_tile + t_skip, t_first, t_count};
     for (u32 i = threadIdx.x; i < todo; i += BLOCK) {
         const u32 j = work[i];
         auto lcp_first = [&](u32 at) -> u32 {
             bool whole;
-            return at > 0 ? lvl0_lcp_of_keys(f, w, b, spare, at, whole) : 0u;
+            return at > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, tstarts.key(at), tstarts.key(at - 1), whole) : 0u;
         };
-        if (lvl0_place_tied(j, vals, f, (const u32 *)nullptr, m, s8, n0, (u32)w, order_g, names_g, lcp_g, lcp_first, fail,
-                            limit, max_len, (u32 *)nullptr, lr)) {
+        if (lvl0_place_tied(j, telems, tstarts, (const u32 *)nullptr, m, s8, n0, (u32)w, order_g, names_g, lcp_g, lcp_first, fail,
+                            limit, max_len, (u32 *)nullptr, lr, ns)) {
             const u32 local = j - blockIdx.x * (BLOCK * PLACE_IPT);
             atomicOr(&keep_bits[local >> 5], 1u << (local & 31u));
             atomicAdd(&n_keep, 1u);

@@ -333,10 +333,11 @@ def extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D):
     # child tables: built by the first east_hip_get_tables request that asks for them
     index.profile_enable(True)
     index.tables(0, names=("childtab_up",))
-    child = index.profile_report().get("child_kernel")
+    rep = index.profile_report()
     index.profile_enable(False)
+    child = [rep[k] for k in ("child_stream_kernel", "child_wide_kernel") if k in rep]
     if child:
-        res["child_tables_ms"] = child[1] / child[0]
+        res["child_tables_ms"] = sum(ms / launches for launches, ms in child)
     # the build from host-resident symbols (east_hip_build: one 4 B/symbol H2D copy in front), wall clock
     walls = []
     for _ in range(3):

@@ -80,8 +80,11 @@ int east_hip_reset(east_hip_handle_t h);
  *   doc_offsets   D+1 offsets into symbols, doc_offsets[0]=0, [D]=n_total
  *   n_strings     D values m_d (strings per document = terminators per document)
  *
- * On success the suffix array, LCP table, child tables and annotation table of
- * every document are resident on the device.  (How: a window sort over all
+ * On success the suffix array, LCP table and annotation table of every document
+ * are resident on the device -- everything score() needs.  The three child tables
+ * (easa.py:22-23) are only needed by callers that read them: they are built by the
+ * first east_hip_get_tables request that asks for them (two more launches, about a
+ * quarter of a build; bench.py reports them as child_tables_ms).  (How: a window sort over all
  * suffixes with tie refinement, data-parallel DC3 as the fallback -- DESIGN.md 4;
  * either way the tables are bit for bit what easa.py computes.)  east_hip_build_device takes a
  * DEVICE pointer for `symbols` (doc_offsets / n_strings stay host pointers);
