@@ -288,7 +288,9 @@ __global__ __launch_bounds__(BLOCK) void dc3_scatter_names_kernel(const u32 *__r
 // mode the rounds switch to prefix doubling (further down) and finish in O(log n) rounds; in DC3's
 // sample mode they stop when the domain stalls -- the refined names still are valid DC3 names
 // (order-preserving over a window that covers the triple) and feed the recursion.
+#ifndef REFINE_SMALL_GROUP
 #define REFINE_SMALL_GROUP 8
+#endif
 #define REFINE_MAX_ROUNDS 32
 #define REFINE_ENDGAME_DOMAIN 262144     // domains this small: groups up to REFINE_ENDGAME_GROUP are ordered directly,
 #define REFINE_ENDGAME_GROUP 128         // with comparisons of at most REFINE_ENDGAME_LEN symbols (longer: give up)

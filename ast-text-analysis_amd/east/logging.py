@@ -27,3 +27,8 @@ def clear():
     """Blank the progress line."""
     if _interactive():
         _rewrite_line(" " * _LINE_WIDTH + "\r")
+
+
+def warning(message):
+    """A line on stderr (new here: the reference has no warnings of its own)."""
+    sys.stderr.write("east: warning: %s\n" % message)

@@ -16,6 +16,7 @@ import numpy as np
 from east import consts
 from east import exceptions
 from east import hip_backend
+from east import logging
 from east import utils
 from east.asts import utils as ast_utils
 
@@ -119,8 +120,16 @@ class _DocumentAST(object):
 
 class ASTRelevanceMeasure(RelevanceMeasure):
 
-    def __init__(self, ast_algorithm=consts.ASTAlgorithm.EASA, normalized=True, device=None):
+    def __init__(self, ast_algorithm=consts.ASTAlgorithm.EASA, normalized=True, device=None, on_out_of_domain="raise"):
+        """on_out_of_domain: what to do with a text that holds a word character >= U+0A00 (outside the method's
+        domain): "raise" SymbolOutOfDomainException naming the text (default), or "skip": index that
+        text as an empty one (every score 0), list it in `self.skipped` as (text number, code point) and go on with
+        the rest of the collection."""
         super(ASTRelevanceMeasure, self).__init__()
+        if on_out_of_domain not in ("raise", "skip"):
+            raise ValueError("on_out_of_domain must be 'raise' or 'skip'")
+        self.on_out_of_domain = on_out_of_domain
+        self.skipped = []
         if ast_algorithm not in list(consts.ASTAlgorithm):
             from east import exceptions
             raise exceptions.NoSuchASTAlgorithm(name=ast_algorithm)
@@ -139,6 +148,20 @@ class ASTRelevanceMeasure(RelevanceMeasure):
 
     # HOT LOOP A (relevance.py:34-49) as one batched build
     def set_text_collection(self, texts, language=consts.Language.ENGLISH):
+        self.skipped = []
+        texts = list(texts)
+        while True:
+            try:
+                return self._set_text_collection(texts, language)
+            except exceptions.SymbolOutOfDomainException as e:
+                if self.on_out_of_domain != "skip" or not isinstance(e.document, int):
+                    raise
+                self.skipped.append((e.document, e.code))
+                logging.warning("text number %d holds U+%04X (outside the method's domain): indexed as an empty text"
+                                % (e.document, e.code))
+                texts[e.document] = b""
+
+    def _set_text_collection(self, texts, language):
         self.texts = texts
         self.language = language
         if os.environ.get("EAST_HIP_TEXT_PREP", "device") == "device":

@@ -1124,6 +1124,20 @@ def test_out_of_domain_text_is_reported_with_its_document(hip, tmp_path, capsys)
     (tmp_path / "kp.txt").write_text("alpha\n")
     assert east_main.main(["keyphrases", "table", str(tmp_path / "kp.txt"), str(tdir)]) == 1
     assert "U+4E2D" in capsys.readouterr().out
+    # "skip": the offending texts count as empty ones, the others are scored as if they had been alone
+    assert east_main.main(["--skip-out-of-domain", "keyphrases", "table", str(tmp_path / "kp.txt"), str(tdir)]) == 0
+    assert "alpha" in capsys.readouterr().out
+    for prep in ("device", "host"):
+        os.environ["EAST_HIP_TEXT_PREP"] = prep
+        try:
+            measure = relevance.ASTRelevanceMeasure(on_out_of_domain="skip")
+            table = applications.keyphrases_table(["alpha", "beta gamma"], texts, measure)
+            assert sorted(d for d, _ in measure.skipped) == [1, 2] and (1, 0x4E2D) in measure.skipped
+            alone = applications.keyphrases_table(["alpha", "beta gamma"], {"plain": texts["plain"]}, relevance.ASTRelevanceMeasure())
+            assert table["alpha"]["plain"] == alone["alpha"]["plain"] and table["beta gamma"]["plain"] == alone["beta gamma"]["plain"]
+            assert table["alpha"]["cjk"] == 0 and table["alpha"]["later"] == 0
+        finally:
+            os.environ.pop("EAST_HIP_TEXT_PREP", None)
     # texts without such characters next to it are fine
     del texts["cjk"], texts["later"]
     assert applications.keyphrases_table(["alpha"], texts, relevance.ASTRelevanceMeasure())["alpha"]["plain"] > 0
