@@ -26,7 +26,7 @@ __device__ __forceinline__ u32 dc3_sample_pos(u32 t, u32 n0)
 __device__ __forceinline__ u32 lvl0_pos(u32 t, u32 n0) { return n0 ? dc3_sample_pos(t, n0) : t; }
 
 static const bool g_trace = getenv("EAST_HIP_TRACE") != nullptr;   // per-round progress on stderr
-static bool g_force_wide_keys = false;                      // east_hip_debug_set_window_sort(3) (tests)
+static bool g_force_wide_keys = getenv("EAST_HIP_WIDE_KEYS") != nullptr;                      // east_hip_debug_set_window_sort(3) (tests)
 static bool g_force_lean = false;                           // east_hip_debug_set_window_sort(2) (tests)
 static bool g_window_sort = true;                            // east_hip_debug_set_window_sort (tests)
 
@@ -568,11 +568,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     // phase 2: the tied elements, one per thread, so that their text gathers run side by side
     // instead of one after the other inside the thread that met them.  First every one of them fetches the 8
     // symbols behind the window once (NextSymbols), then they rank themselves inside their groups.
-#ifdef PLACE_SKIP_PHASE2
-    const u32 todo = 0;             // (timing experiment only: wrong tables)
-#else
     const u32 todo = n_work;
-#endif
     const u32 stretch = blockIdx.x * (BLOCK * PLACE_IPT);
     for (u32 i = threadIdx.x; i < todo; i += BLOCK) {
         const u32 j = work[i];
@@ -1095,7 +1091,9 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
     const size_t mark = ar.mark();
     const int bt = bit_width_u32(term_first);
     if (docs.bits + 3 * bt > 64) return false;          // (no room for a window next to the document number)
-    const int w = lvl0_window(docs.bits ? longest : n, bt, term_first, docs.bits);
+    int w = lvl0_window(docs.bits ? longest : n, bt, term_first, docs.bits);
+    // (experiments, DESIGN.md 5.2: EAST_HIP_WINDOW=<symbols> overrides the width of the first window)
+    if (getenv("EAST_HIP_WINDOW")) w = std::max(3, std::min(atoi(getenv("EAST_HIP_WINDOW")), std::min(12, (64 - docs.bits) / bt)));
     u32 n_names = 0;
     const bool ok = w * bt + docs.bits <= 32 && !g_force_wide_keys
                         ? dc3_level0_bytes<u32>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
