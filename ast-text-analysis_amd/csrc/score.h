@@ -19,7 +19,10 @@
 #define Q_NOMATCH 0xFFFFFFFFu
 #define KGRAM_MAX_K 3                    // tables built from the finished arrays (mark / search kernels)
 #define KGRAM_MAX_BINS 65536u
+#ifndef KGRAM_KEYS_MAX_K
 #define KGRAM_KEYS_MAX_K 4               // tables marked off the sorted window keys (window_sort.h): one level more
+#endif
+//               // tables marked off the sorted window keys (window_sort.h): one level more
 #define KGRAM_KEYS_MAX_BINS 1048576u
 
 // ---- k-gram bucket tables ---------------------------------------------------------
