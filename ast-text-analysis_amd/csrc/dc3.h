@@ -664,7 +664,7 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
             LAUNCH(ctx, (dc3_triple_keys_term_kernel<u32>), g02, s, n0, n02, bt, term_first, sb.keys[0], sb.vals[0]);
             sorted_vals = dc3_sort_and_name<u32>(ctx, sb, n02, 3 * bt, names, [&](const u32 *k) {
                 return KeyNeqTermIn<u32>{k, bt, term_first}; });
-        } else if (term_first > 0) {                       // bt <= 12 always, so 3*bt <= 36 fits 64 bits
+        } else if (term_first > 0) {                       // bt <= 21 (at most every code point), so 3*bt <= 63 fits 64 bits
             SortBufs<u64> sb;
             for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u64>(n02); sb.vals[k] = ar.alloc<u32>(n02); }
             LAUNCH(ctx, (dc3_triple_keys_term_kernel<u64>), g02, s, n0, n02, bt, term_first, sb.keys[0], sb.vals[0]);

@@ -29,6 +29,9 @@
 
 #define TEXT_SYMBOLS EAST_HIP_TERMINATOR_START      // 0x0A00 = 2560 possible text code points
 #define PRESENT_WORDS (TEXT_SYMBOLS / 32)           // 80
+#define TERM_TAG EAST_HIP_TERMINATOR_TAG            // tagged encoding: bit 31 marks a terminator, text is any code point
+#define HI_SYMBOLS (0x110000u - TEXT_SYMBOLS)       // text code points at or above the reference's terminator base
+#define HI_WORDS (HI_SYMBOLS / 32u)                 // 34736
 
 static thread_local std::string g_last_error;
 static bool g_speculate = getenv("EAST_HIP_NO_SPECULATION") == nullptr;     // east_hip_debug_set_speculation (tests)
@@ -78,10 +81,12 @@ __global__ __launch_bounds__(BLOCK) void presence_kernel(const u32 *__restrict__
 #define FLAG_SIGMA 2
 #define FLAG_KEEP 3
 #define FLAG_FAIL 4
+#define FLAG_SIGMA_HI 5
 #define FLAG_WORDS 8
 #define STATUS_NO_TERMINATOR 1u
 #define STATUS_N_STRINGS 2u
 #define STATUS_SIGMA_GUESS 4u
+#define STATUS_BAD_SYMBOL 8u
 __global__ __launch_bounds__(BLOCK) void codemap_kernel(const u32 *__restrict__ present, u32 assumed,
                                                         u32 *__restrict__ code_map, u32 *__restrict__ flags)
 {
@@ -110,11 +115,73 @@ __global__ __launch_bounds__(BLOCK) void codemap_kernel(const u32 *__restrict__ 
 struct TermIn {                                 // 1 at terminators; defined on [0, n]
     const u32 *sym;
     u32 n;
+    u32 tagged;
     __device__ __forceinline__ u32 operator()(u32 i) const
     {
-        return (i < n && sym[i] >= TEXT_SYMBOLS) ? 1u : 0u;
+        return (i < n && (tagged ? sym[i] >> 31 : (u32)(sym[i] >= TEXT_SYMBOLS))) ? 1u : 0u;
     }
 };
+
+// ---- tagged encoding: text code points at or above U+0A00 ------------------------------------------
+// (a stream whose terminators carry EAST_HIP_TERMINATOR_TAG may hold any code point as text; the kernels above
+// and below read such a stream unchanged as long as no text symbol reaches U+0A00 -- a tagged terminator is
+// ">= U+0A00" --, and that is found out here)
+__global__ __launch_bounds__(BLOCK) void presence_hi_kernel(const u32 *__restrict__ sym, u32 n, u32 *__restrict__ hi_bits,
+                                                            u32 *__restrict__ status)
+{
+    const u32 stride = gridDim.x * BLOCK;
+    for (u32 i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const u32 c = sym[i];
+        if (c < TEXT_SYMBOLS || (c >> 31)) continue;
+        if (c >= 0x110000u) { atomicOr(status, STATUS_BAD_SYMBOL); continue; }
+        const u32 k = c - TEXT_SYMBOLS;
+        if (!(((volatile u32 *)hi_bits)[k >> 5] & (1u << (k & 31u)))) atomicOr(&hi_bits[k >> 5], 1u << (k & 31u));
+    }
+}
+
+// hi_rank[w] = code points present below word w of the bitmap; flags[FLAG_SIGMA_HI] = their number.  One workgroup.
+__global__ __launch_bounds__(BLOCK) void hi_rank_kernel(const u32 *__restrict__ hi_bits, u32 *__restrict__ hi_rank,
+                                                        u32 *__restrict__ flags)
+{
+    __shared__ u32 lds4[WAVES_PER_BLOCK];
+    const u32 per = (HI_WORDS + BLOCK - 1) / BLOCK;
+    const u32 w0 = threadIdx.x * per, w1 = w0 + per < HI_WORDS ? w0 + per : HI_WORDS;
+    u32 cnt = 0;
+    for (u32 w = w0; w < w1; w++) cnt += __popc(hi_bits[w]);
+    u32 total;
+    u32 run = block_exclusive_sum(cnt, lds4, total);
+    for (u32 w = w0; w < w1; w++) { hi_rank[w] = run; run += __popc(hi_bits[w]); }
+    if (threadIdx.x == 0) flags[FLAG_SIGMA_HI] = total;
+}
+
+__device__ __forceinline__ u32 hi_rank_of(const u32 *__restrict__ hi_bits, const u32 *__restrict__ hi_rank, u32 k)
+{
+    return hi_rank[k >> 5] + __popc(hi_bits[k >> 5] & ((1u << (k & 31u)) - 1u));
+}
+
+// dense codes when text at or above U+0A00 is present (tagged encoding): ONE text alphabet in code-point order --
+// code points below U+0A00 through the code map (1..sigma_lo), those above by their rank in the bitmap
+// (sigma_lo+1 ..) --, the terminators above it as ever.  s8 / s: the byte stream (sigma_t <= 254) or the u32 codes.
+__global__ __launch_bounds__(BLOCK) void remap_hi_kernel(const u32 *__restrict__ sym, const u32 *__restrict__ term_ex,
+                                                         const u32 *__restrict__ code_map,
+                                                         const u32 *__restrict__ hi_bits, const u32 *__restrict__ hi_rank,
+                                                         u32 sigma_lo, u32 sigma_t, u32 n, u32 *__restrict__ s,
+                                                         uint8_t *__restrict__ s8)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) {
+        const u32 c = sym[i];
+        const bool term = c >> 31;
+        u32 code;
+        if (term) code = s ? sigma_t + 1u + term_ex[i] : 0xFFu;
+        else if (c < TEXT_SYMBOLS) code = code_map[c];
+        else code = sigma_lo + 1u + hi_rank_of(hi_bits, hi_rank, c < 0x110000u ? c - TEXT_SYMBOLS : 0u);
+        if (s) s[i] = code; else s8[i] = (uint8_t)code;
+    } else {
+        if (s && i < n + 3) s[i] = 0;
+        if (s8 && i < n + 16) s8[i] = 0;
+    }
+}
 
 // byte path: only the byte stream is built (0xFF = terminator); the exact terminator numbers are
 // never needed there, so no terminator scan runs
@@ -148,10 +215,12 @@ __global__ __launch_bounds__(BLOCK) void remap_bytes_kernel(const u32 *__restric
 // memory safety: every document must end in a terminator (it stops every suffix comparison)
 __global__ __launch_bounds__(BLOCK) void validate_last_symbol_kernel(const u32 *__restrict__ sym,
                                                                      const u32 *__restrict__ doc_off, u32 n_docs,
-                                                                     u32 *__restrict__ status)
+                                                                     u32 tagged, u32 *__restrict__ status)
 {
     const u32 d = blockIdx.x * BLOCK + threadIdx.x;
-    if (d < n_docs && sym[doc_off[d + 1] - 1] < TEXT_SYMBOLS) atomicOr(status, STATUS_NO_TERMINATOR);
+    if (d >= n_docs) return;
+    const u32 c = sym[doc_off[d + 1] - 1];
+    if (tagged ? !(c >> 31) : c < TEXT_SYMBOLS) atomicOr(status, STATUS_NO_TERMINATOR);
 }
 
 // n_strings[d] must equal the terminators of document d.  Terminators sort above every text
@@ -204,6 +273,10 @@ struct east_hip_index {
     Profiler prof;
     bool built = false, child_built = false;
     u32 n = 0, n_docs = 0, sigma_t = 0, m_total = 0;
+    u32 sigma_hi = 0;            // text code points >= U+0A00 present (tagged encoding only): the top sigma_hi codes of the text alphabet
+    u32 *hi_bits = nullptr, *hi_rank = nullptr;      // presence bitmap over [U+0A00, U+110000) and its rank directory
+    bool tagged_input = false;   // east_hip_set_symbol_encoding: the symbol entry points take the tagged encoding
+    bool prep_tagged = false;    // the prepared symbols (east_hip_build_texts) are in the tagged encoding
     int bits0 = 0;
     std::vector<i64> h_doc_off;
     std::vector<u32> h_n_strings;
@@ -217,7 +290,8 @@ struct east_hip_index {
     // what the last successful build found, the guesses of the next (speculative) one
     bool hint_valid = false, hint_no_rounds = false;
     u32 hint_sigma = 0;
-    u32 plan_n = 0, plan_docs = 0, plan_epoch = 0;   // shape of the last sizing run (and test-knob epoch), its result
+    u32 plan_n = 0, plan_docs = 0, plan_epoch = 0;
+    bool plan_tagged = false;   // shape of the last sizing run (and test-knob epoch), its result
     size_t plan_bytes = 0;
     // keyphrases + score scratch (own allocation, grown on demand)
     char *q_buf = nullptr;
@@ -286,7 +360,7 @@ static void annotate(east_hip_index *h, Ctx &ctx)
 // The build proper.  With ctx.dry it only measures the arena high-water mark
 // (worst case: widest keys, recursion to the bottom).
 static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32 n_docs,
-                       const i64 *doc_offsets, const int32_t *n_strings, u32 spec_sigma = 0)
+                       const i64 *doc_offsets, const int32_t *n_strings, u32 spec_sigma = 0, bool tagged = false)
 {
     Arena &ar = *ctx.arena;
     ar.release(0);
@@ -302,6 +376,8 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     h->doc_off = ar.alloc<u32>((size_t)n_docs + 1);
     h->n_strings = ar.alloc<u32>(n_docs);
     h->code_map = ar.alloc<u32>(TEXT_SYMBOLS + FLAG_WORDS);   // + the flag words (FLAG_*)
+    h->hi_bits = tagged ? ar.alloc<u32>(HI_WORDS) : nullptr;
+    h->hi_rank = tagged ? ar.alloc<u32>(HI_WORDS) : nullptr;
     Pyramid pyr;
     pyr.levels = 1;
     pyr.ptr[0] = h->lcp;
@@ -329,6 +405,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
 
     const u32 gn = ceil_div_u32(n, BLOCK);
     u32 sigma_t = TEXT_SYMBOLS - 1, m_total = n;          // dry-run worst case
+    u32 sigma_hi = tagged ? HI_SYMBOLS : 0;
     u32 *flags = h->code_map + TEXT_SYMBOLS;              // flag words behind the code map
     u32 *capped = flags + FLAG_CAPPED, *status = flags + FLAG_STATUS;
     if (!ctx.dry) HIP_CHECK(hipMemsetAsync(flags, 0, FLAG_WORDS * sizeof(u32), ctx.stream));
@@ -342,7 +419,12 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         const int vec = ((uintptr_t)d_sym & 15u) == 0;
         LAUNCH(ctx, presence_kernel, std::min<u32>(gn, 2048), d_sym, n, vec, present);
         LAUNCH(ctx, validate_last_symbol_kernel, ceil_div_u32(n_docs, BLOCK), d_sym, (const u32 *)h->doc_off, n_docs,
-               present + PRESENT_WORDS);
+               (u32)tagged, present + PRESENT_WORDS);
+        if (tagged) {
+            if (!ctx.dry) HIP_CHECK(hipMemsetAsync(h->hi_bits, 0, HI_WORDS * 4, ctx.stream));
+            LAUNCH(ctx, presence_hi_kernel, std::min<u32>(gn, 2048), d_sym, n, h->hi_bits, status);
+            LAUNCH(ctx, hi_rank_kernel, 1, (const u32 *)h->hi_bits, h->hi_rank, flags);
+        }
         LAUNCH(ctx, codemap_kernel, 1, (const u32 *)present, ctx.spec ? spec_sigma : 0xFFFFFFFFu, h->code_map, flags);
         if (!ctx.dry) {
             if (ctx.spec) {
@@ -352,25 +434,41 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
                 HIP_CHECK(hipMemcpyAsync(hf, flags, sizeof(hf), hipMemcpyDeviceToHost, ctx.stream));
                 HIP_CHECK(hipStreamSynchronize(ctx.stream));
                 if (hf[FLAG_STATUS] & STATUS_NO_TERMINATOR)
-                    east_throw(EAST_HIP_ERR_DOMAIN, "a document does not end in a string terminator (>= U+0A00)");
+                    east_throw(EAST_HIP_ERR_DOMAIN, tagged ? "a document does not end in a (tagged) string terminator"
+                                                           : "a document does not end in a string terminator (>= U+0A00)");
+                if (hf[FLAG_STATUS] & STATUS_BAD_SYMBOL)
+                    east_throw(EAST_HIP_ERR_DOMAIN, "a symbol is neither a tagged terminator nor a code point < U+110000");
                 sigma_t = hf[FLAG_SIGMA];
+                sigma_hi = tagged ? hf[FLAG_SIGMA_HI] : 0;
             }
             m_total = 0;
             for (u32 d = 0; d < n_docs; d++) m_total += (u32)n_strings[d];     // checked after the build
-            h->use_s8 = sigma_t <= 254;
+            h->use_s8 = sigma_t + sigma_hi <= 254;
         }
-        if (h->use_s8 && !ctx.dry) {
+        sigma_t += sigma_hi;                                  // one text alphabet, the high code points above the low ones
+        if (sigma_hi && h->use_s8 && !ctx.dry) {
+            LAUNCH(ctx, remap_hi_kernel, ceil_div_u32((u64)n + 16, BLOCK), d_sym, (const u32 *)nullptr,
+                   (const u32 *)h->code_map, (const u32 *)h->hi_bits, (const u32 *)h->hi_rank, sigma_t - sigma_hi, sigma_t, n,
+                   (u32 *)nullptr, h->s8);
+        } else if (h->use_s8 && !ctx.dry) {
             LAUNCH(ctx, remap_bytes_kernel, ceil_div_u32((u64)n + 16, BLOCK * 16), d_sym, (const u32 *)h->code_map, n,
                    vec, h->s8);
         } else {
             // wide alphabets: dense u32 codes, terminators numbered globally by a scan
-            device_scan<TermIn, false>(ctx, TermIn{d_sym, n}, n + 1, term_ex);
-            LAUNCH(ctx, remap_kernel, ceil_div_u32((u64)n + 16, BLOCK), d_sym, (const u32 *)term_ex,
-                   (const u32 *)h->code_map, sigma_t, n, h->s, (uint8_t *)nullptr);
+            device_scan<TermIn, false>(ctx, TermIn{d_sym, n, (u32)tagged}, n + 1, term_ex);
+            if (sigma_hi)
+                LAUNCH(ctx, remap_hi_kernel, ceil_div_u32((u64)n + 16, BLOCK), d_sym, (const u32 *)term_ex,
+                       (const u32 *)h->code_map, (const u32 *)h->hi_bits, (const u32 *)h->hi_rank, sigma_t - sigma_hi, sigma_t, n,
+                       h->s, (uint8_t *)nullptr);
+            else
+                LAUNCH(ctx, remap_kernel, ceil_div_u32((u64)n + 16, BLOCK), d_sym, (const u32 *)term_ex,
+                       (const u32 *)h->code_map, sigma_t, n, h->s, (uint8_t *)nullptr);
         }
         ar.release(mark);
     }
     const u32 sigma = sigma_t + m_total;
+    const u32 term_first = sigma_t + 1u;
+    h->sigma_hi = ctx.dry ? 0u : sigma_hi;
     h->sigma_t = sigma_t;
     h->m_total = m_total;
     h->bits0 = bit_width_u32(sigma);
@@ -422,7 +520,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     if (window_sorted) {
         ctx.stats->levels = 0;
     } else if (n_docs == 1) {
-        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr,
+        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, h->sa, 0, term_first, h->use_s8 ? h->s8 : nullptr,
                                              fused_lcp ? h->lcp : nullptr, capped);
     } else {
         // the suffix array of the whole shard lands in vals[0]; the partition is a stable radix sort of
@@ -432,7 +530,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         const int last = radix_pass_count(doc_bits) & 1;
         for (int k = 0; k < 2; k++) { sb.keys[k] = ar.alloc<u32>((size_t)n + 4); sb.vals[k] = k == last ? h->sa : ar.alloc<u32>((size_t)n + 4); }
         u32 *sa_whole = sb.vals[0];
-        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sa_whole, 0, sigma_t + 1, h->use_s8 ? h->s8 : nullptr);
+        ctx.stats->levels = dc3_suffix_array(ctx, h->s, n, sigma, sa_whole, 0, term_first, h->use_s8 ? h->s8 : nullptr);
         if (n_docs <= DOC_LDS_MAX) {
             LAUNCH(ctx, doc_keys_lds_kernel, ceil_div_u32(n, BLOCK * 4), (const u32 *)sa_whole, (const u32 *)h->doc_off, n_docs,
                    n, sb.keys[0]);
@@ -504,7 +602,7 @@ static void finish_capped_lcp(east_hip_index *h, Ctx &ctx)
     annotate(h, ctx);
 }
 
-static size_t plan_arena_bytes(u32 n, u32 n_docs, bool lean = false)
+static size_t plan_arena_bytes(u32 n, u32 n_docs, bool lean = false, bool tagged = false)
 {
     east_hip_index tmp;
     Arena dry;
@@ -515,7 +613,7 @@ static size_t plan_arena_bytes(u32 n, u32 n_docs, bool lean = false)
     ctx.dry = true;
     ctx.lean = lean;
     ctx.stats = &st;
-    build_impl(&tmp, ctx, nullptr, n, n_docs, nullptr, nullptr);
+    build_impl(&tmp, ctx, nullptr, n, n_docs, nullptr, nullptr, 0, tagged);
     return dry.high + (1u << 20);
 }
 
@@ -553,7 +651,7 @@ static void check_build_args(i64 n_total, const i64 *doc_offsets, const int32_t 
 }
 
 static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i64 n_total, const i64 *doc_offsets,
-                         const int32_t *n_strings, int32_t n_docs)
+                         const int32_t *n_strings, int32_t n_docs, bool tagged)
 {
     if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
     if (!sym) east_throw(EAST_HIP_ERR_INVALID, "null symbols");
@@ -562,8 +660,9 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     h->built = false;
     const u32 n = (u32)n_total;
     const size_t staging_bytes = sym_on_host ? ((size_t)n * 4 + 255) & ~(size_t)255 : 0;
-    if (h->plan_n != n || h->plan_docs != (u32)n_docs || h->plan_epoch != g_plan_epoch) {     // (the sizing run costs host time: remembered per shape)
-        h->plan_bytes = plan_arena_bytes(n, (u32)n_docs);
+    if (h->plan_n != n || h->plan_docs != (u32)n_docs || h->plan_epoch != g_plan_epoch || h->plan_tagged != tagged) {     // (the sizing run costs host time: remembered per shape)
+        h->plan_bytes = plan_arena_bytes(n, (u32)n_docs, false, tagged);
+        h->plan_tagged = tagged;
         h->plan_n = n;
         h->plan_docs = (u32)n_docs;
         h->plan_epoch = g_plan_epoch;
@@ -577,7 +676,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         lean = need > (size_t)(0.92 * (double)(free_b + h->arena.cap));
     }
-    if (lean) need = plan_arena_bytes(n, (u32)n_docs, true) + staging_bytes;
+    if (lean) need = plan_arena_bytes(n, (u32)n_docs, true, tagged) + staging_bytes;
     u32 *staging = nullptr;
     ensure_arena(h, need);
     if (sym_on_host) {   // raw symbols are staged at the top of the arena
@@ -600,7 +699,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     auto run = [&](bool spec) -> bool {
         ctx.spec = spec;
         try {
-            build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings, h->hint_sigma);
+            build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings, h->hint_sigma, tagged);
         } catch (const SpecAbort &) {
             HIP_CHECK(hipStreamSynchronize(h->stream));
             return false;
@@ -611,7 +710,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
         return true;
     };
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));
-    const bool speculate = g_speculate && g_window_sort && h->hint_valid && h->hint_no_rounds && h->hint_sigma <= 254;
+    const bool speculate = g_speculate && g_window_sort && h->hint_valid && h->hint_no_rounds && h->hint_sigma <= 254 && !tagged;
     const bool went_through = run(speculate);
     if (speculate && (!went_through || (flags[FLAG_STATUS] & STATUS_SIGMA_GUESS) || flags[FLAG_KEEP] || flags[FLAG_FAIL])) {
         if (g_trace) fprintf(stderr, "[east_hip] speculative build guessed wrong: building again\n");
@@ -627,9 +726,10 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
         HIP_CHECK(hipStreamSynchronize(h->stream));
     }
     if (status & STATUS_N_STRINGS)
-        east_throw(EAST_HIP_ERR_DOMAIN, "n_strings does not match the terminators found in a document "
-                                        "(text symbols must be < U+0A00)");
-    h->hint_valid = true;
+        east_throw(EAST_HIP_ERR_DOMAIN, tagged ? "n_strings does not match the tagged terminators found in a document"
+                                               : "n_strings does not match the terminators found in a document "
+                                                 "(text symbols must be < U+0A00 unless the terminators are tagged)");
+    h->hint_valid = !tagged || h->sigma_hi == 0;
     h->hint_sigma = h->sigma_t;
     h->hint_no_rounds = h->stats.window_sorted && h->stats.refine_rounds == 0 && !h->stats.long_repeats;
     h->prof.collect();
@@ -686,7 +786,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     u32 *d_word_hi = ar.alloc<u32>(TP_WORD_HI_WORDS);
     u32 *d_digit_hi = ar.alloc<u32>(TP_WORD_HI_WORDS);
     u32 *d_hi_from = ar.alloc<u32>((size_t)n_hi_upper + 1), *d_hi_to = ar.alloc<u32>((size_t)n_hi_upper + 1);
-    unsigned long long *d_bad = ar.alloc<unsigned long long>(1);
+    u32 *d_high = ar.alloc<u32>(1);
     std::vector<u32> off32((size_t)D + 1);
     for (u32 d = 0; d <= D; d++) off32[d] = (u32)text_offsets[d];
     if (texts) {
@@ -708,7 +808,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
         HIP_CHECK(hipMemcpyAsync(d_hi_from, hi_upper_from, (size_t)n_hi_upper * 4, hipMemcpyHostToDevice, h->stream));
         HIP_CHECK(hipMemcpyAsync(d_hi_to, hi_upper_to, (size_t)n_hi_upper * 4, hipMemcpyHostToDevice, h->stream));
     }
-    HIP_CHECK(hipMemsetAsync(d_bad, 0xFF, 8, h->stream));
+    HIP_CHECK(hipMemsetAsync(d_high, 0, 4, h->stream));
     const TpTables tables{d_class, d_upper, d_word_hi, d_digit_hi, d_hi_from, d_hi_to, (u32)n_hi_upper};
 
     // bytes -> code points
@@ -731,7 +831,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     device_scan<TpTokStartIn, true>(ctx, TpTokStartIn{cw, n_cp}, n_cp, tok_inc);
     device_scan<TpNonDigitIn, false>(ctx, TpNonDigitIn{cw, n_cp}, n_cp + 1, nd_ex);
     u32 n_tok = 0;
-    unsigned long long bad = 0;
+    u32 high = 0;
     HIP_CHECK(hipMemcpyAsync(&n_tok, tok_inc + (n_cp - 1), 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
     u32 *tstart = ar.alloc<u32>((size_t)n_tok + 1), *tend = ar.alloc<u32>((size_t)n_tok + 1);
@@ -775,21 +875,23 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
                (const u32 *)klen_ex, (const u32 *)doc_cp_off, (const u32 *)first_tok, (const u32 *)doc_sym_off, D, n_tok,
                tok_out, tok_term);
         LAUNCH(ctx, tp_emit_kernel, ceil_div_u32(n_cp, BLOCK), (const u32 *)cpu, (const uint8_t *)cw, (const u32 *)tok_inc,
-               (const u32 *)tstart, (const u32 *)tend, (const u32 *)tok_out, (const u32 *)tok_term, n_cp,
-               (const u32 *)doc_cp_off, D, h->prep_sym, d_bad);
+               (const u32 *)tstart, (const u32 *)tend, (const u32 *)tok_out, (const u32 *)tok_term, n_cp, h->prep_sym,
+               d_high);
     }
     LAUNCH(ctx, tp_empty_docs_kernel, ceil_div_u32(D, BLOCK), (const u32 *)first_tok, (const u32 *)keep_ex,
            (const u32 *)doc_sym_off, D, h->prep_sym);
     HIP_CHECK(hipEventRecord(h->ev1, h->stream));
-    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(&high, d_high, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipEventElapsedTime(&h->last_prep_ms, h->ev0, h->ev1));
-    if (bad != ~0ull) {
-        h->prep_doc_off.clear();
-        char msg[200];
-        snprintf(msg, sizeof(msg), "text %u contains the word character U+%04X >= U+0A00 (outside the method's domain)",
-                 (unsigned)(bad >> 32), (unsigned)(bad & 0xFFFFFFFFu));
-        east_throw(EAST_HIP_ERR_DOMAIN, msg);
+    h->prep_tagged = high != 0;
+    if (h->prep_tagged) {
+        // kept word characters at or above U+0A00: the symbols go on in the tagged encoding
+        if (n_tok)
+            LAUNCH(ctx, tp_tag_terminators_kernel, ceil_div_u32(n_tok, BLOCK), (const u32 *)tstart, (const u32 *)tend,
+                   (const u32 *)keep, (const u32 *)klen, n_tok, h->prep_sym);
+        LAUNCH(ctx, tp_tag_empty_docs_kernel, ceil_div_u32(D, BLOCK), (const u32 *)first_tok, (const u32 *)keep_ex,
+               (const u32 *)doc_sym_off, D, h->prep_sym);
     }
 
     h->prep_n = n_sym;
@@ -797,7 +899,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     h->prep_n_strings.resize(D);
     for (u32 d = 0; d <= D; d++) h->prep_doc_off[d] = h_off[d];
     for (u32 d = 0; d < D; d++) h->prep_n_strings[d] = (int32_t)h_m[d];
-    build_common(h, h->prep_sym, false, n_sym, h->prep_doc_off.data(), h->prep_n_strings.data(), n_docs);
+    build_common(h, h->prep_sym, false, n_sym, h->prep_doc_off.data(), h->prep_n_strings.data(), n_docs, h->prep_tagged);
 }
 
 // ------------------------------------------------------------------ score --
@@ -947,7 +1049,8 @@ static void score_resident(east_hip_index *h, int normalized, unsigned long long
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));
     ensure_kgram(h, ctx);
     LAUNCH(ctx, query_map_kernel, ceil_div_u32(h->n_q, BLOCK), (const u32 *)h->q_raw, h->n_q,
-           (const u32 *)h->code_map, h->q_code);
+           (const u32 *)h->code_map, (const u32 *)h->hi_bits, (const u32 *)h->hi_rank,
+           h->sigma_hi ? h->sigma_t - h->sigma_hi + 1u : 0u, h->q_code);
     const u32 chunk = h->score_chunk;
     for (u32 first = 0; first < h->n_docs; first += chunk) {
         const u32 count = std::min(chunk, h->n_docs - first);
@@ -1053,13 +1156,28 @@ void east_hip_destroy(east_hip_handle_t h)
 int east_hip_build(east_hip_handle_t h, const uint32_t *symbols, int64_t n_total, const int64_t *doc_offsets,
                    const int32_t *n_strings, int32_t n_docs)
 {
-    return guarded([&] { build_common(h, symbols, true, n_total, doc_offsets, n_strings, n_docs); });
+    return guarded([&] { build_common(h, symbols, true, n_total, doc_offsets, n_strings, n_docs, h && h->tagged_input); });
 }
 
 int east_hip_build_device(east_hip_handle_t h, const uint32_t *d_symbols, int64_t n_total,
                           const int64_t *doc_offsets, const int32_t *n_strings, int32_t n_docs)
 {
-    return guarded([&] { build_common(h, d_symbols, false, n_total, doc_offsets, n_strings, n_docs); });
+    return guarded([&] { build_common(h, d_symbols, false, n_total, doc_offsets, n_strings, n_docs, h && h->tagged_input); });
+}
+
+int east_hip_set_symbol_encoding(east_hip_handle_t h, int32_t encoding)
+{
+    return guarded([&] {
+        if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
+        if (encoding != EAST_HIP_SYMBOLS_REFERENCE && encoding != EAST_HIP_SYMBOLS_TAGGED)
+            east_throw(EAST_HIP_ERR_INVALID, "unknown symbol encoding");
+        h->tagged_input = encoding == EAST_HIP_SYMBOLS_TAGGED;
+    });
+}
+
+int east_hip_prepared_encoding(east_hip_handle_t h)
+{
+    return h && h->prep_tagged ? EAST_HIP_SYMBOLS_TAGGED : EAST_HIP_SYMBOLS_REFERENCE;
 }
 
 int east_hip_build_texts(east_hip_handle_t h, const uint8_t *bytes, int64_t n_bytes, const int64_t *text_offsets,
@@ -1261,6 +1379,9 @@ int east_hip_reset(east_hip_handle_t h)
         h->prep_n = 0;
         h->prep_doc_off.clear();
         h->prep_n_strings.clear();
+        h->prep_tagged = false;
+        h->tagged_input = false;
+        h->sigma_hi = 0;
         h->prof.enabled = false;
         h->stats = Stats();
         // a recycled handle keeps its stream and a small arena, not gigabytes of side allocations

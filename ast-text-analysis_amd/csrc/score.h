@@ -247,6 +247,8 @@ __global__ __launch_bounds__(BLOCK) void kgram_chunk_fill_kernel(const u32 *__re
 // raw query code points -> dense codes of the corpus alphabet
 __global__ __launch_bounds__(BLOCK) void query_map_kernel(const u32 *__restrict__ q_raw, u32 n_q,
                                                           const u32 *__restrict__ code_map,
+                                                          const u32 *__restrict__ hi_bits,
+                                                          const u32 *__restrict__ hi_rank, u32 hi_base,
                                                           u32 *__restrict__ q_code)
 {
     const u32 i = blockIdx.x * BLOCK + threadIdx.x;
@@ -256,6 +258,10 @@ __global__ __launch_bounds__(BLOCK) void query_map_kernel(const u32 *__restrict_
     if (c < EAST_HIP_TERMINATOR_START) {
         code = code_map[c];
         if (code == 0) code = Q_NOMATCH;          // symbol absent from the corpus
+    } else if (hi_base && c < 0x110000u) {        // the corpus holds text at or above U+0A00 (tagged encoding): hi_base = its first code
+        const u32 k = c - EAST_HIP_TERMINATOR_START;
+        if ((hi_bits[k >> 5] >> (k & 31u)) & 1u)
+            code = hi_base + hi_rank[k >> 5] + __popc(hi_bits[k >> 5] & ((1u << (k & 31u)) - 1u));
     }
     q_code[i] = code;
 }

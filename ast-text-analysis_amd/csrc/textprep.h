@@ -233,8 +233,7 @@ __global__ __launch_bounds__(BLOCK) void tp_emit_kernel(const u32 *__restrict__ 
                                                         const u32 *__restrict__ tstart, const u32 *__restrict__ tend,
                                                         const u32 *__restrict__ tok_out,
                                                         const u32 *__restrict__ tok_term, u32 n_cp,
-                                                        const u32 *__restrict__ doc_cp_off, u32 n_docs,
-                                                        u32 *__restrict__ sym, unsigned long long *__restrict__ bad)
+                                                        u32 *__restrict__ sym, u32 *__restrict__ high)
 {
     const u32 p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= n_cp || !(cw[p] & TP_CLASS_WORD)) return;
@@ -243,17 +242,32 @@ __global__ __launch_bounds__(BLOCK) void tp_emit_kernel(const u32 *__restrict__ 
     if (base == TP_DROPPED) return;                         // token dropped
     const u32 out = base + (p - tstart[k]);
     const u32 cp = cpu[p];
-    if (cp >= TP_TEXT_LIMIT) {                              // a kept word character outside the method's domain:
-        u32 lo = 0, hi = n_docs;                            // remember the first document it occurs in, and the character
-        while (hi - lo > 1) {
-            const u32 mid = (lo + hi) >> 1;
-            if (doc_cp_off[mid] <= p) lo = mid; else hi = mid;
-        }
-        atomicMin(bad, ((unsigned long long)lo << 32) | cp);
-    }
+    if (cp >= TP_TEXT_LIMIT) *high = 1u;                    // kept text at or above U+0A00: the build takes the tagged encoding
     sym[out] = cp;
     const u32 term = tok_term[k];
     if (term && p == tend[k]) sym[out + 1u] = term;
+}
+
+// Kept word characters at or above U+0A00 were found: the terminators are rewritten in the tagged encoding
+// (EAST_HIP_TERMINATOR_TAG | index), in which text may be any code point.
+__global__ __launch_bounds__(BLOCK) void tp_tag_terminators_kernel(const u32 *__restrict__ tstart,
+                                                                   const u32 *__restrict__ tend,
+                                                                   const u32 *__restrict__ tok_out,
+                                                                   const u32 *__restrict__ tok_term, u32 n_tok,
+                                                                   u32 *__restrict__ sym)
+{
+    const u32 k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n_tok || tok_out[k] == TP_DROPPED || !tok_term[k]) return;
+    sym[tok_out[k] + (tend[k] - tstart[k]) + 1u] = EAST_HIP_TERMINATOR_TAG | (tok_term[k] - TP_TEXT_LIMIT);
+}
+
+__global__ __launch_bounds__(BLOCK) void tp_tag_empty_docs_kernel(const u32 *__restrict__ first_tok,
+                                                                  const u32 *__restrict__ keep_ex,
+                                                                  const u32 *__restrict__ doc_sym_off, u32 n_docs,
+                                                                  u32 *__restrict__ sym)
+{
+    const u32 d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d < n_docs && keep_ex[first_tok[d + 1]] == keep_ex[first_tok[d]]) sym[doc_sym_off[d] + 1u] = EAST_HIP_TERMINATOR_TAG;
 }
 
 __global__ __launch_bounds__(BLOCK) void tp_empty_docs_kernel(const u32 *__restrict__ first_tok,

@@ -2,7 +2,6 @@
 """keyphrases_table / keyphrases_graph (reference east/applications.py:11-149)."""
 
 from east import consts
-from east import exceptions
 from east import logging
 from east import relevance
 from east import utils
@@ -21,12 +20,7 @@ def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=Non
 
     text_titles = list(texts.keys())
     text_collection = list(texts.values())
-    try:
-        similarity_measure.set_text_collection(text_collection, language)
-    except exceptions.SymbolOutOfDomainException as e:        # name the text instead of numbering it
-        if isinstance(e.document, int) and 0 <= e.document < len(text_titles):
-            raise exceptions.SymbolOutOfDomainException(code=e.code, document=str(text_titles[e.document]))
-        raise
+    similarity_measure.set_text_collection(text_collection, language)
 
     keyphrases_prepared = {keyphrase: utils.prepare_text(keyphrase) for keyphrase in keyphrases}
     res = {}

@@ -26,7 +26,7 @@ class HipEnhancedAnnotatedSuffixArray(base.AST):
         super(HipEnhancedAnnotatedSuffixArray, self).__init__(strings_collection)   # empty check, base.py:20-22
         self.strings_collection = strings_collection
         symbols = utils.strings_to_symbols(strings_collection)                        # easa.py:19
-        self._symbols = symbols
+        self._symbols = utils.reference_code_points(symbols)      # the code points of the reference's self.string
         self._index = hip_backend.HipIndex(device)
         self._index.build(symbols, np.array([0, symbols.size], dtype=np.int64),
                           np.array([len(strings_collection)], dtype=np.int32))       # easa.py:20-24

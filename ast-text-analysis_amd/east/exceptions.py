@@ -32,10 +32,11 @@ class EmptyStringsCollectionException(EastException):
 
 
 class SymbolOutOfDomainException(EastException):
-    """New: the reference is only defined for text code points below U+0A00
-    (its string terminators start there, east/asts/utils.py:25-40); it crashes or
-    gives algorithm-dependent scores beyond.  The HIP backend rejects such input."""
-    msg_fmt = ("Text%(where)s contains the code point U+%(code)04X >= U+0A00, which collides with the "
+    """New: the reference's string terminators are the code points U+0A00+i (east/asts/utils.py:25-40), so
+    its own symbol encoding cannot hold text at or above U+0A00.  Raised where that encoding is asked for
+    explicitly (asts/utils.py: strings_to_symbols(tagged=False)); the HIP backend itself indexes such text
+    in the tagged encoding."""
+    msg_fmt = ("Text%(where)s contains the code point U+%(code)04X, which collides with the "
                "string terminators of the annotated suffix tree (outside the method's domain).")
 
     def __init__(self, code, document=None):

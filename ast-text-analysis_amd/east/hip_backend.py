@@ -40,6 +40,8 @@ SIGNATURES = {
                                               ctypes.POINTER(ctypes.c_uint8), _c_u32p, _c_u32p, _c_u32p, _c_u32p,
                                               _c_u32p, ctypes.c_int32]),
     "east_hip_get_prepared": (ctypes.c_int, [ctypes.c_void_p, _c_i64p, _c_i64p, _c_i32p, _c_u32p]),
+    "east_hip_prepared_encoding": (ctypes.c_int, [ctypes.c_void_p]),
+    "east_hip_set_symbol_encoding": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "east_hip_last_prep_ms": (ctypes.c_double, [ctypes.c_void_p]),
     "east_hip_get_tables": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32] + [_c_i32p] * 6),
     "east_hip_score_table": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, _c_i64p, ctypes.c_int32, ctypes.c_int,
@@ -219,19 +221,23 @@ class HipIndex(object):
 
     # -- build ---------------------------------------------------------------
     def build(self, symbols, doc_offsets, n_strings):
+        """symbols: the reference encoding (terminator i of a document = 0x0A00+i, text below), or -- told
+        by the tag bit of the last symbol -- the tagged one (asts/utils.py: strings_to_symbols)."""
         symbols = np.ascontiguousarray(symbols, dtype=np.uint32)
         doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.int64)
         n_strings = np.ascontiguousarray(n_strings, dtype=np.int32)
+        _check(self._lib.east_hip_set_symbol_encoding(self._h, 1 if symbols.size and int(symbols[-1]) >> 31 else 0))
         _check(self._lib.east_hip_build(self._h, _ptr(symbols, _c_u32p), symbols.size, _ptr(doc_offsets, _c_i64p),
                                         _ptr(n_strings, _c_i32p), n_strings.size))
         self.n_docs = int(n_strings.size)
         self.doc_offsets = doc_offsets.copy()
         self._host_symbols = symbols
 
-    def build_device(self, d_symbols_ptr, n_total, doc_offsets, n_strings):
+    def build_device(self, d_symbols_ptr, n_total, doc_offsets, n_strings, tagged=False):
         """d_symbols_ptr: integer address of a uint32 device buffer (e.g. tensor.data_ptr())."""
         doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.int64)
         n_strings = np.ascontiguousarray(n_strings, dtype=np.int32)
+        _check(self._lib.east_hip_set_symbol_encoding(self._h, 1 if tagged else 0))
         _check(self._lib.east_hip_build_device(self._h, ctypes.c_void_p(int(d_symbols_ptr)), int(n_total),
                                                _ptr(doc_offsets, _c_i64p), _ptr(n_strings, _c_i32p), n_strings.size))
         self.n_docs = int(n_strings.size)
@@ -265,7 +271,9 @@ class HipIndex(object):
         self.doc_offsets = doc_offsets
 
     def prepared(self):
-        """(symbols uint32, doc_offsets int64, n_strings int32) of the last build_texts."""
+        """(symbols uint32, doc_offsets int64, n_strings int32) of the last build_texts.  The symbols are in
+        the reference encoding (terminator i = 0x0A00+i) unless kept tokens hold characters at or above
+        U+0A00: then in the tagged one (asts/utils.py: is_tagged / reference_code_points)."""
         n_total = ctypes.c_int64(0)
         _check(self._lib.east_hip_get_prepared(self._h, ctypes.byref(n_total), None, None, None))
         doc_offsets = np.zeros(self.n_docs + 1, dtype=np.int64)

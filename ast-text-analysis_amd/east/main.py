@@ -5,7 +5,6 @@ README.rst:27-63; the shipped reference main crashes with a NameError, SURVEY.md
     east [-s ast] [-a easa|easa_hip|ast_linear|ast_naive] [-d] [-f xml|csv] \\
          keyphrases table <keyphrases file> <directory with .txt files | single file>
     east [-c confidence] [-r relevance] [-p support] [-f edges|gml] keyphrases graph <keyphrases file> <texts>
-    --skip-out-of-domain   (new) a text holding word characters >= U+0A00 is indexed as an empty text, with a warning
 """
 import getopt
 import os
@@ -26,7 +25,7 @@ def _read(path):
 def main(argv=None):
     args = sys.argv[1:] if argv is None else list(argv)
     try:
-        opts, args = getopt.getopt(args, "s:a:w:v:l:f:c:r:p:dy", ["skip-out-of-domain"])
+        opts, args = getopt.getopt(args, "s:a:w:v:l:f:c:r:p:dy")
     except getopt.GetoptError as e:
         print(e)
         return 1
@@ -71,9 +70,7 @@ def main(argv=None):
 
     measure_name = opts["-s"]
     if measure_name.lower() == "ast":
-        # (--skip-out-of-domain, new: a text with word characters >= U+0A00 counts as empty instead of ending the run)
-        similarity_measure = relevance.ASTRelevanceMeasure(opts["-a"], "-d" not in opts,          # main.py:95-98
-                                                           on_out_of_domain="skip" if "--skip-out-of-domain" in opts else "raise")
+        similarity_measure = relevance.ASTRelevanceMeasure(opts["-a"], "-d" not in opts)          # main.py:95-98
     else:
         print("Relevance measure '%s' is not available in the MI355X build (only 'ast')." % measure_name)
         return 1
@@ -83,7 +80,7 @@ def main(argv=None):
 
     try:
         return _run(subcommand, keyphrases, texts, similarity_measure, opts)
-    except exceptions.EastException as e:       # (input outside the method's domain, no device, ...): a message, not a traceback
+    except exceptions.EastException as e:       # (no device, a failed build ...): a message, not a traceback
         print(e)
         return 1
 

@@ -9,14 +9,12 @@ CosineRelevanceMeasure is a different method and out of scope.
 """
 import itertools
 import os
-import re
 
 import numpy as np
 
 from east import consts
 from east import exceptions
 from east import hip_backend
-from east import logging
 from east import utils
 from east.asts import utils as ast_utils
 
@@ -75,7 +73,7 @@ class _Shard(object):
     def symbols(self, doc):
         """The EASA string of one document as code points (host copy, fetched once per build)."""
         if self.host_symbols is None:
-            self.host_symbols = self.index.symbols()
+            self.host_symbols = ast_utils.reference_code_points(self.index.symbols())
         off = self.index.doc_offsets
         return self.host_symbols[int(off[doc]):int(off[doc + 1])]
 
@@ -120,16 +118,8 @@ class _DocumentAST(object):
 
 class ASTRelevanceMeasure(RelevanceMeasure):
 
-    def __init__(self, ast_algorithm=consts.ASTAlgorithm.EASA, normalized=True, device=None, on_out_of_domain="raise"):
-        """on_out_of_domain: what to do with a text that holds a word character >= U+0A00 (outside the method's
-        domain): "raise" SymbolOutOfDomainException naming the text (default), or "skip": index that
-        text as an empty one (every score 0), list it in `self.skipped` as (text number, code point) and go on with
-        the rest of the collection."""
+    def __init__(self, ast_algorithm=consts.ASTAlgorithm.EASA, normalized=True, device=None):
         super(ASTRelevanceMeasure, self).__init__()
-        if on_out_of_domain not in ("raise", "skip"):
-            raise ValueError("on_out_of_domain must be 'raise' or 'skip'")
-        self.on_out_of_domain = on_out_of_domain
-        self.skipped = []
         if ast_algorithm not in list(consts.ASTAlgorithm):
             from east import exceptions
             raise exceptions.NoSuchASTAlgorithm(name=ast_algorithm)
@@ -148,34 +138,14 @@ class ASTRelevanceMeasure(RelevanceMeasure):
 
     # HOT LOOP A (relevance.py:34-49) as one batched build
     def set_text_collection(self, texts, language=consts.Language.ENGLISH):
-        self.skipped = []
         texts = list(texts)
-        while True:
-            try:
-                return self._set_text_collection(texts, language)
-            except exceptions.SymbolOutOfDomainException as e:
-                if self.on_out_of_domain != "skip" or not isinstance(e.document, int):
-                    raise
-                self.skipped.append((e.document, e.code))
-                logging.warning("text number %d holds U+%04X (outside the method's domain): indexed as an empty text"
-                                % (e.document, e.code))
-                texts[e.document] = b""
-
-    def _set_text_collection(self, texts, language):
         self.texts = texts
         self.language = language
         if os.environ.get("EAST_HIP_TEXT_PREP", "device") == "device":
             # utils.text_to_strings_collection + make_unique_endings (relevance.py:44-45) on the device
             if self.index is None:
                 self.index = hip_backend.HipIndex(self.device)
-            try:
-                self.index.build_texts(list(texts))
-            except exceptions.HipBackendError as e:
-                if "outside the method's domain" in str(e):
-                    found = re.search(r"text (\d+) contains the word character U\+([0-9A-Fa-f]+)", str(e))
-                    if found:
-                        raise exceptions.SymbolOutOfDomainException(code=int(found.group(2), 16), document=int(found.group(1)))
-                raise
+            self.index.build_texts(list(texts))
             self.asts = [_DocumentAST(self._shard, d) for d in range(len(texts))]
             self._shard.row_cache = (None, None, None)
             self._shard.host_symbols = None
@@ -185,12 +155,9 @@ class ASTRelevanceMeasure(RelevanceMeasure):
 
     def set_strings_collections(self, collections):
         """collections[d] = the strings collection of document d (one AST each)."""
-        parts = []
-        for d, sc in enumerate(collections):
-            try:
-                parts.append(ast_utils.strings_to_symbols(sc))
-            except exceptions.SymbolOutOfDomainException as e:
-                raise exceptions.SymbolOutOfDomainException(code=e.code, document=d)
+        parts = [ast_utils.strings_to_symbols(sc) for sc in collections]
+        if any(ast_utils.is_tagged(p) for p in parts):       # text at or above U+0A00 somewhere: one encoding for the shard
+            parts = [ast_utils.tag_terminators(p) for p in parts]
         self._build_from_parts(parts, collections)
 
     def _build_from_parts(self, parts, collections):
@@ -203,7 +170,7 @@ class ASTRelevanceMeasure(RelevanceMeasure):
         self.index.build(symbols, doc_offsets, n_strings)
         self.asts = [_DocumentAST(self._shard, d) for d in range(len(parts))]
         self._shard.row_cache = (None, None, None)
-        self._shard.host_symbols = symbols
+        self._shard.host_symbols = ast_utils.reference_code_points(symbols)
 
     def relevance(self, keyphrase, text, synonimizer=None):
         """relevance.py:51-53: the score of a prepared keyphrase in text number `text`."""

@@ -20,8 +20,11 @@
  *   - indices are int32 on the device (n_total < 2^31 - 8); the Python side
  *     widens to int64 to match the reference's np.int tables
  *   - symbols are Unicode code points; a symbol >= 0x0A00 is a string
- *     terminator (east/consts.py:23-24, east/asts/utils.py:25-40); text symbols
- *     must be < 0x0A00 (the reference's defined input domain)
+ *     terminator (east/consts.py:23-24, east/asts/utils.py:25-40) and text symbols
+ *     are < 0x0A00 -- the reference's own encoding, in which text at or above U+0A00
+ *     cannot be told from a terminator.  Text of any script goes through the TAGGED
+ *     encoding (east_hip_set_symbol_encoding): terminator i of a document is
+ *     EAST_HIP_TERMINATOR_TAG | i, every other symbol a text code point < 0x110000
  *   - there is NO CPU fallback: without a HIP device every compute entry point
  *     fails with EAST_HIP_ERR_NO_DEVICE
  */
@@ -44,6 +47,9 @@ extern "C" {
 #define EAST_HIP_ERR_INTERNAL      -7  /* self-check failed (a bug)                     */
 
 #define EAST_HIP_TERMINATOR_START 0x0A00u /* east/consts.py:23-24 */
+#define EAST_HIP_TERMINATOR_TAG   0x80000000u /* tagged encoding: this bit marks a string terminator */
+#define EAST_HIP_SYMBOLS_REFERENCE 0 /* terminators are the code points 0x0A00+i, text is < 0x0A00 (the default) */
+#define EAST_HIP_SYMBOLS_TAGGED    1 /* terminators are EAST_HIP_TERMINATOR_TAG|i, text is any code point        */
 
 typedef struct east_hip_index *east_hip_handle_t;
 
@@ -90,6 +96,20 @@ int east_hip_reset(east_hip_handle_t h);
  * DEVICE pointer for `symbols` (doc_offsets / n_strings stay host pointers);
  * the buffer is only read.
  */
+/*
+ * Which encoding east_hip_build / east_hip_build_device read on this handle (default: the reference's).
+ * With EAST_HIP_SYMBOLS_TAGGED the text may hold code points at or above U+0A00 (Indic scripts, Thai, CJK,
+ * Hangul, precomposed Vietnamese, IPA capitals ...).  The text symbols are ordered by code point and the
+ * terminators sort ABOVE all of them, as they do for every text the reference is defined on.  The reference
+ * itself has no meaningful answer there: its terminators chr(0x0A00+i) fall below such text, and then
+ * easa.py loses the root annotation (anntab[0] = -m, negative scores: the bottom-up traversal,
+ * easa.py:57-85, is never flushed when the last suffix is not a terminator) or raises IndexError
+ * (easa.py:349-356 reads childtab_up[n]), and ast_linear disagrees with ast_naive
+ * (tests/golden/high_text.json records all three).  What is computed here is the method itself: the
+ * scores of ast_naive, and the tables easa.py gives after an order-preserving renaming of the text
+ * alphabet into code points below U+0A00.
+ */
+int east_hip_set_symbol_encoding(east_hip_handle_t h, int32_t encoding);
 int east_hip_build(east_hip_handle_t h, const uint32_t *symbols, int64_t n_total,
                    const int64_t *doc_offsets, const int32_t *n_strings, int32_t n_docs);
 int east_hip_build_device(east_hip_handle_t h, const uint32_t *d_symbols, int64_t n_total,
@@ -109,8 +129,11 @@ int east_hip_build_device(east_hip_handle_t h, const uint32_t *d_symbols, int64_
  *   text_offsets  D+1 offsets: text d is bytes[text_offsets[d] .. text_offsets[d+1]-1) + its 0xFF
  *   cp_class      0x0A00 bytes: bit 0 = the code point matches [\w'], bit 1 = str.isdigit()
  *   cp_upper      0x0A00 words: 1:1 upper-case mapping (identity where upper() is not one code point)
- *   word_hi       bitmap of the [\w'] code points in [0x0A00, 0x110000), bit (cp - 0x0A00); such
- *                 characters are outside the method's domain and fail with EAST_HIP_ERR_DOMAIN
+ *   word_hi       bitmap of the [\w'] code points in [0x0A00, 0x110000), bit (cp - 0x0A00)
+ *   digit_hi      the same for str.isdigit(); hi_upper_from / hi_upper_to: the sorted 1:1 upper-case
+ *                 mappings of code points >= 0x0A00
+ * Texts whose kept tokens hold characters at or above U+0A00 are built in the tagged encoding (see
+ * east_hip_set_symbol_encoding; east_hip_prepared_encoding says which one east_hip_get_prepared returns).
  * The Unicode tables come from the caller's interpreter, so the device agrees with the host's
  * re / str semantics by construction.  east_hip_get_prepared returns what was built:
  * n_total symbols, D+1 symbol offsets, D string counts, and the symbols (each pointer nullable).
@@ -128,6 +151,7 @@ int east_hip_build_texts_v(east_hip_handle_t h, const uint8_t *const *texts, con
                            const uint32_t *hi_upper_from, const uint32_t *hi_upper_to, int32_t n_hi_upper);
 int east_hip_get_prepared(east_hip_handle_t h, int64_t *n_total, int64_t *doc_offsets,
                           int32_t *n_strings, uint32_t *symbols);
+int east_hip_prepared_encoding(east_hip_handle_t h);   /* EAST_HIP_SYMBOLS_REFERENCE or _TAGGED */
 double east_hip_last_prep_ms(east_hip_handle_t h);
 
 /*

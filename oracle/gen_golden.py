@@ -16,6 +16,8 @@ Files written (tests/golden/):
   hse_graph.json        keyphrases_graph + gml/edges output on the HSE corpus (17 keyphrases)
   fuzz_small.json       random small collections: every table + scores (easa == ast_linear)
   zipf_docs.json        natural-language-like docs scored by ast_linear and easa (config 5 sub-sample)
+  high_text.json        text at or above U+0A00 (Thai, Georgian, CJK, Hangul, precomposed Vietnamese, a supplementary-
+                        plane letter): tables + scores of strings collections, and a keyphrase table over raw texts
   traversal_synonyms.json  pre-/post-order lcp-interval traversals (easa.py:38-85) and synonym-expanded
                         scores (easa.py:27-34, relevance.py:51-53, applications.py:43-52) with a stub synonimizer
 """
@@ -319,6 +321,65 @@ def gen_traversal_synonyms():
     write("traversal_synonyms.json", d)
 
 
+def high_text_dump(strings, queries):
+    """Scores of ast_naive -- the method as defined, indifferent to how the symbols are ordered.  With text at or
+    above U+0A00 the reference's terminators chr(0x0A00+i) sort BELOW such text and the other two algorithms stop
+    agreeing with it: easa.py loses the root annotation when the largest symbol occurs more than once (the bottom-up
+    traversal, easa.py:57-85, never pops the root: anntab[0] = -m) or raises IndexError (easa.py:349-356 reads
+    childtab_up[n]); ast_linear gives yet other numbers.  What they answer is recorded next to the naive scores."""
+    naive = base.AST.get_ast(strings, "ast_naive")
+    others = {a: base.AST.get_ast(strings, a) for a in ("easa", "ast_linear")}
+    d = {"strings": strings, "n_strings": len(strings), "easa_anntab0": int(others["easa"].anntab[0]), "queries": []}
+    for q in queries:
+        qq = q.replace(" ", "")
+        if not qq:
+            continue
+        sn, suf_n = naive.score(q, normalized=True, return_suffix_scores=True)
+        sd, suf_d = naive.score(q, normalized=False, return_suffix_scores=True)
+        entry = {"query": q, "normalized": float(sn), "denormalized": float(sd),
+                 "suffix_normalized": [float(suf_n[qq[i:]]) for i in range(len(qq))],
+                 "suffix_denormalized": [float(suf_d[qq[i:]]) for i in range(len(qq))]}
+        for a, o in others.items():
+            try:
+                entry[a] = float(o.score(q, normalized=True))
+            except IndexError:
+                entry[a] = "IndexError"
+        d["queries"].append(entry)
+    return d
+
+
+def gen_high_text():
+    """Text code points at or above the terminator base U+0A00 (the reference indexes them as long as its
+    terminators chr(0x0A00+i) do not reach them: asts/utils.py:25-40)."""
+    rng = random.Random(977)
+    cases = []
+    alphabets = ["\u0e01\u0e02\u0e04", "\u4e2d\u6587\u5b57\u5178\u8a9e", "AB\u10d0\u10d1", "\u1ea0\u1ea2B\u00c0C",
+                 "\ud55c\uae00 \uac00", "A\U00010400\U00010401\u0416", "\u0a7f\u0a80Z"]
+    for alpha in alphabets:
+        for _ in range(6):
+            m = rng.randint(1, 5)
+            strings = ["".join(rng.choice(alpha) for _ in range(rng.randint(0, 12))) for _ in range(m)]
+            if sum(len(s) for s in strings) + m < 2:
+                continue
+            queries = ["".join(rng.choice(alpha + "Z\u4e00") for _ in range(rng.randint(1, 8))) for _ in range(4)]
+            queries.append(strings[0][:5] if strings[0] else alpha[0])
+            cases.append(high_text_dump(strings, queries))
+    texts = {
+        "thai": "\u0e01\u0e32\u0e23\u0e28\u0e36\u0e01 \u0e29\u0e32\u0e44\u0e17\u0e22 \u0e01\u0e32\u0e23\u0e28\u0e36\u0e01 study of thai".encode("utf-8"),
+        "cjk": "\u4e2d\u6587\u5b57\u5178 alpha \u8a9e\u8a00\u5b66\u7fd2 \u4e2d\u6587\u5b57\u5178 \u6587\u5b57\u5217".encode("utf-8"),
+        "viet": "Vi\u1ec7t Nam \u0111\u1ea5t n\u01b0\u1edbc con ng\u01b0\u1eddi ti\u1ebfng Vi\u1ec7t".encode("utf-8"),
+        "plain": b"alpha beta gamma delta alpha beta",
+        "georgian": "\u10e5\u10d0\u10e0\u10d7\u10e3\u10da\u10d8 \u10d4\u10dc\u10d0 \u10e5\u10d0\u10e0\u10d7\u10e3\u10da\u10d8 ipa \u0250\u0251\u0252".encode("utf-8"),
+    }
+    keyphrases = ["\u4e2d\u6587\u5b57\u5178", "alpha beta", "ti\u1ebfng vi\u1ec7t", "\u0e01\u0e32\u0e23\u0e28\u0e36\u0e01",
+                  "\u10e5\u10d0\u10e0\u10d7\u10e3\u10da\u10d8 \u10d4\u10dc\u10d0", "\u0250\u0251\u0252", "thai"]
+    d = table_dump(keyphrases, texts, alg="ast_naive")
+    d["keyphrases"] = keyphrases
+    d["texts"] = {k: v.decode("utf-8") for k, v in texts.items()}
+    d["strings_collections"] = {k: utils.text_to_strings_collection(v) for k, v in texts.items()}
+    write("high_text.json", {"cases": cases, "table": d})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_readme()
@@ -329,3 +390,4 @@ if __name__ == "__main__":
     gen_fuzz()
     gen_zipf()
     gen_traversal_synonyms()
+    gen_high_text()

@@ -52,6 +52,29 @@ def hip():
     return hip_backend
 
 
+class Renamed(object):
+    """A strings collection with its text alphabet renamed, order-preserving, into code points 2, 3, ... below the
+    terminator base U+0A00 -- the form in which easa.py (and the oracle, its restatement) is defined for text of any
+    script: the method does not care what the symbols are called, the reference only needs its terminators
+    chr(0x0A00+i) to sort above the text.  `alphabet`: every code point that must get a name (default: those of
+    the strings)."""
+
+    def __init__(self, strings, alphabet=None):
+        cps = sorted(set(ord(c) for s in strings for c in s) if alphabet is None else set(alphabet))
+        assert len(cps) + 3 < 0x0A00
+        self.name = {c: 2 + i for i, c in enumerate(cps)}
+        self.unused = 2 + len(cps)                     # what a query symbol absent from the text becomes
+        parts = []
+        for i, s in enumerate(strings):
+            parts.append(np.array([self.name[ord(c)] for c in s] + [0x0A00 + i], dtype=np.uint32))
+        self.symbols = np.concatenate(parts)
+        self.n_strings = len(strings)
+
+    def query(self, q):
+        """score() strips U+0020 only (easa.py:36) -- before the renaming."""
+        return np.array([self.name.get(ord(c), self.unused) for c in q.replace(" ", "")], dtype=np.uint32)
+
+
 def word_stream(rng, n_bytes, lo=3, hi=10):
     """BASELINE synthetic text: uniform A-Z words of length U{lo..hi}, single spaces."""
     n_words = n_bytes // ((lo + hi) // 2) + 16

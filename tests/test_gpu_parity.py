@@ -85,8 +85,7 @@ def test_factory_errors(hip):
         base.AST.get_ast([])
     with pytest.raises(exceptions.NoSuchASTAlgorithm):
         base.AST.get_ast(["A"], "no_such")
-    with pytest.raises(exceptions.SymbolOutOfDomainException):
-        base.AST.get_ast(["中文AB"])
+    assert base.AST.get_ast(["中文AB"]).score("中文") > 0        # (text of any script: test_text_above_the_terminator_base_*)
     with pytest.raises(ZeroDivisionError):
         base.AST.get_ast(["AB"]).score(" ")
 
@@ -961,19 +960,14 @@ def _host_prepared(texts):
     from east.asts import utils as ast_utils
     colls = [utils.text_to_strings_collection(t) for t in texts]
     parts = [ast_utils.strings_to_symbols(sc) for sc in colls]
+    if any(ast_utils.is_tagged(p) for p in parts):            # kept text at or above U+0A00 anywhere: the tagged encoding
+        parts = [ast_utils.tag_terminators(p) for p in parts]
     return (np.concatenate(parts), np.concatenate([[0], np.cumsum([p.size for p in parts])]),
             np.array([len(sc) for sc in colls]))
 
 
 def _check_device_prep(hip, texts):
-    from east import exceptions
     index = hip.HipIndex()
-    try:
-        _host_prepared(texts)
-    except exceptions.SymbolOutOfDomainException:             # a word character beyond U+0A00: both must refuse
-        with pytest.raises(exceptions.HipBackendError, match="outside the method's domain"):
-            index.build_texts(texts)
-        return None
     index.build_texts(texts)
     sym, off, m = index.prepared()
     want_sym, want_off, want_m = _host_prepared(texts)
@@ -1005,21 +999,24 @@ def test_device_text_preparation_fuzz(hip):
                                             "\U0001F600", "—", "’", "﻿", " ", "İ", "ͅ"]
     junk = [b"\x80", b"\xbf", b"\xc0", b"\xc1\x81", b"\xc2", b"\xe0\x80", b"\xe0\xa0", b"\xe4\xb8", b"\xed\xa0\x80",
             b"\xf0\x90\x80", b"\xf4\x90\x80\x80", b"\xf5", b"\xff", b"\xe2\x82", b"\xf0\x9f\x98"]
-    for it in range(120):
+    # word characters at or above U+0A00 (every third round: the symbols then come in the tagged encoding)
+    high = ["\u4e2d", "\u6587", "\u0e01", "\u0e02", "\u1ec7", "\u10e5", "\u2c6f", "\ud55c", "\U00010428", "\u0e53", "\u2177", "\u1fb3"]
+    for it in range(180):
         texts = []
+        pool = chars + high if it % 3 == 2 else chars
         for _ in range(rng.randint(1, 6)):
             parts = []
             for _ in range(rng.randint(0, 40)):
                 if rng.random() < 0.12:
                     parts.append(rng.choice(junk))
                 else:
-                    parts.append("".join(rng.choice(chars) for _ in range(rng.randint(1, 6))).encode("utf-8"))
+                    parts.append("".join(rng.choice(pool) for _ in range(rng.randint(1, 6))).encode("utf-8"))
             texts.append(b"".join(parts))
         _check_device_prep(hip, texts)
 
 
-def test_device_text_preparation_large_and_domain(hip):
-    from east import exceptions, relevance, synthetic
+def test_device_text_preparation_large(hip):
+    from east import synthetic
     rng = np.random.default_rng(3)
     text, sym, m = synthetic.word_stream_document(rng, 16 << 20)
     index = hip.HipIndex()
@@ -1027,10 +1024,6 @@ def test_device_text_preparation_large_and_domain(hip):
     got, off, ms = index.prepared()
     assert ms[0] == m and np.array_equal(got[: off[1]], sym)
     assert got[off[2]:off[3]].tolist() == [32, 0x0A00] and got[off[3]:].tolist() == [32, 0x0A00]
-    measure = relevance.ASTRelevanceMeasure()
-    with pytest.raises(exceptions.SymbolOutOfDomainException) as e:
-        measure.set_text_collection([b"fine text", "word 中文字 here".encode("utf-8")])
-    assert "4E2D" in str(e.value)
 
 
 def test_host_and_device_text_preparation_give_the_same_table(hip, monkeypatch):
@@ -1101,46 +1094,146 @@ def test_many_small_documents(hip, oracle):
             assert table[k, d] == o.score(kp, fast=True), (d, kp)
 
 
-def test_out_of_domain_text_is_reported_with_its_document(hip, tmp_path, capsys):
-    """A kept word character >= U+0A00 is outside the method's domain: the error names the first
-    text it occurs in -- on the device and on the host text preparation -- and the CLI prints it and returns 1."""
-    from east import applications, exceptions, main as east_main, relevance
-    texts = {"plain": b"alpha beta gamma delta", "cjk": "alpha \u4e2d\u6587\u5b57\u5178 beta".encode("utf-8"), "later": "\u0e01\u0e02\u0e03\u0e04".encode("utf-8")}
+def _check_renamed(hip, oracle, docs, queries, alphabet=None):
+    """docs: strings collections of one shard.  Tables and scores of every document against the oracle on the
+    renamed alphabet (conftest.Renamed); returns the index."""
+    from conftest import Renamed
+    from east.asts import utils as ast_utils
+    parts = [ast_utils.strings_to_symbols(sc) for sc in docs]
+    if any(ast_utils.is_tagged(p) for p in parts):
+        parts = [ast_utils.tag_terminators(p) for p in parts]
+    index = hip.HipIndex()
+    index.build(np.concatenate(parts), np.concatenate([[0], np.cumsum([p.size for p in parts])]),
+                np.array([len(sc) for sc in docs]))
+    stripped = [q.replace(" ", "") for q in queries]
+    qs, qo = hip.pack_queries(stripped)
+    tables = {norm: index.score_table(qs, qo, norm) for norm in (True, False)}
+    for d, sc in enumerate(docs):
+        r = Renamed(sc, alphabet)
+        o = oracle.OracleEASA(symbols=r.symbols, n_strings=r.n_strings)
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d, sc)
+        for k, q in enumerate(queries):
+            for norm in (True, False):
+                assert tables[norm][k, d] == o.score_symbols(r.query(q), norm), (d, q, norm)
+    return index
+
+
+def test_text_above_the_terminator_base_fixture(hip, oracle, tmp_path, capsys):
+    """high_text.json (generated from the reference): text at or above U+0A00 -- Thai, CJK, Hangul, Georgian,
+    precomposed Vietnamese, a supplementary-plane letter.  The scores are those of ast_naive, the method as defined
+    (the reference's easa and ast_linear break there, see the fixture); the tables those of easa.py on the
+    order-preserving renaming of the text alphabet below U+0A00 (the oracle)."""
+    from east import applications, main as east_main, relevance
+    from east.asts import base
+    g = load_golden("high_text.json")
+    for case in g["cases"]:
+        ast = base.AST.get_ast(case["strings"])
+        assert ast.string == "".join(s + chr(0x0A00 + i) for i, s in enumerate(case["strings"]))
+        for q in case["queries"]:
+            qq = q["query"].replace(" ", "")
+            for mode, norm in (("normalized", True), ("denormalized", False)):
+                total, suffixes = ast.score(q["query"], normalized=norm, return_suffix_scores=True)
+                assert abs(total - q[mode]) <= 1e-12, (case["strings"], q["query"], mode)
+                assert all(abs(suffixes[qq[i:]] - q["suffix_" + mode][i]) <= 1e-12 for i in range(len(qq)))
+        _check_renamed(hip, oracle, [case["strings"]], [q["query"] for q in case["queries"]])
+    t = g["table"]
+    texts = {k: v.encode("utf-8") for k, v in t["texts"].items()}
     for prep in ("device", "host"):
         os.environ["EAST_HIP_TEXT_PREP"] = prep
         try:
-            with pytest.raises(exceptions.SymbolOutOfDomainException) as e:
-                applications.keyphrases_table(["alpha"], texts, relevance.ASTRelevanceMeasure())
-            assert e.value.document == "cjk" and e.value.code == 0x4E2D and "'cjk'" in str(e.value)
-            with pytest.raises(exceptions.SymbolOutOfDomainException) as e:
-                relevance.ASTRelevanceMeasure().set_text_collection(list(texts.values()))
-            assert e.value.document == 1
+            for mode, norm in (("normalized", True), ("denormalized", False)):
+                table = applications.keyphrases_table(t["keyphrases"], texts, relevance.ASTRelevanceMeasure(normalized=norm))
+                for kp in t["keyphrases"]:
+                    for name in texts:
+                        assert abs(table[kp][name] - t[mode][kp][name]) <= 1e-12, (prep, mode, kp, name)
         finally:
             os.environ.pop("EAST_HIP_TEXT_PREP", None)
+    # the CLI on the same collection
     tdir = tmp_path / "texts"
     tdir.mkdir()
     for name, raw in texts.items():
         (tdir / (name + ".txt")).write_bytes(raw)
-    (tmp_path / "kp.txt").write_text("alpha\n")
-    assert east_main.main(["keyphrases", "table", str(tmp_path / "kp.txt"), str(tdir)]) == 1
-    assert "U+4E2D" in capsys.readouterr().out
-    # "skip": the offending texts count as empty ones, the others are scored as if they had been alone
-    assert east_main.main(["--skip-out-of-domain", "keyphrases", "table", str(tmp_path / "kp.txt"), str(tdir)]) == 0
-    assert "alpha" in capsys.readouterr().out
-    for prep in ("device", "host"):
-        os.environ["EAST_HIP_TEXT_PREP"] = prep
-        try:
-            measure = relevance.ASTRelevanceMeasure(on_out_of_domain="skip")
-            table = applications.keyphrases_table(["alpha", "beta gamma"], texts, measure)
-            assert sorted(d for d, _ in measure.skipped) == [1, 2] and (1, 0x4E2D) in measure.skipped
-            alone = applications.keyphrases_table(["alpha", "beta gamma"], {"plain": texts["plain"]}, relevance.ASTRelevanceMeasure())
-            assert table["alpha"]["plain"] == alone["alpha"]["plain"] and table["beta gamma"]["plain"] == alone["beta gamma"]["plain"]
-            assert table["alpha"]["cjk"] == 0 and table["alpha"]["later"] == 0
-        finally:
-            os.environ.pop("EAST_HIP_TEXT_PREP", None)
-    # texts without such characters next to it are fine
-    del texts["cjk"], texts["later"]
-    assert applications.keyphrases_table(["alpha"], texts, relevance.ASTRelevanceMeasure())["alpha"]["plain"] > 0
+    (tmp_path / "kp.txt").write_text("\n".join(t["keyphrases"]) + "\n", encoding="utf-8")
+    assert east_main.main(["-f", "csv", "keyphrases", "table", str(tmp_path / "kp.txt"), str(tdir)]) == 0
+    assert "0.472" in capsys.readouterr().out
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_text_above_the_terminator_base_random_shards(hip, oracle, seed):
+    """Shards mixing documents with and without text above U+0A00, narrow alphabets (the byte path and the window
+    sort) and wide ones (more than 254 distinct text symbols: dense u32 codes, DC3), code points next to the
+    terminator base and on the supplementary planes; queries with symbols absent from the text."""
+    rng = np.random.default_rng(4200 + seed)
+    pools = [list("ABC") + [chr(c) for c in (0x0A00, 0x0A01, 0x0A02, 0x0E01, 0x4E2D)],
+             [chr(c) for c in range(0x4E00, 0x4E00 + 300)] + list("xy"),
+             [chr(c) for c in (0x09FF, 0x0A00, 0x10FFFF, 0x10400, 0xFFFD, 0x41)],
+             list("ABCDEFG"),
+             [chr(c) for c in range(0x0400, 0x0400 + 200)] + [chr(c) for c in range(0xAC00, 0xAC00 + 100)]]
+    pool_of_doc = [pools[int(rng.integers(len(pools)))] for _ in range(int(rng.integers(1, 7)))]
+    if seed == 0:
+        pool_of_doc = [pools[3], pools[0], pools[3]]          # (only some documents hold high text)
+    docs = []
+    for pool in pool_of_doc:
+        m = int(rng.integers(1, 8))
+        docs.append(["".join(pool[int(i)] for i in rng.integers(0, len(pool), size=int(rng.integers(0, 60)))) for _ in range(m)])
+        if sum(len(s) for s in docs[-1]) == 0:
+            docs[-1][0] = pool[0]
+    every = sorted(set(ord(c) for sc in docs for s in sc for c in s))
+    queries = []
+    for _ in range(24):
+        sc = docs[int(rng.integers(len(docs)))]
+        s = sc[int(rng.integers(len(sc)))] or "A"
+        a = int(rng.integers(len(s)))
+        q = s[a:a + int(rng.integers(1, 9))]
+        if rng.random() < 0.3:
+            q = q + chr(int(rng.choice([0x0A00, 0x4E01, 0x42, 0x10FFFE])))
+        queries.append(q)
+    # one alphabet for the whole shard: the device numbers the text symbols of all documents together
+    index = _check_renamed(hip, oracle, docs, queries, alphabet=every)
+    assert index.info()["sigma_text"] == len(every)
+
+
+def test_tagged_encoding_c_abi(hip, oracle):
+    """The tagged encoding without any high text gives what the reference encoding gives; a symbol that is neither a
+    tagged terminator nor a code point is refused; the encoding is a property of the handle until reset."""
+    from east import exceptions
+    from east.asts import utils as ast_utils
+    docs = [["XABXAC", "BABXAC"], ["HELLO", "", "HELP"]]
+    parts = [ast_utils.strings_to_symbols(sc) for sc in docs]
+    off = np.concatenate([[0], np.cumsum([p.size for p in parts])])
+    m = np.array([len(sc) for sc in docs])
+    plain, tagged = hip.HipIndex(), hip.HipIndex()
+    plain.build(np.concatenate(parts), off, m)
+    tagged.build(np.concatenate([ast_utils.tag_terminators(p) for p in parts]), off, m)
+    for d in range(2):
+        a, b = plain.tables(d), tagged.tables(d)
+        for name in TABLES:
+            assert np.array_equal(a[name], b[name])
+    qs, qo = hip.pack_queries(["ABX", "HEL", "Q"])
+    assert np.array_equal(plain.score_table(qs, qo, True), tagged.score_table(qs, qo, True))
+    bad = np.concatenate([ast_utils.tag_terminators(p) for p in parts])
+    bad[1] = 0x110000
+    with pytest.raises(exceptions.HipBackendError, match="neither a tagged terminator nor a code point"):
+        tagged.build(bad, off, m)
+    bad[1] = 0x4E2D
+    bad[-1] = 0x0A02                                              # the reference's terminator in a tagged stream: text
+    with pytest.raises(exceptions.HipBackendError, match="terminator"):
+        _build_tagged(hip, tagged, bad, off, m)
+
+
+def _build_tagged(hip, index, symbols, off, m):
+    """east_hip_build with the tagged encoding set by hand (HipIndex.build tells it from the last symbol)."""
+    import ctypes
+    lib = hip.load()
+    assert lib.east_hip_set_symbol_encoding(index._h, 1) == 0
+    symbols = np.ascontiguousarray(symbols, dtype=np.uint32)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    m = np.ascontiguousarray(m, dtype=np.int32)
+    hip._check(lib.east_hip_build(index._h, symbols.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), symbols.size,
+                                  off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                  m.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), m.size))
 
 
 def test_score_in_stretches_of_documents(hip, oracle):

@@ -46,8 +46,16 @@ def test_prepare_text_is_code_point_to_code_point():
 def test_strings_to_symbols_domain_and_large_collections():
     from east import exceptions
     from east.asts import utils as ast_utils
+    # text at or above U+0A00: the tagged encoding (terminator i = TAG | i), unless the reference's is insisted on
     with pytest.raises(exceptions.SymbolOutOfDomainException):
-        ast_utils.strings_to_symbols(["ok", "中"])
+        ast_utils.strings_to_symbols(["ok", "中"], tagged=False)
+    sym = ast_utils.strings_to_symbols(["ok", "中"])
+    assert sym.tolist() == [111, 107, 0x80000000, 0x4E2D, 0x80000001] and ast_utils.is_tagged(sym)
+    assert ast_utils.reference_code_points(sym).tolist() == [111, 107, 0x0A00, 0x4E2D, 0x0A01]
+    plain = ast_utils.strings_to_symbols(["ok", "no"])
+    assert not ast_utils.is_tagged(plain) and plain.tolist() == [111, 107, 0x0A00, 110, 111, 0x0A01]
+    assert ast_utils.tag_terminators(plain).tolist() == ast_utils.strings_to_symbols(["ok", "no"], tagged=True).tolist()
+    assert ast_utils.tag_terminators(sym) is sym and ast_utils.reference_code_points(plain) is plain
     m = 1_200_000                                         # beyond the reference's 1 111 552-string limit
     sym = ast_utils.strings_to_symbols(["A"] * m)
     assert sym.size == 2 * m and int(sym[-1]) == 0x0A00 + m - 1 and int(sym[0]) == 65
