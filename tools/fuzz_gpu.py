@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Randomised differential test of the device build against the CPU oracle, beyond what tests/ runs
-every time: random alphabets (2..254 symbols), one or several documents, short strings and long
+every time: random alphabets (2..1200 symbols), one or several documents, short strings and long
 strings, planted repeats (copied passages, runs of one symbol, whole strings repeated many times),
 and a random choice of the code paths a test knob selects (window sort / DC3 only / 64-bit window
-keys / lean).  Every table of every document bit-exact, a few scores bit-equal.
+keys / lean).  A third of the collections go to the device with the upper part of their alphabet
+lifted, order-preserving, to random code points at or above U+0A00 (tagged symbol encoding) while
+the oracle sees the original.  Every table of every document bit-exact, a few scores bit-equal.
 
     python tools/fuzz_gpu.py [--seconds 300] [--seed 1] [--max-symbols 400000]
 """
@@ -47,7 +49,7 @@ def random_string(rng, alphabet, length, repeats):
 
 
 def random_collection(rng, max_symbols):
-    sigma = int(rng.choice([2, 3, 4, 8, 26, 27, 60, 120, 254]))
+    sigma = int(rng.choice([2, 3, 4, 8, 26, 27, 60, 120, 254, 255, 400, 1200]))
     # (code points >= 2: the reference -- and with it the oracle -- pads with chr(1) and is undefined below that)
     alphabet = (np.arange(sigma) + int(rng.choice([2, 33, 65, 0x100, 0x400]))).astype(np.uint32)
     alphabet = alphabet[alphabet < TERM]
@@ -102,14 +104,26 @@ def main():
         parts = [to_symbols(sc) for sc in docs]
         sym = np.concatenate(parts)
         off = np.concatenate([[0], np.cumsum([p.size for p in parts])])
+        # what the device is given: the same, or the upper part of the alphabet lifted above U+0A00 (tagged terminators)
+        used = np.unique(sym[sym < TERM])
+        lifted = rng.random() < 0.35
+        if lifted:
+            split = int(rng.integers(0, used.size + 1))
+            target = used.copy()
+            target[split:] = np.sort(rng.choice(0x110000 - TERM, size=used.size - split, replace=False).astype(np.uint32) + TERM)
+            lift = lambda a: target[np.searchsorted(used, a)]      # noqa: E731
+            dev_sym = np.where(sym >= TERM, (sym - TERM) | np.uint32(0x80000000), lift(np.minimum(sym, used[-1]))).astype(np.uint32)
+        else:
+            lift = lambda a: a                                     # noqa: E731
+            dev_sym = sym
         index = hip_backend.HipIndex()
         if os.environ.get("FUZZ_VERBOSE"):
             print("case %d: knob %d, %d docs, %d symbols, strings %s" % (cases, knob, len(docs), sym.size,
                                                                          [len(sc) for sc in docs]), flush=True)
         try:
-            index.build(sym, off, np.array([len(sc) for sc in docs], dtype=np.int32))
+            index.build(dev_sym, off, np.array([len(sc) for sc in docs], dtype=np.int32))
             info = index.info()
-            key = (knob, info["window_sorted"], min(info["dc3_levels"], 3), min(info["refine_rounds"], 3))
+            key = (knob, info["window_sorted"], min(info["dc3_levels"], 3), min(info["refine_rounds"], 3), int(lifted))
             paths[key] = paths.get(key, 0) + 1
             queries = []
             for sc in docs[:2]:
@@ -119,7 +133,7 @@ def main():
                     queries.append(s[a:a + int(rng.integers(1, 12))])
             queries.append(rng.choice(sym[sym < TERM], size=3).astype(np.uint32))
             qo = np.concatenate([[0], np.cumsum([q.size for q in queries])]).astype(np.int64)
-            qs = np.concatenate(queries)
+            qs = lift(np.concatenate(queries)).astype(np.uint32)
             table = {norm: index.score_table(qs, qo, norm) for norm in (True, False)}
             for d, p in enumerate(parts):
                 if p.size > 250000 and d > 0:
@@ -142,7 +156,7 @@ def main():
             index.close()
         cases += 1
     lib.east_hip_debug_set_window_sort(1)
-    print("fuzz ok: %d collections, %d documents, %d symbols checked; paths (knob, window_sorted, dc3_levels, rounds):"
+    print("fuzz ok: %d collections, %d documents, %d symbols checked; paths (knob, window_sorted, dc3_levels, rounds, lifted):"
           % (cases, docs_checked, symbols))
     for k in sorted(paths):
         print("   ", k, paths[k])
