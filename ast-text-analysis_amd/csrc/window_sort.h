@@ -242,6 +242,7 @@ static int lvl0_spare_bits(int used, int key_bits, int bt, int w)
 }
 
 template <class K> struct KeyNeqWindowIn {
+    static constexpr bool HAS_KEYS = true;
     const K *keys;
     K rep_t, ones, highs;       // terminator code / 1 / top bit replicated into every full-symbol field
     // "does any of the w full symbols equal the terminator code": xor turns such a field into zero,
@@ -303,6 +304,7 @@ struct BitIn {                                  // one flag per element, 64 to a
 };
 
 struct FlagArrIn {                              // the naming predicate of a compacted domain
+    static constexpr bool HAS_KEYS = false;
     const u32 *flags;
     __device__ __forceinline__ u32 operator()(u32 i) const { return flags[i]; }
 };
@@ -436,7 +438,13 @@ __device__ __forceinline__ u32 lvl0_place_tied(u32 j, const Elem &elem, const St
     order_g[at_g] = e;
     if (names_g) names_g[first ? j : slot[j]] = 1;
     if (name_of) name_of[p] = at_g;                     // (prefix doubling: a placed suffix is named by its exact position)
-    if (lcp_g) lcp_g[at] = r > 0 ? best : lcp_first(at);
+    // (its LCP entry: with a smaller member of the group, or -- the first of a group of the keyed first domain -- from
+    // the keys; the first of a group of a later domain keeps the entry it got when its group split off, see
+    // dc3_refine_writeback_kernel)
+    if (lcp_g) {
+        if (r > 0) lcp_g[at_g] = best;
+        else if (first) lcp_g[at_g] = lcp_first(at);
+    }
     return 0;
 }
 
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
                                                                     u32 *__restrict__ order_g, u32 *__restrict__ names_g,
                                                                     u64 *__restrict__ keep, u32 *__restrict__ fail,
                                                                     u32 limit, u32 max_len, u32 *__restrict__ name_of,
-                                                                    LongRepeats lr)
+                                                                    LongRepeats lr, u32 *__restrict__ lcp_g)
 {
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
     u32 my_keep = 0;
@@ -621,7 +629,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
         const bool left_same = j > 0 && !starts(j);
         const bool right_same = j + 1 < m && !starts(j + 1);
         if (left_same || right_same)
-            my_keep = lvl0_place_tied(j, elem, starts, slot, m, s8, n0, depth, order_g, names_g, (u32 *)nullptr, NoLcp(),
+            my_keep = lvl0_place_tied(j, elem, starts, slot, m, s8, n0, depth, order_g, names_g, lcp_g, NoLcp(),
                                       fail, limit, max_len, name_of, lr);
     }
     // keep[]: one bit per element (entries m.. of the last word are 0: the exclusive scan over m + 1 yields the total)
@@ -649,14 +657,25 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__
                                                                    const u32 *__restrict__ slot, BitIn keep,
                                                                    const u32 *__restrict__ idx, u32 m,
                                                                    u32 *__restrict__ slot_out, u32 *__restrict__ elem_out,
-                                                                   u32 *__restrict__ group_start)
+                                                                   u32 *__restrict__ group_start,
+                                                                   u32 *__restrict__ lcp_g = nullptr, int w = 0, int b = 0,
+                                                                   int spare = 0)
 {
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
     if (j >= m || !keep(j)) return;
     const u32 k = idx[j];
+    const u32 st = starts(j);
     slot_out[k] = slot ? slot[j] : j;
     elem_out[k] = elem[j];
-    group_start[k] = starts(j);
+    group_start[k] = st;
+    if constexpr (Starts::HAS_KEYS) {
+        // the keyed first domain: the first rank of a group left to the rounds gets its LCP entry here, from the
+        // two keys -- whichever member ends up there
+        if (lcp_g && st) {
+            bool whole;
+            lcp_g[j] = j > 0 ? lvl0_lcp_of_keys(starts, w, b, spare, j, whole) : 0u;
+        }
+    }
 }
 
 // key = (dense group number << w2*b) | next window of w2 symbols at offset `depth`
@@ -739,19 +758,33 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_writeback_kernel(const u64 *
                                                                      const u32 *__restrict__ elems, u32 n_tied,
                                                                      u64 rep_t, u64 ones, u64 highs,
                                                                      u32 *__restrict__ order_g, u32 *__restrict__ names_g,
-                                                                     u32 *__restrict__ elem_out, u32 *__restrict__ flag_out)
+                                                                     u32 *__restrict__ elem_out, u32 *__restrict__ flag_out,
+                                                                     u32 *__restrict__ lcp_g = nullptr, u32 depth = 0,
+                                                                     int w2 = 0, int b = 0)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n_tied) return;
-    const u64 k = keys[r];
+    const u64 k = keys[r], kp = r ? keys[r - 1] : 0;
     const u64 x = k ^ rep_t;
-    const bool has_term = ((x - ones) & ~x & highs) != 0;       // a terminator inside the window: unique
+    const u64 tz = (x - ones) & ~x & highs;
+    const bool has_term = tz != 0;                              // a terminator inside the window: unique
     const u32 slot = slots[r], e = vals[r];
-    const u32 f = (r == 0 || has_term || k != keys[r - 1]) ? 1u : 0u;
+    const u32 f = (r == 0 || has_term || k != kp) ? 1u : 0u;
     order_g[slot] = e;
     if (names_g) names_g[slot] = f;
     elem_out[r] = e;
     flag_out[r] = f;
+    // symbol windows: where a group splits, the LCP entry of the rank that starts the new group is what the two
+    // windows have in common behind the `depth` symbols the group shares (cut at a terminator: two equal terminator
+    // codes are different terminators) -- final whichever members end up at the seam.  The first rank of the old
+    // group keeps the entry it has.
+    const int gshift = w2 * b;
+    if (lcp_g && f && r > 0 && (k >> gshift) == (kp >> gshift)) {
+        const u64 d = (k ^ kp) & (((u64)1 << gshift) - 1u);
+        const u32 mism = d ? (u32)(w2 - 1 - (63 - __builtin_clzll(d)) / b) : (u32)w2;
+        const u32 term = tz ? (u32)(w2 - 1 - __builtin_ctzll(tz) / b) : (u32)w2;
+        lcp_g[slot] = depth + (mism < term ? mism : term);
+    }
 }
 
 // LCP table straight from the sorted window keys (all-suffix mode, one document): neighbours with
@@ -759,14 +792,19 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_writeback_kernel(const u64 *
 // first terminator field (equal terminator codes are two DIFFERENT terminators) -- no text is
 // touched.  Only neighbours whose whole window agrees (the tied ones, reordered in place since)
 // read their suffixes, from offset w on.  Same cap rule as lcp8_kernel.
+// only != nullptr: one bit per rank, set for the members of the groups the placement pass left to the rounds --
+// every other entry was written by that pass and stands (a rank outside those groups has a neighbour with another
+// key: its entry never depended on which member of the neighbouring group ended up next to it).
 template <class K>
 __global__ __launch_bounds__(BLOCK) void lvl0_lcp_keys_kernel(KeyNeqWindowIn<K> f, int w, int b, int spare,
                                                               const uint8_t *__restrict__ s8,
                                                               const u32 *__restrict__ sa, u32 n,
+                                                              const u64 *__restrict__ only,
                                                               u32 *__restrict__ lcp, u32 *__restrict__ capped)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
+    if (only && !((only[r >> 6] >> (r & 63u)) & 1ull)) return;
     if (r == 0) { lcp[0] = 0; return; }
     bool whole;
     u32 h = lvl0_lcp_of_keys(f, w, b, spare, r, whole);
@@ -911,7 +949,12 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
 
     // ---- refinement rounds on the members of large groups ---------------------------------
     // (ctx.lean: the device is short of memory for the rounds' buffers -- straight on to the recursion / DC3)
+    // the placement pass's verdict is kept: the LCP entries of everything it placed are final (lvl0_lcp_keys_kernel)
+    u64 *keep0 = lcp_out ? ar.alloc<u64>(((size_t)n02 >> 6) + 2) : nullptr;
+    if (keep0 && !ctx.dry && !ctx.lean)
+        HIP_CHECK(hipMemcpyAsync(keep0, keep, (((size_t)n02 >> 6) + 1) * sizeof(u64), hipMemcpyDeviceToDevice, ctx.stream));
     bool done = false;
+    bool lcp_from_rounds = true;                        // the rounds write the LCP entries of what they place (symbol windows)
     if (!ctx.lean) {
         const size_t mark_rounds = ar.mark();
         const u32 cap = n02 + 1;                        // natural-language text: most suffixes can be in large groups
@@ -944,6 +987,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             if (name_of && !doubling && round > 0 && m_next > m / 2) {
                 // slow shrinking = long repeats: from here on the depth doubles every round (see above)
                 doubling = true;
+                lcp_from_rounds = false;                // (names instead of symbols: the seams' entries are computed at the end)
                 LAUNCH(ctx, dc3_names_init_kernel, ceil_div_u32(n02, BLOCK), (const u32 *)sa12, n02, name_of);
                 device_scan<ArrIn, true>(ctx, ArrIn{flag}, m, group);
                 LAUNCH(ctx, dc3_group_starts_kernel, gm, flag, (const u32 *)group, slot, m, gstart);
@@ -957,7 +1001,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             u32 *slot_c = sbuf[s_dom ^ 1];
             if (!slot)
                 LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<KeyNeqWindowIn<K>>), gm, elem,
-                             starts, slot, BitIn{keep}, (const u32 *)idx, m, slot_c, ebuf[e_c], gstart);
+                             starts, slot, BitIn{keep}, (const u32 *)idx, m, slot_c, ebuf[e_c], gstart, lcp_out, w, bt, spare);
             else
                 LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<FlagArrIn>), gm, elem,
                              FlagArrIn{flag}, slot, BitIn{keep}, (const u32 *)idx, m, slot_c, ebuf[e_c], gstart);
@@ -982,7 +1026,8 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                        (const u64 *)nullptr, name_of);
                 depth *= 2;
             } else {
-                const int w2 = std::min(12, (64 - gbits) / bt);
+                int w2 = std::min(12, (64 - gbits) / bt);
+                if (const char *e = getenv("EAST_HIP_REFINE_W2")) w2 = std::min(w2, atoi(e));      // (experiment)
                 if (w2 < 1) break;
                 LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)ebuf[e_c], (const u32 *)group, m, n0, depth, w2, bt,
                        term_first, rb.keys[0], rb.vals[0]);
@@ -990,7 +1035,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 const KeyNeqWindowIn<u64> f = KeyNeqWindowIn<u64>::make(nullptr, w2, bt, 0, term_first);
                 LAUNCH(ctx, dc3_refine_writeback_kernel, gt, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr],
                        (const u32 *)slot_c, (const u32 *)ebuf[e_c], m, f.rep_t, f.ones, f.highs, sa12, names_g, ebuf[e_out],
-                       fbuf[f_dom ^ 1]);
+                       fbuf[f_dom ^ 1], lcp_out, depth, w2, bt);
                 depth += (u32)w2;
             }
             e_dom = e_out; s_dom ^= 1; f_dom ^= 1;
@@ -1004,7 +1049,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 LAUNCH(ctx, dc3_refine_classify_kernel, gt, elem, FlagArrIn{flag}, slot, m, s8, n0, depth, sa12, names_g, keep,
                        fail, endgame ? (u32)REFINE_ENDGAME_GROUP : (u32)REFINE_SMALL_GROUP,
                        endgame ? (u32)REFINE_ENDGAME_LEN : (u32)RESOLVE_MAX_LEN, doubling ? name_of : (u32 *)nullptr,
-                       LongRepeats{bad, mode});
+                       LongRepeats{bad, mode}, lcp_out);
                 if (mode == 1) return;
                 device_scan<BitIn, false>(ctx, BitIn{keep}, m + 1, idx);
                 have_idx = true;
@@ -1036,9 +1081,9 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     }
     if (done) {
         if (ctx.stats) ctx.stats->levels_resolved++;
-        if (lcp_out)                                    // (the entries written by the first pass are overwritten)
+        if (lcp_out && !lcp_from_rounds)                // (prefix doubling: the entries of everything the rounds placed)
             LAUNCH_NAMED(ctx, "lvl0_lcp_keys_kernel", (lvl0_lcp_keys_kernel<K>), ceil_div_u32(n02, BLOCK), starts, w, bt,
-                         spare, s8, (const u32 *)sa12, n02, lcp_out, lcp_capped);
+                         spare, s8, (const u32 *)sa12, n02, (const u64 *)keep0, lcp_out, lcp_capped);
         return true;
     }
     if (!s12) return false;                            // all-suffix mode: the caller falls back to DC3

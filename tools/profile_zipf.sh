@@ -1,0 +1,19 @@
+#!/bin/bash
+# rocprofv3 kernel statistics of the config 5 stand-in (100 x 1 MiB Zipf documents) -> gpurun_out/zipf/
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+mkdir -p gpurun_out/zipf
+ARGS="--corpus zipf --docs 100 --doc-mib 1 --keyphrases 1000 --no-cpu-baseline --no-config2 --no-extras"
+timeout 300 python3 bench.py $ARGS 2>/dev/null | tail -1 > gpurun_out/zipf/bench.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/zipf/trace -- python3 bench.py $ARGS --steps 5 --warmup 2 > gpurun_out/zipf/bench_profiled.json 2>/dev/null
+python3 - <<'PY'
+import csv, glob, json
+b = json.load(open("gpurun_out/zipf/bench.json"))
+print("step %.2f ms  build %.2f  score %.2f  %.3e chars/s" % (b["ms_per_step"], b["build_ms"], b["score_ms"], b["value"]))
+f = glob.glob("gpurun_out/zipf/trace/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows[:28]:
+    print("%-90s %5s calls %9.1f us avg %6.2f%%" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+PY
