@@ -76,6 +76,7 @@ struct Stats {
     i64 levels = 0, levels_resolved = 0, refine_rounds = 0, window_sorted = 0, merge_elems = 0, radix_passes = 0, radix_elems = 0, radix_elem_bytes = 0;
     i64 radix_elems_u32 = 0, radix_elems_u64 = 0, radix_passes_u32 = 0, radix_passes_u64 = 0;
     i64 long_repeats = 0;       // the placement pass had to be repeated as mark + commit (duplicated passages)
+    i64 lds_sorted = 0;         // elements the refinement rounds ordered inside a workgroup's LDS (lds_group_sort.h)
 };
 
 // Optional per-kernel timing with HIP events on the handle's own stream (the

@@ -1406,14 +1406,14 @@ void *east_hip_stream(east_hip_handle_t h) { return h ? (void *)h->stream : null
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap)
 {
     if (!h || !out) return EAST_HIP_ERR_INVALID;
-    const int64_t v[19] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
+    const int64_t v[20] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
                            (int64_t)h->arena.cap, (int64_t)h->arena.high, h->stats.radix_passes,
                            h->stats.radix_elems, h->stats.radix_elem_bytes, h->stats.radix_passes_u32,
                            h->stats.radix_elems_u32, h->stats.radix_passes_u64, h->stats.radix_elems_u64,
                            h->stats.levels_resolved, h->stats.merge_elems, h->stats.refine_rounds,
-                           h->stats.window_sorted};
-    for (int i = 0; i < 19 && i < cap; i++) out[i] = v[i];
-    return 19;
+                           h->stats.window_sorted, h->stats.lds_sorted};
+    for (int i = 0; i < 20 && i < cap; i++) out[i] = v[i];
+    return 20;
 }
 
 int east_hip_profile_enable(east_hip_handle_t h, int on)
@@ -1531,6 +1531,12 @@ int east_hip_debug_set_window_sort(int enabled)
     g_force_lean = enabled == 2;
     g_force_wide_keys = enabled == 3;
     g_plan_epoch++;
+    return EAST_HIP_OK;
+}
+
+int east_hip_debug_set_lds_rounds(int enabled)
+{
+    g_lds_rounds = enabled != 0;
     return EAST_HIP_OK;
 }
 

@@ -24,6 +24,8 @@ __device__ __forceinline__ u32 dc3_sample_pos(u32 t, u32 n0)
 // Level 0 on the byte stream runs either over the DC3 sample (element t = sample number, n0 > 0)
 // or over ALL suffixes (n0 == 0: element t = text position), see window_suffix_sort.
 __device__ __forceinline__ u32 lvl0_pos(u32 t, u32 n0) { return n0 ? dc3_sample_pos(t, n0) : t; }
+#include "lds_group_sort.h"
+static bool g_lds_rounds = getenv("EAST_HIP_NO_LDS_ROUNDS") == nullptr;     // east_hip_debug_set_lds_rounds (tests, A/B timing)
 
 static const bool g_trace = getenv("EAST_HIP_TRACE") != nullptr;   // per-round progress on stderr
 static bool g_force_wide_keys = getenv("EAST_HIP_WIDE_KEYS") != nullptr;                      // east_hip_debug_set_window_sort(3) (tests)
@@ -679,19 +681,30 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__
 }
 
 // key = (dense group number << w2*b) | next window of w2 symbols at offset `depth`
+// (sub_idx != nullptr: only the positions the in-LDS round left -- `left` --, compacted: position j goes to
+// sub_idx[j], and full_idx remembers where it came from)
 __global__ __launch_bounds__(BLOCK) void dc3_refine_keys_kernel(const uint8_t *__restrict__ s8,
                                                                 const u32 *__restrict__ elems,
                                                                 const u32 *__restrict__ group, u32 n_tied, u32 n0,
                                                                 u32 depth, int w2, int b, u32 term_first,
-                                                                u64 *__restrict__ keys, u32 *__restrict__ vals)
+                                                                u64 *__restrict__ keys, u32 *__restrict__ vals,
+                                                                LgUncovered left = LgUncovered{nullptr, 0},
+                                                                const u32 *__restrict__ sub_idx = nullptr,
+                                                                u32 *__restrict__ full_idx = nullptr)
 {
-    const u32 j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= n_tied) return;
-    const u32 p = lvl0_pos(elems[j], n0) + depth;
+    const u32 j0 = blockIdx.x * BLOCK + threadIdx.x;
+    if (j0 >= n_tied) return;
+    u32 j = j0;
+    if (sub_idx) {
+        if (!left(j0)) return;
+        j = sub_idx[j0];
+        full_idx[j] = j0;
+    }
+    const u32 p = lvl0_pos(elems[j0], n0) + depth;
     u64 lo8, hi8;
     __builtin_memcpy(&lo8, s8 + p, 8);
     __builtin_memcpy(&hi8, s8 + p + 8, 8);
-    u64 key = group[j];
+    u64 key = group[j0];
     bool ended = false;
     for (int i = 0; i < w2; i++) {
         const u32 byte = (u32)((i < 8 ? lo8 >> (8 * i) : hi8 >> (8 * (i - 8))) & 0xFFu);
@@ -700,7 +713,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_keys_kernel(const uint8_t *_
         key = (key << b) | (u64)(x == 0xFFu ? term_first : x);
     }
     keys[j] = key;
-    vals[j] = elems[j];                 // (the suffix itself travels with its key: no look-up after the sort)
+    vals[j] = elems[j0];                // (the suffix itself travels with its key: no look-up after the sort)
 }
 
 // ---- prefix doubling for long repeats (all-suffix mode) ------------------------------------------
@@ -760,7 +773,8 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_writeback_kernel(const u64 *
                                                                      u32 *__restrict__ order_g, u32 *__restrict__ names_g,
                                                                      u32 *__restrict__ elem_out, u32 *__restrict__ flag_out,
                                                                      u32 *__restrict__ lcp_g = nullptr, u32 depth = 0,
-                                                                     int w2 = 0, int b = 0)
+                                                                     int w2 = 0, int b = 0,
+                                                                     const u32 *__restrict__ full_idx = nullptr)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n_tied) return;
@@ -768,12 +782,15 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_writeback_kernel(const u64 *
     const u64 x = k ^ rep_t;
     const u64 tz = (x - ones) & ~x & highs;
     const bool has_term = tz != 0;                              // a terminator inside the window: unique
-    const u32 slot = slots[r], e = vals[r];
+    // (full_idx: the sorted pairs are the compacted rest of a domain; groups keep their stretches, so the r-th of
+    // them belongs where the r-th of the rest came from)
+    const u32 at = full_idx ? full_idx[r] : r;
+    const u32 slot = slots[at], e = vals[r];
     const u32 f = (r == 0 || has_term || k != kp) ? 1u : 0u;
     order_g[slot] = e;
     if (names_g) names_g[slot] = f;
-    elem_out[r] = e;
-    flag_out[r] = f;
+    elem_out[at] = e;
+    flag_out[at] = f;
     // symbol windows: where a group splits, the LCP entry of the rank that starts the new group is what the two
     // windows have in common behind the `depth` symbols the group shares (cut at a terminator: two equal terminator
     // codes are different terminators) -- final whichever members end up at the seam.  The first rank of the old
@@ -966,6 +983,9 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         SortBufs<u64> rb;
         for (int k = 0; k < 2; k++) { rb.keys[k] = ar.alloc<u64>(cap); rb.vals[k] = ar.alloc<u32>(cap); }
         u32 *name_of = n0 == 0 ? ar.alloc<u32>(n02) : nullptr;      // all-suffix mode: names for prefix doubling
+        // the in-LDS round (lds_group_sort.h): what each workgroup took, and the compaction of the rest
+        uint2 *cover = ar.alloc<uint2>((size_t)cap / LG_CHUNK + 2);
+        u32 *sub_idx = ar.alloc<u32>((size_t)cap + 1), *full_idx = ar.alloc<u32>(cap);
         if (ctx.dry) {                                  // sizing run: the transient buffers of one round (on top of all of the above)
             device_scan<BitIn, false>(ctx, BitIn{keep}, n02 + 1, idx);
             (void)radix_sort_pairs<u64>(ctx, rb, cap, 8);
@@ -1026,16 +1046,39 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                        (const u64 *)nullptr, name_of);
                 depth *= 2;
             } else {
-                int w2 = std::min(12, (64 - gbits) / bt);
-                if (const char *e = getenv("EAST_HIP_REFINE_W2")) w2 = std::min(w2, atoi(e));      // (experiment)
+                // (13 bits: room for the group numbers inside a workgroup's tile of the in-LDS round)
+                const int w2 = std::min(12, (64 - std::max(gbits, 13)) / bt);
                 if (w2 < 1) break;
-                LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)ebuf[e_c], (const u32 *)group, m, n0, depth, w2, bt,
-                       term_first, rb.keys[0], rb.vals[0]);
-                const int rr = radix_sort_pairs<u64>(ctx, rb, m, gbits + w2 * bt);
                 const KeyNeqWindowIn<u64> f = KeyNeqWindowIn<u64>::make(nullptr, w2, bt, 0, term_first);
-                LAUNCH(ctx, dc3_refine_writeback_kernel, gt, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr],
-                       (const u32 *)slot_c, (const u32 *)ebuf[e_c], m, f.rep_t, f.ones, f.highs, sa12, names_g, ebuf[e_out],
-                       fbuf[f_dom ^ 1], lcp_out, depth, w2, bt);
+                u32 m_left = m;
+                if (g_lds_rounds) {
+                    // groups that fit a workgroup's LDS: keys, sort and write-back in one launch; the rest is compacted
+                    hipLaunchKernelGGL(refine_lds_sort_kernel, dim3(ceil_div_u32(m, LG_CHUNK)), dim3(LG_THREADS), 0, ctx.stream, s8,
+                                       (const u32 *)ebuf[e_c], (const u32 *)gstart, (const u32 *)slot_c, m, n0, depth, w2, bt,
+                                       term_first, (u64)f.rep_t, (u64)f.ones, (u64)f.highs, sa12, names_g, ebuf[e_out],
+                                       fbuf[f_dom ^ 1], lcp_out, cover);
+                    HIP_CHECK(hipGetLastError());
+                    device_scan<LgUncovered, false>(ctx, LgUncovered{cover, m}, m + 1, sub_idx);
+                    HIP_CHECK(hipMemcpyAsync(&m_left, sub_idx + m, 4, hipMemcpyDeviceToHost, ctx.stream));
+                    HIP_CHECK(hipStreamSynchronize(ctx.stream));
+                    if (ctx.stats) ctx.stats->lds_sorted += m - m_left;
+                    if (g_trace) fprintf(stderr, "[east_hip]   round %d: %u of %u sorted in LDS\n", round, m - m_left, m);
+                }
+                if (m_left == m) {
+                    LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)ebuf[e_c], (const u32 *)group, m, n0, depth, w2, bt,
+                           term_first, rb.keys[0], rb.vals[0]);
+                    const int rr = radix_sort_pairs<u64>(ctx, rb, m, gbits + w2 * bt);
+                    LAUNCH(ctx, dc3_refine_writeback_kernel, gt, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr],
+                           (const u32 *)slot_c, (const u32 *)ebuf[e_c], m, f.rep_t, f.ones, f.highs, sa12, names_g, ebuf[e_out],
+                           fbuf[f_dom ^ 1], lcp_out, depth, w2, bt);
+                } else if (m_left > 0) {
+                    LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)ebuf[e_c], (const u32 *)group, m, n0, depth, w2, bt,
+                           term_first, rb.keys[0], rb.vals[0], LgUncovered{cover, m}, (const u32 *)sub_idx, full_idx);
+                    const int rr = radix_sort_pairs<u64>(ctx, rb, m_left, gbits + w2 * bt);
+                    LAUNCH(ctx, dc3_refine_writeback_kernel, ceil_div_u32(m_left, BLOCK), (const u64 *)rb.keys[rr],
+                           (const u32 *)rb.vals[rr], (const u32 *)slot_c, (const u32 *)ebuf[e_c], m_left, f.rep_t, f.ones, f.highs,
+                           sa12, names_g, ebuf[e_out], fbuf[f_dom ^ 1], lcp_out, depth, w2, bt, (const u32 *)full_idx);
+                }
                 depth += (u32)w2;
             }
             e_dom = e_out; s_dom ^= 1; f_dom ^= 1;

@@ -238,7 +238,7 @@ void *east_hip_stream(east_hip_handle_t h);
  * [14] elements with 64-bit keys, [15] DC3 levels whose few tied names were
  * ordered directly instead of recursing, [16] suffixes merged (sum over levels), [17] rounds of
  * tie refinement by further windows, [18] 1 if the all-suffix window sort produced the suffix array
- * (no DC3 level ran; [5] is 0 then).
+ * (no DC3 level ran; [5] is 0 then), [19] elements the refinement rounds ordered inside a workgroup's LDS.
  */
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap);
 
@@ -276,6 +276,9 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes);
  * the device were short of memory for the tie-refinement rounds ("lean"); 3 = window sort on with
  * 64-bit window keys even where 32 bits suffice (the code path of large inputs, on small ones). */
 int east_hip_debug_set_window_sort(int enabled);
+/* Test knob: 0 = the tie-refinement rounds sort every group with the global radix sort; 1 (default) = groups
+ * that fit a workgroup's LDS are sorted there (csrc/lds_group_sort.h), the global sort takes the rest. */
+int east_hip_debug_set_lds_rounds(int enabled);
 /* Test knob: 0 = every build waits for the device's answers (alphabet size, tie groups) as a handle's
  * first build does; 1 (default) = later builds on a handle are queued without waiting, on the strength
  * of what the build before found, and checked by the one read-back at their end. */

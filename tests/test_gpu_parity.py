@@ -590,6 +590,38 @@ def test_small_vocabulary_text_tie_refinement_vs_oracle(hip, oracle, seed):
             assert np.array_equal(t[name], getattr(o, name)), (name, d, index.info())
 
 
+@pytest.mark.parametrize("lds_rounds", [1, 0])
+@pytest.mark.parametrize("seed", range(4))
+def test_refinement_rounds_in_lds_and_by_the_global_sort(hip, oracle, suffix_sort_path, seed, lds_rounds):
+    """The rounds order tie groups that fit a workgroup's LDS there (csrc/lds_group_sort.h) and leave longer ones to
+    the global radix sort: word text over small vocabularies gives both kinds in one domain -- groups of a few
+    dozen members next to groups of tens of thousands --, single documents and several, with the in-LDS path on
+    (default) and off.  All six tables bit-exact against the oracle, the LCP entries the rounds write included."""
+    from east import hip_backend, synthetic
+    lib = hip.load()
+    rng = np.random.default_rng(7700 + seed)
+    vocab = synthetic.zipf_vocabulary(rng, size=int(rng.choice([12, 60, 400, 3000])), exponent=1.0)
+    n_docs = int(rng.choice([1, 2, 5]))
+    docs = [synthetic.zipf_document(rng, int(rng.integers(100000, 700000)), vocab) for _ in range(n_docs)]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    assert lib.east_hip_debug_set_lds_rounds(lds_rounds) == 0
+    try:
+        index = hip_backend.HipIndex()
+        index.build(sym, off, np.array([d[1] for d in docs]))
+        info = index.info()
+        if suffix_sort_path == "window_sort":
+            assert info["window_sorted"] == 1 and info["refine_rounds"] >= 1, info
+            assert (info["lds_sorted"] > 0) == bool(lds_rounds), info
+        for d in range(n_docs):
+            o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+            t = index.tables(d)
+            for name in TABLES:
+                assert np.array_equal(t[name], getattr(o, name)), (name, d, info)
+    finally:
+        assert lib.east_hip_debug_set_lds_rounds(1) == 0
+
+
 @pytest.mark.parametrize("shift", [0, 1, 2, 3])
 def test_build_from_resident_symbols_at_any_alignment(hip, oracle, shift):
     """east_hip_build_device on a symbol array that starts 0..3 words into a device buffer (a view of
