@@ -15,9 +15,13 @@
 #include "common.h"
 
 #define LG_THREADS 1024
+#ifndef LG_IPT
 #define LG_IPT 5
+#endif
 #define LG_CAP (LG_THREADS * LG_IPT)        // 5120 elements per workgroup
+#ifndef LG_CHUNK
 #define LG_CHUNK 2048                       // a workgroup owns the groups that start in its chunk
+#endif
 #define LG_MAX_GROUP (LG_CAP - LG_CHUNK - 64)   // 3008: longer groups take the global path
 #define LG_WORDS (LG_CAP / 64)              // 80 words of start bits
 #define LG_NONE 0xFFFFFFFFu
@@ -40,30 +44,80 @@ struct LgLds {
 // (LG_NONE: no group starts in its chunk).  A position in front of its chunk's first group start belongs
 // to the last group of the nearest earlier chunk that has a start -- at most two chunks back, or the group
 // is longer than any workgroup takes.
+// Inside chunk c the positions left over are two stretches: [a0, a1) in front of the chunk's first group start --
+// what the tile of an earlier chunk did not reach --, and [b0, b1) behind the chunk's own tile.
 struct LgUncovered {
     const uint2 *cover;
     u32 m;
+    __device__ __forceinline__ void rest(u32 c, u32 &a0, u32 &a1, u32 &b0, u32 &b1) const
+    {
+        const u32 lo = c * LG_CHUNK, hi = lo + LG_CHUNK < m ? lo + LG_CHUNK : m;
+        const uint2 own = cover[c];
+        u32 reached = lo;                               // how far an earlier tile reaches into this chunk
+        for (u32 k = 1; k <= 2 && k <= c; k++) {
+            const uint2 prev = cover[c - k];
+            if (prev.x != LG_NONE) { reached = prev.y > lo ? prev.y : lo; break; }
+        }
+        if (reached > hi) reached = hi;
+        a0 = reached;
+        a1 = own.x != LG_NONE ? own.x : hi;             // (own.x >= reached: a tile ends where a group ends)
+        if (a1 < a0) a1 = a0;
+        b0 = own.x != LG_NONE ? (own.y < hi ? own.y : hi) : hi;
+        b1 = hi;
+    }
     __device__ __forceinline__ u32 operator()(u32 j) const
     {
         if (j >= m) return 0u;
-        const u32 c = j / LG_CHUNK;
-        const uint2 own = cover[c];
-        if (own.x != LG_NONE && j >= own.x) return j < own.y ? 0u : 1u;
-        for (u32 k = 1; k <= 2 && k <= c; k++) {
-            const uint2 prev = cover[c - k];
-            if (prev.x != LG_NONE) return j < prev.y ? 0u : 1u;
-        }
-        return 1u;
+        u32 a0, a1, b0, b1;
+        rest(j / LG_CHUNK, a0, a1, b0, b1);
+        return ((j >= a0 && j < a1) || (j >= b0 && j < b1)) ? 1u : 0u;
     }
 };
+
+__global__ __launch_bounds__(BLOCK) void lg_rest_count_kernel(const uint2 *__restrict__ cover, u32 m, u32 n_chunks,
+                                                              u32 *__restrict__ rest_cnt)
+{
+    const u32 c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c > n_chunks) return;
+    u32 cnt = 0;
+    if (c < n_chunks) {
+        u32 a0, a1, b0, b1;
+        LgUncovered{cover, m}.rest(c, a0, a1, b0, b1);
+        cnt = (a1 - a0) + (b1 - b0);
+    }
+    rest_cnt[c] = cnt;
+}
+
+// the rest of the domain, compacted: rest_pre[c] = left-over positions in front of chunk c
+__global__ __launch_bounds__(BLOCK) void lg_rest_compact_kernel(LgUncovered left, const u32 *__restrict__ rest_pre,
+                                                                const u32 *__restrict__ elems,
+                                                                const u32 *__restrict__ gstart, u32 m,
+                                                                u32 *__restrict__ sub_elem, u32 *__restrict__ sub_gstart,
+                                                                u32 *__restrict__ full_idx)
+{
+    const u32 j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    const u32 c = j / LG_CHUNK;
+    u32 a0, a1, b0, b1;
+    left.rest(c, a0, a1, b0, b1);
+    u32 o;
+    if (j >= a0 && j < a1) o = rest_pre[c] + (j - a0);
+    else if (j >= b0 && j < b1) o = rest_pre[c] + (a1 - a0) + (j - b0);
+    else return;
+    sub_elem[o] = elems[j];
+    sub_gstart[o] = gstart[j];
+    full_idx[o] = j;
+}
 
 // One stable pass of the in-LDS radix sort: the elements of active waves (wave w owns the LG_IPT * 64
 // consecutive positions from w * LG_IPT * 64 on, row j = 64 consecutive ones) move to their places by the
 // 8-bit digit at `shift`; on return key[] / val[] hold the new occupants of the thread's positions.
-__device__ __forceinline__ void lg_radix_pass(LgLds &lds, u64 (&key)[LG_IPT], u32 (&val)[LG_IPT], int shift, bool active)
+// (n_waves: the active waves, 0 .. n_waves - 1 -- the others hold nothing and only keep the barriers)
+__device__ __forceinline__ void lg_radix_pass(LgLds &lds, u64 (&key)[LG_IPT], u32 (&val)[LG_IPT], int shift, bool active,
+                                              u32 n_waves)
 {
     const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    for (u32 i = tid; i < LG_WAVES * 128u; i += LG_THREADS) (&lds.wave_cnt[0][0])[i] = 0;
+    for (u32 i = tid; i < n_waves * 128u; i += LG_THREADS) (&lds.wave_cnt[0][0])[i] = 0;
     __syncthreads();
     u32 slot[LG_IPT];
     if (active) {
@@ -93,8 +147,7 @@ __device__ __forceinline__ void lg_radix_pass(LgLds &lds, u64 (&key)[LG_IPT], u3
     u32 tot_lo = 0, tot_hi = 0;
     if (tid < 128u) {
         u32 run = 0;                                    // both halves at once: the sums stay below 2^16
-#pragma unroll
-        for (int k = 0; k < LG_WAVES; k++) {
+        for (u32 k = 0; k < n_waves; k++) {
             const u32 c = lds.wave_cnt[k][tid];
             lds.wave_cnt[k][tid] = run;
             run += c;
@@ -235,7 +288,12 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
             }
         }
     }
-    for (int shift = 0; shift < bits; shift += 8) lg_radix_pass(lds, key, val, shift, active);
+    const u32 n_waves = (n_act + LG_IPT * WAVE - 1u) / (LG_IPT * WAVE);
+#ifdef LG_EXPERIMENT_PASSES
+    for (int shift = 0; shift < 8 * LG_EXPERIMENT_PASSES; shift += 8) lg_radix_pass(lds, key, val, shift, active, n_waves);
+#else
+    for (int shift = 0; shift < bits; shift += 8) lg_radix_pass(lds, key, val, shift, active, n_waves);
+#endif
     if (bits <= 0) {                                    // (cannot happen: a window has at least one symbol)
         return;
     }

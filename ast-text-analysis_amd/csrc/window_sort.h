@@ -305,6 +305,22 @@ struct BitIn {                                  // one flag per element, 64 to a
     __device__ __forceinline__ u32 operator()(u32 i) const { return (u32)(bits[i >> 6] >> (i & 63u)) & 1u; }
 };
 
+// The rank of a set bit among the set bits -- where a kept element goes when the domain is compacted -- from
+// the number of set bits in front of its word (an exclusive scan over the WORDS, 1/64 of the elements).
+struct PopIn {
+    const u64 *bits;
+    u32 n_words;
+    __device__ __forceinline__ u32 operator()(u32 w) const { return w < n_words ? (u32)__popcll(bits[w]) : 0u; }
+};
+struct BitRank {
+    const u64 *bits;
+    const u32 *word_prefix;
+    __device__ __forceinline__ u32 operator()(u32 i) const
+    {
+        return word_prefix[i >> 6] + (u32)__popcll(bits[i >> 6] & (((u64)1 << (i & 63u)) - 1ull));
+    }
+};
+
 struct FlagArrIn {                              // the naming predicate of a compacted domain
     static constexpr bool HAS_KEYS = false;
     const u32 *flags;
@@ -657,7 +673,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_restore_kernel(const u32 *__
 template <class Starts>
 __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__restrict__ elem, Starts starts,
                                                                    const u32 *__restrict__ slot, BitIn keep,
-                                                                   const u32 *__restrict__ idx, u32 m,
+                                                                   BitRank idx, u32 m,
                                                                    u32 *__restrict__ slot_out, u32 *__restrict__ elem_out,
                                                                    u32 *__restrict__ group_start,
                                                                    u32 *__restrict__ lcp_g = nullptr, int w = 0, int b = 0,
@@ -665,7 +681,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__
 {
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
     if (j >= m || !keep(j)) return;
-    const u32 k = idx[j];
+    const u32 k = idx(j);
     const u32 st = starts(j);
     slot_out[k] = slot ? slot[j] : j;
     elem_out[k] = elem[j];
@@ -681,30 +697,19 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__
 }
 
 // key = (dense group number << w2*b) | next window of w2 symbols at offset `depth`
-// (sub_idx != nullptr: only the positions the in-LDS round left -- `left` --, compacted: position j goes to
-// sub_idx[j], and full_idx remembers where it came from)
 __global__ __launch_bounds__(BLOCK) void dc3_refine_keys_kernel(const uint8_t *__restrict__ s8,
                                                                 const u32 *__restrict__ elems,
                                                                 const u32 *__restrict__ group, u32 n_tied, u32 n0,
                                                                 u32 depth, int w2, int b, u32 term_first,
-                                                                u64 *__restrict__ keys, u32 *__restrict__ vals,
-                                                                LgUncovered left = LgUncovered{nullptr, 0},
-                                                                const u32 *__restrict__ sub_idx = nullptr,
-                                                                u32 *__restrict__ full_idx = nullptr)
+                                                                u64 *__restrict__ keys, u32 *__restrict__ vals)
 {
-    const u32 j0 = blockIdx.x * BLOCK + threadIdx.x;
-    if (j0 >= n_tied) return;
-    u32 j = j0;
-    if (sub_idx) {
-        if (!left(j0)) return;
-        j = sub_idx[j0];
-        full_idx[j] = j0;
-    }
-    const u32 p = lvl0_pos(elems[j0], n0) + depth;
+    const u32 j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= n_tied) return;
+    const u32 p = lvl0_pos(elems[j], n0) + depth;
     u64 lo8, hi8;
     __builtin_memcpy(&lo8, s8 + p, 8);
     __builtin_memcpy(&hi8, s8 + p + 8, 8);
-    u64 key = group[j0];
+    u64 key = group[j];
     bool ended = false;
     for (int i = 0; i < w2; i++) {
         const u32 byte = (u32)((i < 8 ? lo8 >> (8 * i) : hi8 >> (8 * (i - 8))) & 0xFFu);
@@ -713,7 +718,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_keys_kernel(const uint8_t *_
         key = (key << b) | (u64)(x == 0xFFu ? term_first : x);
     }
     keys[j] = key;
-    vals[j] = elems[j0];                // (the suffix itself travels with its key: no look-up after the sort)
+    vals[j] = elems[j];                 // (the suffix itself travels with its key: no look-up after the sort)
 }
 
 // ---- prefix doubling for long repeats (all-suffix mode) ------------------------------------------
@@ -986,6 +991,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         // the in-LDS round (lds_group_sort.h): what each workgroup took, and the compaction of the rest
         uint2 *cover = ar.alloc<uint2>((size_t)cap / LG_CHUNK + 2);
         u32 *sub_idx = ar.alloc<u32>((size_t)cap + 1), *full_idx = ar.alloc<u32>(cap);
+        u32 *rest_cnt = ar.alloc<u32>((size_t)cap / LG_CHUNK + 3), *rest_pre = ar.alloc<u32>((size_t)cap / LG_CHUNK + 3);
         if (ctx.dry) {                                  // sizing run: the transient buffers of one round (on top of all of the above)
             device_scan<BitIn, false>(ctx, BitIn{keep}, n02 + 1, idx);
             (void)radix_sort_pairs<u64>(ctx, rb, cap, 8);
@@ -1015,23 +1021,28 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                        name_of);
                 if (g_trace) fprintf(stderr, "[east_hip]   switching to prefix doubling at depth %u\n", depth);
             }
-            if (!have_idx) device_scan<BitIn, false>(ctx, BitIn{keep}, m + 1, idx);
+            if (!have_idx) device_scan<PopIn, false>(ctx, PopIn{keep, (m >> 6) + 1u}, (m >> 6) + 2u, idx);
             // compact the members of large groups, number their groups, sort by (group, next window)
             const int e_c = (e_dom + 4) % 3, e_out = (e_dom + 5) % 3;      // the two buffers the domain is not in
             u32 *slot_c = sbuf[s_dom ^ 1];
             if (!slot)
                 LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<KeyNeqWindowIn<K>>), gm, elem,
-                             starts, slot, BitIn{keep}, (const u32 *)idx, m, slot_c, ebuf[e_c], gstart, lcp_out, w, bt, spare);
+                             starts, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart, lcp_out, w, bt, spare);
             else
                 LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<FlagArrIn>), gm, elem,
-                             FlagArrIn{flag}, slot, BitIn{keep}, (const u32 *)idx, m, slot_c, ebuf[e_c], gstart);
+                             FlagArrIn{flag}, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart);
             m = m_next;
-            device_scan<ArrIn, true>(ctx, ArrIn{gstart}, m, group);
+            bool have_group = false;                    // group[] = inclusive scan of gstart: the groups' numbers
+            auto number_groups = [&]() {
+                if (!have_group) device_scan<ArrIn, true>(ctx, ArrIn{gstart}, m, group);
+                have_group = true;
+            };
             // (every group here has more than REFINE_SMALL_GROUP members -- at least 2 once groups with long repeats
             // were handed over: a bound on their number saves a read-back)
             const int gbits = bit_width_u32(m / (long_repeats ? 2u : REFINE_SMALL_GROUP + 1u) + 1);
             const u32 gt = ceil_div_u32((u64)m + 1, BLOCK);
             if (doubling) {
+                number_groups();
                 LAUNCH(ctx, dc3_double_keys_kernel, gt, (const u32 *)name_of, (const u32 *)ebuf[e_c], (const u32 *)group, m,
                        depth, rb.keys[0], rb.vals[0]);
                 const int rr = radix_sort_pairs<u64>(ctx, rb, m, 32 + gbits);
@@ -1053,18 +1064,20 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 u32 m_left = m;
                 if (g_lds_rounds) {
                     // groups that fit a workgroup's LDS: keys, sort and write-back in one launch; the rest is compacted
-                    hipLaunchKernelGGL(refine_lds_sort_kernel, dim3(ceil_div_u32(m, LG_CHUNK)), dim3(LG_THREADS), 0, ctx.stream, s8,
-                                       (const u32 *)ebuf[e_c], (const u32 *)gstart, (const u32 *)slot_c, m, n0, depth, w2, bt,
-                                       term_first, (u64)f.rep_t, (u64)f.ones, (u64)f.highs, sa12, names_g, ebuf[e_out],
-                                       fbuf[f_dom ^ 1], lcp_out, cover);
-                    HIP_CHECK(hipGetLastError());
-                    device_scan<LgUncovered, false>(ctx, LgUncovered{cover, m}, m + 1, sub_idx);
-                    HIP_CHECK(hipMemcpyAsync(&m_left, sub_idx + m, 4, hipMemcpyDeviceToHost, ctx.stream));
+                    LAUNCH_BLOCK(ctx, refine_lds_sort_kernel, ceil_div_u32(m, LG_CHUNK), LG_THREADS, s8, (const u32 *)ebuf[e_c],
+                                 (const u32 *)gstart, (const u32 *)slot_c, m, n0, depth, w2, bt, term_first, (u64)f.rep_t,
+                                 (u64)f.ones, (u64)f.highs, sa12, names_g, ebuf[e_out], fbuf[f_dom ^ 1], lcp_out, cover);
+                    // what is left: counted per chunk from cover[] (no pass over the elements)
+                    const u32 n_chunks = ceil_div_u32(m, LG_CHUNK);
+                    LAUNCH(ctx, lg_rest_count_kernel, ceil_div_u32(n_chunks + 1, BLOCK), (const uint2 *)cover, m, n_chunks, rest_cnt);
+                    device_scan<ArrIn, false>(ctx, ArrIn{rest_cnt}, n_chunks + 1, rest_pre);
+                    HIP_CHECK(hipMemcpyAsync(&m_left, rest_pre + n_chunks, 4, hipMemcpyDeviceToHost, ctx.stream));
                     HIP_CHECK(hipStreamSynchronize(ctx.stream));
                     if (ctx.stats) ctx.stats->lds_sorted += m - m_left;
                     if (g_trace) fprintf(stderr, "[east_hip]   round %d: %u of %u sorted in LDS\n", round, m - m_left, m);
                 }
                 if (m_left == m) {
+                    number_groups();
                     LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)ebuf[e_c], (const u32 *)group, m, n0, depth, w2, bt,
                            term_first, rb.keys[0], rb.vals[0]);
                     const int rr = radix_sort_pairs<u64>(ctx, rb, m, gbits + w2 * bt);
@@ -1072,8 +1085,13 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                            (const u32 *)slot_c, (const u32 *)ebuf[e_c], m, f.rep_t, f.ones, f.highs, sa12, names_g, ebuf[e_out],
                            fbuf[f_dom ^ 1], lcp_out, depth, w2, bt);
                 } else if (m_left > 0) {
-                    LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)ebuf[e_c], (const u32 *)group, m, n0, depth, w2, bt,
-                           term_first, rb.keys[0], rb.vals[0], LgUncovered{cover, m}, (const u32 *)sub_idx, full_idx);
+                    // the rest, compacted (elements, group starts, where they came from), its groups numbered, then as ever
+                    u32 *sub_elem = sub_idx, *sub_gstart = rb.vals[1];           // (rb.vals[1]: idle until the sort's first pass)
+                    LAUNCH(ctx, lg_rest_compact_kernel, gt, LgUncovered{cover, m}, (const u32 *)rest_pre, (const u32 *)ebuf[e_c],
+                           (const u32 *)gstart, m, sub_elem, sub_gstart, full_idx);
+                    device_scan<ArrIn, true>(ctx, ArrIn{sub_gstart}, m_left, group);
+                    LAUNCH(ctx, dc3_refine_keys_kernel, ceil_div_u32(m_left, BLOCK), s8, (const u32 *)sub_elem, (const u32 *)group,
+                           m_left, n0, depth, w2, bt, term_first, rb.keys[0], rb.vals[0]);
                     const int rr = radix_sort_pairs<u64>(ctx, rb, m_left, gbits + w2 * bt);
                     LAUNCH(ctx, dc3_refine_writeback_kernel, ceil_div_u32(m_left, BLOCK), (const u64 *)rb.keys[rr],
                            (const u32 *)rb.vals[rr], (const u32 *)slot_c, (const u32 *)ebuf[e_c], m_left, f.rep_t, f.ones, f.highs,
@@ -1094,9 +1112,9 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                        endgame ? (u32)REFINE_ENDGAME_LEN : (u32)RESOLVE_MAX_LEN, doubling ? name_of : (u32 *)nullptr,
                        LongRepeats{bad, mode}, lcp_out);
                 if (mode == 1) return;
-                device_scan<BitIn, false>(ctx, BitIn{keep}, m + 1, idx);
+                device_scan<PopIn, false>(ctx, PopIn{keep, (m >> 6) + 1u}, (m >> 6) + 2u, idx);
                 have_idx = true;
-                HIP_CHECK(hipMemcpyAsync(&m_next, idx + m, 4, hipMemcpyDeviceToHost, ctx.stream));
+                HIP_CHECK(hipMemcpyAsync(&m_next, idx + ((m >> 6) + 1u), 4, hipMemcpyDeviceToHost, ctx.stream));
                 HIP_CHECK(hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, ctx.stream));
                 HIP_CHECK(hipStreamSynchronize(ctx.stream));
                 if (g_trace)
