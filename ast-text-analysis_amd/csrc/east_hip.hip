@@ -225,7 +225,8 @@ __global__ __launch_bounds__(BLOCK) void validate_last_symbol_kernel(const u32 *
 
 // n_strings[d] must equal the terminators of document d.  Terminators sort above every text
 // symbol, so the terminator-first suffixes are the tail of the document's suffix array: one
-// binary search per document on the finished array replaces a counting pass over the corpus.
+// search per document on the finished array replaces a counting pass over the corpus.  A wavefront
+// per document, 64 probes per step: a 64 MiB document takes 5 steps of two dependent loads instead of 26.
 template <class SYM>
 __global__ __launch_bounds__(BLOCK) void validate_n_strings_kernel(const SYM *__restrict__ s, u32 term_first,
                                                                    const u32 *__restrict__ sa,
@@ -233,16 +234,27 @@ __global__ __launch_bounds__(BLOCK) void validate_n_strings_kernel(const SYM *__
                                                                    const u32 *__restrict__ n_strings, u32 n_docs,
                                                                    u32 *__restrict__ status)
 {
-    const u32 d = blockIdx.x * BLOCK + threadIdx.x;
+    const u32 d = blockIdx.x * WAVES_PER_BLOCK + wave_id(), lane = lane_id();
     if (d >= n_docs) return;
-    u32 lo = doc_off[d], hi = doc_off[d + 1];
+    u32 lo = doc_off[d], hi = doc_off[d + 1];           // the first terminator-first rank lies in [lo, hi]
     const u32 end = hi, last = doc_off[n_docs] - 1u;
-    while (lo < hi) {                       // first rank whose suffix starts with a terminator
-        const u32 mid = (lo + hi) >> 1;
-        const u32 p = sa[mid] < last ? sa[mid] : last;      // (a speculative build that guessed wrong leaves stale entries)
-        if ((u32)s[p] >= term_first) hi = mid; else lo = mid + 1;
+    while (lo < hi) {
+        const u32 step = (hi - lo + 63u) / 64u;
+        const u64 probe = (u64)lo + (u64)lane * step;
+        bool term = true;                               // (probes at or behind hi count as terminator-first)
+        if (probe < hi) {
+            const u32 q = sa[(u32)probe];
+            const u32 p = q < last ? q : last;          // (a speculative build that guessed wrong leaves stale entries)
+            term = (u32)s[p] >= term_first;
+        }
+        const u64 bal = __ballot(term);
+        const u32 t = bal ? (u32)__ffsll((unsigned long long)bal) - 1u : 64u;
+        const u32 new_hi = t < 64u ? (u32)((u64)lo + (u64)t * step < hi ? (u64)lo + (u64)t * step : hi) : hi;
+        const u32 new_lo = t > 0u ? lo + (t - 1u) * step + 1u : lo;
+        lo = new_lo < new_hi ? new_lo : new_hi;
+        hi = new_hi;
     }
-    if (end - lo != n_strings[d]) atomicOr(status, STATUS_N_STRINGS);
+    if (lane == 0 && end - lo != n_strings[d]) atomicOr(status, STATUS_N_STRINGS);
 }
 
 __global__ __launch_bounds__(BLOCK) void remap_kernel(const u32 *__restrict__ sym,
@@ -550,11 +562,11 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
 
     // n_strings against the terminators actually present (read back at the end of the build)
     if (h->use_s8)
-        LAUNCH_NAMED(ctx, "validate_n_strings_kernel", (validate_n_strings_kernel<uint8_t>), ceil_div_u32(n_docs, BLOCK),
+        LAUNCH_NAMED(ctx, "validate_n_strings_kernel", (validate_n_strings_kernel<uint8_t>), ceil_div_u32(n_docs, WAVES_PER_BLOCK),
                      (const uint8_t *)h->s8, 0xFFu, (const u32 *)h->sa, (const u32 *)h->doc_off,
                      (const u32 *)h->n_strings, n_docs, status);
     else
-        LAUNCH_NAMED(ctx, "validate_n_strings_kernel", (validate_n_strings_kernel<u32>), ceil_div_u32(n_docs, BLOCK),
+        LAUNCH_NAMED(ctx, "validate_n_strings_kernel", (validate_n_strings_kernel<u32>), ceil_div_u32(n_docs, WAVES_PER_BLOCK),
                      (const u32 *)h->s, sigma_t + 1u, (const u32 *)h->sa, (const u32 *)h->doc_off,
                      (const u32 *)h->n_strings, n_docs, status);
 

@@ -131,12 +131,14 @@ __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u3
 }
 
 // ---- spine: exclusive scan down the groups, per digit column, plus the digit bases --------------------
-// A workgroup owns 16 digit columns; its 256 threads cut the column into 16 stretches scanned side by
+// A workgroup owns 8 digit columns; its 256 threads cut the column into 32 stretches scanned side by
 // side (all of it lives in the L2: the rows were written by the kernel before).  digit_total is read
 // by every workgroup (its exclusive scan = the digit bases); workgroup 0 clears the OTHER total buffer
 // for the next pass's histogram.
-#define RS_SPINE_COLS 16
-#define RS_SPINE_PARTS 16
+#ifndef RS_SPINE_COLS
+#define RS_SPINE_COLS 8
+#endif
+#define RS_SPINE_PARTS (BLOCK / RS_SPINE_COLS)
 __global__ __launch_bounds__(BLOCK) void radix_spine_kernel(const u32 *__restrict__ group_sum, u32 n_groups,
                                                             const u32 *__restrict__ digit_total,
                                                             u32 *__restrict__ next_total, u32 *__restrict__ group_prefix)

@@ -292,6 +292,8 @@ def main():
             "dc3_refine_rounds": info["refine_rounds"], "window_sorted": info["window_sorted"],
             "radix_passes": info["radix_passes"],
             "roofline": roofline, "roofline_by_kernel": by_kernel, "kernels_ms_per_step": per_step,
+            "kernel_launches_per_step": {k: v[0] // args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+            "lds_sorted": info.get("lds_sorted", 0),
         }
         if not args.no_extras:
             out.update(extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D))

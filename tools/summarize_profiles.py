@@ -104,6 +104,18 @@ for name in (tag + "_bench.json", tag + "_bench_profiled.json"):
     for e in line.get("roofline_by_kernel", []):
         if "traffic" in e or e["kernel"] in out:
             e["traffic"] = out.get(e["kernel"])
+    # the whole-build figure with THIS run's counters (bench.py computed it with the traffic.json of the run before)
+    launches, ms = line.get("kernel_launches_per_step"), line.get("kernels_ms_per_step")
+    if launches and ms and isinstance(line["roofline"].get("rocprof_hbm_fraction"), dict):
+        sys.path.insert(0, ROOT)
+        import bench
+        num = den = 0.0
+        for k, t in ms.items():
+            if k.startswith(bench.BUILD_KERNEL_PREFIXES) and k in out and k in launches:
+                num += out[k] * launches[k]
+                den += t * 1e-3
+        if den:
+            line["roofline"]["rocprof_hbm_fraction"].update({"GBps": num / den / 1e9, "frac": num / den / 1e9 / bench.HBM_PEAK_GBS})
     with open(path, "w") as f:
         f.write(json.dumps(line) + "\n")
 for k, expect in (("remap_kernel", 8.0 * n), ("remap_bytes_kernel", 4.0 * n), ("presence_kernel", 4.0 * n)):
