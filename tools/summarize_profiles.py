@@ -54,9 +54,14 @@ def short(name):
     return name
 
 
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: of several runs' outputs only the last one counts."""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
+
 def agg(pattern, counter):
     out = collections.defaultdict(lambda: [0, 0.0])
-    for path in glob.glob(pattern):
+    for path in newest(pattern):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
                 k = short(r["Kernel_Name"])
@@ -65,7 +70,7 @@ def agg(pattern, counter):
     return out
 
 
-stats = glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = newest(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(DST, tag + "_kernel_stats.csv"))
 shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, tag + "_bench.json"))
 shutil.copy(os.path.join(SRC, "bench_profiled.json"), os.path.join(DST, tag + "_bench_profiled.json"))
