@@ -616,17 +616,23 @@ static void finish_capped_lcp(east_hip_index *h, Ctx &ctx)
 
 static size_t plan_arena_bytes(u32 n, u32 n_docs, bool lean = false, bool tagged = false)
 {
-    east_hip_index tmp;
-    Arena dry;
-    dry.dry = true;
-    Stats st;
-    Ctx ctx;
-    ctx.arena = &dry;
-    ctx.dry = true;
-    ctx.lean = lean;
-    ctx.stats = &st;
-    build_impl(&tmp, ctx, nullptr, n, n_docs, nullptr, nullptr, 0, tagged);
-    return dry.high + (1u << 20);
+    // (a tagged stream is priced both ways: as the byte stream it becomes when its alphabet is small -- the window
+    // sort with its rounds, which the sizing run of the widest alphabet never enters -- and as dense u32 codes)
+    size_t high = 0;
+    for (int t = 0; t <= (tagged ? 1 : 0); t++) {
+        east_hip_index tmp;
+        Arena dry;
+        dry.dry = true;
+        Stats st;
+        Ctx ctx;
+        ctx.arena = &dry;
+        ctx.dry = true;
+        ctx.lean = lean;
+        ctx.stats = &st;
+        build_impl(&tmp, ctx, nullptr, n, n_docs, nullptr, nullptr, 0, t == 1);
+        high = std::max(high, dry.high + (tagged ? 2 * (size_t)HI_WORDS * 4 + 1024 : 0));
+    }
+    return high + (1u << 20);
 }
 
 static void ensure_arena(east_hip_index *h, size_t bytes)

@@ -1227,6 +1227,30 @@ def test_text_above_the_terminator_base_random_shards(hip, oracle, seed):
     assert index.info()["sigma_text"] == len(every)
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_text_above_the_terminator_base_with_refinement_rounds(hip, oracle, seed):
+    """Word text over a small vocabulary whose letters lie above U+0A00: the tagged stream becomes a byte stream,
+    takes the window sort and its refinement rounds (the arena is sized for that, not only for the widest alphabet a
+    tagged stream could bring), and gives the tables of the same text spelled below U+0A00."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(8800 + seed)
+    vocab = synthetic.zipf_vocabulary(rng, size=int(rng.choice([10, 50, 300])), exponent=1.0)
+    docs = [synthetic.zipf_document(rng, int(rng.integers(150000, 600000)), vocab) for _ in range(int(rng.integers(1, 5)))]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    used = np.unique(sym[sym < 0x0A00])
+    target = np.sort(rng.choice(0x110000 - 0x0A00, size=used.size, replace=False).astype(np.uint32) + 0x0A00)
+    lifted = np.where(sym >= 0x0A00, (sym - 0x0A00) | np.uint32(0x80000000),
+                      target[np.searchsorted(used, np.minimum(sym, used[-1]))]).astype(np.uint32)
+    index = hip_backend.HipIndex()
+    index.build(lifted, off, np.array([d[1] for d in docs]))
+    for d in range(len(docs)):
+        o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d, index.info())
+
+
 def test_tagged_encoding_c_abi(hip, oracle):
     """The tagged encoding without any high text gives what the reference encoding gives; a symbol that is neither a
     tagged terminator nor a code point is refused; the encoding is a property of the handle until reset."""
