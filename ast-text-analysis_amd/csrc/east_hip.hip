@@ -87,9 +87,19 @@ __global__ __launch_bounds__(BLOCK) void presence_kernel(const u32 *__restrict__
 #define STATUS_N_STRINGS 2u
 #define STATUS_SIGMA_GUESS 4u
 #define STATUS_BAD_SYMBOL 8u
+// guess: the code map (TEXT_SYMBOLS words) and the presence bitmap (PRESENT_WORDS words) of the handle's last build,
+// kept outside the arena.  A speculative build has already turned the symbols into bytes with that map
+// (presence_remap_kernel); `check` then compares the bitmaps -- any difference, and the bytes are wrong: STATUS_SIGMA_GUESS --,
+// and in any case the guess is replaced by what this build found.
 __global__ __launch_bounds__(BLOCK) void codemap_kernel(const u32 *__restrict__ present, u32 assumed,
-                                                        u32 *__restrict__ code_map, u32 *__restrict__ flags)
+                                                        u32 *__restrict__ code_map, u32 *__restrict__ flags,
+                                                        u32 *__restrict__ guess = nullptr, int check = 0)
 {
+    if (guess && threadIdx.x < PRESENT_WORDS) {
+        u32 *gp = guess + TEXT_SYMBOLS;
+        if (check && gp[threadIdx.x] != present[threadIdx.x]) atomicOr(&flags[FLAG_STATUS], STATUS_SIGMA_GUESS);
+        gp[threadIdx.x] = present[threadIdx.x];
+    }
     static_assert(TEXT_SYMBOLS == BLOCK * 10, "ten code points per thread");
     __shared__ u32 lds4[WAVES_PER_BLOCK];
     const u32 c0 = threadIdx.x * 10u;
@@ -103,13 +113,55 @@ __global__ __launch_bounds__(BLOCK) void codemap_kernel(const u32 *__restrict__ 
     u32 total;
     u32 run = block_exclusive_sum(cnt, lds4, total);
 #pragma unroll
-    for (u32 i = 0; i < 10; i++) code_map[c0 + i] = ((bits >> i) & 1u) ? ++run : 0u;
+    for (u32 i = 0; i < 10; i++) {
+        const u32 code = ((bits >> i) & 1u) ? ++run : 0u;
+        code_map[c0 + i] = code;
+        if (guess) guess[c0 + i] = code;
+    }
     if (threadIdx.x == 0) {
         flags[FLAG_SIGMA] = total;
         u32 st = present[PRESENT_WORDS] & STATUS_NO_TERMINATOR;
         if (assumed != 0xFFFFFFFFu && assumed != total) st |= STATUS_SIGMA_GUESS;
         if (st) atomicOr(&flags[FLAG_STATUS], st);
     }
+}
+
+// Speculative build: presence bitmap AND byte stream in one pass over the symbols, the bytes through the code map of
+// the handle's last build (guess; codemap_kernel finds out whether that was right).  16-byte aligned input only.
+__global__ __launch_bounds__(BLOCK) void presence_remap_kernel(const u32 *__restrict__ sym, u32 n,
+                                                               const u32 *__restrict__ guess, u32 *__restrict__ present,
+                                                               uint8_t *__restrict__ s8)
+{
+    __shared__ u32 bits[PRESENT_WORDS];
+    __shared__ uint8_t map8[TEXT_SYMBOLS];
+    if (threadIdx.x < PRESENT_WORDS) bits[threadIdx.x] = 0;
+    for (u32 c = threadIdx.x; c < TEXT_SYMBOLS; c += BLOCK) map8[c] = (uint8_t)guess[c];
+    __syncthreads();
+    auto code = [&](u32 c) -> u32 {
+        if (c >= TEXT_SYMBOLS) return 0xFFu;
+        if (!(((volatile u32 *)bits)[c >> 5] & (1u << (c & 31u)))) atomicOr(&bits[c >> 5], 1u << (c & 31u));
+        return map8[c];
+    };
+    auto word = [&](const uint4 q) -> u32 { return code(q.x) | (code(q.y) << 8) | (code(q.z) << 16) | (code(q.w) << 24); };
+    const u32 stride = gridDim.x * BLOCK, n4 = n >> 2;
+    u32 *out = reinterpret_cast<u32 *>(s8);
+    u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    for (; i + 3u * stride < n4; i += 4u * stride) {       // four 16-byte loads in flight
+        const uint4 a = reinterpret_cast<const uint4 *>(sym)[i], b = reinterpret_cast<const uint4 *>(sym)[i + stride];
+        const uint4 c = reinterpret_cast<const uint4 *>(sym)[i + 2u * stride], d = reinterpret_cast<const uint4 *>(sym)[i + 3u * stride];
+        out[i] = word(a);
+        out[i + stride] = word(b);
+        out[i + 2u * stride] = word(c);
+        out[i + 3u * stride] = word(d);
+    }
+    for (; i < n4; i += stride) out[i] = word(reinterpret_cast<const uint4 *>(sym)[i]);
+    if (blockIdx.x == 0 && threadIdx.x < 20u) {            // the last n % 4 symbols and the 16 pad bytes
+        const u32 j = (n4 << 2) + threadIdx.x;
+        if (j < n) s8[j] = (uint8_t)code(sym[j]);
+        else if (j < n + 16u) s8[j] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < PRESENT_WORDS && bits[threadIdx.x]) atomicOr(&present[threadIdx.x], bits[threadIdx.x]);
 }
 
 struct TermIn {                                 // 1 at terminators; defined on [0, n]
@@ -287,6 +339,7 @@ struct east_hip_index {
     u32 n = 0, n_docs = 0, sigma_t = 0, m_total = 0;
     u32 sigma_hi = 0;            // text code points >= U+0A00 present (tagged encoding only): the top sigma_hi codes of the text alphabet
     u32 *hi_bits = nullptr, *hi_rank = nullptr;      // presence bitmap over [U+0A00, U+110000) and its rank directory
+    u32 *guess = nullptr;        // code map + presence bitmap of the last build (own allocation): what a speculative build starts from
     bool tagged_input = false;   // east_hip_set_symbol_encoding: the symbol entry points take the tagged encoding
     bool prep_tagged = false;    // the prepared symbols (east_hip_build_texts) are in the tagged encoding
     int bits0 = 0;
@@ -429,7 +482,9 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         u32 *term_ex = ar.alloc<u32>((size_t)n + 1);      // wide-alphabet path only
         if (!ctx.dry) HIP_CHECK(hipMemsetAsync(present, 0, (PRESENT_WORDS + 1) * 4, ctx.stream));
         const int vec = ((uintptr_t)d_sym & 15u) == 0;
-        LAUNCH(ctx, presence_kernel, std::min<u32>(gn, 2048), d_sym, n, vec, present);
+        const bool fused = ctx.spec && vec && h->guess;      // (the bytes come out of the same pass, through the last build's map)
+        if (fused) LAUNCH(ctx, presence_remap_kernel, std::min<u32>(gn, 2048), d_sym, n, (const u32 *)h->guess, present, h->s8);
+        else LAUNCH(ctx, presence_kernel, std::min<u32>(gn, 2048), d_sym, n, vec, present);
         LAUNCH(ctx, validate_last_symbol_kernel, ceil_div_u32(n_docs, BLOCK), d_sym, (const u32 *)h->doc_off, n_docs,
                (u32)tagged, present + PRESENT_WORDS);
         if (tagged) {
@@ -437,7 +492,8 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
             LAUNCH(ctx, presence_hi_kernel, std::min<u32>(gn, 2048), d_sym, n, h->hi_bits, status);
             LAUNCH(ctx, hi_rank_kernel, 1, (const u32 *)h->hi_bits, h->hi_rank, flags);
         }
-        LAUNCH(ctx, codemap_kernel, 1, (const u32 *)present, ctx.spec ? spec_sigma : 0xFFFFFFFFu, h->code_map, flags);
+        LAUNCH(ctx, codemap_kernel, 1, (const u32 *)present, ctx.spec ? spec_sigma : 0xFFFFFFFFu, h->code_map, flags, h->guess,
+               (int)fused);
         if (!ctx.dry) {
             if (ctx.spec) {
                 sigma_t = spec_sigma;                        // (checked on the device; found out at the end of the build)
@@ -462,6 +518,8 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
             LAUNCH(ctx, remap_hi_kernel, ceil_div_u32((u64)n + 16, BLOCK), d_sym, (const u32 *)nullptr,
                    (const u32 *)h->code_map, (const u32 *)h->hi_bits, (const u32 *)h->hi_rank, sigma_t - sigma_hi, sigma_t, n,
                    (u32 *)nullptr, h->s8);
+        } else if (fused) {
+            // (done)
         } else if (h->use_s8 && !ctx.dry) {
             LAUNCH(ctx, remap_bytes_kernel, ceil_div_u32((u64)n + 16, BLOCK * 16), d_sym, (const u32 *)h->code_map, n,
                    vec, h->s8);
@@ -1143,6 +1201,9 @@ int east_hip_create(int device, int64_t reserve_symbols, east_hip_handle_t *out)
             HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreate(&h->ev0));
             HIP_CHECK(hipEventCreate(&h->ev1));
+            void *g = nullptr;
+            HIP_CHECK(hipMalloc(&g, (TEXT_SYMBOLS + PRESENT_WORDS) * sizeof(u32)));
+            h->guess = (u32 *)g;
             if (reserve_symbols > 0)
                 ensure_arena(h, plan_arena_bytes((u32)reserve_symbols, 1) + (((size_t)reserve_symbols * 4 + 255) & ~(size_t)255));
         } catch (...) {
@@ -1164,6 +1225,7 @@ void east_hip_destroy(east_hip_handle_t h)
     if (h->q_buf) (void)hipFree(h->q_buf);
     if (h->kg) (void)hipFree(h->kg);
     if (h->prep_sym) (void)hipFree(h->prep_sym);
+    if (h->guess) (void)hipFree(h->guess);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
