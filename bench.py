@@ -99,6 +99,7 @@ def kernel_bytes(name, info, n, n_docs):
         "presence_kernel": n * 4,
         # 4 B read + 1 B written per symbol
         "remap_bytes_kernel": n * 5,
+        "presence_remap_kernel": n * 5,
         # 4 B sorted sample read + one random 4 B rank store per sample
         "dc3_rank_kernel": info["merge_elements"] * 2 // 3 * 8,
         # 8 symbols + 2 ranks read, one 16 B record written per symbol

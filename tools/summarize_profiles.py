@@ -9,7 +9,7 @@
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts a wide coalesced streaming
 read at exactly half its bytes (MI355X_MICROARCH.md, HBM section); checked here on kernels
-with a known byte count (remap_bytes_kernel and presence_kernel read 4 B/symbol):
+with a known byte count (presence_remap_kernel, remap_bytes_kernel and presence_kernel read 4 B/symbol):
 the ratio printed below is ~0.50.  traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 for the
 streaming kernels.  Gather kernels (GATHER below) issue 64-byte sector requests, which the
 counter tallies at their true size, so their FETCH_SIZE is NOT doubled.
@@ -120,10 +120,14 @@ for name in (tag + "_bench.json", tag + "_bench_profiled.json"):
                 num += out[k] * launches[k]
                 den += t * 1e-3
         if den:
-            line["roofline"]["rocprof_hbm_fraction"].update({"GBps": num / den / 1e9, "frac": num / den / 1e9 / bench.HBM_PEAK_GBS})
+            build_ms = sum(t for k, t in ms.items() if k.startswith(bench.BUILD_KERNEL_PREFIXES))
+            n_cov = sum(1 for k in ms if k.startswith(bench.BUILD_KERNEL_PREFIXES) and k in out and k in launches)
+            line["roofline"]["rocprof_hbm_fraction"].update({"GBps": num / den / 1e9, "frac": num / den / 1e9 / bench.HBM_PEAK_GBS,
+                                                             "kernels": n_cov, "share_of_build_kernel_time": den * 1e3 / build_ms})
     with open(path, "w") as f:
         f.write(json.dumps(line) + "\n")
-for k, expect in (("remap_kernel", 8.0 * n), ("remap_bytes_kernel", 4.0 * n), ("presence_kernel", 4.0 * n)):
+for k, expect in (("remap_kernel", 8.0 * n), ("remap_bytes_kernel", 4.0 * n), ("presence_kernel", 4.0 * n),
+                  ("presence_remap_kernel", 4.0 * n)):
     if k in fetch and expect:
         print("calibration %s: FETCH_SIZE*1024 / known read bytes = %.3f"
               % (k, fetch[k][1] / fetch[k][0] * 1024.0 / expect))
