@@ -888,11 +888,24 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     const TpTables tables{d_class, d_upper, d_word_hi, d_digit_hi, d_hi_from, d_hi_to, (u32)n_hi_upper};
 
     // bytes -> code points
+    // (first only the count: text in which every byte is a code point of its own -- ASCII, Latin-1 junk -- needs no
+    // index at all, and the count has to come back to the host anyway)
     u32 *cp_index = ar.alloc<u32>((size_t)n_bytes + 1);
-    device_scan<TpStartIn, false>(ctx, TpStartIn{d_bytes, n_bytes}, n_bytes + 1, cp_index);
-    u32 n_cp = 0;
-    HIP_CHECK(hipMemcpyAsync(&n_cp, cp_index + n_bytes, 4, hipMemcpyDeviceToHost, h->stream));
+    const u32 nb_cp = ceil_div_u32(n_bytes + 1, SCAN_TILE);
+    u32 *cp_sums = ar.alloc<u32>(nb_cp);
+    LAUNCH(ctx, (scan_reduce_kernel<TpStartIn>), nb_cp, TpStartIn{d_bytes, n_bytes}, n_bytes + 1, cp_sums);
+    std::vector<u32> h_cp_sums(nb_cp);
+    HIP_CHECK(hipMemcpyAsync(h_cp_sums.data(), cp_sums, (size_t)nb_cp * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));          // also covers off32
+    u32 n_cp = 0;
+    for (u32 x : h_cp_sums) n_cp += x;
+    if (n_cp == n_bytes) {
+        cp_index = nullptr;
+    } else {
+        device_scan<ArrIn, false>(ctx, ArrIn{cp_sums}, nb_cp, cp_sums);
+        LAUNCH(ctx, (scan_apply_kernel<TpStartIn, false>), nb_cp, TpStartIn{d_bytes, n_bytes}, n_bytes + 1, (const u32 *)cp_sums,
+               cp_index);
+    }
     u32 *cpu = ar.alloc<u32>(n_cp);
     uint8_t *cw = ar.alloc<uint8_t>((size_t)n_cp + 1);
     u32 *doc_cp_off = ar.alloc<u32>((size_t)D + 1);
@@ -903,9 +916,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
 
     // code points -> tokens
     u32 *tok_inc = ar.alloc<u32>(n_cp);
-    u32 *nd_ex = ar.alloc<u32>((size_t)n_cp + 1);
     device_scan<TpTokStartIn, true>(ctx, TpTokStartIn{cw, n_cp}, n_cp, tok_inc);
-    device_scan<TpNonDigitIn, false>(ctx, TpNonDigitIn{cw, n_cp}, n_cp + 1, nd_ex);
     u32 n_tok = 0;
     u32 high = 0;
     HIP_CHECK(hipMemcpyAsync(&n_tok, tok_inc + (n_cp - 1), 4, hipMemcpyDeviceToHost, h->stream));
@@ -913,13 +924,15 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     u32 *tstart = ar.alloc<u32>((size_t)n_tok + 1), *tend = ar.alloc<u32>((size_t)n_tok + 1);
     u32 *keep = ar.alloc<u32>((size_t)n_tok + 1), *klen = ar.alloc<u32>((size_t)n_tok + 1);
     u32 *keep_ex = ar.alloc<u32>((size_t)n_tok + 1), *klen_ex = ar.alloc<u32>((size_t)n_tok + 1);
+    u32 *tok_nd = ar.alloc<u32>((size_t)n_tok + 1);      // token holds a character that is not a digit
+    HIP_CHECK(hipMemsetAsync(tok_nd, 0, ((size_t)n_tok + 1) * 4, h->stream));
     HIP_CHECK(hipMemsetAsync(keep + n_tok, 0, 4, h->stream));
     HIP_CHECK(hipMemsetAsync(klen + n_tok, 0, 4, h->stream));
     if (n_tok) {
         LAUNCH(ctx, tp_token_bounds_kernel, ceil_div_u32(n_cp, BLOCK), (const uint8_t *)cw, (const u32 *)tok_inc, n_cp,
-               tstart, tend);
+               tstart, tend, tok_nd);
         LAUNCH(ctx, tp_token_keep_kernel, ceil_div_u32(n_tok, BLOCK), (const u32 *)tstart, (const u32 *)tend,
-               (const u32 *)nd_ex, n_tok, keep, klen);
+               (const u32 *)tok_nd, n_tok, keep, klen);
     }
     device_scan<ArrIn, false>(ctx, ArrIn{keep}, n_tok + 1, keep_ex);
     device_scan<ArrIn, false>(ctx, ArrIn{klen}, n_tok + 1, klen_ex);

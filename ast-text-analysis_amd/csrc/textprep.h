@@ -113,7 +113,7 @@ __global__ __launch_bounds__(BLOCK) void tp_decode_kernel(const uint8_t *__restr
         const u32 k = cp - TP_TEXT_LIMIT;
         cls = ((T.word_hi[k >> 5] >> (k & 31u)) & 1u) | (((T.digit_hi[k >> 5] >> (k & 31u)) & 1u) << 1);
     }
-    const u32 idx = cp_index[i];
+    const u32 idx = cp_index ? cp_index[i] : i;     // (nullptr: every byte is a code point of its own)
     cpu[idx] = cp;
     cw[idx] = (uint8_t)cls;
 }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(BLOCK) void tp_doc_cp_offsets_kernel(const u32 *__r
                                                                   u32 *__restrict__ doc_cp_off)
 {
     const u32 d = blockIdx.x * BLOCK + threadIdx.x;
-    if (d <= n_docs) doc_cp_off[d] = cp_index[text_off[d]];          // cp_index has n_bytes + 1 entries
+    if (d <= n_docs) doc_cp_off[d] = cp_index ? cp_index[text_off[d]] : text_off[d];      // cp_index has n_bytes + 1 entries
 }
 
 struct TpTokStartIn {                            // 1 at the first code point of a token; defined on [0, n]
@@ -136,38 +136,34 @@ struct TpTokStartIn {                            // 1 at the first code point of
     }
 };
 
-struct TpNonDigitIn {                            // 1 at word characters that are not digits; defined on [0, n]
-    const uint8_t *cw;
-    u32 n;
-    __device__ __forceinline__ u32 operator()(u32 p) const
-    {
-        return (p < n && (cw[p] & (TP_CLASS_WORD | TP_CLASS_DIGIT)) == TP_CLASS_WORD) ? 1u : 0u;
-    }
-};
-
 // tok_inc[p] = inclusive count of token starts: a word position p belongs to token tok_inc[p]-1
+// tok_nd[k] (zeroed by the caller) becomes 1 when token k holds a character that is not a digit
 __global__ __launch_bounds__(BLOCK) void tp_token_bounds_kernel(const uint8_t *__restrict__ cw,
                                                                 const u32 *__restrict__ tok_inc, u32 n_cp,
-                                                                u32 *__restrict__ tstart, u32 *__restrict__ tend)
+                                                                u32 *__restrict__ tstart, u32 *__restrict__ tend,
+                                                                u32 *__restrict__ tok_nd)
 {
     const u32 p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= n_cp || !(cw[p] & TP_CLASS_WORD)) return;
     const u32 k = tok_inc[p] - 1u;
-    if (!(p > 0 && (cw[p - 1] & TP_CLASS_WORD))) tstart[k] = p;
+    const bool first = !(p > 0 && (cw[p - 1] & TP_CLASS_WORD));
+    if (first) tstart[k] = p;
     if (!(p + 1 < n_cp && (cw[p + 1] & TP_CLASS_WORD))) tend[k] = p;
+    // (ordinary words: the first letter says it; a token that starts with digits hears it from its first other character)
+    if (!(cw[p] & TP_CLASS_DIGIT) && (first || (cw[p - 1] & TP_CLASS_DIGIT))) tok_nd[k] = 1u;
 }
 
 // keep[k] = len > 2 and not all digits (utils.py:63); klen[k] = kept length or 0
 __global__ __launch_bounds__(BLOCK) void tp_token_keep_kernel(const u32 *__restrict__ tstart,
                                                               const u32 *__restrict__ tend,
-                                                              const u32 *__restrict__ nd_ex, u32 n_tok,
+                                                              const u32 *__restrict__ tok_nd, u32 n_tok,
                                                               u32 *__restrict__ keep, u32 *__restrict__ klen)
 {
     const u32 k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n_tok) return;
     const u32 a = tstart[k], e = tend[k];
     const u32 len = e - a + 1u;
-    const bool kp = len > 2u && nd_ex[e + 1u] != nd_ex[a];
+    const bool kp = len > 2u && tok_nd[k] != 0u;
     keep[k] = kp ? 1u : 0u;
     klen[k] = kp ? len : 0u;
 }
