@@ -135,7 +135,8 @@ struct Ctx {
     // build on the handle tells it what to expect -- the size of the text alphabet, "no suffix is left in a
     // large tie group after the placement pass".  The device checks both and the one read-back at the
     // end of the build finds out; a wrong guess costs a second, non-speculative build.
-    bool spec = false;
+    bool spec = false;          // the build does not wait for the alphabet (it uses the last build's)
+    bool spec_rounds = false;   // ... nor for the placement pass's counts (it goes on as if no tie group were large)
     u32 *spec_out = nullptr;    // [0] suffixes left in large groups, [1] placement gave up on a long repeat
     Stats *stats = nullptr;
     Profiler *prof = nullptr;

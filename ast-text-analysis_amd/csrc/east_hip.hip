@@ -353,7 +353,7 @@ struct east_hip_index {
     Pyramid pyr;
     u32 build_docs = 0;          // documents of the build in progress (h->n_docs is set when it has succeeded)
     // what the last successful build found, the guesses of the next (speculative) one
-    bool hint_valid = false, hint_no_rounds = false;
+    bool hint_valid = false, hint_no_rounds = false, hint_window = false;
     u32 hint_sigma = 0;
     u32 plan_n = 0, plan_docs = 0, plan_epoch = 0;
     bool plan_tagged = false;   // shape of the last sizing run (and test-knob epoch), its result
@@ -772,12 +772,17 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     // to expect (alphabet size, no large tie groups): one read-back at the end finds out whether it was
     // right.  If not -- or on a handle's first build -- the build runs with its read-backs in place.
     u32 flags[FLAG_WORDS] = {0};
-    auto run = [&](bool spec) -> bool {
+    auto run = [&](bool spec, bool spec_rounds) -> bool {
         ctx.spec = spec;
+        ctx.spec_rounds = spec && spec_rounds;
         try {
             build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings, h->hint_sigma, tagged);
         } catch (const SpecAbort &) {
             HIP_CHECK(hipStreamSynchronize(h->stream));
+            return false;
+        } catch (const EastError &) {
+            if (!spec) throw;                            // (whatever a wrong guess ran into: the build is repeated without guesses)
+            (void)hipStreamSynchronize(h->stream);
             return false;
         }
         HIP_CHECK(hipEventRecord(h->ev1, h->stream));
@@ -786,12 +791,15 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
         return true;
     };
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));
-    const bool speculate = g_speculate && g_window_sort && h->hint_valid && h->hint_no_rounds && h->hint_sigma <= 254 && !tagged;
-    const bool went_through = run(speculate);
-    if (speculate && (!went_through || (flags[FLAG_STATUS] & STATUS_SIGMA_GUESS) || flags[FLAG_KEEP] || flags[FLAG_FAIL])) {
+    // (the alphabet is guessed whenever the last build took the window sort; that no tie group is large only if it found none)
+    const bool speculate = g_speculate && g_window_sort && h->hint_valid && h->hint_window && h->hint_sigma <= 254 && !tagged;
+    const bool spec_rounds = speculate && h->hint_no_rounds;
+    const bool went_through = run(speculate, spec_rounds);
+    if (speculate && (!went_through || (flags[FLAG_STATUS] & STATUS_SIGMA_GUESS) ||
+                      (spec_rounds && (flags[FLAG_KEEP] || flags[FLAG_FAIL])))) {
         if (g_trace) fprintf(stderr, "[east_hip] speculative build guessed wrong: building again\n");
         h->stats = Stats();
-        run(false);
+        run(false, false);
     }
     const u32 status = flags[FLAG_STATUS];
     if (status & STATUS_NO_TERMINATOR)
@@ -807,6 +815,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
                                                  "(text symbols must be < U+0A00 unless the terminators are tagged)");
     h->hint_valid = !tagged || h->sigma_hi == 0;
     h->hint_sigma = h->sigma_t;
+    h->hint_window = h->stats.window_sorted != 0;
     h->hint_no_rounds = h->stats.window_sorted && h->stats.refine_rounds == 0 && !h->stats.long_repeats;
     h->prof.collect();
     HIP_CHECK(hipEventElapsedTime(&h->last_build_ms, h->ev0, h->ev1));

@@ -928,7 +928,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                          bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
         if (mode == 1 || ctx.dry) return;
         LAUNCH(ctx, (scan_reduce_kernel<ArrIn>), nb, ArrIn{block_keep}, gp, block_sums);
-        if (ctx.spec && mode == 0 && n0 == 0) {
+        if (ctx.spec_rounds && mode == 0 && n0 == 0) {
             // speculative build: the host goes on as if nothing were left in large groups; the counts are
             // put next to the build's other flags and read at the end (build_common repeats the build if
             // they are not zero)
