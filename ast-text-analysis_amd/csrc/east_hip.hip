@@ -178,17 +178,27 @@ struct TermIn {                                 // 1 at terminators; defined on 
 // (a stream whose terminators carry EAST_HIP_TERMINATOR_TAG may hold any code point as text; the kernels above
 // and below read such a stream unchanged as long as no text symbol reaches U+0A00 -- a tagged terminator is
 // ">= U+0A00" --, and that is found out here)
-__global__ __launch_bounds__(BLOCK) void presence_hi_kernel(const u32 *__restrict__ sym, u32 n, u32 *__restrict__ hi_bits,
-                                                            u32 *__restrict__ status)
+// (the whole bitmap -- 136 KiB -- lives in the workgroup's LDS: a plain LDS read filters the bits that are set, which
+// in CJK text is every symbol after the first few thousand; one 1024-thread workgroup per CU, grid-stride, and only
+// the words a workgroup has touched go to the global bitmap)
+#define PRESENCE_HI_THREADS 1024
+__global__ __launch_bounds__(PRESENCE_HI_THREADS) void presence_hi_kernel(const u32 *__restrict__ sym, u32 n,
+                                                                          u32 *__restrict__ hi_bits, u32 *__restrict__ status)
 {
-    const u32 stride = gridDim.x * BLOCK;
-    for (u32 i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    __shared__ u32 bits[HI_WORDS];
+    for (u32 w = threadIdx.x; w < HI_WORDS; w += PRESENCE_HI_THREADS) bits[w] = 0;
+    __syncthreads();
+    const u32 stride = gridDim.x * PRESENCE_HI_THREADS;
+    for (u32 i = blockIdx.x * PRESENCE_HI_THREADS + threadIdx.x; i < n; i += stride) {
         const u32 c = sym[i];
         if (c < TEXT_SYMBOLS || (c >> 31)) continue;
         if (c >= 0x110000u) { atomicOr(status, STATUS_BAD_SYMBOL); continue; }
         const u32 k = c - TEXT_SYMBOLS;
-        if (!(((volatile u32 *)hi_bits)[k >> 5] & (1u << (k & 31u)))) atomicOr(&hi_bits[k >> 5], 1u << (k & 31u));
+        if (!(((volatile u32 *)bits)[k >> 5] & (1u << (k & 31u)))) atomicOr(&bits[k >> 5], 1u << (k & 31u));
     }
+    __syncthreads();
+    for (u32 w = threadIdx.x; w < HI_WORDS; w += PRESENCE_HI_THREADS)
+        if (bits[w]) atomicOr(&hi_bits[w], bits[w]);
 }
 
 // hi_rank[w] = code points present below word w of the bitmap; flags[FLAG_SIGMA_HI] = their number.  One workgroup.
@@ -489,7 +499,8 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
                (u32)tagged, present + PRESENT_WORDS);
         if (tagged) {
             if (!ctx.dry) HIP_CHECK(hipMemsetAsync(h->hi_bits, 0, HI_WORDS * 4, ctx.stream));
-            LAUNCH(ctx, presence_hi_kernel, std::min<u32>(gn, 2048), d_sym, n, h->hi_bits, status);
+            LAUNCH_BLOCK(ctx, presence_hi_kernel, std::min<u32>(ceil_div_u32(n, PRESENCE_HI_THREADS), 256), PRESENCE_HI_THREADS,
+                         d_sym, n, h->hi_bits, status);
             LAUNCH(ctx, hi_rank_kernel, 1, (const u32 *)h->hi_bits, h->hi_rank, flags);
         }
         LAUNCH(ctx, codemap_kernel, 1, (const u32 *)present, ctx.spec ? spec_sigma : 0xFFFFFFFFu, h->code_map, flags, h->guess,

@@ -40,3 +40,12 @@ for name, s in (("26 letters (byte stream, window sort)", sym), ("%d code points
     print("%-52s %8d symbols  sigma %5d  build %7.2f ms  %.2e symbols/s  (window_sorted %d, dc3 levels %d)"
           % (name, n, info["sigma_text"], min(times), n / (min(times) * 1e-3), info["window_sorted"], info["dc3_levels"]))
     index.close()
+    if os.environ.get("EAST_PROFILE") and name.startswith("%d code" % (per * 26)):
+        index = hip_backend.HipIndex()
+        index.build(s, off, np.array([m]))
+        index.profile_enable(True)
+        index.build(s, off, np.array([m]))
+        report = index.profile_report()
+        for kname, (count, ms) in sorted(report.items(), key=lambda kv: -kv[1][1])[:22]:
+            print("    %-44s %3d launches %8.3f ms" % (kname, count, ms))
+        index.close()
