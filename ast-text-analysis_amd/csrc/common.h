@@ -88,6 +88,8 @@ struct Profiler {
     std::vector<hipEvent_t> pool;
     std::vector<Sum> sums;
     bool enabled = false;
+    std::string only;           // not empty: only launches of this kernel are bracketed (two events per launch cost time)
+    bool skipped = false;
 
     hipEvent_t get()
     {
@@ -98,11 +100,16 @@ struct Profiler {
     }
     void begin(const char *name, hipStream_t st)
     {
+        skipped = !only.empty() && only != name;
+        if (skipped) return;
         Rec r{name, get(), get()};
         (void)hipEventRecord(r.e0, st);
         recs.push_back(r);
     }
-    void end(hipStream_t st) { (void)hipEventRecord(recs.back().e1, st); }
+    void end(hipStream_t st)
+    {
+        if (!skipped) (void)hipEventRecord(recs.back().e1, st);
+    }
     // call after the stream has been synchronised
     void collect()
     {

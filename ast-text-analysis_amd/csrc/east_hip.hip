@@ -1496,6 +1496,7 @@ int east_hip_reset(east_hip_handle_t h)
         h->tagged_input = false;
         h->sigma_hi = 0;
         h->prof.enabled = false;
+        h->prof.only.clear();
         h->stats = Stats();
         // a recycled handle keeps its stream and a small arena, not gigabytes of side allocations
         const size_t keep = (size_t)64 << 20;
@@ -1538,6 +1539,13 @@ int east_hip_profile_enable(east_hip_handle_t h, int on)
         h->prof.reset();
         h->prof.enabled = on != 0;
     });
+}
+
+int east_hip_profile_only(east_hip_handle_t h, const char *kernel)
+{
+    if (!h) return EAST_HIP_ERR_INVALID;
+    h->prof.only = kernel ? kernel : "";
+    return EAST_HIP_OK;
 }
 
 int64_t east_hip_profile_report(east_hip_handle_t h, char *buf, int64_t cap)

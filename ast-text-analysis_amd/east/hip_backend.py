@@ -71,6 +71,7 @@ SIGNATURES = {
     "east_hip_debug_set_speculation": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_debug_set_score_scratch": (ctypes.c_int, [ctypes.c_int64]),
     "east_hip_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "east_hip_profile_only": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
     "east_hip_profile_report": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
 }
 
@@ -368,6 +369,10 @@ class HipIndex(object):
 
     def profile_enable(self, on=True):
         _check(self._lib.east_hip_profile_enable(self._h, int(bool(on))))
+
+    def profile_only(self, kernel=None):
+        """Bracket only the launches of `kernel` (None: every kernel) while profiling is enabled."""
+        _check(self._lib.east_hip_profile_only(self._h, kernel.encode("ascii") if kernel else None))
 
     def profile_report(self):
         """{kernel name: (launches, total_ms)} accumulated since profile_enable()."""
