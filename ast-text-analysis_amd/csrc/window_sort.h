@@ -292,7 +292,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_scatter_names_kernel(const u32 *__r
 // sample mode they stop when the domain stalls -- the refined names still are valid DC3 names
 // (order-preserving over a window that covers the triple) and feed the recursion.
 #ifndef REFINE_SMALL_GROUP
-#define REFINE_SMALL_GROUP 8
+#define REFINE_SMALL_GROUP 6
 #endif
 #define REFINE_MAX_ROUNDS 32
 #define REFINE_ENDGAME_DOMAIN 262144     // domains this small: groups up to REFINE_ENDGAME_GROUP are ordered directly,
