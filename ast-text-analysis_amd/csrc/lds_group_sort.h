@@ -37,7 +37,7 @@ struct LgLds {
     u32 wsum[LG_WAVES];
     u64 start_bits[LG_WORDS];               // bit q: domain position chunk_base + q starts a group
     u32 word_prefix[LG_WORDS];              // group starts of the tile before the word
-    u32 hdr[4];                             // first position of the tile (relative), elements, groups
+    u32 hdr[2];                             // first position of the tile (relative to the chunk), its elements
 };
 
 // Is domain position j left to the global sort?  cover[c] = the stretch of positions workgroup c took
@@ -289,14 +289,7 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
         }
     }
     const u32 n_waves = (n_act + LG_IPT * WAVE - 1u) / (LG_IPT * WAVE);
-#ifdef LG_EXPERIMENT_PASSES
-    for (int shift = 0; shift < 8 * LG_EXPERIMENT_PASSES; shift += 8) lg_radix_pass(lds, key, val, shift, active, n_waves);
-#else
     for (int shift = 0; shift < bits; shift += 8) lg_radix_pass(lds, key, val, shift, active, n_waves);
-#endif
-    if (bits <= 0) {                                    // (cannot happen: a window has at least one symbol)
-        return;
-    }
     // ---- what the round's write-back writes, for the tile ----
     if (!active) return;
 #pragma unroll
