@@ -145,6 +145,7 @@ struct Ctx {
     bool spec = false;          // the build does not wait for the alphabet (it uses the last build's)
     bool spec_rounds = false;   // ... nor for the placement pass's counts (it goes on as if no tie group were large)
     u32 *spec_out = nullptr;    // [0] suffixes left in large groups, [1] placement gave up on a long repeat
+    u32 *zeroed_word = nullptr; // one word the build has already zeroed: the first level-0 pass takes it for its fail flag
     Stats *stats = nullptr;
     Profiler *prof = nullptr;
 };

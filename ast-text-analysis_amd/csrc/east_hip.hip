@@ -82,6 +82,7 @@ __global__ __launch_bounds__(BLOCK) void presence_kernel(const u32 *__restrict__
 #define FLAG_KEEP 3
 #define FLAG_FAIL 4
 #define FLAG_SIGMA_HI 5
+#define FLAG_PLACE_FAIL 6        // the placement pass's "a repeat too long to order directly" (window_sort.h: fail), zeroed with the flags
 #define FLAG_WORDS 8
 #define STATUS_NO_TERMINATOR 1u
 #define STATUS_N_STRINGS 2u
@@ -423,10 +424,13 @@ static void annotate(east_hip_index *h, Ctx &ctx)
     const bool has_lvl1 = pyr.levels > 1;                // (a table of at most 16 entries has no level 1)
     LAUNCH(ctx, ann_stream_kernel, n_tiles, pyr.ptr[0], (const u32 *)h->doc_off, (const u32 *)h->n_strings,
            h->build_docs, n, h->ann, has_lvl1 ? (u32 *)pyr.ptr[1] : (u32 *)nullptr, has_lvl1 ? pyr.len[1] : 0u,
-           has_lvl1 ? pyr_padded(pyr.len[1]) : 0u, wide_list, wide_count);
-    for (int l = 2; l < pyr.levels; l++)
+           has_lvl1 ? pyr_padded(pyr.len[1]) : 0u, wide_list, wide_count, h->lcp);
+    // the levels above: one launch each while they are large, the top of the pyramid in a single one
+    int l = 2;
+    for (; l < pyr.levels && pyr.len[l] > PYR_TOP; l++)
         LAUNCH(ctx, pyramid_level_kernel, ceil_div_u32(pyr_padded(pyr.len[l]), BLOCK), pyr.ptr[l - 1], pyr.len[l],
                pyr_padded(pyr.len[l]), (u32 *)pyr.ptr[l]);
+    if (l < pyr.levels) LAUNCH(ctx, pyramid_top_kernel, 1, pyr, l);
     LAUNCH(ctx, ann_wide_kernel, ceil_div_u32(n_tiles, BLOCK / ANN_WIDE_SLOTS), pyr, n, n_tiles, (const u32 *)wide_list,
            (const u32 *)wide_count, h->ann);
     ar.release(mark);
@@ -450,7 +454,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     h->next = ar.alloc<u32>(n);
     h->doc_off = ar.alloc<u32>((size_t)n_docs + 1);
     h->n_strings = ar.alloc<u32>(n_docs);
-    h->code_map = ar.alloc<u32>(TEXT_SYMBOLS + FLAG_WORDS);   // + the flag words (FLAG_*)
+    h->code_map = ar.alloc<u32>(TEXT_SYMBOLS + FLAG_WORDS + PRESENT_WORDS + 1);   // + the flag words (FLAG_*) + the presence bitmap and its status word
     h->hi_bits = tagged ? ar.alloc<u32>(HI_WORDS) : nullptr;
     h->hi_rank = tagged ? ar.alloc<u32>(HI_WORDS) : nullptr;
     Pyramid pyr;
@@ -483,14 +487,14 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     u32 sigma_hi = tagged ? HI_SYMBOLS : 0;
     u32 *flags = h->code_map + TEXT_SYMBOLS;              // flag words behind the code map
     u32 *capped = flags + FLAG_CAPPED, *status = flags + FLAG_STATUS;
-    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(flags, 0, FLAG_WORDS * sizeof(u32), ctx.stream));
+    u32 *present = flags + FLAG_WORDS;                    // PRESENT_WORDS + 1 (status word): zeroed in the same fill
+    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(flags, 0, (FLAG_WORDS + PRESENT_WORDS + 1) * sizeof(u32), ctx.stream));
     ctx.spec_out = flags + FLAG_KEEP;
+    ctx.zeroed_word = ctx.dry ? nullptr : flags + FLAG_PLACE_FAIL;
     {
         // ---- alphabet, dense remap ---------------------------------------------
         const size_t mark = ar.mark();
-        u32 *present = ar.alloc<u32>(PRESENT_WORDS + 1);  // + status word
         u32 *term_ex = ar.alloc<u32>((size_t)n + 1);      // wide-alphabet path only
-        if (!ctx.dry) HIP_CHECK(hipMemsetAsync(present, 0, (PRESENT_WORDS + 1) * 4, ctx.stream));
         const int vec = ((uintptr_t)d_sym & 15u) == 0;
         const bool fused = ctx.spec && vec && h->guess;      // (the bytes come out of the same pass, through the last build's map)
         if (fused) LAUNCH(ctx, presence_remap_kernel, std::min<u32>(gn, 2048), d_sym, n, (const u32 *)h->guess, present, h->s8);
@@ -644,8 +648,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         const size_t mark = ar.mark();
         u32 *rank = ctx.dry ? ar.alloc<u32>(n) : nullptr;       // only allocated for real when needed
         if (fused_lcp) {
-            if (!ctx.dry && pyr_padded(n) > n)
-                HIP_CHECK(hipMemsetAsync(h->lcp + n, 0xFF, (size_t)(pyr_padded(n) - n) * sizeof(u32), ctx.stream));
+            // (the table's padding up to a multiple of 16 is written by ann_stream_kernel)
         } else if (h->use_s8) {
             LAUNCH(ctx, lcp8_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const uint8_t *)h->s8, (const u32 *)h->sa,
                    n, h->lcp, capped);

@@ -32,6 +32,7 @@ struct Pyramid {
 };
 
 static inline u32 pyr_padded(u32 len) { return (len + PYR_FAN - 1u) & ~(PYR_FAN - 1u); }
+__device__ __forceinline__ u32 pyr_padded_dev(u32 len) { return (len + PYR_FAN - 1u) & ~(PYR_FAN - 1u); }
 
 // document of a rank / position: last d with doc_off[d] <= x
 __device__ __forceinline__ u32 doc_of(const u32 *__restrict__ doc_off, u32 n_docs, u32 x)
@@ -257,6 +258,41 @@ __global__ __launch_bounds__(BLOCK) void pyramid_level_kernel(const u32 *__restr
     out[i] = v;
 }
 
+// The top of the pyramid in one launch: level `first` (at most PYR_TOP entries) from the level below, and every level
+// above it from LDS.  One workgroup; len[] / ptr[]: as in Pyramid.
+#define PYR_TOP 4096u
+__global__ __launch_bounds__(BLOCK) void pyramid_top_kernel(Pyramid P, int first)
+{
+    __shared__ u32 cur[PYR_TOP], nxt[PYR_TOP / PYR_FAN];
+    const u32 *below = P.ptr[first - 1];
+    u32 len = P.len[first];
+    for (u32 i = threadIdx.x; i < pyr_padded_dev(len); i += BLOCK) {
+        u32 v = NONE_U32;
+        if (i < len) {
+            const uint4 *g = reinterpret_cast<const uint4 *>(below + ((size_t)i << PYR_SHIFT));
+            const uint4 a = g[0], b = g[1], c = g[2], d = g[3];
+            v = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
+            v = min(v, min(min(min(c.x, c.y), min(c.z, c.w)), min(min(d.x, d.y), min(d.z, d.w))));
+        }
+        cur[i] = v;
+        const_cast<u32 *>(P.ptr[first])[i] = v;
+    }
+    __syncthreads();
+    u32 *a = cur, *b = nxt;
+    for (int lvl = first + 1; lvl < P.levels; lvl++) {
+        const u32 len_out = P.len[lvl];
+        for (u32 i = threadIdx.x; i < pyr_padded_dev(len_out); i += BLOCK) {
+            u32 v = NONE_U32;
+            if (i < len_out)
+                for (u32 q = 0; q < PYR_FAN; q++) v = min(v, a[i * PYR_FAN + q]);   // (the padding of the level below holds NONE)
+            b[i] = v;
+            const_cast<u32 *>(P.ptr[lvl])[i] = v;
+        }
+        __syncthreads();
+        u32 *t = a; a = b; b = t;
+    }
+}
+
 // bit i set iff M[start + i] < v (STRICT) or <= v, for the 16-word group at `start`
 template <bool STRICT>
 __device__ __forceinline__ u32 pyr_group_mask(const u32 *__restrict__ M, u32 start, u32 v)
@@ -429,12 +465,17 @@ __global__ __launch_bounds__(BLOCK) void ann_stream_kernel(const u32 *__restrict
                                                            const u32 *__restrict__ n_strings, u32 n_docs, u32 n,
                                                            u32 *__restrict__ ann, u32 *__restrict__ lvl1, u32 len1,
                                                            u32 len1_padded, u32 *__restrict__ wide_list,
-                                                           u32 *__restrict__ wide_count)      // per tile: its own stretch / count
+                                                           u32 *__restrict__ wide_count,      // per tile: its own stretch / count
+                                                           u32 *__restrict__ lcp_pad)         // != nullptr: the table's padding is still to be written
 {
     __shared__ __attribute__((aligned(16))) u32 tile[ANN_TILE + 2 * ANN_HALO];
     __shared__ u32 work[ANN_TILE];
     __shared__ u32 work_count, far_count;
     if (threadIdx.x == 0) { work_count = 0; far_count = 0; }
+    // (the entries between n and the next multiple of 16 -- the pyramid searches of ann_wide_kernel read whole groups;
+    // nothing in this kernel depends on them: ranks outside [0, n) are masked below)
+    if (lcp_pad && blockIdx.x == gridDim.x - 1 && threadIdx.x < PYR_FAN && n + threadIdx.x < ((n + PYR_FAN - 1u) & ~(PYR_FAN - 1u)))
+        lcp_pad[n + threadIdx.x] = NONE_U32;
     const u32 tile_base = blockIdx.x * ANN_TILE;
     const u32 k0 = tile_base + threadIdx.x * ANN_IPT;
     {

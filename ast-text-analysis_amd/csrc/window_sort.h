@@ -847,15 +847,27 @@ __global__ __launch_bounds__(BLOCK) void lvl0_lcp_keys_kernel(KeyNeqWindowIn<K> 
     lcp[r] = h;
 }
 
-// what the placement pass left undone, next to the other flags (speculative build: read at the very end)
-__global__ void spec_counts_kernel(const u32 *__restrict__ block_sums, u32 nb, const u32 *__restrict__ fail,
-                                   u32 *__restrict__ out)
+// what the placement pass left undone, next to the other flags (speculative build: read at the very end):
+// the sum of its workgroups' counts (out[] was zeroed with the build's flag words; a few workgroups add into it)
+#define SPEC_COUNT_TILE (BLOCK * 16)
+__global__ __launch_bounds__(BLOCK) void spec_counts_kernel(const u32 *__restrict__ block_keep, u32 gp,
+                                                            const u32 *__restrict__ fail, u32 *__restrict__ out)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        u32 total = 0;
-        for (u32 i = 0; i < nb; i++) total += block_sums[i];
-        out[0] = total;
-        out[1] = *fail;
+    __shared__ u32 lds[WAVES_PER_BLOCK];
+    const u32 base = blockIdx.x * SPEC_COUNT_TILE;
+    u32 sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const u32 i = base + j * BLOCK + threadIdx.x;
+        if (i < gp) sum += block_keep[i];
+    }
+    sum = wave_sum(sum);
+    if (lane_id() == 0) lds[wave_id()] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 t = lds[0] + lds[1] + lds[2] + lds[3];
+        if (t) atomicAdd(&out[0], t);
+        if (blockIdx.x == 0) out[1] = *fail;
     }
 }
 
@@ -895,12 +907,14 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     u32 *idx = sb.vals[r ^ 1];                          // n02 + 1 entries, likewise
     u32 *names_g = s12 ? ar.alloc<u32>(n02) : nullptr;  // sample mode: the naming predicate as refined so far
     u32 *fail = ar.alloc<u32>(1);
+    const bool fail_is_zero = ctx.zeroed_word != nullptr;               // (zeroed with the build's flag words: one fill less)
+    if (fail_is_zero) { fail = ctx.zeroed_word; ctx.zeroed_word = nullptr; }
     const u32 gp = ceil_div_u32((u64)n02 + 1, BLOCK * PLACE_IPT);      // workgroups of the placement pass
     u32 *block_keep = ar.alloc<u32>(gp);
     const u32 nb = ceil_div_u32(gp, SCAN_TILE);
     u32 *block_sums = ar.alloc<u32>(nb);
     u32 *bad = ar.alloc<u32>(((size_t)n02 >> 5) + 2);   // groups with a repeat too long to compare directly (rare)
-    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
+    if (!ctx.dry && !fail_is_zero) HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
 
     // ---- the whole sorted input as the first domain --------------------------------------
     // (a small input is better off with the direct ordering of much larger groups than with a round of ~50 launches)
@@ -927,18 +941,17 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, false, false>), gp, starts, sorted_vals, n02, s8, n0, w,
                          bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
         if (mode == 1 || ctx.dry) return;
-        LAUNCH(ctx, (scan_reduce_kernel<ArrIn>), nb, ArrIn{block_keep}, gp, block_sums);
         if (ctx.spec_rounds && mode == 0 && n0 == 0) {
             // speculative build: the host goes on as if nothing were left in large groups; the counts are
             // put next to the build's other flags and read at the end (build_common repeats the build if
             // they are not zero)
-            hipLaunchKernelGGL(spec_counts_kernel, dim3(1), dim3(WAVE), 0, ctx.stream, (const u32 *)block_sums, nb,
-                               (const u32 *)fail, ctx.spec_out);
-            HIP_CHECK(hipGetLastError());
+            LAUNCH(ctx, spec_counts_kernel, ceil_div_u32(gp, SPEC_COUNT_TILE), (const u32 *)block_keep, gp, (const u32 *)fail,
+                   ctx.spec_out);
             m_next = 0;
             h_fail = 0;
             return;
         }
+        LAUNCH(ctx, (scan_reduce_kernel<ArrIn>), nb, ArrIn{block_keep}, gp, block_sums);
         std::vector<u32> h_sums(nb);
         HIP_CHECK(hipMemcpyAsync(h_sums.data(), block_sums, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx.stream));
         HIP_CHECK(hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, ctx.stream));
