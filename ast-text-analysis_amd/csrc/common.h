@@ -150,6 +150,22 @@ struct Ctx {
     Profiler *prof = nullptr;
 };
 
+// Wait for a stream the way the build's read-backs want it: they sit between kernels a few microseconds long, and a
+// blocking hipStreamSynchronize comes back tens of microseconds after the stream has drained (the waiter sleeps on an
+// interrupt).  The stream is polled for a short while first; what is still running after that is waited for asleep.
+static bool g_spin_sync = getenv("EAST_HIP_NO_SPIN_SYNC") == nullptr;
+static inline hipError_t sync_stream(hipStream_t stream)
+{
+    if (g_spin_sync) {
+        for (int i = 0; i < 20000; i++) {               // (a query costs about a microsecond: at most ~20 ms of polling)
+            const hipError_t e = hipStreamQuery(stream);
+            if (e == hipSuccess) return hipSuccess;
+            if (e != hipErrorNotReady) return e;
+        }
+    }
+    return hipStreamSynchronize(stream);
+}
+
 static inline u32 ceil_div_u32(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 static inline int bit_width_u32(u32 x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
 

@@ -706,7 +706,7 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         } else {
             HIP_CHECK(hipMemcpyAsync(&n_names, names + (n02 - 1), sizeof(u32), hipMemcpyDeviceToHost,
                                      ctx.stream));
-            HIP_CHECK(hipStreamSynchronize(ctx.stream));
+            HIP_CHECK(sync_stream(ctx.stream));
             if (n_names == 0 || n_names > n02)
                 east_throw(EAST_HIP_ERR_INTERNAL, "dc3: impossible name count");
         }
@@ -721,7 +721,7 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
             LAUNCH(ctx, dc3_resolve_ties_kernel, g02, sorted_vals, (const u32 *)names, (const u32 *)s12, n02, sa12,
                    fail);
             HIP_CHECK(hipMemcpyAsync(&h_fail, fail, sizeof(u32), hipMemcpyDeviceToHost, ctx.stream));
-            HIP_CHECK(hipStreamSynchronize(ctx.stream));
+            HIP_CHECK(sync_stream(ctx.stream));
             if (!h_fail) {
                 n_names = n02;             // SA12 is final
                 if (ctx.stats) ctx.stats->levels_resolved++;

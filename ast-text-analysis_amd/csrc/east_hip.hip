@@ -515,7 +515,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
             } else {
                 u32 hf[FLAG_WORDS];
                 HIP_CHECK(hipMemcpyAsync(hf, flags, sizeof(hf), hipMemcpyDeviceToHost, ctx.stream));
-                HIP_CHECK(hipStreamSynchronize(ctx.stream));
+                HIP_CHECK(sync_stream(ctx.stream));
                 if (hf[FLAG_STATUS] & STATUS_NO_TERMINATOR)
                     east_throw(EAST_HIP_ERR_DOMAIN, tagged ? "a document does not end in a (tagged) string terminator"
                                                            : "a document does not end in a string terminator (>= U+0A00)");
@@ -801,7 +801,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
         }
         HIP_CHECK(hipEventRecord(h->ev1, h->stream));
         HIP_CHECK(hipMemcpyAsync(flags, h->code_map + TEXT_SYMBOLS, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
-        HIP_CHECK(hipStreamSynchronize(h->stream));
+        HIP_CHECK(sync_stream(h->stream));
         return true;
     };
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));

@@ -955,7 +955,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         std::vector<u32> h_sums(nb);
         HIP_CHECK(hipMemcpyAsync(h_sums.data(), block_sums, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx.stream));
         HIP_CHECK(hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, ctx.stream));
-        HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        HIP_CHECK(sync_stream(ctx.stream));
         m_next = 0;
         for (u32 x : h_sums) m_next += x;
         if (g_trace)
@@ -1085,7 +1085,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                     LAUNCH(ctx, lg_rest_count_kernel, ceil_div_u32(n_chunks + 1, BLOCK), (const uint2 *)cover, m, n_chunks, rest_cnt);
                     device_scan<ArrIn, false>(ctx, ArrIn{rest_cnt}, n_chunks + 1, rest_pre);
                     HIP_CHECK(hipMemcpyAsync(&m_left, rest_pre + n_chunks, 4, hipMemcpyDeviceToHost, ctx.stream));
-                    HIP_CHECK(hipStreamSynchronize(ctx.stream));
+                    HIP_CHECK(sync_stream(ctx.stream));
                     if (ctx.stats) ctx.stats->lds_sorted += m - m_left;
                     if (g_trace) fprintf(stderr, "[east_hip]   round %d: %u of %u sorted in LDS\n", round, m - m_left, m);
                 }
@@ -1129,7 +1129,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 have_idx = true;
                 HIP_CHECK(hipMemcpyAsync(&m_next, idx + ((m >> 6) + 1u), 4, hipMemcpyDeviceToHost, ctx.stream));
                 HIP_CHECK(hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, ctx.stream));
-                HIP_CHECK(hipStreamSynchronize(ctx.stream));
+                HIP_CHECK(sync_stream(ctx.stream));
                 if (g_trace)
                     fprintf(stderr, "[east_hip]   round %d: domain %u, %u still in large groups, depth %u%s\n", round, m, m_next,
                             depth, h_fail ? ", a repeat too long to order directly" : "");
@@ -1168,7 +1168,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         n_names = n02 > 4 ? n02 - 1 : n02;            // worst case: recurse
     } else {
         HIP_CHECK(hipMemcpyAsync(&n_names, names + (n02 - 1), 4, hipMemcpyDeviceToHost, ctx.stream));
-        HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        HIP_CHECK(sync_stream(ctx.stream));
         if (n_names == 0 || n_names > n02) east_throw(EAST_HIP_ERR_INTERNAL, "dc3: impossible name count");
     }
     LAUNCH(ctx, dc3_scatter_names_kernel, ceil_div_u32((u64)n02 + 3, BLOCK), (const u32 *)sa12, (const u32 *)names, n02,
