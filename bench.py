@@ -28,6 +28,7 @@ The JSON line also carries
   roofline_score the score walk: 8 B per table read / binary-search probe (counted by the kernel in an
                  extra, untimed run) + 8 B per suffix result written and read + 8 B per score, / its time
   build_from_host_ms  east_hip_build from host-resident symbols (H2D included), wall clock
+  build_ms_without_guesses  the build as a handle's first build runs it (alphabet and tie-group read-backs in place)
   cpu_baseline   the CPU oracle (C port of the reference's easa.py) timed on this box's host cores on the
                  same 64 MiB document (one core) and over the documents of configs[2] (all cores)
 
@@ -328,7 +329,7 @@ def main():
             "lds_sorted": info.get("lds_sorted", 0),
         }
         if not args.no_extras:
-            out.update(extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D))
+            out.update(extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D, d_symbols))
         if world == 1 and not args.no_config2 and default_shape:
             out["config2"] = config2_leg(args, hip_backend, synthetic, torch, dev, local_rank)
             out["config5"] = config5_leg(args, hip_backend, synthetic, torch, dev, local_rank)
@@ -349,7 +350,7 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D):
+def extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D, d_symbols=None):
     """Untimed extras of the same index: score roofline from a counted run, the child-table kernel, the build
     from host-resident symbols."""
     res = {}
@@ -373,6 +374,17 @@ def extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D):
     child = [rep[k] for k in ("child_stream_kernel", "child_wide_kernel") if k in rep]
     if child:
         res["child_tables_ms"] = sum(ms / launches for launches, ms in child)
+    # the build as a handle's FIRST build runs it: nothing guessed from a build before, every read-back in place
+    # (the timed steps rebuild the same collection, so their guesses -- alphabet, no large tie groups -- always hold)
+    if d_symbols is not None:
+        lib = index._lib
+        lib.east_hip_debug_set_speculation(0)
+        times = []
+        for _ in range(3):
+            index.build_device(d_symbols.data_ptr(), int(symbols.size), doc_offsets, n_strings)
+            times.append(index.last_build_ms)
+        lib.east_hip_debug_set_speculation(1)
+        res["build_ms_without_guesses"] = min(times)
     # the build from host-resident symbols (east_hip_build: one 4 B/symbol H2D copy in front), wall clock
     walls = []
     for _ in range(3):
