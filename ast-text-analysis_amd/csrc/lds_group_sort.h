@@ -188,12 +188,13 @@ __device__ __forceinline__ void lg_radix_pass(LgLds &lds, u64 (&key)[LG_IPT], u3
 // elems / gstart / slots: the round's compacted domain (m elements; gstart[j] != 0: j starts a group).
 // Key of an element = (its group's number inside the tile << w2*b) | the w2 symbols at offset `depth` of its
 // suffix, as dc3_refine_keys_kernel builds them (zeros behind a terminator; rep_t / ones / highs: the
-// terminator test on the window fields).
+// terminator test on the window fields).  name_of != nullptr (prefix doubling): the key part is the 32-bit name of
+// the suffix `depth` symbols further on instead, as dc3_double_keys_kernel builds it (no terminators, no LCP seams).
 __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
     const uint8_t *__restrict__ s8, const u32 *__restrict__ elems, const u32 *__restrict__ gstart,
     const u32 *__restrict__ slots, u32 m, u32 n0, u32 depth, int w2, int b, u32 term_first, u64 rep_t, u64 ones, u64 highs,
     u32 *__restrict__ order_g, u32 *__restrict__ names_g, u32 *__restrict__ elem_out, u32 *__restrict__ flag_out,
-    u32 *__restrict__ lcp_g, uint2 *__restrict__ cover)
+    u32 *__restrict__ lcp_g, uint2 *__restrict__ cover, const u32 *__restrict__ name_of)
 {
     __shared__ LgLds lds;
     const u32 lane = lane_id(), w = wave_id();
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
     // groups of the tile: the starts in [begin_q, begin_q + n_act)
     const u32 last = begin_q + n_act - 1u;
     const u32 n_groups = lds.word_prefix[last >> 6] + (u32)__popcll(lds.start_bits[last >> 6] & (((u64)2 << (last & 63u)) - 1ull));
-    const int wbits = w2 * b;
+    const int wbits = name_of ? 32 : w2 * b;
     const int bits = wbits + (n_groups > 1u ? 32 - (int)__builtin_clz(n_groups - 1u) : 0);
     const bool active = w * (LG_IPT * WAVE) < n_act;
     // ---- keys from the text ----
@@ -270,18 +271,22 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
             if (local < n_act) {
                 const u32 q = begin_q + local;
                 const u32 e = elems[base + q];
-                const u32 p = lvl0_pos(e, n0) + depth;
-                u64 lo8, hi8;
-                __builtin_memcpy(&lo8, s8 + p, 8);
-                __builtin_memcpy(&hi8, s8 + p + 8, 8);
                 const u32 gid = lds.word_prefix[q >> 6] + (u32)__popcll(lds.start_bits[q >> 6] & (((u64)2 << (q & 63u)) - 1ull)) - 1u;
                 u64 k = gid;
-                bool ended = false;
-                for (int i = 0; i < w2; i++) {
-                    const u32 byte = (u32)((i < 8 ? lo8 >> (8 * i) : hi8 >> (8 * (i - 8))) & 0xFFu);
-                    const u32 x = ended ? 0u : byte;
-                    ended = ended || x == 0xFFu;
-                    k = (k << b) | (u64)(x == 0xFFu ? term_first : x);
+                if (name_of) {
+                    k = (k << 32) | (u64)name_of[e + depth];
+                } else {
+                    const u32 p = lvl0_pos(e, n0) + depth;
+                    u64 lo8, hi8;
+                    __builtin_memcpy(&lo8, s8 + p, 8);
+                    __builtin_memcpy(&hi8, s8 + p + 8, 8);
+                    bool ended = false;
+                    for (int i = 0; i < w2; i++) {
+                        const u32 byte = (u32)((i < 8 ? lo8 >> (8 * i) : hi8 >> (8 * (i - 8))) & 0xFFu);
+                        const u32 x = ended ? 0u : byte;
+                        ended = ended || x == 0xFFu;
+                        k = (k << b) | (u64)(x == 0xFFu ? term_first : x);
+                    }
                 }
                 key[j] = k;
                 val[j] = e;

@@ -1054,14 +1054,59 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // were handed over: a bound on their number saves a read-back)
             const int gbits = bit_width_u32(m / (long_repeats ? 2u : REFINE_SMALL_GROUP + 1u) + 1);
             const u32 gt = ceil_div_u32((u64)m + 1, BLOCK);
+            // One round's sort: the members of every group ordered by their round key -- the next window of symbols, or
+            // (prefix doubling) the name of the suffix `depth` symbols further on.  Groups that fit a workgroup's LDS are
+            // sorted there, keys, sort and write-back in one launch (lds_group_sort.h); the rest is compacted and takes
+            // the global radix sort by (group, key).
+            auto sort_round = [&](bool names, int w2, const KeyNeqWindowIn<u64> &f) {
+                const int kbits = names ? 32 : w2 * bt;
+                u32 *lcp_r = names ? (u32 *)nullptr : lcp_out;
+                u32 m_left = m;
+                if (g_lds_rounds) {
+                    LAUNCH_BLOCK(ctx, refine_lds_sort_kernel, ceil_div_u32(m, LG_CHUNK), LG_THREADS, s8, (const u32 *)ebuf[e_c],
+                                 (const u32 *)gstart, (const u32 *)slot_c, m, n0, depth, w2, bt, term_first, (u64)f.rep_t,
+                                 (u64)f.ones, (u64)f.highs, sa12, names_g, ebuf[e_out], fbuf[f_dom ^ 1], lcp_r, cover,
+                                 names ? (const u32 *)name_of : (const u32 *)nullptr);
+                    // what is left: counted per chunk from cover[] (no pass over the elements)
+                    const u32 n_chunks = ceil_div_u32(m, LG_CHUNK);
+                    LAUNCH(ctx, lg_rest_count_kernel, ceil_div_u32(n_chunks + 1, BLOCK), (const uint2 *)cover, m, n_chunks, rest_cnt);
+                    device_scan<ArrIn, false>(ctx, ArrIn{rest_cnt}, n_chunks + 1, rest_pre);
+                    HIP_CHECK(hipMemcpyAsync(&m_left, rest_pre + n_chunks, 4, hipMemcpyDeviceToHost, ctx.stream));
+                    HIP_CHECK(sync_stream(ctx.stream));
+                    if (ctx.stats) ctx.stats->lds_sorted += m - m_left;
+                    if (g_trace) fprintf(stderr, "[east_hip]   round %d: %u of %u sorted in LDS\n", round, m - m_left, m);
+                }
+                if (m_left == 0) return;
+                const u32 *elems_s = ebuf[e_c];             // what goes through the global sort: the domain, or its rest
+                const u32 *full = nullptr;
+                int gb = gbits;
+                if (m_left == m) {
+                    number_groups();
+                } else {
+                    // the rest, compacted (elements, group starts, where they came from), its groups numbered -- every
+                    // one of them has more than LG_MAX_GROUP members, which bounds their number
+                    u32 *sub_elem = sub_idx, *sub_gstart = rb.vals[1];           // (rb.vals[1]: idle until the sort's first pass)
+                    LAUNCH(ctx, lg_rest_compact_kernel, gt, LgUncovered{cover, m}, (const u32 *)rest_pre, (const u32 *)ebuf[e_c],
+                           (const u32 *)gstart, m, sub_elem, sub_gstart, full_idx);
+                    device_scan<ArrIn, true>(ctx, ArrIn{sub_gstart}, m_left, group);
+                    elems_s = sub_elem;
+                    full = full_idx;
+                    gb = std::min(gbits, bit_width_u32(m_left / (LG_MAX_GROUP + 1u) + 1u));
+                }
+                const u32 gl = ceil_div_u32(m_left, BLOCK);
+                if (names)
+                    LAUNCH(ctx, dc3_double_keys_kernel, gl, (const u32 *)name_of, elems_s, (const u32 *)group, m_left, depth,
+                           rb.keys[0], rb.vals[0]);
+                else
+                    LAUNCH(ctx, dc3_refine_keys_kernel, gl, s8, elems_s, (const u32 *)group, m_left, n0, depth, w2, bt, term_first,
+                           rb.keys[0], rb.vals[0]);
+                const int rr = radix_sort_pairs<u64>(ctx, rb, m_left, gb + kbits);
+                LAUNCH(ctx, dc3_refine_writeback_kernel, gl, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr], (const u32 *)slot_c,
+                       (const u32 *)ebuf[e_c], m_left, f.rep_t, f.ones, f.highs, sa12, names_g, ebuf[e_out], fbuf[f_dom ^ 1], lcp_r,
+                       depth, w2, bt, full);
+            };
             if (doubling) {
-                number_groups();
-                LAUNCH(ctx, dc3_double_keys_kernel, gt, (const u32 *)name_of, (const u32 *)ebuf[e_c], (const u32 *)group, m,
-                       depth, rb.keys[0], rb.vals[0]);
-                const int rr = radix_sort_pairs<u64>(ctx, rb, m, 32 + gbits);
-                LAUNCH(ctx, dc3_refine_writeback_kernel, gt, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr],
-                       (const u32 *)slot_c, (const u32 *)ebuf[e_c], m, (u64)0, (u64)0, (u64)0, sa12, names_g, ebuf[e_out],
-                       fbuf[f_dom ^ 1]);
+                sort_round(true, 0, KeyNeqWindowIn<u64>{nullptr, 0, 0, 0});
                 // the members' new names: where their (possibly split) group now starts
                 device_scan<ArrIn, true>(ctx, ArrIn{fbuf[f_dom ^ 1]}, m, group);
                 LAUNCH(ctx, dc3_group_starts_kernel, gt, (const u32 *)fbuf[f_dom ^ 1], (const u32 *)group, (const u32 *)slot_c, m,
@@ -1073,43 +1118,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 // (13 bits: room for the group numbers inside a workgroup's tile of the in-LDS round)
                 const int w2 = std::min(12, (64 - std::max(gbits, 13)) / bt);
                 if (w2 < 1) break;
-                const KeyNeqWindowIn<u64> f = KeyNeqWindowIn<u64>::make(nullptr, w2, bt, 0, term_first);
-                u32 m_left = m;
-                if (g_lds_rounds) {
-                    // groups that fit a workgroup's LDS: keys, sort and write-back in one launch; the rest is compacted
-                    LAUNCH_BLOCK(ctx, refine_lds_sort_kernel, ceil_div_u32(m, LG_CHUNK), LG_THREADS, s8, (const u32 *)ebuf[e_c],
-                                 (const u32 *)gstart, (const u32 *)slot_c, m, n0, depth, w2, bt, term_first, (u64)f.rep_t,
-                                 (u64)f.ones, (u64)f.highs, sa12, names_g, ebuf[e_out], fbuf[f_dom ^ 1], lcp_out, cover);
-                    // what is left: counted per chunk from cover[] (no pass over the elements)
-                    const u32 n_chunks = ceil_div_u32(m, LG_CHUNK);
-                    LAUNCH(ctx, lg_rest_count_kernel, ceil_div_u32(n_chunks + 1, BLOCK), (const uint2 *)cover, m, n_chunks, rest_cnt);
-                    device_scan<ArrIn, false>(ctx, ArrIn{rest_cnt}, n_chunks + 1, rest_pre);
-                    HIP_CHECK(hipMemcpyAsync(&m_left, rest_pre + n_chunks, 4, hipMemcpyDeviceToHost, ctx.stream));
-                    HIP_CHECK(sync_stream(ctx.stream));
-                    if (ctx.stats) ctx.stats->lds_sorted += m - m_left;
-                    if (g_trace) fprintf(stderr, "[east_hip]   round %d: %u of %u sorted in LDS\n", round, m - m_left, m);
-                }
-                if (m_left == m) {
-                    number_groups();
-                    LAUNCH(ctx, dc3_refine_keys_kernel, gt, s8, (const u32 *)ebuf[e_c], (const u32 *)group, m, n0, depth, w2, bt,
-                           term_first, rb.keys[0], rb.vals[0]);
-                    const int rr = radix_sort_pairs<u64>(ctx, rb, m, gbits + w2 * bt);
-                    LAUNCH(ctx, dc3_refine_writeback_kernel, gt, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr],
-                           (const u32 *)slot_c, (const u32 *)ebuf[e_c], m, f.rep_t, f.ones, f.highs, sa12, names_g, ebuf[e_out],
-                           fbuf[f_dom ^ 1], lcp_out, depth, w2, bt);
-                } else if (m_left > 0) {
-                    // the rest, compacted (elements, group starts, where they came from), its groups numbered, then as ever
-                    u32 *sub_elem = sub_idx, *sub_gstart = rb.vals[1];           // (rb.vals[1]: idle until the sort's first pass)
-                    LAUNCH(ctx, lg_rest_compact_kernel, gt, LgUncovered{cover, m}, (const u32 *)rest_pre, (const u32 *)ebuf[e_c],
-                           (const u32 *)gstart, m, sub_elem, sub_gstart, full_idx);
-                    device_scan<ArrIn, true>(ctx, ArrIn{sub_gstart}, m_left, group);
-                    LAUNCH(ctx, dc3_refine_keys_kernel, ceil_div_u32(m_left, BLOCK), s8, (const u32 *)sub_elem, (const u32 *)group,
-                           m_left, n0, depth, w2, bt, term_first, rb.keys[0], rb.vals[0]);
-                    const int rr = radix_sort_pairs<u64>(ctx, rb, m_left, gbits + w2 * bt);
-                    LAUNCH(ctx, dc3_refine_writeback_kernel, ceil_div_u32(m_left, BLOCK), (const u64 *)rb.keys[rr],
-                           (const u32 *)rb.vals[rr], (const u32 *)slot_c, (const u32 *)ebuf[e_c], m_left, f.rep_t, f.ones, f.highs,
-                           sa12, names_g, ebuf[e_out], fbuf[f_dom ^ 1], lcp_out, depth, w2, bt, (const u32 *)full_idx);
-                }
+                sort_round(false, w2, KeyNeqWindowIn<u64>::make(nullptr, w2, bt, 0, term_first));
                 depth += (u32)w2;
             }
             e_dom = e_out; s_dom ^= 1; f_dom ^= 1;
