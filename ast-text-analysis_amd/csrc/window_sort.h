@@ -641,15 +641,17 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
                                                                     u32 limit, u32 max_len, u32 *__restrict__ name_of,
                                                                     LongRepeats lr, u32 *__restrict__ lcp_g)
 {
+    // (as in the placement pass: every tied element of the workgroup's stretch fetches the 8 symbols behind the common
+    // depth once, and the members of a group rank themselves against those instead of gathering each other's text)
+    __shared__ u64 next8[BLOCK];
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
     u32 my_keep = 0;
-    if (j < m) {
-        const bool left_same = j > 0 && !starts(j);
-        const bool right_same = j + 1 < m && !starts(j + 1);
-        if (left_same || right_same)
-            my_keep = lvl0_place_tied(j, elem, starts, slot, m, s8, n0, depth, order_g, names_g, lcp_g, NoLcp(),
-                                      fail, limit, max_len, name_of, lr);
-    }
+    const bool tied = j < m && ((j > 0 && !starts(j)) || (j + 1 < m && !starts(j + 1)));
+    if (tied) next8[threadIdx.x] = load_u64_unaligned(s8 + lvl0_pos(elem[j], n0) + depth);
+    __syncthreads();
+    if (tied)
+        my_keep = lvl0_place_tied(j, elem, starts, slot, m, s8, n0, depth, order_g, names_g, lcp_g, NoLcp(), fail, limit, max_len,
+                                  name_of, lr, NextSymbols{next8, blockIdx.x * BLOCK, (u32)BLOCK});
     // keep[]: one bit per element (entries m.. of the last word are 0: the exclusive scan over m + 1 yields the total)
     const u64 bal = __ballot(my_keep != 0);
     if (lane_id() == 0) keep[j >> 6] = bal;
