@@ -849,6 +849,16 @@ __global__ __launch_bounds__(BLOCK) void lvl0_lcp_keys_kernel(KeyNeqWindowIn<K> 
     lcp[r] = h;
 }
 
+// one bit per rank: the slots of the kept members of a domain
+__global__ __launch_bounds__(BLOCK) void lvl0_mark_slots_kernel(const u32 *__restrict__ slot, BitIn keep, u32 m,
+                                                                u32 *__restrict__ mask)
+{
+    const u32 j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m || !keep(j)) return;
+    const u32 s = slot ? slot[j] : j;
+    atomicOr(&mask[s >> 5], 1u << (s & 31u));
+}
+
 // what the placement pass left undone, next to the other flags (speculative build: read at the very end):
 // the sum of its workgroups' counts (out[] was zeroed with the build's flag words; a few workgroups add into it)
 #define SPEC_COUNT_TILE (BLOCK * 16)
@@ -987,9 +997,9 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     // ---- refinement rounds on the members of large groups ---------------------------------
     // (ctx.lean: the device is short of memory for the rounds' buffers -- straight on to the recursion / DC3)
     // the placement pass's verdict is kept: the LCP entries of everything it placed are final (lvl0_lcp_keys_kernel)
-    u64 *keep0 = lcp_out ? ar.alloc<u64>(((size_t)n02 >> 6) + 2) : nullptr;
-    if (keep0 && !ctx.dry && !ctx.lean)
-        HIP_CHECK(hipMemcpyAsync(keep0, keep, (((size_t)n02 >> 6) + 1) * sizeof(u64), hipMemcpyDeviceToDevice, ctx.stream));
+    // (the ranks whose entries the rounds do NOT write -- those that go through prefix-doubling rounds, whose keys are
+    // names -- are marked when the rounds switch over, and only they are computed at the end)
+    u64 *lcp_redo = lcp_out ? ar.alloc<u64>(((size_t)n02 >> 6) + 2) : nullptr;
     bool done = false;
     bool lcp_from_rounds = true;                        // the rounds write the LCP entries of what they place (symbol windows)
     if (!ctx.lean) {
@@ -1029,6 +1039,10 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 // slow shrinking = long repeats: from here on the depth doubles every round (see above)
                 doubling = true;
                 lcp_from_rounds = false;                // (names instead of symbols: the seams' entries are computed at the end)
+                if (lcp_redo) {
+                    HIP_CHECK(hipMemsetAsync(lcp_redo, 0, (((size_t)n02 >> 6) + 2) * sizeof(u64), ctx.stream));
+                    LAUNCH(ctx, lvl0_mark_slots_kernel, gm, slot, BitIn{keep}, m, reinterpret_cast<u32 *>(lcp_redo));
+                }
                 LAUNCH(ctx, dc3_names_init_kernel, ceil_div_u32(n02, BLOCK), (const u32 *)sa12, n02, name_of);
                 device_scan<ArrIn, true>(ctx, ArrIn{flag}, m, group);
                 LAUNCH(ctx, dc3_group_starts_kernel, gm, flag, (const u32 *)group, slot, m, gstart);
@@ -1168,7 +1182,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         if (ctx.stats) ctx.stats->levels_resolved++;
         if (lcp_out && !lcp_from_rounds)                // (prefix doubling: the entries of everything the rounds placed)
             LAUNCH_NAMED(ctx, "lvl0_lcp_keys_kernel", (lvl0_lcp_keys_kernel<K>), ceil_div_u32(n02, BLOCK), starts, w, bt,
-                         spare, s8, (const u32 *)sa12, n02, (const u64 *)keep0, lcp_out, lcp_capped);
+                         spare, s8, (const u32 *)sa12, n02, (const u64 *)lcp_redo, lcp_out, lcp_capped);
         return true;
     }
     if (!s12) return false;                            // all-suffix mode: the caller falls back to DC3
