@@ -365,6 +365,7 @@ struct east_hip_index {
     u32 build_docs = 0;          // documents of the build in progress (h->n_docs is set when it has succeeded)
     // what the last successful build found, the guesses of the next (speculative) one
     bool hint_valid = false, hint_no_rounds = false, hint_window = false;
+    bool hint_wide_window = false;   // the 32-bit first window left more than 60 % of the suffixes in large groups
     u32 hint_sigma = 0;
     u32 plan_n = 0, plan_docs = 0, plan_epoch = 0;
     bool plan_tagged = false;   // shape of the last sizing run (and test-knob epoch), its result
@@ -782,6 +783,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     ctx.stats = &h->stats;
     ctx.prof = &h->prof;
     ctx.lean = lean;
+    ctx.wide_window = h->hint_wide_window;
     // The build is queued WITHOUT waiting for the device wherever the previous build on this handle says what
     // to expect (alphabet size, no large tie groups): one read-back at the end finds out whether it was
     // right.  If not -- or on a handle's first build -- the build runs with its read-backs in place.
@@ -830,6 +832,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     h->hint_valid = !tagged || h->sigma_hi == 0;
     h->hint_sigma = h->sigma_t;
     h->hint_window = h->stats.window_sorted != 0;
+    if (h->stats.first_n > 0 && h->stats.first_kept * 5 > h->stats.first_n * 3) h->hint_wide_window = true;
     h->hint_no_rounds = h->stats.window_sorted && h->stats.refine_rounds == 0 && !h->stats.long_repeats;
     h->prof.collect();
     HIP_CHECK(hipEventElapsedTime(&h->last_build_ms, h->ev0, h->ev1));
@@ -1500,6 +1503,7 @@ int east_hip_reset(east_hip_handle_t h)
         h->sigma_hi = 0;
         h->prof.enabled = false;
         h->prof.only.clear();
+        h->hint_wide_window = false;
         h->stats = Stats();
         // a recycled handle keeps its stream and a small arena, not gigabytes of side allocations
         const size_t keep = (size_t)64 << 20;

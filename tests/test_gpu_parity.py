@@ -622,6 +622,35 @@ def test_refinement_rounds_in_lds_and_by_the_global_sort(hip, oracle, suffix_sor
         assert lib.east_hip_debug_set_lds_rounds(1) == 0
 
 
+def test_second_build_takes_the_wide_window_after_a_mostly_tied_one(hip, oracle, suffix_sort_path):
+    """A build that leaves most suffixes tied behind the 32-bit first window makes the handle's next build take the
+    widest window that fits 64-bit keys (natural-language text over a large alphabet); the tables are the same."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(4711)
+    vocab = synthetic.zipf_vocabulary(rng, size=40, exponent=1.0)
+    docs = [synthetic.zipf_document(rng, 400000, vocab) for _ in range(2)]
+    sym = np.concatenate([d[0] for d in docs])
+    # (more than 63 distinct symbols: 7 bits each, 3 symbols in a 32-bit key next to the document number)
+    extra = np.arange(0x100, 0x100 + 70, dtype=np.uint32)
+    text_pos = np.flatnonzero(sym < 0x0A00)
+    sym[text_pos[rng.integers(0, text_pos.size, size=2000)]] = extra[rng.integers(0, extra.size, size=2000)]
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    m = np.array([d[1] for d in docs])
+    index = hip_backend.HipIndex()
+    index.build(sym, off, m)
+    first = index.info()
+    index.build(sym, off, m)
+    second = index.info()
+    if suffix_sort_path == "window_sort":
+        assert first["window_sorted"] == 1 and second["window_sorted"] == 1
+        assert second["radix_passes_u32"] == 0 and first["radix_passes_u32"] > 0, (first, second)    # 64-bit first-level keys now
+    for d in range(2):
+        o = oracle.OracleEASA(symbols=sym[off[d]:off[d + 1]], n_strings=int(m[d]))
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d, second)
+
+
 @pytest.mark.parametrize("shift", [0, 1, 2, 3])
 def test_build_from_resident_symbols_at_any_alignment(hip, oracle, shift):
     """east_hip_build_device on a symbol array that starts 0..3 words into a device buffer (a view of
