@@ -832,7 +832,12 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     h->hint_valid = !tagged || h->sigma_hi == 0;
     h->hint_sigma = h->sigma_t;
     h->hint_window = h->stats.window_sorted != 0;
-    if (h->stats.first_n > 0 && h->stats.first_kept * 5 > h->stats.first_n * 3) h->hint_wide_window = true;
+    if (h->stats.first_n > 0) {
+        // more than 60 % tied behind the 32-bit window: the wide one next time; hardly anything tied behind the wide one
+        // (another kind of text on the same handle): back to the estimate
+        if (!ctx.wide_window) h->hint_wide_window = h->stats.first_kept * 5 > h->stats.first_n * 3;
+        else if (h->stats.first_kept * 50 < h->stats.first_n) h->hint_wide_window = false;
+    }
     h->hint_no_rounds = h->stats.window_sorted && h->stats.refine_rounds == 0 && !h->stats.long_repeats;
     h->prof.collect();
     HIP_CHECK(hipEventElapsedTime(&h->last_build_ms, h->ev0, h->ev1));
