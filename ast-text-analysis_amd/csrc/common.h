@@ -159,11 +159,17 @@ static bool g_spin_sync = getenv("EAST_HIP_NO_SPIN_SYNC") == nullptr;
 static inline hipError_t sync_stream(hipStream_t stream)
 {
     if (g_spin_sync) {
+        bool waited = false;
         for (int i = 0; i < 20000; i++) {               // (a query costs about a microsecond: at most ~20 ms of polling)
             const hipError_t e = hipStreamQuery(stream);
-            if (e == hipSuccess) return hipSuccess;
+            if (e == hipSuccess) {
+                if (waited) (void)hipGetLastError();    // ("not ready" is an answer, not an error to be found by the next check)
+                return hipSuccess;
+            }
             if (e != hipErrorNotReady) return e;
+            waited = true;
         }
+        (void)hipGetLastError();
     }
     return hipStreamSynchronize(stream);
 }
