@@ -78,6 +78,7 @@ struct Stats {
     i64 long_repeats = 0;       // the placement pass had to be repeated as mark + commit (duplicated passages)
     i64 lds_sorted = 0;         // elements the refinement rounds ordered inside a workgroup's LDS (lds_group_sort.h)
     i64 first_kept = 0, first_n = 0;    // all-suffix window sort: suffixes the placement pass left in large groups, of how many
+    i64 fused_finish = 0;       // the last radix digit and the placement ran as one pass in LDS (lvl0_finish_kernel)
 };
 
 // Optional per-kernel timing with HIP events on the handle's own stream (the
@@ -147,6 +148,7 @@ struct Ctx {
     bool spec_rounds = false;   // ... nor for the placement pass's counts (it goes on as if no tie group were large)
     u32 *spec_out = nullptr;    // [0] suffixes left in large groups, [1] placement gave up on a long repeat
     u32 *zeroed_word = nullptr; // one word the build has already zeroed: the first level-0 pass takes it for its fail flag
+    u32 *kg_bad = nullptr;      // raised by the fused finish when the k-gram marks it writes are incomplete (a bucket handed to the rounds)
     bool wide_window = false;   // the handle's last build left most suffixes tied behind the 32-bit window: take the widest one
     Stats *stats = nullptr;
     Profiler *prof = nullptr;

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(BLOCK) void presence_kernel(const u32 *__restrict__
 #define FLAG_FAIL 4
 #define FLAG_SIGMA_HI 5
 #define FLAG_PLACE_FAIL 6        // the placement pass's "a repeat too long to order directly" (window_sort.h: fail), zeroed with the flags
+#define FLAG_KG_BAD 7            // the fused finish could not mark every k-gram bucket start (Ctx::kg_bad)
 #define FLAG_WORDS 8
 #define STATUS_NO_TERMINATOR 1u
 #define STATUS_N_STRINGS 2u
@@ -492,6 +493,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     if (!ctx.dry) HIP_CHECK(hipMemsetAsync(flags, 0, (FLAG_WORDS + PRESENT_WORDS + 1) * sizeof(u32), ctx.stream));
     ctx.spec_out = flags + FLAG_KEEP;
     ctx.zeroed_word = ctx.dry ? nullptr : flags + FLAG_PLACE_FAIL;
+    ctx.kg_bad = ctx.dry ? nullptr : flags + FLAG_KG_BAD;
     {
         // ---- alphabet, dense remap ---------------------------------------------
         const size_t mark = ar.mark();
@@ -829,6 +831,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
         east_throw(EAST_HIP_ERR_DOMAIN, tagged ? "n_strings does not match the tagged terminators found in a document"
                                                : "n_strings does not match the terminators found in a document "
                                                  "(text symbols must be < U+0A00 unless the terminators are tagged)");
+    if (flags[FLAG_KG_BAD]) h->kg_marked = false;    // (the score side then builds its k-gram tables itself)
     h->hint_valid = !tagged || h->sigma_hi == 0;
     h->hint_sigma = h->sigma_t;
     h->hint_window = h->stats.window_sorted != 0;
@@ -1532,14 +1535,15 @@ void *east_hip_stream(east_hip_handle_t h) { return h ? (void *)h->stream : null
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap)
 {
     if (!h || !out) return EAST_HIP_ERR_INVALID;
-    const int64_t v[20] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
+    const int64_t v[23] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
                            (int64_t)h->arena.cap, (int64_t)h->arena.high, h->stats.radix_passes,
                            h->stats.radix_elems, h->stats.radix_elem_bytes, h->stats.radix_passes_u32,
                            h->stats.radix_elems_u32, h->stats.radix_passes_u64, h->stats.radix_elems_u64,
                            h->stats.levels_resolved, h->stats.merge_elems, h->stats.refine_rounds,
-                           h->stats.window_sorted, h->stats.lds_sorted};
-    for (int i = 0; i < 20 && i < cap; i++) out[i] = v[i];
-    return 20;
+                           h->stats.window_sorted, h->stats.lds_sorted, h->stats.fused_finish, h->stats.first_kept,
+                           h->stats.first_n};
+    for (int i = 0; i < 23 && i < cap; i++) out[i] = v[i];
+    return 23;
 }
 
 int east_hip_profile_enable(east_hip_handle_t h, int on)
@@ -1660,9 +1664,12 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes)
 
 int east_hip_debug_set_window_sort(int enabled)
 {
+    // 0: DC3 only; 1: the default; 2: lean (no refinement rounds); 3: 64-bit window keys; 4 / 5: as 1 / 3 without the
+    // fused finish (every radix pass global, then lvl0_place_kernel)
     g_window_sort = enabled != 0;
     g_force_lean = enabled == 2;
-    g_force_wide_keys = enabled == 3;
+    g_force_wide_keys = enabled == 3 || enabled == 5;
+    g_fused_finish = enabled != 4 && enabled != 5 && getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;
     g_plan_epoch++;
     return EAST_HIP_OK;
 }

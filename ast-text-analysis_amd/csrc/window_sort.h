@@ -31,6 +31,8 @@ static const bool g_trace = getenv("EAST_HIP_TRACE") != nullptr;   // per-round 
 static bool g_force_wide_keys = getenv("EAST_HIP_WIDE_KEYS") != nullptr;                      // east_hip_debug_set_window_sort(3) (tests)
 static bool g_force_lean = false;                           // east_hip_debug_set_window_sort(2) (tests)
 static bool g_window_sort = true;                            // east_hip_debug_set_window_sort (tests)
+static bool g_fused_finish = getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;    // east_hip_debug_set_window_sort(4 / 5) (tests, A/B timing)
+struct FusedAbort {};           // the fused finish met a repeat too long to order directly: the level is redone with the full sort
 
 #define RESOLVE_MAX_LEN 2048            // longest direct comparison of two suffixes (symbols)
 
@@ -630,6 +632,366 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     if (threadIdx.x == 0) block_keep[blockIdx.x] = n_keep;
 }
 
+// ---- the fused end of the sort: last digit + placement in one pass ---------------------------------
+// The global LSD passes stop above the low `L` key bits: the pairs arrive sorted (stably) by the TOP part of
+// their keys -- document number, the leading symbols -- with the suffixes of a *bucket* (equal top part)
+// still in text order.  A window wide enough to tell most suffixes apart leaves a handful of suffixes per
+// bucket, so the last digit is not worth a trip through HBM: a workgroup stages a stretch of FIN_CHUNK
+// pairs (+ FIN_G to either side) in LDS, every member of a bucket of at most FIN_G suffixes finds its rank
+// inside the bucket by counting the members with smaller low bits (equal ones: text order, the sort stays
+// stable), the pairs are permuted inside LDS, and the placement logic of lvl0_place_kernel runs on the
+// staged, now fully sorted keys -- suffix array, LCP entries, k-gram bucket starts, direct ordering of the
+// small tie groups.  One global radix pass (20 B per suffix) and the re-read of the sorted pairs are gone.
+//   * A bucket belongs to the workgroup in whose stretch it STARTS (it may run up to FIN_G - 1 positions
+//     into the next stretch; the neighbour sees from its own halo that the bucket is not its own).
+//   * The LCP entry of a bucket's first rank only depends on the top parts of the two keys (they differ
+//     there), so any member of the bucket in front serves as "the key before".
+//   * A bucket of more than FIN_G suffixes whose top part holds a terminator is constant -- the fields
+//     behind a terminator are zero --: equal keys in text order, final as they stand.
+//   * Any other bucket of more than FIN_G suffixes (skewed text) is handed to the refinement rounds as
+//     ONE tie group: its members agree on the symbols that lie wholly inside the top part, and that
+//     number of symbols is the depth the rounds start from (dc3_level0_bytes: depth0).  Large groups of
+//     equal FULL keys join them at the same depth (they agree on more, which does no harm).
+#define FIN_IPT 4
+#define FIN_CHUNK (BLOCK * FIN_IPT)
+#ifndef FIN_G
+#define FIN_G 64
+#endif
+#define FIN_LEFT (FIN_G + 1)                        // staged entries in front of the stretch
+#define FIN_STAGE (FIN_CHUNK + 2 * FIN_G + 2)       // staged entries: [c0 - FIN_G - 1, c0 + FIN_CHUNK + FIN_G]
+#define FIN_WORDS ((FIN_STAGE + 31) / 32 + 1)
+
+template <class K> struct FinishArgs {
+    const K *keys;
+    const u32 *vals;
+    u32 m;
+    const uint8_t *s8;
+    int w, b, spare, low_bits;
+    K rep_t, ones, highs;                   // KeyNeqWindowIn's constants over all w symbol fields
+    K top_rep_t, top_ones, top_highs;       // ... over the fields that lie wholly inside the top part
+    int kg_top;                             // 1: the k-gram class code reaches below the top part (marks inside a handed-over bucket would be missed)
+    u32 *order_g, *lcp_g;
+    u64 *keep, *gstart;                     // one bit per rank (zeroed; OR-ed into): left to the rounds / first of its group
+    u32 *block_keep, *fail, *kg_bad;
+    KgMark km;
+};
+
+// highest set bit of fl[] in [lo, i] / lowest in [i, hi]; -1 if none (the ranges span at most FIN_G + 1 bits)
+#define FIN_SCAN_WORDS ((FIN_G + 31) / 32 + 1)
+__device__ __forceinline__ int fin_prev_bit(const u32 *fl, int i, int lo)
+{
+    int found = -1;
+    int wi = i >> 5;
+    u32 word = fl[wi] & (0xFFFFFFFFu >> (31 - (i & 31)));
+#pragma unroll
+    for (int step = 0; step < FIN_SCAN_WORDS; step++) {
+        if (found < 0 && word) found = (wi << 5) + 31 - __clz(word);
+        if (found < 0 && wi > 0) { wi--; word = fl[wi]; } else word = 0;
+    }
+    return found >= lo ? found : -1;
+}
+__device__ __forceinline__ int fin_next_bit(const u32 *fl, int i, int hi)
+{
+    int found = -1;
+    int wi = i >> 5;
+    u32 word = fl[wi] & (0xFFFFFFFFu << (i & 31));
+#pragma unroll
+    for (int step = 0; step < FIN_SCAN_WORDS; step++) {
+        if (found < 0 && word) found = (wi << 5) + __ffs(word) - 1;
+        if (found < 0 && wi + 1 < (int)FIN_WORDS) { wi++; word = fl[wi]; } else word = 0;
+    }
+    return found >= 0 && found <= hi ? found : -1;
+}
+
+template <class K> __device__ __forceinline__ void fin_load4(const K *p, K (&out)[5])
+{
+    if constexpr (sizeof(K) == 4) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(p);
+        out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
+    } else {
+        const uint4 q0 = reinterpret_cast<const uint4 *>(p)[0], q1 = reinterpret_cast<const uint4 *>(p)[1];
+        out[0] = ((u64)q0.y << 32) | q0.x; out[1] = ((u64)q0.w << 32) | q0.z;
+        out[2] = ((u64)q1.y << 32) | q1.x; out[3] = ((u64)q1.w << 32) | q1.z;
+    }
+}
+
+template <class K, bool ENDGAME_LIMITS>
+__global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
+{
+    constexpr u32 limit = ENDGAME_LIMITS ? (REFINE_ENDGAME_GROUP < FIN_G ? REFINE_ENDGAME_GROUP : FIN_G) : REFINE_SMALL_GROUP;
+    constexpr u32 max_len = ENDGAME_LIMITS ? REFINE_ENDGAME_LEN : RESOLVE_MAX_LEN;
+    constexpr int HELD = FIN_IPT + 1;                   // a thread holds 4 pairs of the stretch and (threads 0 .. FIN_G) one of the right halo
+    __shared__ __attribute__((aligned(16))) K kt[FIN_STAGE];
+    __shared__ __attribute__((aligned(16))) u32 vt[FIN_STAGE];
+    __shared__ u64 next8[FIN_STAGE];
+    __shared__ u32 work[FIN_CHUNK + FIN_G];
+    __shared__ u32 fl[FIN_WORDS], mine[FIN_WORDS], hotm[FIN_WORDS];     // bucket starts / ranks this workgroup places / of them: in buckets too large to order here
+    __shared__ u32 keep_bits[FIN_WORDS], gs_bits[FIN_WORDS];            // by staged index
+    __shared__ u32 n_keep, n_work;
+    const u32 m = a.m;
+    const u32 c0 = blockIdx.x * FIN_CHUNK;
+    const u32 base = c0 - FIN_LEFT;                     // global rank of staged entry 0 (wraps in the first stretch: such ranks test as >= m)
+    const int L = a.low_bits;
+    if (threadIdx.x < FIN_WORDS) {
+        fl[threadIdx.x] = 0; mine[threadIdx.x] = 0; hotm[threadIdx.x] = 0; keep_bits[threadIdx.x] = 0; gs_bits[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) { n_keep = 0; n_work = 0; }
+    // ---- stage the pairs ---------------------------------------------------------------------------
+    K key[HELD];
+    u32 val[HELD];
+    int at[HELD];                                       // staged index of the held pair, -1: none
+    {
+        const u32 j0 = c0 + threadIdx.x * FIN_IPT;
+        if (j0 + FIN_IPT <= m) {                        // (16-byte loads)
+            fin_load4<K>(a.keys + j0, key);
+            const uint4 q = *reinterpret_cast<const uint4 *>(a.vals + j0);
+            val[0] = q.x; val[1] = q.y; val[2] = q.z; val[3] = q.w;
+#pragma unroll
+            for (int e = 0; e < FIN_IPT; e++) at[e] = (int)(FIN_LEFT + threadIdx.x * FIN_IPT + e);
+        } else {
+#pragma unroll
+            for (int e = 0; e < FIN_IPT; e++) {
+                const bool ok = j0 + e < m;
+                key[e] = ok ? a.keys[j0 + e] : (K)0;
+                val[e] = ok ? a.vals[j0 + e] : 0u;
+                at[e] = ok ? (int)(FIN_LEFT + threadIdx.x * FIN_IPT + e) : -1;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < FIN_IPT; e++) {
+            kt[FIN_LEFT + threadIdx.x * FIN_IPT + e] = key[e];
+            vt[FIN_LEFT + threadIdx.x * FIN_IPT + e] = val[e];
+        }
+        key[FIN_IPT] = 0; val[FIN_IPT] = 0; at[FIN_IPT] = -1;
+        if (threadIdx.x <= FIN_G) {
+            const u32 jr = c0 + FIN_CHUNK + threadIdx.x;        // right halo
+            if (jr < m) {
+                key[FIN_IPT] = a.keys[jr];
+                val[FIN_IPT] = a.vals[jr];
+                at[FIN_IPT] = (int)(FIN_LEFT + FIN_CHUNK + threadIdx.x);
+            }
+            kt[FIN_LEFT + FIN_CHUNK + threadIdx.x] = key[FIN_IPT];
+            vt[FIN_LEFT + FIN_CHUNK + threadIdx.x] = val[FIN_IPT];
+            const u32 jl = base + threadIdx.x;                  // left halo (never moved)
+            const bool okl = jl < m;
+            kt[threadIdx.x] = okl ? a.keys[jl] : (K)0;
+            vt[threadIdx.x] = okl ? a.vals[jl] : 0u;
+        }
+    }
+    __syncthreads();
+    // ---- bucket starts: the top part differs from the rank before (rank 0 and rank m count as starts) ----
+    for (u32 i = threadIdx.x + 1; i < FIN_STAGE; i += BLOCK) {
+        const u32 j = base + i;
+        const bool st = j <= m && (j == 0 || j == m || (K)(kt[i] >> L) != (K)(kt[i - 1] >> L));
+        if (st) atomicOr(&fl[i >> 5], 1u << (i & 31u));
+    }
+    __syncthreads();
+    // ---- every held pair: its bucket, and -- a bucket of this workgroup -- its rank inside it -----------------
+    const u32 lowmask = (1u << L) - 1u;
+    int dest[HELD];
+#pragma unroll
+    for (int e = 0; e < HELD; e++) {
+        dest[e] = -1;
+        const int i = at[e];
+        if (i < 0) continue;
+        const bool in_chunk = e < FIN_IPT;
+        const int s = fin_prev_bit(fl, i, i - (int)FIN_G + 1 > 1 ? i - (int)FIN_G + 1 : 1);
+        if (s < 0) {                                    // the bucket starts more than FIN_G ranks back
+            if (in_chunk) atomicOr(&hotm[i >> 5], 1u << (i & 31u));
+            continue;
+        }
+        if (s >= (int)(FIN_LEFT + FIN_CHUNK)) continue; // (right halo: a bucket of the next workgroup)
+        const int en = fin_next_bit(fl, i + 1, s + (int)FIN_G);
+        if (en < 0) {                                   // more than FIN_G members
+            if (in_chunk) atomicOr(&hotm[i >> 5], 1u << (i & 31u));
+            continue;
+        }
+        if (s < (int)FIN_LEFT) continue;                // the bucket of the workgroup before, which orders it
+        const u32 mine_key = (((u32)key[e] & lowmask) << 11) | (u32)i;
+        u32 rank = 0;
+        for (int x = s; x < en; x++) rank += ((((u32)kt[x] & lowmask) << 11) | (u32)x) < mine_key ? 1u : 0u;
+        dest[e] = s + (int)rank;
+        atomicOr(&mine[i >> 5], 1u << (i & 31u));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < HELD; e++)
+        if (dest[e] >= 0) { kt[dest[e]] = key[e]; vt[dest[e]] = val[e]; }
+    __syncthreads();
+    // ---- placement on the staged, sorted keys ----------------------------------------------------------
+    const KeyNeqWindowIn<K> f{a.keys, a.rep_t, a.ones, a.highs};   // (keys / vals: never read -- everything the tie code touches is staged; a null pointer here crashes hipcc 7.2)
+    const int w = a.w, b = a.b, spare = a.spare;
+    auto kg_mark = [&](u32 j, K k, K kp) {              // k-gram bucket starts, read off the keys (see KgMark)
+        const int top = spare + (w - a.km.k) * b;
+        if (j == 0 || (K)(k >> top) != (K)(kp >> top)) {
+            const u32 d = a.km.n_docs > 1 ? (u32)(k >> (w * b + spare)) : 0u;
+            u32 code = 0;
+            for (int q = 0; q < a.km.k; q++)
+                code = code * a.km.A + ((u32)(k >> (spare + (w - 1 - q) * b)) & ((1u << b) - 1u));
+            if (code < a.km.bins) a.km.kg[(size_t)d * (a.km.bins + 1) + code] = j - a.km.doc_off[d];
+        }
+    };
+    // rank `base + i`: returns true when it is final here (suffix and LCP entry in sa_o / lcp_o, to be stored by the
+    // caller); everything else -- not this workgroup's, handed to the rounds, a member of a small tie group -- is dealt with inside
+    auto place_one = [&](int i, u32 &sa_o, u32 &lcp_o) -> bool {
+        const bool is_mine = (mine[i >> 5] >> (i & 31)) & 1u, is_hot = (hotm[i >> 5] >> (i & 31)) & 1u;
+        if (!is_mine && !is_hot) return false;
+        const u32 j = base + (u32)i;
+        const K k = kt[i], kp = j > 0 ? kt[i - 1] : (K)0;
+        bool whole;
+        sa_o = vt[i];
+        lcp_o = j > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, k, kp, whole) : 0u;
+        if (is_hot) {
+            const bool first = (fl[i >> 5] >> (i & 31)) & 1u;
+            if (a.km.kg && first) kg_mark(j, k, kp);
+            const K xt = k ^ a.top_rep_t;
+            if (((K)(xt - a.top_ones) & ~xt & a.top_highs) != 0) return true;   // a constant bucket: final as it stands
+            a.order_g[j] = sa_o;
+            atomicOr(&keep_bits[i >> 5], 1u << (i & 31));
+            atomicAdd(&n_keep, 1u);
+            if (first) {
+                atomicOr(&gs_bits[i >> 5], 1u << (i & 31));
+                if (a.lcp_g) a.lcp_g[j] = lcp_o;
+            }
+            if (a.kg_top && a.km.kg) *a.kg_bad = 1u;
+            return false;
+        }
+        if (a.km.kg) kg_mark(j, k, kp);
+        const K x = k ^ f.rep_t;
+        const bool st = j == 0 || ((K)(x - f.ones) & ~x & f.highs) != 0 || k != kp;
+        bool st_next = j + 1 >= m;
+        if (!st_next) {
+            const K kn = kt[i + 1], xn = kn ^ f.rep_t;
+            st_next = ((K)(xn - f.ones) & ~xn & f.highs) != 0 || kn != k;
+        }
+        if (st && st_next) return true;
+        // tied: a group of equal keys inside this bucket (all of it is staged).  More than `limit` equal keys around
+        // this one (an equal key `limit` places away): a large group, left to the rounds without the exact bounds.
+        const int lim = (int)limit;
+        bool big = false;
+        {
+            const int lo = i - lim, hi = i + lim;
+            if (lo >= 1) big = kt[lo] == k && (((mine[lo >> 5] >> (lo & 31)) & 1u) != 0);
+            if (!big && hi < (int)FIN_STAGE && j + limit < m) big = kt[hi] == k && (((mine[hi >> 5] >> (hi & 31)) & 1u) != 0);
+        }
+        if (big) {
+            a.order_g[j] = sa_o;
+            atomicOr(&keep_bits[i >> 5], 1u << (i & 31));
+            atomicAdd(&n_keep, 1u);
+            if (st) {
+                atomicOr(&gs_bits[i >> 5], 1u << (i & 31));
+                if (a.lcp_g) a.lcp_g[j] = lcp_o;
+            }
+        } else {
+            work[atomicAdd(&n_work, 1u)] = (u32)i;
+        }
+        return false;
+    };
+    {
+        u32 sa4[FIN_IPT], lc4[FIN_IPT];
+        u32 fin = 0;
+        const int i0 = (int)(FIN_LEFT + threadIdx.x * FIN_IPT);
+        const u32 j0 = c0 + threadIdx.x * FIN_IPT;
+#pragma unroll
+        for (int e = 0; e < FIN_IPT; e++)
+            if (j0 + e < m && place_one(i0 + e, sa4[e], lc4[e])) fin |= 1u << e;
+        if (fin == 15u) {
+            *reinterpret_cast<uint4 *>(a.order_g + j0) = uint4{sa4[0], sa4[1], sa4[2], sa4[3]};
+            if (a.lcp_g) *reinterpret_cast<uint4 *>(a.lcp_g + j0) = uint4{lc4[0], lc4[1], lc4[2], lc4[3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < FIN_IPT; e++)
+                if ((fin >> e) & 1u) {
+                    a.order_g[j0 + e] = sa4[e];
+                    if (a.lcp_g) a.lcp_g[j0 + e] = lc4[e];
+                }
+        }
+        if (threadIdx.x < FIN_G) {                      // the overhang of the last bucket that starts in the stretch
+            const int i = (int)(FIN_LEFT + FIN_CHUNK + threadIdx.x);
+            u32 sa1, lc1;
+            if (base + (u32)i < m && place_one(i, sa1, lc1)) {
+                a.order_g[base + (u32)i] = sa1;
+                if (a.lcp_g) a.lcp_g[base + (u32)i] = lc1;
+            }
+        }
+    }
+    __syncthreads();
+    // phase 2: the members of small tie groups, one per thread (as in lvl0_place_kernel)
+    const u32 todo = n_work;
+    for (u32 q = threadIdx.x; q < todo; q += BLOCK) {
+        const u32 i = work[q];
+        next8[i] = load_u64_unaligned(a.s8 + vt[i] + (u32)w);
+    }
+    __syncthreads();
+    const NextSymbols ns{next8, base, (u32)FIN_STAGE};
+    const TileStarts<K> tstarts{f, kt, base, (u32)FIN_STAGE};
+    const TileElems telems{a.vals, vt, base, (u32)FIN_STAGE};
+    for (u32 q = threadIdx.x; q < todo; q += BLOCK) {
+        const u32 i = work[q];
+        const u32 j = base + i;
+        auto lcp_first = [&](u32 at_j) -> u32 {
+            bool whole;
+            return at_j > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, tstarts.key(at_j), tstarts.key(at_j - 1), whole) : 0u;
+        };
+        if (lvl0_place_tied(j, telems, tstarts, (const u32 *)nullptr, m, a.s8, 0u, (u32)w, a.order_g, (u32 *)nullptr, a.lcp_g,
+                            lcp_first, a.fail, limit, max_len, (u32 *)nullptr, LongRepeats(), ns)) {
+            atomicOr(&keep_bits[i >> 5], 1u << (i & 31u));
+            atomicAdd(&n_keep, 1u);
+            if (tstarts(j)) {
+                atomicOr(&gs_bits[i >> 5], 1u << (i & 31u));
+                if (a.lcp_g) a.lcp_g[j] = lcp_first(j);
+            }
+        }
+    }
+    __syncthreads();
+    // the bits of the ranks [c0, c0 + FIN_CHUNK + FIN_G): OR-ed into the global words (the overhang shares its words with
+    // the next workgroup); nearly all of them are zero
+    if (threadIdx.x < (FIN_CHUNK + FIN_G + 31) / 32) {
+        // staged index FIN_LEFT + 32 t .. + 31  ->  global bit c0 + 32 t ..
+        const u32 i0 = FIN_LEFT + 32u * threadIdx.x;
+        const u32 sh = i0 & 31u, wi = i0 >> 5;
+        u32 kb = keep_bits[wi] >> sh, gb = gs_bits[wi] >> sh;
+        if (sh) { kb |= keep_bits[wi + 1] << (32u - sh); gb |= gs_bits[wi + 1] << (32u - sh); }
+        const u32 bit0 = c0 + 32u * threadIdx.x;
+        if (kb) atomicOr(reinterpret_cast<u32 *>(a.keep) + (bit0 >> 5), kb);
+        if (gb) atomicOr(reinterpret_cast<u32 *>(a.gstart) + (bit0 >> 5), gb);
+    }
+    if (threadIdx.x == 0) a.block_keep[blockIdx.x] = n_keep;
+}
+
+// group starts kept as one bit per rank (the fused finish): the naming predicate of the first compaction
+struct BitStarts {
+    static constexpr bool HAS_KEYS = false;
+    const u64 *bits;
+    __device__ __forceinline__ u32 operator()(u32 i) const { return (u32)(bits[i >> 6] >> (i & 63u)) & 1u; }
+};
+
+// LCP entries of the marked ranks by comparing the two suffixes from their first symbol (prefix-doubling rounds
+// behind the fused finish: no sorted key array to start from).  Same cap rule as lcp8_kernel.
+__global__ __launch_bounds__(BLOCK) void lvl0_lcp_text_kernel(const uint8_t *__restrict__ s8, const u32 *__restrict__ sa, u32 n,
+                                                              const u64 *__restrict__ only, u32 *__restrict__ lcp,
+                                                              u32 *__restrict__ capped)
+{
+    const u32 r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    if (only && !((only[r >> 6] >> (r & 63u)) & 1ull)) return;
+    if (r == 0) { lcp[0] = 0; return; }
+    const u32 i = sa[r - 1], j = sa[r];
+    u32 h = 0;
+    while (true) {
+        const u64 xa = load_u64_unaligned(s8 + i + h), xb = load_u64_unaligned(s8 + j + h);
+        const u64 dd = xa ^ xb, z = ~xa;
+        const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+        const u32 mm = dd ? (u32)__builtin_ctzll(dd) >> 3 : 8u;
+        const u32 tt = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
+        const u32 step = mm < tt ? mm : tt;
+        h += step;
+        if (step < 8u || h >= LCP_DIRECT_CAP) break;
+    }
+    if (h >= LCP_DIRECT_CAP) { h = LCP_CAP_MARK; atomicOr(capped, 1u); }
+    lcp[r] = h;
+}
+
 // A later, compacted domain of m elements (slot[] = where each sits in the global order): untied
 // elements already have their place (written by the previous round's write-back); small groups are
 // placed by lvl0_place_tied; members of large groups are marked in keep[] (one bit each).
@@ -888,16 +1250,34 @@ __global__ __launch_bounds__(BLOCK) void spec_counts_kernel(const u32 *__restric
 // refinement rounds (step 2c).  Returns true when sa12 is final (no name string is ever written);
 // otherwise the refined names are scanned and scattered into s12 for the recursion (sample mode),
 // or the caller falls back to DC3 (all-suffix mode, s12 == nullptr).
+#define FIN_LOW_BITS 8                   // key bits the fused finish orders in LDS (one global radix pass less)
+#define FIN_MAX_EXPECTED 32.0            // ... when a bucket of the top part is expected to hold at most this many suffixes
 template <class K>
 static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w, int bt, u32 term_first, u32 *sa12,
                              u32 *s12, u32 &n_names, u32 *lcp_out = nullptr, u32 *lcp_capped = nullptr,
-                             DocKey docs = DocKey(), KgMark *kg_mark = nullptr)
+                             DocKey docs = DocKey(), KgMark *kg_mark = nullptr, bool allow_fused = false, u32 longest = 0)
 {
     Arena &ar = *ctx.arena;
     const u32 g02 = ceil_div_u32((u64)n02 + 1, BLOCK);
     // whole passes are paid for anyway: fill the last digit with the top bits of the next symbol
     // (the document number, if any, sits above window and spare bits)
     const int spare = lvl0_spare_bits(w * bt + docs.bits, (int)sizeof(K) * 8, bt, w);
+    // The fused finish (lvl0_finish_kernel): the global passes stop above the low FIN_LOW_BITS key bits.  depth0 = the
+    // symbols that lie wholly inside the top part -- what the members of a bucket are known to share.
+    const int total_bits = w * bt + spare + docs.bits;
+    int depth0 = 0;
+    for (int j = 0; j < w; j++)
+        if (spare + j * bt >= FIN_LOW_BITS) depth0++;
+    bool fused = allow_fused && g_fused_finish && n0 == 0 && total_bits >= 2 * FIN_LOW_BITS && depth0 >= 1;
+    if (fused && !ctx.dry) {
+        // expected members of a bucket, were the text uniform (skewed text: the large buckets go to the rounds)
+        double top_codes = pow((double)term_first, depth0);
+        const int part = (spare + (w - depth0) * bt) - FIN_LOW_BITS;   // bits of the next symbol inside the top part
+        if (part > 0) top_codes *= std::max(1.0, (double)term_first / (double)(1u << (bt - part)));
+        fused = (double)(longest ? longest : n02) / top_codes <= FIN_MAX_EXPECTED;
+    }
+    const int low_bits = fused ? FIN_LOW_BITS : 0;
+    if (ctx.stats && n0 == 0) ctx.stats->fused_finish = fused;
     SortBufs<K> sb;
     // (one spare element each: the idle half serves as scratch after the sort)
     // (8 spare entries: the placement pass reads whole 16-byte groups; >= 64 so that the idle half can hold its scratch)
@@ -909,13 +1289,14 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         LAUNCH(ctx, doc_tiles_kernel, ceil_div_u32(n_dt, BLOCK), docs.doc_off, docs.n_docs, n_dt, tile_doc);
         docs.tile_doc = tile_doc;
     }
-    const int r = n0 ? radix_sort_pairs<K, WindowSrc<K>>(ctx, sb, n02, w * bt + spare + docs.bits, 0,
+    const int r = n0 ? radix_sort_pairs<K, WindowSrc<K>>(ctx, sb, n02, total_bits, 0,
                                                          WindowSrc<K>{s8, n0, w, bt, spare, term_first, docs})
-                     : radix_sort_pairs<K, TextWindowGen<K>>(ctx, sb, n02, w * bt + spare + docs.bits, 0,
+                     : radix_sort_pairs<K, TextWindowGen<K>>(ctx, sb, n02, total_bits, low_bits,
                                                              TextWindowGen<K>{s8, n02, w, bt, spare, term_first, docs});
     const KeyNeqWindowIn<K> starts = KeyNeqWindowIn<K>::make(sb.keys[r], w, bt, spare, term_first);
     const u32 *sorted_vals = sb.vals[r];
     u64 *keep = (u64 *)sb.keys[r ^ 1];                   // n02 + 1 bits, in the keys idle since the sort
+    u64 *gstart_bits = ar.alloc<u64>(((size_t)n02 >> 6) + 2);  // fused finish: the first rank of every group left to the rounds
     u32 *idx = sb.vals[r ^ 1];                          // n02 + 1 entries, likewise
     u32 *names_g = s12 ? ar.alloc<u32>(n02) : nullptr;  // sample mode: the naming predicate as refined so far
     u32 *fail = ar.alloc<u32>(1);
@@ -942,8 +1323,33 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         *kg_mark = km;
     }
     u32 m = n02, m_next = n02, h_fail = 0;              // (sizing run: as if everything were tied)
+    FinishArgs<K> fa;
+    if (fused) {
+        fa.keys = sb.keys[r]; fa.vals = sorted_vals; fa.m = n02; fa.s8 = s8;
+        fa.w = w; fa.b = bt; fa.spare = spare; fa.low_bits = low_bits;
+        fa.rep_t = starts.rep_t; fa.ones = starts.ones; fa.highs = starts.highs;
+        fa.top_rep_t = fa.top_ones = fa.top_highs = 0;
+        for (int j = 0; j < w; j++)
+            if (spare + j * bt >= low_bits) {
+                fa.top_rep_t |= (K)term_first << (spare + j * bt);
+                fa.top_ones |= (K)1 << (spare + j * bt);
+                fa.top_highs |= (K)1 << (spare + j * bt + bt - 1);
+            }
+        fa.kg_top = spare + (w - km.k) * bt < low_bits;
+        fa.order_g = sa12; fa.lcp_g = lcp_out; fa.keep = keep; fa.gstart = gstart_bits;
+        fa.block_keep = block_keep; fa.fail = fail; fa.kg_bad = ctx.kg_bad ? ctx.kg_bad : fail;
+        fa.km = small_input ? KgMark() : km;
+        if (!ctx.dry) {
+            HIP_CHECK(hipMemsetAsync(keep, 0, (((size_t)n02 >> 6) + 2) * sizeof(u64), ctx.stream));
+            HIP_CHECK(hipMemsetAsync(gstart_bits, 0, (((size_t)n02 >> 6) + 2) * sizeof(u64), ctx.stream));
+        }
+    }
     auto place = [&](int mode) {
-        if (small_input)
+        if (fused) {
+            if (mode != 0) throw FusedAbort();
+            if (small_input) LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, true>), gp, fa);
+            else LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, false>), gp, fa);
+        } else if (small_input)
             LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, true, false>), gp, starts, sorted_vals, n02, s8, n0, w,
                          bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
         else if (mode == 0)
@@ -979,6 +1385,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     if (ctx.dry) LAUNCH(ctx, (scan_reduce_kernel<ArrIn>), nb, ArrIn{block_keep}, gp, block_sums);
     bool long_repeats = false;                          // small groups were handed to the rounds
     if (h_fail) {
+        if (fused) throw FusedAbort();                   // (duplicated passages: the mark + commit passes want the sorted pairs)
         long_repeats = true;
         if (ctx.stats) ctx.stats->long_repeats++;
         // duplicated passages inside small groups: put the domain back, mark those groups, place the others
@@ -1023,8 +1430,8 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             (void)radix_sort_pairs<u64>(ctx, rb, cap, 8);
         }
         bool doubling = false;
-        u32 depth = (u32)w;
-        const u32 *elem = sorted_vals, *slot = nullptr, *flag = nullptr;
+        u32 depth = fused ? (u32)depth0 : (u32)w;        // what the members of a group are known to share
+        const u32 *elem = fused ? (const u32 *)sa12 : sorted_vals, *slot = nullptr, *flag = nullptr;
         int e_dom = -1, s_dom = 0, f_dom = 0;           // which of the rotating buffers hold the domain
         bool have_idx = false;                          // idx = exclusive scan of keep over the domain
         int stalled = 0;                                // rounds in a row that placed (almost) nothing
@@ -1055,7 +1462,10 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // compact the members of large groups, number their groups, sort by (group, next window)
             const int e_c = (e_dom + 4) % 3, e_out = (e_dom + 5) % 3;      // the two buffers the domain is not in
             u32 *slot_c = sbuf[s_dom ^ 1];
-            if (!slot)
+            if (!slot && fused)
+                LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<BitStarts>), gm, elem,
+                             BitStarts{gstart_bits}, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart);
+            else if (!slot)
                 LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<KeyNeqWindowIn<K>>), gm, elem,
                              starts, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart, lcp_out, w, bt, spare);
             else
@@ -1181,7 +1591,10 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     }
     if (done) {
         if (ctx.stats) ctx.stats->levels_resolved++;
-        if (lcp_out && !lcp_from_rounds)                // (prefix doubling: the entries of everything the rounds placed)
+        if (lcp_out && !lcp_from_rounds && fused)       // (prefix doubling: the entries of everything the rounds placed)
+            LAUNCH(ctx, lvl0_lcp_text_kernel, ceil_div_u32(n02, BLOCK), s8, (const u32 *)sa12, n02, (const u64 *)lcp_redo,
+                   lcp_out, lcp_capped);
+        else if (lcp_out && !lcp_from_rounds)
             LAUNCH_NAMED(ctx, "lvl0_lcp_keys_kernel", (lvl0_lcp_keys_kernel<K>), ceil_div_u32(n02, BLOCK), starts, w, bt,
                          spare, s8, (const u32 *)sa12, n02, (const u64 *)lcp_redo, lcp_out, lcp_capped);
         return true;
@@ -1235,6 +1648,7 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
     Arena &ar = *ctx.arena;
     const size_t mark = ar.mark();
     const int bt = bit_width_u32(term_first);
+    const int kg_k_in = kg_mark ? kg_mark->k : 0;
     if (docs.bits + 3 * bt > 64) return false;          // (no room for a window next to the document number)
     int w = lvl0_window(docs.bits ? longest : n, bt, term_first, docs.bits);
     // (natural-language text over a large alphabet -- upper-case prose with digits and accents: 7 bits a symbol, 3 symbols
@@ -1244,11 +1658,22 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
     // (experiments, DESIGN.md 5.2: EAST_HIP_WINDOW=<symbols> overrides the width of the first window)
     if (getenv("EAST_HIP_WINDOW")) w = std::max(3, std::min(atoi(getenv("EAST_HIP_WINDOW")), std::min(12, (64 - docs.bits) / bt)));
     u32 n_names = 0;
-    const bool ok = w * bt + docs.bits <= 32 && !g_force_wide_keys
-                        ? dc3_level0_bytes<u32>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
-                                                kg_mark)
-                        : dc3_level0_bytes<u64>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
-                                                kg_mark);
+    auto level0 = [&](bool allow_fused) {
+        return w * bt + docs.bits <= 32 && !g_force_wide_keys
+                   ? dc3_level0_bytes<u32>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
+                                           kg_mark, allow_fused, docs.bits ? longest : n)
+                   : dc3_level0_bytes<u64>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
+                                           kg_mark, allow_fused, docs.bits ? longest : n);
+    };
+    bool ok;
+    try {
+        ok = level0(true);
+    } catch (const FusedAbort &) {
+        if (g_trace) fprintf(stderr, "[east_hip] fused finish gave up (a repeat too long to order directly): full sort\n");
+        ar.release(mark);
+        if (kg_mark) kg_mark->k = kg_k_in;
+        ok = level0(false);
+    }
     ar.release(mark);
     return ok;
 }

@@ -238,7 +238,9 @@ void *east_hip_stream(east_hip_handle_t h);
  * [14] elements with 64-bit keys, [15] DC3 levels whose few tied names were
  * ordered directly instead of recursing, [16] suffixes merged (sum over levels), [17] rounds of
  * tie refinement by further windows, [18] 1 if the all-suffix window sort produced the suffix array
- * (no DC3 level ran; [5] is 0 then), [19] elements the refinement rounds ordered inside a workgroup's LDS.
+ * (no DC3 level ran; [5] is 0 then), [19] elements the refinement rounds ordered inside a workgroup's LDS,
+ * [20] 1 when the last radix digit and the placement ran as one pass in LDS (the fused finish), [21] suffixes the
+ * first placement left in large tie groups, [22] of how many.
  */
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap);
 
@@ -278,7 +280,11 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes);
 /* Test knob: 0 skips the all-suffix window sort, so that every build goes through DC3 (the
  * fallback for repetitive inputs); 1 (default) restores it; 2 = window sort on, but built as if
  * the device were short of memory for the tie-refinement rounds ("lean"); 3 = window sort on with
- * 64-bit window keys even where 32 bits suffice (the code path of large inputs, on small ones). */
+ * 64-bit window keys even where 32 bits suffice (the code path of large inputs, on small ones);
+ * 4 / 5 = as 1 / 3 with every radix pass global and the separate placement pass (the fused finish,
+ * csrc/window_sort.h: lvl0_finish_kernel, switched off).
+ * The test knobs of this section are PROCESS-WIDE (they exist to steer a test run through every code path):
+ * set them while no build is in flight on any handle. */
 int east_hip_debug_set_window_sort(int enabled);
 /* Test knob: 0 = the tie-refinement rounds sort every group with the global radix sort; 1 (default) = groups
  * that fit a workgroup's LDS are sorted there (csrc/lds_group_sort.h), the global sort takes the rest. */

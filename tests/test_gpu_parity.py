@@ -16,14 +16,19 @@ from conftest import load_golden, word_stream
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["window_sort", "dc3_only"])
+_PATH_KNOB = {"window_sort": 1, "window_sort_unfused": 4, "dc3_only": 0}
+
+
+@pytest.fixture(autouse=True, params=["window_sort", "window_sort_unfused", "dc3_only"])
 def suffix_sort_path(request, hip):
-    """Every parity test runs twice: through the all-suffix window sort (the path ordinary text
-    takes) and with it switched off, so that DC3 -- the fallback for repetitive inputs -- stays
-    covered on every input as well."""
+    """Every parity test runs three times: through the all-suffix window sort as it ships (the last radix
+    digit ordered in LDS by the fused finish), through the same sort with every pass global and the separate
+    placement pass, and with the window sort switched off, so that DC3 -- the fallback for repetitive
+    inputs -- stays covered on every input as well.  (Tests that read `suffix_sort_path` get "window_sort"
+    for both window-sort variants.)"""
     lib = hip.load()
-    assert lib.east_hip_debug_set_window_sort(int(request.param == "window_sort")) == 0
-    yield request.param
+    assert lib.east_hip_debug_set_window_sort(_PATH_KNOB[request.param]) == 0
+    yield "window_sort" if request.param.startswith("window_sort") else request.param
     assert lib.east_hip_debug_set_window_sort(1) == 0
 
 
@@ -671,13 +676,14 @@ def test_build_from_resident_symbols_at_any_alignment(hip, oracle, shift):
         assert np.array_equal(t[name], getattr(o, name)), name
 
 
+@pytest.mark.parametrize("knob", [3, 5])
 @pytest.mark.parametrize("seed", range(4))
-def test_wide_window_keys_on_small_inputs(hip, oracle, seed):
+def test_wide_window_keys_on_small_inputs(hip, oracle, seed, knob):
     """Inputs of several hundred million symbols sort 64-bit window keys (separate key and element
     arrays, other kernel instantiations); forced here on small texts with few and with many ties, one
     and several documents, so that placement, refinement rounds and LCP-from-keys run on 64-bit keys."""
     from east import hip_backend, synthetic
-    assert hip.load().east_hip_debug_set_window_sort(3) == 0          # (the autouse fixture restores the default)
+    assert hip.load().east_hip_debug_set_window_sort(knob) == 0       # (the autouse fixture restores the default; 5: no fused finish)
     rng = np.random.default_rng(4100 + seed)
     if seed % 2 == 0:
         vocab = synthetic.zipf_vocabulary(rng, size=int(rng.choice([12, 300])), exponent=1.0)

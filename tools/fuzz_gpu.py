@@ -99,7 +99,7 @@ def main():
     paths = {}
     while time.time() < t_end:
         docs = random_collection(rng, args.max_symbols)
-        knob = int(rng.choice([1, 1, 0, 3, 2]))
+        knob = int(rng.choice([1, 1, 1, 0, 3, 2, 4, 5]))
         lib.east_hip_debug_set_window_sort(knob)
         parts = [to_symbols(sc) for sc in docs]
         sym = np.concatenate(parts)
@@ -123,7 +123,8 @@ def main():
         try:
             index.build(dev_sym, off, np.array([len(sc) for sc in docs], dtype=np.int32))
             info = index.info()
-            key = (knob, info["window_sorted"], min(info["dc3_levels"], 3), min(info["refine_rounds"], 3), int(lifted))
+            key = (knob, info["window_sorted"], min(info["dc3_levels"], 3), min(info["refine_rounds"], 3), int(lifted),
+                   info["fused_finish"])
             paths[key] = paths.get(key, 0) + 1
             queries = []
             for sc in docs[:2]:
@@ -156,7 +157,7 @@ def main():
             index.close()
         cases += 1
     lib.east_hip_debug_set_window_sort(1)
-    print("fuzz ok: %d collections, %d documents, %d symbols checked; paths (knob, window_sorted, dc3_levels, rounds, lifted):"
+    print("fuzz ok: %d collections, %d documents, %d symbols checked; paths (knob, window_sorted, dc3_levels, rounds, lifted, fused):"
           % (cases, docs_checked, symbols))
     for k in sorted(paths):
         print("   ", k, paths[k])
