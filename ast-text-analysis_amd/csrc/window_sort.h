@@ -657,8 +657,9 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
 #ifndef FIN_G
 #define FIN_G 64
 #endif
-#define FIN_LEFT (FIN_G + 1)                        // staged entries in front of the stretch
-#define FIN_STAGE (FIN_CHUNK + 2 * FIN_G + 2)       // staged entries: [c0 - FIN_G - 1, c0 + FIN_CHUNK + FIN_G]
+#define FIN_LEFT (FIN_G + 4)                        // staged entries in front of the stretch (>= FIN_G + 1; a multiple of 4: a thread's four flags share a word)
+#define FIN_RIGHT (FIN_G + 4)                       // ... behind it (>= FIN_G + 1)
+#define FIN_STAGE (FIN_LEFT + FIN_CHUNK + FIN_RIGHT)
 #define FIN_WORDS ((FIN_STAGE + 31) / 32 + 1)
 
 template <class K> struct FinishArgs {
@@ -667,6 +668,7 @@ template <class K> struct FinishArgs {
     u32 m;
     const uint8_t *s8;
     int w, b, spare, low_bits;
+    u32 inv_b;                              // ceil(2^16 / b): (x * inv_b) >> 16 = x / b for the bit positions of a key
     K rep_t, ones, highs;                   // KeyNeqWindowIn's constants over all w symbol fields
     K top_rep_t, top_ones, top_highs;       // ... over the fields that lie wholly inside the top part
     int kg_top;                             // 1: the k-gram class code reaches below the top part (marks inside a handed-over bucket would be missed)
@@ -676,8 +678,8 @@ template <class K> struct FinishArgs {
     KgMark km;
 };
 
-// highest set bit of fl[] in [lo, i] / lowest in [i, hi]; -1 if none (the ranges span at most FIN_G + 1 bits)
-#define FIN_SCAN_WORDS ((FIN_G + 31) / 32 + 1)
+// highest set bit of fl[] in [lo, i] / lowest in [i, hi]; -1 if none (the ranges span at most FIN_G + 4 bits)
+#define FIN_SCAN_WORDS ((FIN_G + 4 + 31) / 32 + 1)
 __device__ __forceinline__ int fin_prev_bit(const u32 *fl, int i, int lo)
 {
     int found = -1;
@@ -715,108 +717,186 @@ template <class K> __device__ __forceinline__ void fin_load4(const K *p, K (&out
     }
 }
 
+// lvl0_lcp_of_key_pair without the divisions by the symbol width
+template <class K>
+__device__ __forceinline__ u32 fin_lcp_of_key_pair(const FinishArgs<K> &a, K k, K kp)
+{
+    const int w = a.w, b = a.b, spare = a.spare;
+    const K d = k ^ kp;
+    u32 mism = (u32)w;
+    if (d) {
+        int hb;
+        if constexpr (sizeof(K) == 4) hb = 31 - __clz((u32)d); else hb = 63 - __clzll((u64)d);
+        if (hb >= spare + w * b) mism = 0;              // (different documents: the entry is reset by lcp_doc_starts)
+        else if (hb >= spare) mism = (u32)w - 1u - (((u32)(hb - spare) * a.inv_b) >> 16);
+    }
+    const K x = k ^ a.rep_t;
+    const K tz = (K)(x - a.ones) & ~x & a.highs;        // at most one field holds the terminator code
+    u32 term = (u32)w;
+    if (tz) {
+        int lb;
+        if constexpr (sizeof(K) == 4) lb = __ffs((u32)tz) - 1; else lb = __ffsll((unsigned long long)tz) - 1;
+        term = (u32)w - 1u - (((u32)(lb - spare) * a.inv_b) >> 16);
+    }
+    return mism < term ? mism : term;
+}
+
 template <class K, bool ENDGAME_LIMITS>
 __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
 {
     constexpr u32 limit = ENDGAME_LIMITS ? (REFINE_ENDGAME_GROUP < FIN_G ? REFINE_ENDGAME_GROUP : FIN_G) : REFINE_SMALL_GROUP;
     constexpr u32 max_len = ENDGAME_LIMITS ? REFINE_ENDGAME_LEN : RESOLVE_MAX_LEN;
     constexpr int HELD = FIN_IPT + 1;                   // a thread holds 4 pairs of the stretch and (threads 0 .. FIN_G) one of the right halo
+    constexpr int G = FIN_G;
     __shared__ __attribute__((aligned(16))) K kt[FIN_STAGE];
     __shared__ __attribute__((aligned(16))) u32 vt[FIN_STAGE];
-    __shared__ u64 next8[FIN_STAGE];
+    __shared__ __attribute__((aligned(16))) u64 next8[FIN_STAGE];
     __shared__ u32 work[FIN_CHUNK + FIN_G];
-    __shared__ u32 fl[FIN_WORDS], mine[FIN_WORDS], hotm[FIN_WORDS];     // bucket starts / ranks this workgroup places / of them: in buckets too large to order here
-    __shared__ u32 keep_bits[FIN_WORDS], gs_bits[FIN_WORDS];            // by staged index
+    __shared__ u32 fl[FIN_WORDS];                       // bucket starts, by staged index
+    __shared__ u32 keep_bits[FIN_WORDS], gs_bits[FIN_WORDS];
     __shared__ u32 n_keep, n_work;
+    u32 *comp = reinterpret_cast<u32 *>(next8);         // (bucket start, low key bits, staged index) of every pair; next8 is used after the ranking
     const u32 m = a.m;
     const u32 c0 = blockIdx.x * FIN_CHUNK;
-    const u32 base = c0 - FIN_LEFT;                     // global rank of staged entry 0 (wraps in the first stretch: such ranks test as >= m)
+    const u32 base = c0 - FIN_LEFT;                     // global rank of staged entry 0 (wraps in the first stretch: such ranks test as > m)
     const int L = a.low_bits;
-    if (threadIdx.x < FIN_WORDS) {
-        fl[threadIdx.x] = 0; mine[threadIdx.x] = 0; hotm[threadIdx.x] = 0; keep_bits[threadIdx.x] = 0; gs_bits[threadIdx.x] = 0;
-    }
-    if (threadIdx.x == 0) { n_keep = 0; n_work = 0; }
+    const u32 tid = threadIdx.x;
+    if (tid < FIN_WORDS) { fl[tid] = 0; keep_bits[tid] = 0; gs_bits[tid] = 0; }
+    if (tid == 0) { n_keep = 0; n_work = 0; }
     // ---- stage the pairs ---------------------------------------------------------------------------
     K key[HELD];
     u32 val[HELD];
-    int at[HELD];                                       // staged index of the held pair, -1: none
+    const int i0 = (int)(FIN_LEFT + tid * FIN_IPT);     // staged index of the thread's first pair
+    const int ih = (int)(FIN_LEFT + FIN_CHUNK + tid);   // ... of its right-halo pair (threads 0 .. FIN_G)
+    const u32 j0 = c0 + tid * FIN_IPT;
+    u32 valid = 0;                                      // bit e: the held pair e exists (rank < m)
     {
-        const u32 j0 = c0 + threadIdx.x * FIN_IPT;
         if (j0 + FIN_IPT <= m) {                        // (16-byte loads)
             fin_load4<K>(a.keys + j0, key);
             const uint4 q = *reinterpret_cast<const uint4 *>(a.vals + j0);
             val[0] = q.x; val[1] = q.y; val[2] = q.z; val[3] = q.w;
-#pragma unroll
-            for (int e = 0; e < FIN_IPT; e++) at[e] = (int)(FIN_LEFT + threadIdx.x * FIN_IPT + e);
+            valid = 15u;
         } else {
 #pragma unroll
             for (int e = 0; e < FIN_IPT; e++) {
                 const bool ok = j0 + e < m;
                 key[e] = ok ? a.keys[j0 + e] : (K)0;
                 val[e] = ok ? a.vals[j0 + e] : 0u;
-                at[e] = ok ? (int)(FIN_LEFT + threadIdx.x * FIN_IPT + e) : -1;
+                valid |= ok ? 1u << e : 0u;
             }
         }
+        if constexpr (sizeof(K) == 4) *reinterpret_cast<uint4 *>(&kt[i0]) = uint4{(u32)key[0], (u32)key[1], (u32)key[2], (u32)key[3]};
+        else {
 #pragma unroll
-        for (int e = 0; e < FIN_IPT; e++) {
-            kt[FIN_LEFT + threadIdx.x * FIN_IPT + e] = key[e];
-            vt[FIN_LEFT + threadIdx.x * FIN_IPT + e] = val[e];
+            for (int e = 0; e < FIN_IPT; e++) kt[i0 + e] = key[e];
         }
-        key[FIN_IPT] = 0; val[FIN_IPT] = 0; at[FIN_IPT] = -1;
-        if (threadIdx.x <= FIN_G) {
-            const u32 jr = c0 + FIN_CHUNK + threadIdx.x;        // right halo
-            if (jr < m) {
-                key[FIN_IPT] = a.keys[jr];
-                val[FIN_IPT] = a.vals[jr];
-                at[FIN_IPT] = (int)(FIN_LEFT + FIN_CHUNK + threadIdx.x);
-            }
-            kt[FIN_LEFT + FIN_CHUNK + threadIdx.x] = key[FIN_IPT];
-            vt[FIN_LEFT + FIN_CHUNK + threadIdx.x] = val[FIN_IPT];
-            const u32 jl = base + threadIdx.x;                  // left halo (never moved)
+        *reinterpret_cast<uint4 *>(&vt[i0]) = uint4{val[0], val[1], val[2], val[3]};
+        key[FIN_IPT] = 0; val[FIN_IPT] = 0;
+        if (tid <= (u32)G) {
+            const u32 jr = c0 + FIN_CHUNK + tid;        // right halo
+            if (jr < m) { key[FIN_IPT] = a.keys[jr]; val[FIN_IPT] = a.vals[jr]; valid |= 16u; }
+            kt[ih] = key[FIN_IPT];
+            vt[ih] = val[FIN_IPT];
+        }
+        if (tid < (u32)FIN_LEFT) {                      // left halo (never moved)
+            const u32 jl = base + tid;
             const bool okl = jl < m;
-            kt[threadIdx.x] = okl ? a.keys[jl] : (K)0;
-            vt[threadIdx.x] = okl ? a.vals[jl] : 0u;
+            kt[tid] = okl ? a.keys[jl] : (K)0;
+            vt[tid] = okl ? a.vals[jl] : 0u;
         }
     }
     __syncthreads();
     // ---- bucket starts: the top part differs from the rank before (rank 0 and rank m count as starts) ----
-    for (u32 i = threadIdx.x + 1; i < FIN_STAGE; i += BLOCK) {
-        const u32 j = base + i;
-        const bool st = j <= m && (j == 0 || j == m || (K)(kt[i] >> L) != (K)(kt[i - 1] >> L));
-        if (st) atomicOr(&fl[i >> 5], 1u << (i & 31u));
+    u32 myfl = 0;                                       // bit e: the held pair e starts a bucket
+    {
+        K prev = kt[i0 - 1];
+#pragma unroll
+        for (int e = 0; e < FIN_IPT; e++) {
+            const u32 j = j0 + e;
+            if (j <= m && (j == 0 || j == m || (K)(key[e] >> L) != (K)(prev >> L))) myfl |= 1u << e;
+            prev = key[e];
+        }
+        if (myfl) atomicOr(&fl[i0 >> 5], myfl << (i0 & 31));
+        if (tid <= (u32)G) {
+            const u32 j = base + (u32)ih;
+            if (j <= m && (j == m || (K)(key[FIN_IPT] >> L) != (K)(kt[ih - 1] >> L))) { myfl |= 16u; atomicOr(&fl[ih >> 5], 1u << (ih & 31)); }
+        }
+        if (tid >= 1 && tid < (u32)FIN_LEFT) {
+            const u32 j = base + tid;
+            if (j <= m && (j == 0 || j == m || (K)(kt[tid] >> L) != (K)(kt[tid - 1] >> L))) atomicOr(&fl[tid >> 5], 1u << (tid & 31));
+        }
     }
     __syncthreads();
-    // ---- every held pair: its bucket, and -- a bucket of this workgroup -- its rank inside it -----------------
+    // ---- every held pair: its bucket [s, en) ----------------------------------------------------------------
+    // own: a bucket of at most FIN_G pairs that starts in this workgroup's stretch (it is ordered here);
+    // hot: a pair of the stretch in a larger bucket.  Everything else belongs to a neighbour.
+    int s[HELD], en[HELD];
+    u32 own = 0, hot = 0;
+    {
+        int run = (myfl & 1u) ? i0 : fin_prev_bit(fl, i0, i0 - G + 1);
+#pragma unroll
+        for (int e = 0; e < FIN_IPT; e++) {
+            if (e > 0 && ((myfl >> e) & 1u)) run = i0 + e;
+            s[e] = run >= i0 + e - G + 1 ? run : -1;
+        }
+        int nxt = fin_next_bit(fl, i0 + FIN_IPT, i0 + FIN_IPT - 1 + G);
+#pragma unroll
+        for (int e = FIN_IPT - 1; e >= 0; e--) {
+            en[e] = nxt;
+            if ((myfl >> e) & 1u) nxt = i0 + e;
+        }
+#pragma unroll
+        for (int e = 0; e < FIN_IPT; e++) {
+            if (!((valid >> e) & 1u)) continue;
+            if (s[e] < 0 || en[e] < 0 || en[e] - s[e] > G) hot |= 1u << e;
+            else if (s[e] >= (int)FIN_LEFT) own |= 1u << e;         // (s < FIN_LEFT: the bucket of the workgroup before)
+        }
+        s[FIN_IPT] = en[FIN_IPT] = -1;
+        if (valid & 16u) {
+            const int sh = (myfl & 16u) ? ih : fin_prev_bit(fl, ih, ih - G + 1);
+            if (sh >= (int)FIN_LEFT && sh < (int)(FIN_LEFT + FIN_CHUNK)) {
+                const int eh = fin_next_bit(fl, ih + 1, sh + G);
+                if (eh >= 0) { s[FIN_IPT] = sh; en[FIN_IPT] = eh; own |= 16u; }
+            }
+        }
+    }
     const u32 lowmask = (1u << L) - 1u;
-    int dest[HELD];
+    u32 ck[HELD];
 #pragma unroll
     for (int e = 0; e < HELD; e++) {
-        dest[e] = -1;
-        const int i = at[e];
-        if (i < 0) continue;
-        const bool in_chunk = e < FIN_IPT;
-        const int s = fin_prev_bit(fl, i, i - (int)FIN_G + 1 > 1 ? i - (int)FIN_G + 1 : 1);
-        if (s < 0) {                                    // the bucket starts more than FIN_G ranks back
-            if (in_chunk) atomicOr(&hotm[i >> 5], 1u << (i & 31u));
-            continue;
+        const int i = e < FIN_IPT ? i0 + e : ih;
+        ck[e] = ((u32)s[e] << 19) | (((u32)key[e] & lowmask) << 11) | (u32)i;
+        if ((own >> e) & 1u) comp[i] = ck[e];
+    }
+    __syncthreads();
+    // ---- ranks: the pairs of the stretch [lo, hi) that cover this thread's buckets, counted once for all four ----
+    // (comp orders the pairs by bucket first: dest = lo + the number of pairs in [lo, hi) below this one)
+    int dest[HELD];
+    {
+        int lo = FIN_STAGE, hi = 0;
+#pragma unroll
+        for (int e = 0; e < FIN_IPT; e++)
+            if ((own >> e) & 1u) { lo = s[e] < lo ? s[e] : lo; hi = en[e] > hi ? en[e] : hi; }
+        u32 c0_ = 0, c1_ = 0, c2_ = 0, c3_ = 0;
+        for (int x = lo; x < hi; x++) {
+            const u32 c = comp[x];
+            c0_ += c < ck[0] ? 1u : 0u;
+            c1_ += c < ck[1] ? 1u : 0u;
+            c2_ += c < ck[2] ? 1u : 0u;
+            c3_ += c < ck[3] ? 1u : 0u;
         }
-        if (s >= (int)(FIN_LEFT + FIN_CHUNK)) continue; // (right halo: a bucket of the next workgroup)
-        const int en = fin_next_bit(fl, i + 1, s + (int)FIN_G);
-        if (en < 0) {                                   // more than FIN_G members
-            if (in_chunk) atomicOr(&hotm[i >> 5], 1u << (i & 31u));
-            continue;
+        dest[0] = lo + (int)c0_; dest[1] = lo + (int)c1_; dest[2] = lo + (int)c2_; dest[3] = lo + (int)c3_;
+        dest[FIN_IPT] = -1;
+        if (own & 16u) {
+            u32 c = 0;
+            for (int x = s[FIN_IPT]; x < en[FIN_IPT]; x++) c += comp[x] < ck[FIN_IPT] ? 1u : 0u;
+            dest[FIN_IPT] = s[FIN_IPT] + (int)c;
         }
-        if (s < (int)FIN_LEFT) continue;                // the bucket of the workgroup before, which orders it
-        const u32 mine_key = (((u32)key[e] & lowmask) << 11) | (u32)i;
-        u32 rank = 0;
-        for (int x = s; x < en; x++) rank += ((((u32)kt[x] & lowmask) << 11) | (u32)x) < mine_key ? 1u : 0u;
-        dest[e] = s + (int)rank;
-        atomicOr(&mine[i >> 5], 1u << (i & 31u));
     }
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < HELD; e++)
-        if (dest[e] >= 0) { kt[dest[e]] = key[e]; vt[dest[e]] = val[e]; }
+        if ((own >> e) & 1u) { kt[dest[e]] = key[e]; vt[dest[e]] = val[e]; }
     __syncthreads();
     // ---- placement on the staged, sorted keys ----------------------------------------------------------
     const KeyNeqWindowIn<K> f{a.keys, a.rep_t, a.ones, a.highs};   // (keys / vals: never read -- everything the tie code touches is staged; a null pointer here crashes hipcc 7.2)
@@ -831,18 +911,14 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
             if (code < a.km.bins) a.km.kg[(size_t)d * (a.km.bins + 1) + code] = j - a.km.doc_off[d];
         }
     };
-    // rank `base + i`: returns true when it is final here (suffix and LCP entry in sa_o / lcp_o, to be stored by the
-    // caller); everything else -- not this workgroup's, handed to the rounds, a member of a small tie group -- is dealt with inside
-    auto place_one = [&](int i, u32 &sa_o, u32 &lcp_o) -> bool {
-        const bool is_mine = (mine[i >> 5] >> (i & 31)) & 1u, is_hot = (hotm[i >> 5] >> (i & 31)) & 1u;
-        if (!is_mine && !is_hot) return false;
+    // rank `base + i` (one of this workgroup's): returns true when it is final here (suffix and LCP entry in sa_o / lcp_o,
+    // to be stored by the caller); a rank handed to the rounds or a member of a small tie group is dealt with inside
+    auto place_one = [&](int i, bool is_hot, bool first, u32 &sa_o, u32 &lcp_o) -> bool {
         const u32 j = base + (u32)i;
         const K k = kt[i], kp = j > 0 ? kt[i - 1] : (K)0;
-        bool whole;
         sa_o = vt[i];
-        lcp_o = j > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, k, kp, whole) : 0u;
+        lcp_o = j > 0 ? fin_lcp_of_key_pair(a, k, kp) : 0u;
         if (is_hot) {
-            const bool first = (fl[i >> 5] >> (i & 31)) & 1u;
             if (a.km.kg && first) kg_mark(j, k, kp);
             const K xt = k ^ a.top_rep_t;
             if (((K)(xt - a.top_ones) & ~xt & a.top_highs) != 0) return true;   // a constant bucket: final as it stands
@@ -866,13 +942,13 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
         }
         if (st && st_next) return true;
         // tied: a group of equal keys inside this bucket (all of it is staged).  More than `limit` equal keys around
-        // this one (an equal key `limit` places away): a large group, left to the rounds without the exact bounds.
-        const int lim = (int)limit;
+        // this one (an equal key `limit` places away -- equal keys share their bucket, so that place is sorted too):
+        // a large group, left to the rounds without the exact bounds.
         bool big = false;
         {
-            const int lo = i - lim, hi = i + lim;
-            if (lo >= 1) big = kt[lo] == k && (((mine[lo >> 5] >> (lo & 31)) & 1u) != 0);
-            if (!big && hi < (int)FIN_STAGE && j + limit < m) big = kt[hi] == k && (((mine[hi >> 5] >> (hi & 31)) & 1u) != 0);
+            const int lo = i - (int)limit, hi = i + (int)limit;
+            if (lo >= 1) big = kt[lo] == k;
+            if (!big && hi <= (int)(FIN_LEFT + FIN_CHUNK + FIN_G) && j + limit < m) big = kt[hi] == k;   // (staged up to there)
         }
         if (big) {
             a.order_g[j] = sa_o;
@@ -890,11 +966,10 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     {
         u32 sa4[FIN_IPT], lc4[FIN_IPT];
         u32 fin = 0;
-        const int i0 = (int)(FIN_LEFT + threadIdx.x * FIN_IPT);
-        const u32 j0 = c0 + threadIdx.x * FIN_IPT;
+        const u32 todo4 = (own | hot) & 15u;
 #pragma unroll
         for (int e = 0; e < FIN_IPT; e++)
-            if (j0 + e < m && place_one(i0 + e, sa4[e], lc4[e])) fin |= 1u << e;
+            if (((todo4 >> e) & 1u) && place_one(i0 + e, (hot >> e) & 1u, (myfl >> e) & 1u, sa4[e], lc4[e])) fin |= 1u << e;
         if (fin == 15u) {
             *reinterpret_cast<uint4 *>(a.order_g + j0) = uint4{sa4[0], sa4[1], sa4[2], sa4[3]};
             if (a.lcp_g) *reinterpret_cast<uint4 *>(a.lcp_g + j0) = uint4{lc4[0], lc4[1], lc4[2], lc4[3]};
@@ -906,19 +981,18 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
                     if (a.lcp_g) a.lcp_g[j0 + e] = lc4[e];
                 }
         }
-        if (threadIdx.x < FIN_G) {                      // the overhang of the last bucket that starts in the stretch
-            const int i = (int)(FIN_LEFT + FIN_CHUNK + threadIdx.x);
+        if (own & 16u) {                                // the overhang of the last bucket that starts in the stretch
             u32 sa1, lc1;
-            if (base + (u32)i < m && place_one(i, sa1, lc1)) {
-                a.order_g[base + (u32)i] = sa1;
-                if (a.lcp_g) a.lcp_g[base + (u32)i] = lc1;
+            if (place_one(ih, false, false, sa1, lc1)) {
+                a.order_g[base + (u32)ih] = sa1;
+                if (a.lcp_g) a.lcp_g[base + (u32)ih] = lc1;
             }
         }
     }
     __syncthreads();
     // phase 2: the members of small tie groups, one per thread (as in lvl0_place_kernel)
     const u32 todo = n_work;
-    for (u32 q = threadIdx.x; q < todo; q += BLOCK) {
+    for (u32 q = tid; q < todo; q += BLOCK) {
         const u32 i = work[q];
         next8[i] = load_u64_unaligned(a.s8 + vt[i] + (u32)w);
     }
@@ -926,12 +1000,11 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     const NextSymbols ns{next8, base, (u32)FIN_STAGE};
     const TileStarts<K> tstarts{f, kt, base, (u32)FIN_STAGE};
     const TileElems telems{a.vals, vt, base, (u32)FIN_STAGE};
-    for (u32 q = threadIdx.x; q < todo; q += BLOCK) {
+    for (u32 q = tid; q < todo; q += BLOCK) {
         const u32 i = work[q];
         const u32 j = base + i;
         auto lcp_first = [&](u32 at_j) -> u32 {
-            bool whole;
-            return at_j > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, tstarts.key(at_j), tstarts.key(at_j - 1), whole) : 0u;
+            return at_j > 0 ? fin_lcp_of_key_pair(a, tstarts.key(at_j), tstarts.key(at_j - 1)) : 0u;
         };
         if (lvl0_place_tied(j, telems, tstarts, (const u32 *)nullptr, m, a.s8, 0u, (u32)w, a.order_g, (u32 *)nullptr, a.lcp_g,
                             lcp_first, a.fail, limit, max_len, (u32 *)nullptr, LongRepeats(), ns)) {
@@ -946,17 +1019,17 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     __syncthreads();
     // the bits of the ranks [c0, c0 + FIN_CHUNK + FIN_G): OR-ed into the global words (the overhang shares its words with
     // the next workgroup); nearly all of them are zero
-    if (threadIdx.x < (FIN_CHUNK + FIN_G + 31) / 32) {
+    if (tid < (FIN_CHUNK + FIN_G + 31) / 32) {
         // staged index FIN_LEFT + 32 t .. + 31  ->  global bit c0 + 32 t ..
-        const u32 i0 = FIN_LEFT + 32u * threadIdx.x;
-        const u32 sh = i0 & 31u, wi = i0 >> 5;
+        const u32 ib = FIN_LEFT + 32u * tid;
+        const u32 sh = ib & 31u, wi = ib >> 5;
         u32 kb = keep_bits[wi] >> sh, gb = gs_bits[wi] >> sh;
         if (sh) { kb |= keep_bits[wi + 1] << (32u - sh); gb |= gs_bits[wi + 1] << (32u - sh); }
-        const u32 bit0 = c0 + 32u * threadIdx.x;
+        const u32 bit0 = c0 + 32u * tid;
         if (kb) atomicOr(reinterpret_cast<u32 *>(a.keep) + (bit0 >> 5), kb);
         if (gb) atomicOr(reinterpret_cast<u32 *>(a.gstart) + (bit0 >> 5), gb);
     }
-    if (threadIdx.x == 0) a.block_keep[blockIdx.x] = n_keep;
+    if (tid == 0) a.block_keep[blockIdx.x] = n_keep;
 }
 
 // group starts kept as one bit per rank (the fused finish): the naming predicate of the first compaction
@@ -1327,6 +1400,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     if (fused) {
         fa.keys = sb.keys[r]; fa.vals = sorted_vals; fa.m = n02; fa.s8 = s8;
         fa.w = w; fa.b = bt; fa.spare = spare; fa.low_bits = low_bits;
+        fa.inv_b = (65536u + (u32)bt - 1u) / (u32)bt;
         fa.rep_t = starts.rep_t; fa.ones = starts.ones; fa.highs = starts.highs;
         fa.top_rep_t = fa.top_ones = fa.top_highs = 0;
         for (int j = 0; j < w; j++)
