@@ -741,6 +741,62 @@ __device__ __forceinline__ u32 fin_lcp_of_key_pair(const FinishArgs<K> &a, K k, 
     return mism < term ? mism : term;
 }
 
+// lvl0_place_tied for the fused finish: a member of a group of equal keys ranks itself inside the group by comparing
+// the suffixes from offset w on and is placed for good (suffix array, LCP entry).  The group lies inside its bucket,
+// so everything touched is staged (staged indices throughout); next4[] holds the 4 symbols behind the window of every
+// tied pair (enough to tell nearly all of them apart; longer comparisons go on reading the text, 8 symbols a step).
+// Returns 1 when the group has more than `limit` members (left to the rounds).
+template <class K>
+__device__ __forceinline__ u32 fin_place_tied(const FinishArgs<K> &a, int i, const K *kt, const u32 *vt, const u32 *next4,
+                                              u32 base, u32 limit, u32 max_len)
+{
+    auto starts = [&](int x) -> bool {
+        if (base + (u32)x == 0) return true;
+        const K k = kt[x], xx = k ^ a.rep_t;
+        return ((K)(xx - a.ones) & ~xx & a.highs) != 0 || k != kt[x - 1];
+    };
+    int lo = i, hi = i + 1;
+    while (!starts(lo) && (u32)(i - lo) <= limit) lo--;
+    while (base + (u32)hi < a.m && !starts(hi) && (u32)(hi - i) <= limit) hi++;
+    if ((u32)(hi - lo) > limit) return 1;
+    const uint8_t *s8 = a.s8;
+    const u32 depth = (u32)a.w, p = vt[i];
+    const u32 u0 = next4[i];
+    u32 r = 0, best = 0;                                // best: longest common prefix with a smaller member
+    for (int x = lo; x < hi; x++) {
+        if (x == i) continue;
+        const u32 p2 = vt[x];
+        bool decided = false, less = false;             // less: suffix p2 < suffix p
+        u32 h = depth;
+        {
+            const u32 v0 = next4[x];
+            const u32 d = u0 ^ v0, z = ~u0;
+            const u32 tz = (z - 0x01010101u) & ~z & 0x80808080u;
+            const u32 mism = d ? (u32)(__ffs(d) - 1) >> 3 : 4u;
+            const u32 term = tz ? (u32)(__ffs(tz) - 1) >> 3 : 4u;
+            if (term < mism) { less = p2 < p; decided = true; h += term; }        // both end in (different) terminators
+            else if (mism < 4u) { less = ((v0 >> (8 * mism)) & 0xFFu) < ((u0 >> (8 * mism)) & 0xFFu); decided = true; h += mism; }
+            else h += 4;
+        }
+        for (; h < depth + max_len && !decided; h += 8) {
+            const u64 u = load_u64_unaligned(s8 + p + h), v = load_u64_unaligned(s8 + p2 + h);
+            const u64 d = u ^ v, z = ~u;
+            const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+            const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+            const u32 term = tz ? (u32)__builtin_ctzll(tz) >> 3 : 8u;
+            if (term < mism) { less = p2 < p; decided = true; h += term; break; }
+            if (mism < 8u) { less = ((v >> (8 * mism)) & 0xFFu) < ((u >> (8 * mism)) & 0xFFu); decided = true; h += mism; break; }
+        }
+        if (!decided) { atomicOr(a.fail, 1u); return 0; }   // (a repeat too long to compare: the host redoes the level with the full sort)
+        if (less) { r++; best = h > best ? h : best; }
+    }
+    const int at = lo + (int)r;
+    const u32 at_g = base + (u32)at;
+    a.order_g[at_g] = p;
+    if (a.lcp_g) a.lcp_g[at_g] = r > 0 ? best : (at_g > 0 ? fin_lcp_of_key_pair(a, kt[at], kt[at - 1]) : 0u);
+    return 0;
+}
+
 template <class K, bool ENDGAME_LIMITS>
 __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
 {
@@ -750,12 +806,12 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     constexpr int G = FIN_G;
     __shared__ __attribute__((aligned(16))) K kt[FIN_STAGE];
     __shared__ __attribute__((aligned(16))) u32 vt[FIN_STAGE];
-    __shared__ __attribute__((aligned(16))) u64 next8[FIN_STAGE];
-    __shared__ u32 work[FIN_CHUNK + FIN_G];
+    __shared__ u32 next4[FIN_STAGE];                    // the 4 symbols behind the window of the tied pairs; before: comp
+    __shared__ uint16_t work[FIN_CHUNK + FIN_G];
     __shared__ u32 fl[FIN_WORDS];                       // bucket starts, by staged index
     __shared__ u32 keep_bits[FIN_WORDS], gs_bits[FIN_WORDS];
     __shared__ u32 n_keep, n_work;
-    u32 *comp = reinterpret_cast<u32 *>(next8);         // (bucket start, low key bits, staged index) of every pair; next8 is used after the ranking
+    u32 *comp = next4;                                  // (bucket start, low key bits, staged index) of every pair; next4 is used after the ranking
     const u32 m = a.m;
     const u32 c0 = blockIdx.x * FIN_CHUNK;
     const u32 base = c0 - FIN_LEFT;                     // global rank of staged entry 0 (wraps in the first stretch: such ranks test as > m)
@@ -878,13 +934,25 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
         for (int e = 0; e < FIN_IPT; e++)
             if ((own >> e) & 1u) { lo = s[e] < lo ? s[e] : lo; hi = en[e] > hi ? en[e] : hi; }
         u32 c0_ = 0, c1_ = 0, c2_ = 0, c3_ = 0;
-        for (int x = lo; x < hi; x++) {
+#ifndef FIN_DIAG_NORANK
+        int x = lo;
+        for (; x + 1 < hi; x += 2) {                    // (two pairs per step: one ds_read2)
+            const u32 ca = comp[x], cb = comp[x + 1];
+            c0_ += (ca < ck[0] ? 1u : 0u) + (cb < ck[0] ? 1u : 0u);
+            c1_ += (ca < ck[1] ? 1u : 0u) + (cb < ck[1] ? 1u : 0u);
+            c2_ += (ca < ck[2] ? 1u : 0u) + (cb < ck[2] ? 1u : 0u);
+            c3_ += (ca < ck[3] ? 1u : 0u) + (cb < ck[3] ? 1u : 0u);
+        }
+        if (x < hi) {
             const u32 c = comp[x];
             c0_ += c < ck[0] ? 1u : 0u;
             c1_ += c < ck[1] ? 1u : 0u;
             c2_ += c < ck[2] ? 1u : 0u;
             c3_ += c < ck[3] ? 1u : 0u;
         }
+#else
+        c0_ = (u32)(i0 - lo); c1_ = c0_ + 1; c2_ = c0_ + 2; c3_ = c0_ + 3;
+#endif
         dest[0] = lo + (int)c0_; dest[1] = lo + (int)c1_; dest[2] = lo + (int)c2_; dest[3] = lo + (int)c3_;
         dest[FIN_IPT] = -1;
         if (own & 16u) {
@@ -913,10 +981,9 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     };
     // rank `base + i` (one of this workgroup's): returns true when it is final here (suffix and LCP entry in sa_o / lcp_o,
     // to be stored by the caller); a rank handed to the rounds or a member of a small tie group is dealt with inside
-    auto place_one = [&](int i, bool is_hot, bool first, u32 &sa_o, u32 &lcp_o) -> bool {
+    auto place_one = [&](int i, bool is_hot, bool first, K k, K kp, K kn, u32 v, u32 &sa_o, u32 &lcp_o) -> bool {
         const u32 j = base + (u32)i;
-        const K k = kt[i], kp = j > 0 ? kt[i - 1] : (K)0;
-        sa_o = vt[i];
+        sa_o = v;
         lcp_o = j > 0 ? fin_lcp_of_key_pair(a, k, kp) : 0u;
         if (is_hot) {
             if (a.km.kg && first) kg_mark(j, k, kp);
@@ -937,7 +1004,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
         const bool st = j == 0 || ((K)(x - f.ones) & ~x & f.highs) != 0 || k != kp;
         bool st_next = j + 1 >= m;
         if (!st_next) {
-            const K kn = kt[i + 1], xn = kn ^ f.rep_t;
+            const K xn = kn ^ f.rep_t;
             st_next = ((K)(xn - f.ones) & ~xn & f.highs) != 0 || kn != k;
         }
         if (st && st_next) return true;
@@ -959,7 +1026,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
                 if (a.lcp_g) a.lcp_g[j] = lcp_o;
             }
         } else {
-            work[atomicAdd(&n_work, 1u)] = (u32)i;
+            work[atomicAdd(&n_work, 1u)] = (uint16_t)i;
         }
         return false;
     };
@@ -967,9 +1034,33 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
         u32 sa4[FIN_IPT], lc4[FIN_IPT];
         u32 fin = 0;
         const u32 todo4 = (own | hot) & 15u;
+        // the sorted keys of the thread's four ranks and of the two next to them, the suffixes: 16-byte LDS reads
+        K kq[FIN_IPT + 2];
+        u32 vq[FIN_IPT];
+        kq[0] = j0 > 0 ? kt[i0 - 1] : (K)0;
+        if constexpr (sizeof(K) == 4) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(&kt[i0]);
+            kq[1] = q.x; kq[2] = q.y; kq[3] = q.z; kq[4] = q.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < FIN_IPT; e++) kq[e + 1] = kt[i0 + e];
+        }
+        kq[FIN_IPT + 1] = kt[i0 + FIN_IPT];
+        {
+            const uint4 q = *reinterpret_cast<const uint4 *>(&vt[i0]);
+            vq[0] = q.x; vq[1] = q.y; vq[2] = q.z; vq[3] = q.w;
+        }
+#ifndef FIN_DIAG_NOPLACE
 #pragma unroll
         for (int e = 0; e < FIN_IPT; e++)
-            if (((todo4 >> e) & 1u) && place_one(i0 + e, (hot >> e) & 1u, (myfl >> e) & 1u, sa4[e], lc4[e])) fin |= 1u << e;
+            if (((todo4 >> e) & 1u) &&
+                place_one(i0 + e, (hot >> e) & 1u, (myfl >> e) & 1u, kq[e + 1], kq[e], kq[e + 2], vq[e], sa4[e], lc4[e]))
+                fin |= 1u << e;
+#else
+#pragma unroll
+        for (int e = 0; e < FIN_IPT; e++) { sa4[e] = vq[e]; lc4[e] = (u32)kq[e + 1] ^ (u32)kq[e]; }
+        fin = todo4;
+#endif
         if (fin == 15u) {
             *reinterpret_cast<uint4 *>(a.order_g + j0) = uint4{sa4[0], sa4[1], sa4[2], sa4[3]};
             if (a.lcp_g) *reinterpret_cast<uint4 *>(a.lcp_g + j0) = uint4{lc4[0], lc4[1], lc4[2], lc4[3]};
@@ -983,7 +1074,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
         }
         if (own & 16u) {                                // the overhang of the last bucket that starts in the stretch
             u32 sa1, lc1;
-            if (place_one(ih, false, false, sa1, lc1)) {
+            if (place_one(ih, false, false, kt[ih], kt[ih - 1], kt[ih + 1], vt[ih], sa1, lc1)) {
                 a.order_g[base + (u32)ih] = sa1;
                 if (a.lcp_g) a.lcp_g[base + (u32)ih] = lc1;
             }
@@ -994,25 +1085,22 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     const u32 todo = n_work;
     for (u32 q = tid; q < todo; q += BLOCK) {
         const u32 i = work[q];
-        next8[i] = load_u64_unaligned(a.s8 + vt[i] + (u32)w);
+        u32 x4;
+        __builtin_memcpy(&x4, a.s8 + vt[i] + (u32)w, 4);
+        next4[i] = x4;
     }
     __syncthreads();
-    const NextSymbols ns{next8, base, (u32)FIN_STAGE};
-    const TileStarts<K> tstarts{f, kt, base, (u32)FIN_STAGE};
-    const TileElems telems{a.vals, vt, base, (u32)FIN_STAGE};
     for (u32 q = tid; q < todo; q += BLOCK) {
-        const u32 i = work[q];
-        const u32 j = base + i;
-        auto lcp_first = [&](u32 at_j) -> u32 {
-            return at_j > 0 ? fin_lcp_of_key_pair(a, tstarts.key(at_j), tstarts.key(at_j - 1)) : 0u;
-        };
-        if (lvl0_place_tied(j, telems, tstarts, (const u32 *)nullptr, m, a.s8, 0u, (u32)w, a.order_g, (u32 *)nullptr, a.lcp_g,
-                            lcp_first, a.fail, limit, max_len, (u32 *)nullptr, LongRepeats(), ns)) {
-            atomicOr(&keep_bits[i >> 5], 1u << (i & 31u));
+        const int i = (int)work[q];
+        if (fin_place_tied(a, i, kt, vt, next4, base, limit, max_len)) {
+            const u32 j = base + (u32)i;
+            a.order_g[j] = vt[i];
+            atomicOr(&keep_bits[i >> 5], 1u << (i & 31));
             atomicAdd(&n_keep, 1u);
-            if (tstarts(j)) {
-                atomicOr(&gs_bits[i >> 5], 1u << (i & 31u));
-                if (a.lcp_g) a.lcp_g[j] = lcp_first(j);
+            const K k = kt[i], x = k ^ a.rep_t;
+            if (j == 0 || ((K)(x - a.ones) & ~x & a.highs) != 0 || k != kt[i - 1]) {     // the first of its group
+                atomicOr(&gs_bits[i >> 5], 1u << (i & 31));
+                if (a.lcp_g) a.lcp_g[j] = j > 0 ? fin_lcp_of_key_pair(a, k, kt[i - 1]) : 0u;
             }
         }
     }
