@@ -149,7 +149,13 @@ struct Ctx {
     u32 *spec_out = nullptr;    // [0] suffixes left in large groups, [1] placement gave up on a long repeat
     u32 *zeroed_word = nullptr; // one word the build has already zeroed: the first level-0 pass takes it for its fail flag
     u32 *kg_bad = nullptr;      // raised by the fused finish when the k-gram marks it writes are incomplete (a bucket handed to the rounds)
-    bool wide_window = false;   // the handle's last build left most suffixes tied behind the 32-bit window: take the widest one
+    // What the sample of the build's own text says (sample_prefix_kernel; a handle's first build and every build that
+    // waits for the alphabet): of sample_n consecutive suffixes, sample_dup2[l] / sample_dup4[l] share their first
+    // l symbols with at least 1 / 3 others of the sample.  sample_n == 0: no sample (speculative build: the plan of
+    // the build before is taken instead -- plan_wide / plan_fused).
+    u32 sample_n = 0, sample_dup2[9] = {0}, sample_dup4[9] = {0};
+    int plan_wide = -1, plan_fused = -1;    // -1 = decide from the sample / the estimates; 0 / 1 = as the build before did
+    int did_wide = 0, did_fused = 0;        // out: what the all-suffix window sort did (the next speculative build's plan)
     Stats *stats = nullptr;
     Profiler *prof = nullptr;
 };

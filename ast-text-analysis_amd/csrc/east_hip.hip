@@ -84,7 +84,8 @@ __global__ __launch_bounds__(BLOCK) void presence_kernel(const u32 *__restrict__
 #define FLAG_SIGMA_HI 5
 #define FLAG_PLACE_FAIL 6        // the placement pass's "a repeat too long to order directly" (window_sort.h: fail), zeroed with the flags
 #define FLAG_KG_BAD 7            // the fused finish could not mark every k-gram bucket start (Ctx::kg_bad)
-#define FLAG_WORDS 8
+#define FLAG_SAMPLE 8             // 17 words: sample_prefix_kernel's counts (dup2, dup4 for l = 1 .. 8) and the sample size
+#define FLAG_WORDS 32
 #define STATUS_NO_TERMINATOR 1u
 #define STATUS_N_STRINGS 2u
 #define STATUS_SIGMA_GUESS 4u
@@ -126,6 +127,73 @@ __global__ __launch_bounds__(BLOCK) void codemap_kernel(const u32 *__restrict__ 
         if (assumed != 0xFFFFFFFFu && assumed != total) st |= STATUS_SIGMA_GUESS;
         if (st) atomicOr(&flags[FLAG_STATUS], st);
     }
+}
+
+// Planning sample ("The plan of a first build"): SAMPLE_N consecutive suffixes of the raw symbol stream;
+// for every prefix length l = 1 .. SAMPLE_MAX_L, how many of them share their first l symbols (no terminator among
+// them) with at least one / at least three others of the sample.  Natural-language text repeats words within a few
+// thousand characters, random text does not: the host takes the window width and the fused finish from these counts
+// in the same build, no history needed.  One workgroup; counts by hashing into a table of 16-bit counters in LDS,
+// twice with different hashes, the smaller count taken (count-min).
+#define SAMPLE_N 8192
+#define SAMPLE_MAX_L 8
+#define SAMPLE_SLOTS 16384
+#define SAMPLE_THREADS 1024
+__global__ __launch_bounds__(SAMPLE_THREADS) void sample_prefix_kernel(const u32 *__restrict__ sym, u32 n, u32 pos0, u32 count,
+                                                                       u32 *__restrict__ out)
+{
+    constexpr int PER = SAMPLE_N / SAMPLE_THREADS;
+    __shared__ uint16_t s16[SAMPLE_N + SAMPLE_MAX_L];   // the symbols; 0xFFFF = a terminator (or the end of the stream)
+    __shared__ u32 tab[SAMPLE_SLOTS / 2];               // 16-bit counters, two to a word
+    __shared__ u32 acc[2 * SAMPLE_MAX_L];
+    for (u32 i = threadIdx.x; i < SAMPLE_N + SAMPLE_MAX_L; i += SAMPLE_THREADS) {
+        const u32 p = pos0 + i;
+        const u32 c = p < n ? sym[p] : 0xFFFFFFFFu;
+        s16[i] = c < TEXT_SYMBOLS ? (uint16_t)c : (uint16_t)0xFFFFu;
+    }
+    if (threadIdx.x < 2 * SAMPLE_MAX_L) acc[threadIdx.x] = 0;
+    for (int l = 1; l <= SAMPLE_MAX_L; l++) {
+        u32 first_count[PER];
+        u32 d2 = 0, d4 = 0;
+        for (int variant = 0; variant < 2; variant++) {
+            __syncthreads();
+            for (u32 i = threadIdx.x; i < SAMPLE_SLOTS / 2; i += SAMPLE_THREADS) tab[i] = 0;
+            __syncthreads();
+            u32 slot[PER];
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const u32 p = threadIdx.x + SAMPLE_THREADS * q;
+                u32 h = 0x811C9DC5u;
+                bool ok = p < count;
+                for (int t = 0; t < l; t++) {
+                    const u32 c = s16[p + t];
+                    ok = ok && c != 0xFFFFu;
+                    h = (h ^ c) * 0x01000193u;
+                }
+                h ^= h >> 15;
+                h *= variant ? 0x9E3779B1u : 0x85EBCA6Bu;
+                slot[q] = ok ? h >> 18 : 0xFFFFFFFFu;   // 14 bits
+                if (ok) atomicAdd(&tab[slot[q] >> 1], 1u << (16u * (slot[q] & 1u)));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const u32 c = slot[q] != 0xFFFFFFFFu ? (tab[slot[q] >> 1] >> (16u * (slot[q] & 1u))) & 0xFFFFu : 0u;
+                if (variant == 0) first_count[q] = c;
+                else {
+                    const u32 both = c < first_count[q] ? c : first_count[q];
+                    d2 += both >= 2u ? 1u : 0u;
+                    d4 += both >= 4u ? 1u : 0u;
+                }
+            }
+        }
+        d2 = wave_sum(d2);
+        d4 = wave_sum(d4);
+        if (lane_id() == 0) { atomicAdd(&acc[2 * (l - 1)], d2); atomicAdd(&acc[2 * (l - 1) + 1], d4); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * SAMPLE_MAX_L) out[threadIdx.x] = acc[threadIdx.x];
+    if (threadIdx.x == 0) out[2 * SAMPLE_MAX_L] = count;
 }
 
 // Speculative build: presence bitmap AND byte stream in one pass over the symbols, the bytes through the code map of
@@ -366,7 +434,7 @@ struct east_hip_index {
     u32 build_docs = 0;          // documents of the build in progress (h->n_docs is set when it has succeeded)
     // what the last successful build found, the guesses of the next (speculative) one
     bool hint_valid = false, hint_no_rounds = false, hint_window = false;
-    bool hint_wide_window = false;   // the 32-bit first window left more than 60 % of the suffixes in large groups
+    int plan_wide = -1, plan_fused = -1;   // what the last build's window sort did (wide first window, fused finish): a speculative build does the same
     u32 hint_sigma = 0;
     u32 plan_n = 0, plan_docs = 0, plan_epoch = 0;
     bool plan_tagged = false;   // shape of the last sizing run (and test-knob epoch), its result
@@ -512,6 +580,15 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         }
         LAUNCH(ctx, codemap_kernel, 1, (const u32 *)present, ctx.spec ? spec_sigma : 0xFFFFFFFFu, h->code_map, flags, h->guess,
                (int)fused);
+        ctx.sample_n = 0;
+        if (!ctx.dry && !ctx.spec && !tagged && n >= 4 * SAMPLE_N) {
+            // the planning sample: the middle of the longest document (read back together with the alphabet)
+            u32 dl = 0;
+            for (u32 d = 1; d < n_docs; d++)
+                if (off32[d + 1] - off32[d] > off32[dl + 1] - off32[dl]) dl = d;
+            const u32 len = off32[dl + 1] - off32[dl], cnt = std::min<u32>(SAMPLE_N, len);
+            LAUNCH_BLOCK(ctx, sample_prefix_kernel, 1, SAMPLE_THREADS, d_sym, n, off32[dl] + (len - cnt) / 2, cnt, flags + FLAG_SAMPLE);
+        }
         if (!ctx.dry) {
             if (ctx.spec) {
                 sigma_t = spec_sigma;                        // (checked on the device; found out at the end of the build)
@@ -526,6 +603,16 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
                     east_throw(EAST_HIP_ERR_DOMAIN, "a symbol is neither a tagged terminator nor a code point < U+110000");
                 sigma_t = hf[FLAG_SIGMA];
                 sigma_hi = tagged ? hf[FLAG_SIGMA_HI] : 0;
+                ctx.sample_n = hf[FLAG_SAMPLE + 2 * SAMPLE_MAX_L];
+                for (int l = 1; l <= SAMPLE_MAX_L; l++) {
+                    ctx.sample_dup2[l] = hf[FLAG_SAMPLE + 2 * (l - 1)];
+                    ctx.sample_dup4[l] = hf[FLAG_SAMPLE + 2 * (l - 1) + 1];
+                }
+                if (g_trace && ctx.sample_n) {
+                    fprintf(stderr, "[east_hip] sample of %u suffixes, shared prefixes (>= 2 / >= 4 of the sample) by length:", ctx.sample_n);
+                    for (int l = 1; l <= SAMPLE_MAX_L; l++) fprintf(stderr, " %d: %u/%u", l, ctx.sample_dup2[l], ctx.sample_dup4[l]);
+                    fprintf(stderr, "\n");
+                }
             }
             m_total = 0;
             for (u32 d = 0; d < n_docs; d++) m_total += (u32)n_strings[d];     // checked after the build
@@ -785,7 +872,6 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     ctx.stats = &h->stats;
     ctx.prof = &h->prof;
     ctx.lean = lean;
-    ctx.wide_window = h->hint_wide_window;
     // The build is queued WITHOUT waiting for the device wherever the previous build on this handle says what
     // to expect (alphabet size, no large tie groups): one read-back at the end finds out whether it was
     // right.  If not -- or on a handle's first build -- the build runs with its read-backs in place.
@@ -793,6 +879,8 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     auto run = [&](bool spec, bool spec_rounds) -> bool {
         ctx.spec = spec;
         ctx.spec_rounds = spec && spec_rounds;
+        ctx.plan_wide = spec ? h->plan_wide : -1;        // (a build that waits for the alphabet plans from its own sample)
+        ctx.plan_fused = spec ? h->plan_fused : -1;
         try {
             build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings, h->hint_sigma, tagged);
         } catch (const SpecAbort &) {
@@ -835,12 +923,10 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     h->hint_valid = !tagged || h->sigma_hi == 0;
     h->hint_sigma = h->sigma_t;
     h->hint_window = h->stats.window_sorted != 0;
-    if (h->stats.first_n > 0) {
-        // more than 60 % tied behind the 32-bit window: the wide one next time; hardly anything tied behind the wide one
-        // (another kind of text on the same handle): back to the estimate
-        if (!ctx.wide_window) h->hint_wide_window = h->stats.first_kept * 5 > h->stats.first_n * 3;
-        else if (h->stats.first_kept * 50 < h->stats.first_n) h->hint_wide_window = false;
-    }
+    h->plan_wide = h->stats.window_sorted ? ctx.did_wide : -1;
+    // (hardly anything tied behind the wide window -- another kind of text on the same handle: back to the estimate)
+    if (ctx.did_wide && h->stats.first_n > 0 && h->stats.first_kept * 50 < h->stats.first_n) h->plan_wide = -1;
+    h->plan_fused = h->stats.window_sorted ? ctx.did_fused : -1;
     h->hint_no_rounds = h->stats.window_sorted && h->stats.refine_rounds == 0 && !h->stats.long_repeats;
     h->prof.collect();
     HIP_CHECK(hipEventElapsedTime(&h->last_build_ms, h->ev0, h->ev1));
@@ -1511,7 +1597,7 @@ int east_hip_reset(east_hip_handle_t h)
         h->sigma_hi = 0;
         h->prof.enabled = false;
         h->prof.only.clear();
-        h->hint_wide_window = false;
+        h->plan_wide = h->plan_fused = -1;
         h->stats = Stats();
         // a recycled handle keeps its stream and a small arena, not gigabytes of side allocations
         const size_t keep = (size_t)64 << 20;

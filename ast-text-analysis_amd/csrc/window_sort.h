@@ -1431,13 +1431,23 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         if (spare + j * bt >= FIN_LOW_BITS) depth0++;
     bool fused = allow_fused && g_fused_finish && n0 == 0 && total_bits >= 2 * FIN_LOW_BITS && depth0 >= 1;
     if (fused && !ctx.dry) {
-        // expected members of a bucket, were the text uniform (skewed text: the large buckets go to the rounds)
-        double top_codes = pow((double)term_first, depth0);
-        const int part = (spare + (w - depth0) * bt) - FIN_LOW_BITS;   // bits of the next symbol inside the top part
-        if (part > 0) top_codes *= std::max(1.0, (double)term_first / (double)(1u << (bt - part)));
-        fused = (double)(longest ? longest : n02) / top_codes <= FIN_MAX_EXPECTED;
+        if (ctx.plan_fused >= 0) {
+            fused = ctx.plan_fused != 0;                 // (speculative build: as the build before)
+        } else {
+            // expected members of a bucket, were the text uniform
+            double top_codes = pow((double)term_first, depth0);
+            const int part = (spare + (w - depth0) * bt) - FIN_LOW_BITS;   // bits of the next symbol inside the top part
+            if (part > 0) top_codes *= std::max(1.0, (double)term_first / (double)(1u << (bt - part)));
+            fused = (double)(longest ? longest : n02) / top_codes <= FIN_MAX_EXPECTED;
+            // skewed text behind a narrow window: many buckets would be handed to the rounds whole (measured on the
+            // Zipf stand-in: 8.9 against 8.2 ms); the sample tells -- more than 1 in 20 of its suffixes sharing the
+            // symbols of the top part with three others of the sample is natural language, random text has none
+            if (fused && ctx.sample_n && sizeof(K) == 4)
+                fused = (u64)ctx.sample_dup4[std::min(depth0 + 1, 8)] * 20u <= ctx.sample_n;
+        }
     }
     const int low_bits = fused ? FIN_LOW_BITS : 0;
+    if (n0 == 0) ctx.did_fused = fused;
     if (ctx.stats && n0 == 0) ctx.stats->fused_finish = fused;
     SortBufs<K> sb;
     // (one spare element each: the idle half serves as scratch after the sort)
@@ -1814,9 +1824,18 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
     if (docs.bits + 3 * bt > 64) return false;          // (no room for a window next to the document number)
     int w = lvl0_window(docs.bits ? longest : n, bt, term_first, docs.bits);
     // (natural-language text over a large alphabet -- upper-case prose with digits and accents: 7 bits a symbol, 3 symbols
-    // in a 32-bit key -- resolves far less per symbol than the estimate above assumes; when the build before left most
-    // suffixes tied, the widest window that fits 64 bits costs less than the rounds it saves: real prose 7.45 -> 6.55 ms)
-    if (ctx.wide_window) w = std::max(w, std::min(12, (64 - docs.bits) / bt));
+    // in a 32-bit key -- resolves far less per symbol than the estimate above assumes; where most suffixes stay tied
+    // behind it, the widest window that fits 64 bits costs less than the rounds it saves: real prose 7.45 -> 6.55 ms)
+    // Which of the two it is comes from the text itself ("The plan of a first build"): when more than half
+    // of the sample's suffixes share the symbols of the narrow window with another suffix of the SAMPLE -- 8192
+    // consecutive suffixes --, most of the corpus is tied behind it.  (A speculative build does as the build before.)
+    const int w_wide = std::min(12, (64 - docs.bits) / bt);
+    bool wide = false;
+    if (ctx.plan_wide >= 0) wide = ctx.plan_wide != 0;
+    else if (ctx.sample_n && w < w_wide && w * bt + docs.bits <= 32)
+        wide = (u64)ctx.sample_dup2[std::min(w, 8)] * 2u > ctx.sample_n;
+    if (wide) w = std::max(w, w_wide);
+    ctx.did_wide = wide;
     // (experiments, DESIGN.md 5.2: EAST_HIP_WINDOW=<symbols> overrides the width of the first window)
     if (getenv("EAST_HIP_WINDOW")) w = std::max(3, std::min(atoi(getenv("EAST_HIP_WINDOW")), std::min(12, (64 - docs.bits) / bt)));
     u32 n_names = 0;

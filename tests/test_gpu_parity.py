@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 
 _PATH_KNOB = {"window_sort": 1, "window_sort_unfused": 4, "dc3_only": 0}
+_CURRENT = {"knob": 1}          # the knob of the running test (tests that check which path a build took)
 
 
 @pytest.fixture(autouse=True, params=["window_sort", "window_sort_unfused", "dc3_only"])
@@ -28,8 +29,10 @@ def suffix_sort_path(request, hip):
     for both window-sort variants.)"""
     lib = hip.load()
     assert lib.east_hip_debug_set_window_sort(_PATH_KNOB[request.param]) == 0
+    _CURRENT["knob"] = _PATH_KNOB[request.param]
     yield "window_sort" if request.param.startswith("window_sort") else request.param
     assert lib.east_hip_debug_set_window_sort(1) == 0
+    _CURRENT["knob"] = 1
 
 
 TABLES = ("suftab", "lcptab", "anntab", "childtab_up", "childtab_down", "childtab_next_l_index")
@@ -627,9 +630,12 @@ def test_refinement_rounds_in_lds_and_by_the_global_sort(hip, oracle, suffix_sor
         assert lib.east_hip_debug_set_lds_rounds(1) == 0
 
 
-def test_second_build_takes_the_wide_window_after_a_mostly_tied_one(hip, oracle, suffix_sort_path):
-    """A build that leaves most suffixes tied behind the 32-bit first window makes the handle's next build take the
-    widest window that fits 64-bit keys (natural-language text over a large alphabet); the tables are the same."""
+def test_first_build_plans_the_window_from_its_own_text(hip, oracle, suffix_sort_path):
+    """The first build on a fresh handle takes the window width and the fused finish from a sample of its own text
+    (csrc/east_hip.hip: sample_prefix_kernel) -- no build has to go before: natural-language-like text over a large
+    alphabet (most suffixes tied behind the three symbols that fit a 32-bit key) sorts 64-bit first-level keys at once,
+    a random word stream 32-bit keys with the last digit ordered in LDS; a second build on the handle (queued without
+    waiting, no sample) does as the first.  The tables are the oracle's either way."""
     from east import hip_backend, synthetic
     rng = np.random.default_rng(4711)
     vocab = synthetic.zipf_vocabulary(rng, size=40, exponent=1.0)
@@ -648,12 +654,29 @@ def test_second_build_takes_the_wide_window_after_a_mostly_tied_one(hip, oracle,
     second = index.info()
     if suffix_sort_path == "window_sort":
         assert first["window_sorted"] == 1 and second["window_sorted"] == 1
-        assert second["radix_passes_u32"] == 0 and first["radix_passes_u32"] > 0, (first, second)    # 64-bit first-level keys now
+        assert first["radix_passes_u32"] == 0 and second["radix_passes_u32"] == 0, (first, second)   # 64-bit first-level keys at once
     for d in range(2):
         o = oracle.OracleEASA(symbols=sym[off[d]:off[d + 1]], n_strings=int(m[d]))
         t = index.tables(d)
         for name in TABLES:
             assert np.array_equal(t[name], getattr(o, name)), (name, d, second)
+    # a random word stream on a fresh handle: the narrow window, and (unless switched off) the fused finish
+    docs = [synthetic.word_stream_document(rng, 300000, want_text=False)[1:] for _ in range(2)]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    m = np.array([d[1] for d in docs])
+    index = hip_backend.HipIndex()
+    for _ in range(2):
+        index.build(sym, off, m)
+        info = index.info()
+        if suffix_sort_path == "window_sort":
+            assert info["radix_passes_u64"] == 0 and info["refine_rounds"] == 0, info
+            assert info["fused_finish"] == int(_CURRENT["knob"] == 1), info
+    for d in range(2):
+        o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
 
 
 @pytest.mark.parametrize("shift", [0, 1, 2, 3])
