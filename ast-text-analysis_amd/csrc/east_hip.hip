@@ -1567,12 +1567,13 @@ int east_hip_get_lcp_intervals(east_hip_handle_t h, int32_t doc, int32_t *left)
         ctx.stream = h->stream;
         ctx.prof = &h->prof;
         const u32 seg = (u32)h->h_doc_off[doc], nd = (u32)(h->h_doc_off[doc + 1] - h->h_doc_off[doc]);
-        // (h->up is rewritten by child_kernel on the next east_hip_get_tables request that wants it)
-        u32 *scratch = h->up;
-        h->child_built = false;
+        // (scratch from the arena's temporary region, idle between builds: the child tables stay as they are)
+        const size_t mark = h->arena.mark();
+        u32 *scratch = h->arena.alloc<u32>(nd);
         LAUNCH(ctx, interval_left_kernel, ceil_div_u32(nd, BLOCK), h->pyr, (const u32 *)h->ann, seg, nd, scratch);
         HIP_CHECK(hipMemcpyAsync(left, scratch, (size_t)nd * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
+        h->arena.release(mark);
     });
 }
 

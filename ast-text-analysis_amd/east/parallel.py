@@ -93,6 +93,16 @@ class DistributedASTRelevanceMeasure(relevance.ASTRelevanceMeasure):
         if e > b:
             self.local.set_text_collection(list(texts[b:e]), language)
 
+    def _check_queries(self, prepared_keyphrases, synonimizer):
+        """What the reference raises on a query (easa.py:134 on an empty keyphrase or synonym variant, KeyError out of
+        the synonym dictionary), raised on EVERY rank before anyone looks at its shard: a rank with an empty shard
+        would otherwise walk into the collective alone and wait there for the others."""
+        if synonimizer:
+            for kp in prepared_keyphrases:
+                relevance.synonym_variants(kp, synonimizer)
+        elif not all(kp.replace(" ", "") for kp in prepared_keyphrases):
+            raise ZeroDivisionError("float division by zero")
+
     def _local_block(self, prepared_keyphrases, synonimizer):
         """K x D_local block of this rank as a torch tensor on the collective's device."""
         import torch
@@ -102,15 +112,15 @@ class DistributedASTRelevanceMeasure(relevance.ASTRelevanceMeasure):
         self.local.normalized = self.normalized
         if self._on_gpu():
             dev = torch.device("cuda", self.gpu)
-            block = torch.zeros((K, D), dtype=torch.float64, device=dev)
             if D and not synonimizer and getattr(self.local, "index", None) is not None:
-                queries = [kp.replace(" ", "") for kp in prepared_keyphrases]
-                if not all(queries):
-                    raise ZeroDivisionError("float division by zero")
-                qs, qo = hip_backend.pack_queries(queries)
+                # (empty, not zeros: a fill queued on torch's stream is not ordered with the library's own stream,
+                # which writes every entry of the block)
+                block = torch.empty((K, D), dtype=torch.float64, device=dev)
+                qs, qo = hip_backend.pack_queries([kp.replace(" ", "") for kp in prepared_keyphrases])
                 self.local.index.set_keyphrases(qs, qo)
                 self.local.index.score_resident(self.normalized, block.data_ptr())    # device to device, synchronised
                 return block
+            block = torch.zeros((K, D), dtype=torch.float64, device=dev)
             if D:
                 args = (prepared_keyphrases, synonimizer) if synonimizer else (prepared_keyphrases,)
                 block.copy_(torch.from_numpy(np.ascontiguousarray(self.local.relevance_table(*args))))
@@ -121,7 +131,24 @@ class DistributedASTRelevanceMeasure(relevance.ASTRelevanceMeasure):
         return torch.zeros((K, 0), dtype=torch.float64)
 
     def relevance_table(self, prepared_keyphrases, synonimizer=None):
-        table = all_gather_table(self._local_block(prepared_keyphrases, synonimizer), self.counts, self.group)
+        import torch
+        import torch.distributed as dist
+        self._check_queries(prepared_keyphrases, synonimizer)       # the same verdict on every rank
+        # whatever else goes wrong on one rank (device error, out of memory) must not leave the others in the
+        # collective: the ranks agree on an error flag first and raise together
+        block, error = None, None
+        try:
+            block = self._local_block(prepared_keyphrases, synonimizer)
+        except Exception as exc:                                    # noqa: BLE001 (re-raised below, on every rank)
+            error = exc
+        flag_dev = torch.device("cuda", self.gpu) if self._on_gpu() else torch.device("cpu")
+        flag = torch.tensor([1 if error is not None else 0], dtype=torch.int32, device=flag_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if error is not None:
+            raise error
+        if int(flag.item()):
+            raise RuntimeError("relevance_table failed on another rank of the process group")
+        table = all_gather_table(block, self.counts, self.group)
         return table.cpu().numpy()
 
     def relevance(self, keyphrase, text, synonimizer=None):

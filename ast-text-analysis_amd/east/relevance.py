@@ -55,11 +55,14 @@ class _Shard(object):
 
     def row(self, query, normalized, synonimizer=None):
         q = query.replace(" ", "")
-        key = (q, bool(normalized)) if synonimizer is None else (query, id(synonimizer))
+        # (the synonym row is keyed by the expanded variants themselves: a synonimizer whose mapping changes, or a new
+        # one at a collected one's address, must not get a stale row)
+        variants = tuple(synonym_variants(query, synonimizer)) if synonimizer is not None else None
+        key = (q, bool(normalized)) if synonimizer is None else ("synonyms", variants)
         if self.row_cache[0] != key:
             if synonimizer is not None:
                 # easa.py:27-34: max over the variants, scored with normalized=True whatever was asked for
-                variants = synonym_variants(query, synonimizer)
+                variants = list(variants)
                 qs, qo = hip_backend.pack_queries(variants, keep_spaces=True)
                 row = self.index.score_table_grouped(qs, qo, [0, len(variants)], True)[0]
             else:

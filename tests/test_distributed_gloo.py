@@ -76,6 +76,55 @@ def test_world_size_2_table_equals_single_process(tmp_path, n_texts):
             assert np.array_equal(got, want)       # every rank holds the full table, bit-equal
 
 
+class FailingMeasure(OracleMeasure):
+    """Scores like OracleMeasure, but its relevance_table fails -- on the rank that holds documents only."""
+
+    def relevance_table(self, prepared):
+        raise RuntimeError("device lost")
+
+
+def _error_worker(rank, world, port, out_dir):
+    for p in (PKG, ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from east import parallel
+    texts, kps = _make_inputs()
+    seen = []
+    # one document, two ranks: rank 1's shard is empty.  (a) an empty keyphrase is refused on BOTH ranks, before
+    # anyone enters the collective; (b) a failure inside rank 0's scorer is raised on both as well.
+    m = parallel.DistributedASTRelevanceMeasure(measure_factory=lambda: OracleMeasure(True))
+    m.set_text_collection(texts[:1])
+    try:
+        m.relevance_table(kps[:3] + [" "])
+    except ZeroDivisionError:
+        seen.append("zero")
+    m = parallel.DistributedASTRelevanceMeasure(measure_factory=lambda: FailingMeasure(True))
+    m.set_text_collection(texts[:1])
+    try:
+        m.relevance_table(kps[:3])
+    except RuntimeError as exc:
+        seen.append("own" if "device lost" in str(exc) else "other")
+    # ... and the group is still usable afterwards
+    m = parallel.DistributedASTRelevanceMeasure(measure_factory=lambda: OracleMeasure(True))
+    m.set_text_collection(texts[:1])
+    seen.append(str(m.relevance_table(kps[:3]).shape))
+    with open(os.path.join(out_dir, "seen_%d.txt" % rank), "w") as f:
+        f.write(",".join(seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_errors_are_raised_on_every_rank(tmp_path):
+    """A rank with an empty shard must not be left alone in the all-gather when the other one raises."""
+    port = 29500 + (os.getpid() % 2000) + 17
+    mp.spawn(_error_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(os.path.join(str(tmp_path), "seen_0.txt")).read() == "zero,own,(3, 1)"
+    assert open(os.path.join(str(tmp_path), "seen_1.txt")).read() == "zero,other,(3, 1)"
+
+
 def test_all_gather_table_single_rank_roundtrip():
     from east import parallel
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -86,7 +86,9 @@ def test_golden_fixtures_are_reproducible(tmp_path):
     (tmp_path / "tests" / "golden").mkdir(parents=True)
     r = subprocess.run([sys.executable, str(gen / "gen_golden.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
-    for name in ["readme_example.json", "test_base_case.json", "utils_vectors.json", "sample_table.json",
-                 "hse_config1.json", "hse_graph.json", "fuzz_small.json", "zipf_docs.json"]:
+    committed = sorted(f for f in os.listdir(os.path.join(ROOT, "tests", "golden")) if f.endswith(".json"))
+    assert len(committed) == 10 and "high_text.json" in committed and "traversal_synonyms.json" in committed
+    assert sorted(os.listdir(str(tmp_path / "tests" / "golden"))) == committed      # every fixture, and nothing else
+    for name in committed:
         assert filecmp.cmp(str(tmp_path / "tests" / "golden" / name), os.path.join(ROOT, "tests", "golden", name),
                            shallow=False), name
