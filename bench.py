@@ -236,11 +236,20 @@ def main():
     index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)    # also sizes the score scratch
     index.set_keyphrases(q_symbols, q_offsets)
 
+    local_s = [0.0]                                       # host time of the rank-local part of the steps (build + score)
+    gather_events = []                                    # (start, end) events around every all-gather
+
     def step():
+        t_a = time.perf_counter()
         index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)
-        index.score_resident(not args.denormalized, local_block.data_ptr())
+        index.score_resident(not args.denormalized, local_block.data_ptr())     # (returns when the block is written)
+        local_s[0] += time.perf_counter() - t_a
         if use_dist:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             dist.all_gather_into_tensor(full_table, local_block)           # RCCL over xGMI
+            e1.record()
+            gather_events.append((e0, e1))
 
     def fence():
         torch.cuda.synchronize()
@@ -268,6 +277,8 @@ def main():
     index.profile_enable(True)
     build_ms, score_ms = [], []
     fence()
+    local_s[0] = 0.0
+    del gather_events[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -278,10 +289,14 @@ def main():
     prof_timed = index.profile_report()
     index.profile_enable(False)
     index.profile_only(None)
+    step_local_ms = local_s[0] * 1e3 / args.steps
+    allgather_ms = sum(a.elapsed_time(b) for a, b in gather_events) / args.steps if gather_events else 0.0
+    rccl_world = None
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, step_local_ms, allgather_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, step_local_ms, allgather_ms = (float(x) for x in t.tolist())
+        rccl_world = dist.get_world_size()
     info = index.info()
 
     if rank == 0:
@@ -331,6 +346,19 @@ def main():
                               "rocprof_hbm_fraction; the timed steps bracket the dominant kernel only" % profile_steps,
             "lds_sorted": info.get("lds_sorted", 0),
         }
+        if use_dist:
+            # Multi-GPU accounting (the driver computes scaling efficiency itself from `value` at N = 1, 2, 4, 8 -- the
+            # same-shape N = 1 base of this line is the `config2` leg of the N = 1 line, see below): the rank-local
+            # part of a step (build + score, no collective; max over ranks), the all-gather behind it, and how much of
+            # the step the local part is -- the figure a perfectly scaling run keeps at 1.
+            out["multi_gpu"] = {"step_local_ms": step_local_ms, "allgather_ms": allgather_ms,
+                                "weak_scaling_efficiency": step_local_ms / ms_per_step if ms_per_step else None,
+                                "rccl_world_size": rccl_world, "backend": dist.get_backend(),
+                                "same_shape_single_gpu_base": "config2.value of the N=1 line (256 x 1 MiB docs, 10000 keyphrases)",
+                                "note": "max over ranks; efficiency = local / whole step (1 = the collective is free)"}
+        else:
+            out["scaling_base_note"] = ("--gpus N > 1 runs BASELINE configs[3]'s per-GPU shape (256 x 1 MiB documents, 10000 "
+                                        "keyphrases per rank): its single-GPU base is this line's config2.value, not value")
         if world == 1:
             out.update(first_build_leg(hip_backend, torch, local_rank, d_symbols, n, doc_offsets, n_strings, q_symbols,
                                        q_offsets, local_block, not args.denormalized, n_bytes))
