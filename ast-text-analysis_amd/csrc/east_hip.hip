@@ -133,8 +133,8 @@ __global__ __launch_bounds__(BLOCK) void codemap_kernel(const u32 *__restrict__ 
 // for every prefix length l = 1 .. SAMPLE_MAX_L, how many of them share their first l symbols (no terminator among
 // them) with at least one / at least three others of the sample.  Natural-language text repeats words within a few
 // thousand characters, random text does not: the host takes the window width and the fused finish from these counts
-// in the same build, no history needed.  One workgroup; counts by hashing into a table of 16-bit counters in LDS,
-// twice with different hashes, the smaller count taken (count-min).
+// in the same build, no history needed.  One workgroup per prefix length; counts by hashing into a table of 16-bit
+// counters in LDS, twice with different hashes, the smaller count taken (count-min).
 #define SAMPLE_N 8192
 #define SAMPLE_MAX_L 8
 #define SAMPLE_SLOTS 16384
@@ -152,7 +152,8 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_prefix_kernel(const u32
         s16[i] = c < TEXT_SYMBOLS ? (uint16_t)c : (uint16_t)0xFFFFu;
     }
     if (threadIdx.x < 2 * SAMPLE_MAX_L) acc[threadIdx.x] = 0;
-    for (int l = 1; l <= SAMPLE_MAX_L; l++) {
+    {
+        const int l = (int)blockIdx.x + 1;              // one workgroup per prefix length, side by side
         u32 first_count[PER];
         u32 d2 = 0, d4 = 0;
         for (int variant = 0; variant < 2; variant++) {
@@ -192,8 +193,8 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_prefix_kernel(const u32
         if (lane_id() == 0) { atomicAdd(&acc[2 * (l - 1)], d2); atomicAdd(&acc[2 * (l - 1) + 1], d4); }
     }
     __syncthreads();
-    if (threadIdx.x < 2 * SAMPLE_MAX_L) out[threadIdx.x] = acc[threadIdx.x];
-    if (threadIdx.x == 0) out[2 * SAMPLE_MAX_L] = count;
+    if (threadIdx.x < 2) out[2 * blockIdx.x + threadIdx.x] = acc[2 * blockIdx.x + threadIdx.x];
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[2 * SAMPLE_MAX_L] = count;
 }
 
 // Speculative build: presence bitmap AND byte stream in one pass over the symbols, the bytes through the code map of
@@ -587,7 +588,8 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
             for (u32 d = 1; d < n_docs; d++)
                 if (off32[d + 1] - off32[d] > off32[dl + 1] - off32[dl]) dl = d;
             const u32 len = off32[dl + 1] - off32[dl], cnt = std::min<u32>(SAMPLE_N, len);
-            LAUNCH_BLOCK(ctx, sample_prefix_kernel, 1, SAMPLE_THREADS, d_sym, n, off32[dl] + (len - cnt) / 2, cnt, flags + FLAG_SAMPLE);
+            LAUNCH_BLOCK(ctx, sample_prefix_kernel, SAMPLE_MAX_L, SAMPLE_THREADS, d_sym, n, off32[dl] + (len - cnt) / 2, cnt,
+                         flags + FLAG_SAMPLE);
         }
         if (!ctx.dry) {
             if (ctx.spec) {

@@ -370,6 +370,7 @@ def main():
                 # the reference's constructor also fills the child tables (easa.py:16-24); here they are built on first request
                 out["build_ms_constructor"] = out["build_ms"] + out["child_tables_ms"]
         if world == 1 and not args.no_config2 and default_shape:
+            out["from_text"] = from_text_leg(hip_backend, synthetic, local_rank)
             out["config2"] = config2_leg(args, hip_backend, synthetic, torch, dev, local_rank)
             out["config5"] = config5_leg(args, hip_backend, synthetic, torch, dev, local_rank)
         if world == 1 and not args.no_cpu_baseline:
@@ -469,6 +470,49 @@ def first_build_leg(hip_backend, torch, local_rank, d_symbols, n, doc_offsets, n
                                  "u32_passes": info.get("radix_passes_u32"), "refine_rounds": info.get("refine_rounds")},
             "first_build_note": "fresh handle per repetition (%d), no hints from earlier builds; value_first_build = input "
                                 "bytes / (build wall + score wall)" % reps}
+
+
+def from_text_leg(hip_backend, synthetic, local_rank):
+    """What `east keyphrases table` runs before it can score (reference east/main.py:67-89 -> utils.py:31-79): raw
+    text as Python `bytes` -> prepared, indexed collection on the device, through east_hip_build_texts[_v] (upload of
+    the raw bytes, text preparation kernels, build).  Wall clock around HipIndex.build_texts; configs[1]'s 64 MiB
+    ASCII word stream, and 64 documents of 1 MiB drawn from the prose that ships with the image (if there is any)."""
+    res = {}
+    hip_backend.unicode_tables()
+    cases = []
+    text = synthetic.word_stream_document(np.random.default_rng(20240 + 2), 64 << 20)[0]
+    cases.append(("ascii_64MiB", [text]))
+    raw, _ = synthetic.image_prose(24 << 20, False)
+    if len(raw) > (2 << 20):
+        rng = np.random.default_rng(20245)
+        lines = [ln for ln in raw.split(b"\n") if len(ln) > 20]
+        lens = np.array([len(ln) + 1 for ln in lines])
+        picks = rng.integers(0, len(lines), size=int((64 << 20) / lens.mean()) + 1)
+        big = b"\n".join(lines[i] for i in picks)[:64 << 20]
+        cases.append(("prose_64x1MiB", [big[i:i + (1 << 20)] for i in range(0, len(big), 1 << 20)]))
+    for name, texts in cases:
+        n_bytes = sum(len(t) for t in texts)
+        firsts, walls, preps, builds = [], [], [], []
+        for rep in range(3):                                # fresh handles: the first call of a process (+ arena allocation)
+            index = hip_backend.HipIndex(local_rank)
+            t0 = time.perf_counter()
+            index.build_texts(texts)
+            firsts.append((time.perf_counter() - t0) * 1e3)
+            if rep == 2:
+                for _ in range(3):                          # the same handle again: allocations in place
+                    t0 = time.perf_counter()
+                    index.build_texts(texts)
+                    walls.append((time.perf_counter() - t0) * 1e3)
+                    preps.append(index.last_prep_ms)
+                    builds.append(index.last_build_ms)
+                info = index.info()
+            index.close()
+        res[name] = {"bytes": n_bytes, "docs": len(texts), "symbols": info["n_total"],
+                     "wall_ms": min(walls), "prep_ms": min(preps), "build_ms": min(builds),
+                     "first_call_wall_ms": min(firsts[1:]), "chars_per_s": n_bytes / (min(walls) * 1e-3),
+                     "note": "wall = Python bytes -> finished index (H2D of the raw text from pageable memory included); "
+                             "first_call = fresh handle, arena allocation included"}
+    return res
 
 
 def config5_leg(args, hip_backend, synthetic, torch, dev, local_rank):
