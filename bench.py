@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured)
 BUILD_KERNEL_PREFIXES = ("radix_", "lvl0_", "ann_", "pyramid_", "presence_", "remap_", "codemap_", "validate_", "scan_",
-                         "dc3_", "lcp", "doc_", "inverse_sa", "spec_counts")
+                         "dc3_", "lcp", "doc_", "inverse_sa", "spec_counts", "refine_", "lg_", "sample_")
 
 
 def parse():
@@ -133,6 +133,29 @@ def make_corpus(args, synthetic, rng, n_docs, doc_bytes):
     symbols = np.concatenate(parts) if len(parts) > 1 else parts[0]
     doc_offsets = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.int64)
     return symbols, doc_offsets, np.array(ms, dtype=np.int32), vocab is not None
+
+
+def load_traffic(name):
+    """HBM bytes per launch per kernel from the PMC passes (profiles/traffic*.json, tools/summarize_profiles.py)."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+
+
+def pmc_by_kernel(prof, steps, traffic, top=14):
+    """Per kernel: time per step and -- where the PMC passes have a figure -- HBM bytes per step and the fraction of the
+    8 TB/s peak that is (counter bytes / HIP-event time)."""
+    total = sum(ms for _, ms in prof.values())
+    rows = []
+    for name, (launches, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:top]:
+        row = {"kernel": name, "ms_per_step": ms / steps, "launches_per_step": launches / steps, "share_of_kernel_time": ms / total}
+        if name in traffic:
+            gbs = traffic[name] * launches / (ms * 1e-3) / 1e9
+            row.update({"pmc_bytes_per_step": traffic[name] * launches / steps, "pmc_GBps": gbs, "pmc_frac": gbs / HBM_PEAK_GBS})
+        rows.append(row)
+    return rows
 
 
 def roofline_of(prof, info, n, n_docs, steps, traffic):
@@ -302,12 +325,10 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * n_bytes / (elapsed / args.steps)
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        traffic = {}
         default_shape = (D, doc_mib, K, args.mode, args.corpus) == (1, 64.0, 1000, "text", "words") and not args.duplicate_docs
-        if os.path.exists(traffic_file) and default_shape:       # (the counters were collected on the default workload)
-            with open(traffic_file) as f:
-                traffic = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        zipf_shape = (D, doc_mib, K, args.mode, args.corpus) == (100, 1.0, 1000, "text", "zipf") and not args.duplicate_docs
+        # (the counters were collected on these two workloads: tools/profile_round.sh, tools/profile_zipf.sh)
+        traffic = load_traffic("traffic.json") if default_shape else load_traffic("traffic_zipf.json") if zipf_shape else {}
         roofline, by_kernel, per_step = roofline_of(prof, info, n, D, profile_steps, traffic)
         live = prof_timed.get(dom_name)
         if live and live[0]:                             # the dominant kernel as measured inside the timed region
@@ -555,8 +576,10 @@ def config5_leg(args, hip_backend, synthetic, torch, dev, local_rank):
     index.close()
     first = first_build_leg(hip_backend, torch, local_rank, d_symbols, n, doc_offsets, n_strings, qs, qo, block, True,
                             D * (1 << 20), reps=2)
+    traffic = load_traffic("traffic_zipf.json")             # PMC passes of this workload (tools/profile_zipf.sh)
     return {"first_build_ms": first["first_build_ms"], "value_first_build": first["value_first_build"],
             "first_build_plan": first["first_build_plan"],
+            "roofline_by_kernel": pmc_by_kernel(prof, steps, traffic), "rocprof_hbm_fraction": hbm_fraction(prof, traffic),
             "workload": "100 synthetic 1 MiB Zipf natural-language-like docs (text mode), 1000 keyphrases, normalized",
             "steps": steps, "ms_per_step": elapsed * 1e3 / steps, "value": D * (1 << 20) / (elapsed / steps), "unit": "chars/s",
             "symbols": n, "build_ms": float(np.mean(build_ms)), "score_ms": float(np.mean(score_ms)),

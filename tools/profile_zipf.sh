@@ -1,12 +1,16 @@
 #!/bin/bash
-# rocprofv3 kernel statistics of the config 5 stand-in (100 x 1 MiB Zipf documents) -> gpurun_out/zipf/
+# rocprofv3 kernel statistics + the two PMC passes of the config 5 stand-in (100 x 1 MiB Zipf documents)
+# -> gpurun_out/zipf/; summarise with  tools/summarize_profiles.py r03_zipf zipf traffic_zipf.json
 set -u
+cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-export TMPDIR=/tmp
-mkdir -p gpurun_out/zipf
+OUT=gpurun_out/zipf
+rm -rf "$OUT"; mkdir -p "$OUT"
 ARGS="--corpus zipf --docs 100 --doc-mib 1 --keyphrases 1000 --no-cpu-baseline --no-config2 --no-extras"
-timeout 300 python3 bench.py $ARGS 2>/dev/null | tail -1 > gpurun_out/zipf/bench.json
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/zipf/trace -- python3 bench.py $ARGS --steps 5 --warmup 2 > gpurun_out/zipf/bench_profiled.json 2>/dev/null
+timeout 300 python3 bench.py $ARGS 2>/dev/null | tail -1 > $OUT/bench.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS --steps 5 --warmup 2 > $OUT/bench_profiled.json 2>/dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS --steps 2 --warmup 1 > $OUT/fetch.json 2> $OUT/fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 bench.py $ARGS --steps 2 --warmup 1 > $OUT/write.json 2> $OUT/write.err
 python3 - <<'PY'
 import csv, glob, json
 b = json.load(open("gpurun_out/zipf/bench.json"))

@@ -23,9 +23,13 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "final")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
+# summarize_profiles.py <tag> [<directory under gpurun_out/>] [<traffic file name>]
+#   r03_final final traffic.json        (tools/profile_round.sh, the default workload)
+#   r03_zipf  zipf  traffic_zipf.json   (tools/profile_zipf.sh, the config 5 stand-in)
+SRC = os.path.join(ROOT, "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "final")
+TRAFFIC = sys.argv[3] if len(sys.argv) > 3 else "traffic.json"
 
 
 # kernels whose reads are dominated by random gathers / whose writes by random scatters
@@ -36,7 +40,12 @@ GATHER = ("dc3_merge_tile_kernel", "dc3_merge_partition_kernel", "dc3_merge_lcp_
           "dc3_pair_keys_kernel", "dc3_gather_third_kernel", "ann_wide_kernel", "child_kernel", "doc_keys_kernel",
           # mixed: a streaming pass (counted at 1/2) plus text gathers for the tied suffixes (counted in full);
           # with c = 1 the figure is a lower bound, short by the streamed half (4 B/suffix)
-          "dc3_refine_classify_kernel", "lvl0_place_kernel", "lvl0_lcp_keys_kernel", "dc3_refine_keys_kernel")
+          "dc3_refine_classify_kernel", "lvl0_place_kernel", "lvl0_lcp_keys_kernel", "dc3_refine_keys_kernel",
+          # the fused finish: 8 B per suffix streamed in (counted at 1/2: the figure is short by 4 B per suffix) plus one
+          # 4-byte text gather per tied suffix (a 64-byte sector, counted in full)
+          "lvl0_finish_kernel", "lvl0_lcp_text_kernel",
+          # the in-LDS round: 12 B per element streamed (short by 6 B per element) plus a 16-byte text gather each
+          "refine_lds_sort_kernel", "dc3_double_keys_kernel")
 
 
 def short(name):
@@ -48,7 +57,7 @@ def short(name):
         name = name.replace(", PairSrc<%s>>" % k, ">").replace(", WindowSrc<%s>>" % k, ",gen>")
         name = name.replace(", TextWindowGen<%s>>" % k, ",gen>")
     for plain in ("dc3_refine_classify_kernel", "dc3_refine_compact_kernel", "dc3_refine_restore_kernel", "lvl0_place_kernel",
-                  "lvl0_lcp_keys_kernel", "validate_n_strings_kernel", "score_walk_kernel"):
+                  "lvl0_lcp_keys_kernel", "validate_n_strings_kernel", "score_walk_kernel", "lvl0_finish_kernel"):
         if name.startswith(plain + "<"):
             name = plain
     return name
@@ -96,10 +105,13 @@ names = {"radix_scatter_kernel<u64>": "radix_scatter_kernel<u64>", "radix_scatte
 out = {"_note": "HBM bytes per launch = (c*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of "
                 "`python3 bench.py --steps 2 --warmup 1`; c = 2 for streaming kernels (gfx950 counts wide streaming "
                 "reads at 1/2, calibrated on remap_kernel), c = 1 for gather kernels (64-byte sector requests)",
+       "_fetch_correction_1": "kernels priced with c = 1 (a LOWER bound where part of their reads is 16-byte streaming: "
+                              "lvl0_finish_kernel / lvl0_place_kernel are short by about 4 B per suffix, the refinement "
+                              "rounds' kernels by half of their streamed reads): " + ", ".join(sorted(k for k in traffic if k in GATHER)),
        "_workload": bench["config"]["workload"]}
 for k, v in traffic.items():
     out[names.get(k, k)] = v
-json.dump(out, open(os.path.join(DST, "traffic.json"), "w"), indent=1, sort_keys=True)
+json.dump(out, open(os.path.join(DST, TRAFFIC), "w"), indent=1, sort_keys=True)
 # the bench lines of this very run carry the PMC traffic of this run (bench.py itself reads the
 # traffic.json that was committed before it started)
 for name in (tag + "_bench.json", tag + "_bench_profiled.json"):
