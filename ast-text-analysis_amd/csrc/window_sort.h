@@ -499,6 +499,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     if (threadIdx.x == 0) { n_keep = 0; n_work = 0; }
     __syncthreads();
     const u32 j0 = (blockIdx.x * BLOCK + threadIdx.x) * PLACE_IPT;
+    u32 my_keep = 0;                                    // suffixes this thread left to the rounds
     {   // PLACE_HALO entries to either side of the stretch (threads 0 .. 2*PLACE_HALO-1, one each)
         const u32 stretch0 = blockIdx.x * (BLOCK * PLACE_IPT);
         if (threadIdx.x < 2 * PLACE_HALO) {
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
                     if (names_g) names_g[j] = start[e];
                     const u32 local = threadIdx.x * PLACE_IPT + e;
                     atomicOr(&keep_bits[local >> 5], 1u << (local & 31u));
-                    atomicAdd(&n_keep, 1u);
+                    my_keep++;
                 } else {
                     work[atomicAdd(&n_work, 1u)] = j;    // phase 2
                 }
@@ -621,9 +622,13 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
                             limit, max_len, (u32 *)nullptr, lr, ns)) {
             const u32 local = j - blockIdx.x * (BLOCK * PLACE_IPT);
             atomicOr(&keep_bits[local >> 5], 1u << (local & 31u));
-            atomicAdd(&n_keep, 1u);
+            my_keep++;
         }
     }
+    // (the count: one LDS atomic per wavefront -- natural-language text keeps hundreds of suffixes per stretch, and as
+    // many adds to one word queue up behind one another)
+    my_keep = wave_sum(my_keep);
+    if (lane_id() == 0 && my_keep) atomicAdd(&n_keep, my_keep);
     __syncthreads();
     // (entries m.. are 0: the exclusive scan over m + 1 entries yields the total)
     if (threadIdx.x < BLOCK * PLACE_IPT / 64)
@@ -969,6 +974,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     // ---- placement on the staged, sorted keys ----------------------------------------------------------
     const KeyNeqWindowIn<K> f{a.keys, a.rep_t, a.ones, a.highs};   // (keys / vals: never read -- everything the tie code touches is staged; a null pointer here crashes hipcc 7.2)
     const int w = a.w, b = a.b, spare = a.spare;
+    u32 my_keep = 0;                                    // suffixes this thread left to the rounds (summed per wavefront at the end)
     auto kg_mark = [&](u32 j, K k, K kp) {              // k-gram bucket starts, read off the keys (see KgMark)
         const int top = spare + (w - a.km.k) * b;
         if (j == 0 || (K)(k >> top) != (K)(kp >> top)) {
@@ -991,7 +997,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
             if (((K)(xt - a.top_ones) & ~xt & a.top_highs) != 0) return true;   // a constant bucket: final as it stands
             a.order_g[j] = sa_o;
             atomicOr(&keep_bits[i >> 5], 1u << (i & 31));
-            atomicAdd(&n_keep, 1u);
+            my_keep++;
             if (first) {
                 atomicOr(&gs_bits[i >> 5], 1u << (i & 31));
                 if (a.lcp_g) a.lcp_g[j] = lcp_o;
@@ -1020,7 +1026,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
         if (big) {
             a.order_g[j] = sa_o;
             atomicOr(&keep_bits[i >> 5], 1u << (i & 31));
-            atomicAdd(&n_keep, 1u);
+            my_keep++;
             if (st) {
                 atomicOr(&gs_bits[i >> 5], 1u << (i & 31));
                 if (a.lcp_g) a.lcp_g[j] = lcp_o;
@@ -1096,7 +1102,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
             const u32 j = base + (u32)i;
             a.order_g[j] = vt[i];
             atomicOr(&keep_bits[i >> 5], 1u << (i & 31));
-            atomicAdd(&n_keep, 1u);
+            my_keep++;
             const K k = kt[i], x = k ^ a.rep_t;
             if (j == 0 || ((K)(x - a.ones) & ~x & a.highs) != 0 || k != kt[i - 1]) {     // the first of its group
                 atomicOr(&gs_bits[i >> 5], 1u << (i & 31));
@@ -1104,6 +1110,8 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
             }
         }
     }
+    my_keep = wave_sum(my_keep);
+    if (lane_id() == 0 && my_keep) atomicAdd(&n_keep, my_keep);
     __syncthreads();
     // the bits of the ranks [c0, c0 + FIN_CHUNK + FIN_G): OR-ed into the global words (the overhang shares its words with
     // the next workgroup); nearly all of them are zero
