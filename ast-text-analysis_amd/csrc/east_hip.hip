@@ -1759,6 +1759,7 @@ int east_hip_debug_set_window_sort(int enabled)
     g_force_lean = enabled == 2;
     g_force_wide_keys = enabled == 3 || enabled == 5;
     g_fused_finish = enabled != 4 && enabled != 5 && getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;
+    g_force_fused = enabled == 6;                        // 6: as 1, the fused finish whatever the plan says (skewed text through it)
     g_plan_epoch++;
     return EAST_HIP_OK;
 }

@@ -32,6 +32,7 @@ static bool g_force_wide_keys = getenv("EAST_HIP_WIDE_KEYS") != nullptr;        
 static bool g_force_lean = false;                           // east_hip_debug_set_window_sort(2) (tests)
 static bool g_window_sort = true;                            // east_hip_debug_set_window_sort (tests)
 static bool g_fused_finish = getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;    // east_hip_debug_set_window_sort(4 / 5) (tests, A/B timing)
+static bool g_force_fused = false;                           // east_hip_debug_set_window_sort(6): the fused finish whatever the plan says (tests: skewed text through it)
 struct FusedAbort {};           // the fused finish met a repeat too long to order directly: the level is redone with the full sort
 
 #define RESOLVE_MAX_LEN 2048            // longest direct comparison of two suffixes (symbols)
@@ -659,13 +660,15 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
 //     equal FULL keys join them at the same depth (they agree on more, which does no harm).
 #define FIN_IPT 4
 #define FIN_CHUNK (BLOCK * FIN_IPT)
-#ifndef FIN_G
-#define FIN_G 64
-#endif
-#define FIN_LEFT (FIN_G + 4)                        // staged entries in front of the stretch (>= FIN_G + 1; a multiple of 4: a thread's four flags share a word)
-#define FIN_RIGHT (FIN_G + 4)                       // ... behind it (>= FIN_G + 1)
-#define FIN_STAGE (FIN_LEFT + FIN_CHUNK + FIN_RIGHT)
-#define FIN_WORDS ((FIN_STAGE + 31) / 32 + 1)
+// FIN_G = the largest bucket ordered here; the kernel exists for 64 (the default) and 32 (a smaller halo: 3 % less to
+// stage, for inputs whose buckets are expected to hold at most ten suffixes)
+template <int G> struct FinGeom {
+    static constexpr int LEFT = G + 4;                  // staged entries in front of the stretch (>= G + 1; a multiple of 4: a thread's four flags share a word)
+    static constexpr int RIGHT = G + 4;                 // ... behind it (>= G + 1)
+    static constexpr int STAGE = LEFT + FIN_CHUNK + RIGHT;
+    static constexpr int WORDS = (STAGE + 31) / 32 + 1;
+    static constexpr int SCAN_WORDS = (G + 4 + 31) / 32 + 1;
+};
 
 template <class K> struct FinishArgs {
     const K *keys;
@@ -683,29 +686,28 @@ template <class K> struct FinishArgs {
     KgMark km;
 };
 
-// highest set bit of fl[] in [lo, i] / lowest in [i, hi]; -1 if none (the ranges span at most FIN_G + 4 bits)
-#define FIN_SCAN_WORDS ((FIN_G + 4 + 31) / 32 + 1)
-__device__ __forceinline__ int fin_prev_bit(const u32 *fl, int i, int lo)
+// highest set bit of fl[] in [lo, i] / lowest in [i, hi]; -1 if none (the ranges span at most G + 4 bits)
+template <class GE> __device__ __forceinline__ int fin_prev_bit(const u32 *fl, int i, int lo)
 {
     int found = -1;
     int wi = i >> 5;
     u32 word = fl[wi] & (0xFFFFFFFFu >> (31 - (i & 31)));
 #pragma unroll
-    for (int step = 0; step < FIN_SCAN_WORDS; step++) {
+    for (int step = 0; step < GE::SCAN_WORDS; step++) {
         if (found < 0 && word) found = (wi << 5) + 31 - __clz(word);
         if (found < 0 && wi > 0) { wi--; word = fl[wi]; } else word = 0;
     }
     return found >= lo ? found : -1;
 }
-__device__ __forceinline__ int fin_next_bit(const u32 *fl, int i, int hi)
+template <class GE> __device__ __forceinline__ int fin_next_bit(const u32 *fl, int i, int hi)
 {
     int found = -1;
     int wi = i >> 5;
     u32 word = fl[wi] & (0xFFFFFFFFu << (i & 31));
 #pragma unroll
-    for (int step = 0; step < FIN_SCAN_WORDS; step++) {
+    for (int step = 0; step < GE::SCAN_WORDS; step++) {
         if (found < 0 && word) found = (wi << 5) + __ffs(word) - 1;
-        if (found < 0 && wi + 1 < (int)FIN_WORDS) { wi++; word = fl[wi]; } else word = 0;
+        if (found < 0 && wi + 1 < GE::WORDS) { wi++; word = fl[wi]; } else word = 0;
     }
     return found >= 0 && found <= hi ? found : -1;
 }
@@ -802,9 +804,11 @@ __device__ __forceinline__ u32 fin_place_tied(const FinishArgs<K> &a, int i, con
     return 0;
 }
 
-template <class K, bool ENDGAME_LIMITS>
+template <class K, bool ENDGAME_LIMITS, int FIN_G>
 __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
 {
+    using GE = FinGeom<FIN_G>;
+    constexpr int FIN_LEFT = GE::LEFT, FIN_STAGE = GE::STAGE, FIN_WORDS = GE::WORDS;
     constexpr u32 limit = ENDGAME_LIMITS ? (REFINE_ENDGAME_GROUP < FIN_G ? REFINE_ENDGAME_GROUP : FIN_G) : REFINE_SMALL_GROUP;
     constexpr u32 max_len = ENDGAME_LIMITS ? REFINE_ENDGAME_LEN : RESOLVE_MAX_LEN;
     constexpr int HELD = FIN_IPT + 1;                   // a thread holds 4 pairs of the stretch and (threads 0 .. FIN_G) one of the right halo
@@ -894,13 +898,13 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     int s[HELD], en[HELD];
     u32 own = 0, hot = 0;
     {
-        int run = (myfl & 1u) ? i0 : fin_prev_bit(fl, i0, i0 - G + 1);
+        int run = (myfl & 1u) ? i0 : fin_prev_bit<GE>(fl, i0, i0 - G + 1);
 #pragma unroll
         for (int e = 0; e < FIN_IPT; e++) {
             if (e > 0 && ((myfl >> e) & 1u)) run = i0 + e;
             s[e] = run >= i0 + e - G + 1 ? run : -1;
         }
-        int nxt = fin_next_bit(fl, i0 + FIN_IPT, i0 + FIN_IPT - 1 + G);
+        int nxt = fin_next_bit<GE>(fl, i0 + FIN_IPT, i0 + FIN_IPT - 1 + G);
 #pragma unroll
         for (int e = FIN_IPT - 1; e >= 0; e--) {
             en[e] = nxt;
@@ -914,9 +918,9 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
         }
         s[FIN_IPT] = en[FIN_IPT] = -1;
         if (valid & 16u) {
-            const int sh = (myfl & 16u) ? ih : fin_prev_bit(fl, ih, ih - G + 1);
+            const int sh = (myfl & 16u) ? ih : fin_prev_bit<GE>(fl, ih, ih - G + 1);
             if (sh >= (int)FIN_LEFT && sh < (int)(FIN_LEFT + FIN_CHUNK)) {
-                const int eh = fin_next_bit(fl, ih + 1, sh + G);
+                const int eh = fin_next_bit<GE>(fl, ih + 1, sh + G);
                 if (eh >= 0) { s[FIN_IPT] = sh; en[FIN_IPT] = eh; own |= 16u; }
             }
         }
@@ -1438,15 +1442,21 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     for (int j = 0; j < w; j++)
         if (spare + j * bt >= FIN_LOW_BITS) depth0++;
     bool fused = allow_fused && g_fused_finish && n0 == 0 && total_bits >= 2 * FIN_LOW_BITS && depth0 >= 1;
+    bool fin_small_halo = false;                        // buckets of at most ten suffixes expected: the kernel with the halo of 32
     if (fused && !ctx.dry) {
-        if (ctx.plan_fused >= 0) {
+        if (g_force_fused) {
+            // (test knob: buckets of any size -- the large ones go to the rounds)
+        } else if (ctx.plan_fused >= 0) {
             fused = ctx.plan_fused != 0;                 // (speculative build: as the build before)
+            fin_small_halo = ctx.plan_fused == 2;
         } else {
             // expected members of a bucket, were the text uniform
             double top_codes = pow((double)term_first, depth0);
             const int part = (spare + (w - depth0) * bt) - FIN_LOW_BITS;   // bits of the next symbol inside the top part
             if (part > 0) top_codes *= std::max(1.0, (double)term_first / (double)(1u << (bt - part)));
-            fused = (double)(longest ? longest : n02) / top_codes <= FIN_MAX_EXPECTED;
+            const double expected = (double)(longest ? longest : n02) / top_codes;
+            fused = expected <= FIN_MAX_EXPECTED;
+            fin_small_halo = expected <= 10.0;
             // skewed text behind a narrow window: many buckets would be handed to the rounds whole (measured on the
             // Zipf stand-in: 8.9 against 8.2 ms); the sample tells -- more than 1 in 20 of its suffixes sharing the
             // symbols of the top part with three others of the sample is natural language, random text has none
@@ -1455,7 +1465,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         }
     }
     const int low_bits = fused ? FIN_LOW_BITS : 0;
-    if (n0 == 0) ctx.did_fused = fused;
+    if (n0 == 0) ctx.did_fused = fused ? (fin_small_halo ? 2 : 1) : 0;
     if (ctx.stats && n0 == 0) ctx.stats->fused_finish = fused;
     SortBufs<K> sb;
     // (one spare element each: the idle half serves as scratch after the sort)
@@ -1527,8 +1537,9 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     auto place = [&](int mode) {
         if (fused) {
             if (mode != 0) throw FusedAbort();
-            if (small_input) LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, true>), gp, fa);
-            else LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, false>), gp, fa);
+            if (small_input) LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, true, 64>), gp, fa);
+            else if (fin_small_halo) LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, false, 32>), gp, fa);
+            else LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, false, 64>), gp, fa);
         } else if (small_input)
             LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, true, false>), gp, starts, sorted_vals, n02, s8, n0, w,
                          bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());

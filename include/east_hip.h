@@ -282,7 +282,8 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes);
  * the device were short of memory for the tie-refinement rounds ("lean"); 3 = window sort on with
  * 64-bit window keys even where 32 bits suffice (the code path of large inputs, on small ones);
  * 4 / 5 = as 1 / 3 with every radix pass global and the separate placement pass (the fused finish,
- * csrc/window_sort.h: lvl0_finish_kernel, switched off).
+ * csrc/window_sort.h: lvl0_finish_kernel, switched off); 6 = as 1 with the fused finish whatever the build's
+ * plan says (skewed text, whose large buckets it hands to the refinement rounds).
  * The test knobs of this section are PROCESS-WIDE (they exist to steer a test run through every code path):
  * set them while no build is in flight on any handle. */
 int east_hip_debug_set_window_sort(int enabled);

@@ -699,6 +699,47 @@ def test_build_from_resident_symbols_at_any_alignment(hip, oracle, shift):
         assert np.array_equal(t[name], getattr(o, name)), name
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_fused_finish_on_skewed_text(hip, oracle, seed):
+    """The fused finish forced (knob 6) on text it is not planned for: natural-language-like documents with planted
+    repeats, whose top-part buckets hold hundreds of suffixes -- they are handed to the refinement rounds as tie groups at the
+    depth of the top part, the k-gram marks are found incomplete and the score side builds its own tables.  Tables and
+    scores are the oracle's."""
+    from east import hip_backend, synthetic
+    assert hip.load().east_hip_debug_set_window_sort(6) == 0          # (the autouse fixture restores the default)
+    rng = np.random.default_rng(8800 + seed)
+    vocab = synthetic.zipf_vocabulary(rng, size=int(rng.choice([30, 400])), exponent=1.0)
+    docs = [synthetic.zipf_document(rng, int(rng.integers(120000, 400000)), vocab) for _ in range(1 + seed)]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    ms = np.array([d[1] for d in docs])
+    index = hip_backend.HipIndex()
+    index.build(sym, off, ms)
+    info = index.info()
+    assert info["fused_finish"] == 1 and info["window_sorted"] == 1 and info["refine_rounds"] >= 1, info
+    queries = []
+    for d in range(len(docs)):
+        text = docs[d][0]
+        for _ in range(6):
+            a = int(rng.integers(0, text.size - 40))
+            q = text[a:a + int(rng.integers(3, 30))]
+            q = q[q < 0x0A00]
+            if q.size:
+                queries.append(q)
+    qs = np.concatenate(queries)
+    qo = np.concatenate([[0], np.cumsum([q.size for q in queries])])
+    for normalized in (True, False):
+        table = index.score_table(qs, qo, normalized)
+        for d in range(len(docs)):
+            o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+            if normalized:
+                t = index.tables(d)
+                for name in TABLES:
+                    assert np.array_equal(t[name], getattr(o, name)), (name, d, info)
+            for k, q in enumerate(queries):
+                assert table[k, d] == o.score_symbols(q, normalized, fast=True), (k, d, normalized)
+
+
 @pytest.mark.parametrize("knob", [3, 5])
 @pytest.mark.parametrize("seed", range(4))
 def test_wide_window_keys_on_small_inputs(hip, oracle, seed, knob):
