@@ -454,6 +454,11 @@ struct east_hip_index {
     bool kg_built = false;
     bool kg_marked = false;      // the bucket starts were written by the build (off the window keys): only the fill is due
     float last_build_ms = -1.f, last_score_ms = -1.f, last_prep_ms = -1.f;
+    // the caller's Unicode tables of the device text preparation (own allocation, re-uploaded when their hash changes)
+    char *tp_tables = nullptr;
+    size_t tp_tables_bytes = 0;
+    u64 tp_tables_hash = 0;
+    std::vector<uint8_t> tp_host_tables;
     // symbols prepared on the device by east_hip_build_texts (own allocation)
     u32 *prep_sym = nullptr;
     size_t prep_cap = 0;
@@ -977,13 +982,8 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     ctx.prof = &h->prof;
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));
 
-    uint8_t *d_bytes = ar.alloc<uint8_t>((size_t)n_bytes + 8);
+    uint8_t *d_bytes = ar.alloc<uint8_t>((size_t)n_bytes + 32);    // (padding: the byte-class pass loads whole 16-byte groups)
     u32 *d_text_off = ar.alloc<u32>((size_t)D + 1);
-    uint8_t *d_class = ar.alloc<uint8_t>(TP_TEXT_LIMIT);
-    u32 *d_upper = ar.alloc<u32>(TP_TEXT_LIMIT);
-    u32 *d_word_hi = ar.alloc<u32>(TP_WORD_HI_WORDS);
-    u32 *d_digit_hi = ar.alloc<u32>(TP_WORD_HI_WORDS);
-    u32 *d_hi_from = ar.alloc<u32>((size_t)n_hi_upper + 1), *d_hi_to = ar.alloc<u32>((size_t)n_hi_upper + 1);
     u32 *d_high = ar.alloc<u32>(1);
     std::vector<u32> off32((size_t)D + 1);
     for (u32 d = 0; d <= D; d++) off32[d] = (u32)text_offsets[d];
@@ -996,16 +996,68 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     } else {
         HIP_CHECK(hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, h->stream));
     }
-    HIP_CHECK(hipMemsetAsync(d_bytes + n_bytes, 0, 8, h->stream));
+    HIP_CHECK(hipMemsetAsync(d_bytes + n_bytes, 0, 32, h->stream));
     HIP_CHECK(hipMemcpyAsync(d_text_off, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(hipMemcpyAsync(d_class, cp_class, TP_TEXT_LIMIT, hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(hipMemcpyAsync(d_upper, cp_upper, TP_TEXT_LIMIT * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(hipMemcpyAsync(d_word_hi, word_hi, TP_WORD_HI_WORDS * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(hipMemcpyAsync(d_digit_hi, digit_hi, TP_WORD_HI_WORDS * 4, hipMemcpyHostToDevice, h->stream));
-    if (n_hi_upper) {
-        HIP_CHECK(hipMemcpyAsync(d_hi_from, hi_upper_from, (size_t)n_hi_upper * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_CHECK(hipMemcpyAsync(d_hi_to, hi_upper_to, (size_t)n_hi_upper * 4, hipMemcpyHostToDevice, h->stream));
+    // The caller's Unicode tables (290 KB) stay on the device between calls (own allocation): they are uploaded again only
+    // when their content changes -- a 64-bit hash over all of them, taken while the text is on its way.  With them go the two
+    // 256-entry tables of the byte-wise fast path (class and upper-cased code point of a byte that is a code point of its own).
+    const size_t tb_class = 0, tb_upper = tb_class + TP_TEXT_LIMIT, tb_word = tb_upper + (size_t)TP_TEXT_LIMIT * 4,
+                 tb_digit = tb_word + (size_t)TP_WORD_HI_WORDS * 4, tb_from = tb_digit + (size_t)TP_WORD_HI_WORDS * 4,
+                 tb_to = tb_from + ((size_t)n_hi_upper + 1) * 4, tb_cls256 = tb_to + ((size_t)n_hi_upper + 1) * 4,
+                 tb_up256 = tb_cls256 + 256, tb_total = tb_up256 + 1024;
+    {
+        u64 hash = 0x9E3779B97F4A7C15ull ^ (u64)n_hi_upper;
+        auto mix = [&](const void *p, size_t bytes) {
+            const u64 *q = (const u64 *)p;
+            for (size_t i = 0; i < bytes / 8; i++) hash = (hash ^ q[i]) * 0x100000001B3ull + (hash >> 29);
+        };
+        mix(cp_class, TP_TEXT_LIMIT); mix(cp_upper, (size_t)TP_TEXT_LIMIT * 4); mix(word_hi, (size_t)TP_WORD_HI_WORDS * 4);
+        mix(digit_hi, (size_t)TP_WORD_HI_WORDS * 4);
+        for (int32_t q = 0; q < n_hi_upper; q++) hash = (hash ^ (((u64)hi_upper_from[q] << 32) | hi_upper_to[q])) * 0x100000001B3ull + (hash >> 29);
+        if (!h->tp_tables || h->tp_tables_bytes < tb_total || h->tp_tables_hash != hash) {
+            if (h->tp_tables_bytes < tb_total) {
+                HIP_CHECK(hipStreamSynchronize(h->stream));
+                if (h->tp_tables) HIP_CHECK(hipFree(h->tp_tables));
+                h->tp_tables = nullptr;
+                h->tp_tables_bytes = 0;
+                void *p = nullptr;
+                if (hipMalloc(&p, tb_total) != hipSuccess) east_throw(EAST_HIP_ERR_OOM, "hipMalloc of the Unicode tables failed");
+                h->tp_tables = (char *)p;
+                h->tp_tables_bytes = tb_total;
+            }
+            h->tp_host_tables.resize(256 + 1024);
+            uint8_t *cls256 = h->tp_host_tables.data();
+            u32 *up256 = reinterpret_cast<u32 *>(h->tp_host_tables.data() + 256);
+            for (u32 x = 0; x < 256; x++) {              // (as tp_decode_kernel: upper first, then the class of the result)
+                u32 cp = x < 0x80u ? cp_upper[x] : TP_REPLACEMENT;
+                if (cp >= TP_TEXT_LIMIT) {
+                    for (int32_t q = 0; q < n_hi_upper; q++)
+                        if (hi_upper_from[q] == cp) { cp = hi_upper_to[q]; break; }
+                }
+                u32 cls;
+                if (cp < TP_TEXT_LIMIT) cls = cp_class[cp];
+                else { const u32 k = cp - TP_TEXT_LIMIT; cls = ((word_hi[k >> 5] >> (k & 31u)) & 1u) | (((digit_hi[k >> 5] >> (k & 31u)) & 1u) << 1); }
+                cls256[x] = (uint8_t)cls;
+                up256[x] = cp;
+            }
+            char *t = h->tp_tables;
+            HIP_CHECK(hipMemcpyAsync(t + tb_class, cp_class, TP_TEXT_LIMIT, hipMemcpyHostToDevice, h->stream));
+            HIP_CHECK(hipMemcpyAsync(t + tb_upper, cp_upper, (size_t)TP_TEXT_LIMIT * 4, hipMemcpyHostToDevice, h->stream));
+            HIP_CHECK(hipMemcpyAsync(t + tb_word, word_hi, (size_t)TP_WORD_HI_WORDS * 4, hipMemcpyHostToDevice, h->stream));
+            HIP_CHECK(hipMemcpyAsync(t + tb_digit, digit_hi, (size_t)TP_WORD_HI_WORDS * 4, hipMemcpyHostToDevice, h->stream));
+            if (n_hi_upper) {
+                HIP_CHECK(hipMemcpyAsync(t + tb_from, hi_upper_from, (size_t)n_hi_upper * 4, hipMemcpyHostToDevice, h->stream));
+                HIP_CHECK(hipMemcpyAsync(t + tb_to, hi_upper_to, (size_t)n_hi_upper * 4, hipMemcpyHostToDevice, h->stream));
+            }
+            HIP_CHECK(hipMemcpyAsync(t + tb_cls256, cls256, 256, hipMemcpyHostToDevice, h->stream));
+            HIP_CHECK(hipMemcpyAsync(t + tb_up256, up256, 1024, hipMemcpyHostToDevice, h->stream));
+            h->tp_tables_hash = hash;                   // (the read-back below waits for the stream: the host buffers are the caller's / the handle's)
+        }
     }
+    const uint8_t *d_class = (const uint8_t *)(h->tp_tables + tb_class), *d_cls256 = (const uint8_t *)(h->tp_tables + tb_cls256);
+    const u32 *d_upper = (const u32 *)(h->tp_tables + tb_upper), *d_word_hi = (const u32 *)(h->tp_tables + tb_word),
+              *d_digit_hi = (const u32 *)(h->tp_tables + tb_digit), *d_hi_from = (const u32 *)(h->tp_tables + tb_from),
+              *d_hi_to = (const u32 *)(h->tp_tables + tb_to), *d_up256 = (const u32 *)(h->tp_tables + tb_up256);
     HIP_CHECK(hipMemsetAsync(d_high, 0, 4, h->stream));
     const TpTables tables{d_class, d_upper, d_word_hi, d_digit_hi, d_hi_from, d_hi_to, (u32)n_hi_upper};
 
@@ -1028,11 +1080,19 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
         LAUNCH(ctx, (scan_apply_kernel<TpStartIn, false>), nb_cp, TpStartIn{d_bytes, n_bytes}, n_bytes + 1, (const u32 *)cp_sums,
                cp_index);
     }
-    u32 *cpu = ar.alloc<u32>(n_cp);
-    uint8_t *cw = ar.alloc<uint8_t>((size_t)n_cp + 1);
+    // (every byte a code point of its own: no code point array -- classes from a byte table, the kept bytes are mapped when
+    // they are emitted)
+    const bool bytewise = cp_index == nullptr;
+    u32 *cpu = bytewise ? nullptr : ar.alloc<u32>(n_cp);
+    uint8_t *cw = ar.alloc<uint8_t>((size_t)n_cp + 32);
     u32 *doc_cp_off = ar.alloc<u32>((size_t)D + 1);
-    LAUNCH(ctx, tp_decode_kernel, ceil_div_u32(n_bytes, BLOCK), (const uint8_t *)d_bytes, n_bytes, (const u32 *)cp_index,
-           tables, cpu, cw);
+    if (bytewise) {
+        LAUNCH(ctx, tp_classify_bytes_kernel, ceil_div_u32(n_bytes, BLOCK * 16), (const uint8_t *)d_bytes, n_bytes,
+               (const uint8_t *)d_cls256, cw);
+    } else {
+        LAUNCH(ctx, tp_decode_kernel, ceil_div_u32(n_bytes, BLOCK), (const uint8_t *)d_bytes, n_bytes, (const u32 *)cp_index,
+               tables, cpu, cw);
+    }
     LAUNCH(ctx, tp_doc_cp_offsets_kernel, ceil_div_u32(D + 1, BLOCK), (const u32 *)cp_index, (const u32 *)d_text_off, D,
            doc_cp_off);
 
@@ -1051,7 +1111,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     HIP_CHECK(hipMemsetAsync(keep + n_tok, 0, 4, h->stream));
     HIP_CHECK(hipMemsetAsync(klen + n_tok, 0, 4, h->stream));
     if (n_tok) {
-        LAUNCH(ctx, tp_token_bounds_kernel, ceil_div_u32(n_cp, BLOCK), (const uint8_t *)cw, (const u32 *)tok_inc, n_cp,
+        LAUNCH(ctx, tp_token_bounds_kernel, ceil_div_u32(n_cp, BLOCK * TP_VEC), (const uint8_t *)cw, (const u32 *)tok_inc, n_cp,
                tstart, tend, tok_nd);
         LAUNCH(ctx, tp_token_keep_kernel, ceil_div_u32(n_tok, BLOCK), (const u32 *)tstart, (const u32 *)tend,
                (const u32 *)tok_nd, n_tok, keep, klen);
@@ -1082,12 +1142,12 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     }
     if (n_tok) {
         u32 *tok_out = keep, *tok_term = klen;           // (keep / klen are dead once their scans exist)
+        uint4 *tok_rec = ar.alloc<uint4>(n_tok);
         LAUNCH(ctx, tp_token_out_kernel, ceil_div_u32(n_tok, BLOCK), (const u32 *)tstart, (const u32 *)keep_ex,
                (const u32 *)klen_ex, (const u32 *)doc_cp_off, (const u32 *)first_tok, (const u32 *)doc_sym_off, D, n_tok,
-               tok_out, tok_term);
-        LAUNCH(ctx, tp_emit_kernel, ceil_div_u32(n_cp, BLOCK), (const u32 *)cpu, (const uint8_t *)cw, (const u32 *)tok_inc,
-               (const u32 *)tstart, (const u32 *)tend, (const u32 *)tok_out, (const u32 *)tok_term, n_cp, h->prep_sym,
-               d_high);
+               (const u32 *)tend, tok_out, tok_term, tok_rec);
+        LAUNCH(ctx, tp_emit_kernel, ceil_div_u32(n_cp, BLOCK), (const u32 *)cpu, (const uint8_t *)d_bytes,
+               (const u32 *)d_up256, (const uint8_t *)cw, (const u32 *)tok_inc, (const uint4 *)tok_rec, n_cp, h->prep_sym, d_high);
     }
     LAUNCH(ctx, tp_empty_docs_kernel, ceil_div_u32(D, BLOCK), (const u32 *)first_tok, (const u32 *)keep_ex,
            (const u32 *)doc_sym_off, D, h->prep_sym);
@@ -1360,6 +1420,7 @@ void east_hip_destroy(east_hip_handle_t h)
     if (h->q_buf) (void)hipFree(h->q_buf);
     if (h->kg) (void)hipFree(h->kg);
     if (h->prep_sym) (void)hipFree(h->prep_sym);
+    if (h->tp_tables) (void)hipFree(h->tp_tables);
     if (h->guess) (void)hipFree(h->guess);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -118,6 +118,26 @@ __global__ __launch_bounds__(BLOCK) void tp_decode_kernel(const uint8_t *__restr
     cw[idx] = (uint8_t)cls;
 }
 
+// The same for text in which every byte is a code point of its own (ASCII; stray bytes >= 0x80 each decode to U+FFFD):
+// the class of a byte is a 256-entry table (built on the host from the caller's tables: class of the upper-cased code
+// point), the code points themselves are not stored at all -- tp_emit_kernel maps the bytes it keeps through a second
+// 256-entry table.  Sixteen bytes per thread, one 16-byte load and one 16-byte store (the buffers are padded).
+__global__ __launch_bounds__(BLOCK) void tp_classify_bytes_kernel(const uint8_t *__restrict__ b, u32 n_bytes,
+                                                                  const uint8_t *__restrict__ cls256,
+                                                                  uint8_t *__restrict__ cw)
+{
+    __shared__ uint8_t cls[256];
+    cls[threadIdx.x] = cls256[threadIdx.x];             // (BLOCK == 256)
+    __syncthreads();
+    const u32 i = (blockIdx.x * BLOCK + threadIdx.x) * 16u;
+    if (i >= n_bytes) return;
+    const uint4 x = *reinterpret_cast<const uint4 *>(b + i);
+    auto four = [&](u32 v) -> u32 {
+        return (u32)cls[v & 0xFFu] | ((u32)cls[(v >> 8) & 0xFFu] << 8) | ((u32)cls[(v >> 16) & 0xFFu] << 16) | ((u32)cls[v >> 24] << 24);
+    };
+    *reinterpret_cast<uint4 *>(cw + i) = uint4{four(x.x), four(x.y), four(x.z), four(x.w)};
+}
+
 // code-point index of every document's first byte
 __global__ __launch_bounds__(BLOCK) void tp_doc_cp_offsets_kernel(const u32 *__restrict__ cp_index,
                                                                   const u32 *__restrict__ text_off, u32 n_docs,
@@ -138,19 +158,34 @@ struct TpTokStartIn {                            // 1 at the first code point of
 
 // tok_inc[p] = inclusive count of token starts: a word position p belongs to token tok_inc[p]-1
 // tok_nd[k] (zeroed by the caller) becomes 1 when token k holds a character that is not a digit
+#define TP_VEC 8                                  // code points per thread in the two per-code-point passes (8-byte class loads)
 __global__ __launch_bounds__(BLOCK) void tp_token_bounds_kernel(const uint8_t *__restrict__ cw,
                                                                 const u32 *__restrict__ tok_inc, u32 n_cp,
                                                                 u32 *__restrict__ tstart, u32 *__restrict__ tend,
                                                                 u32 *__restrict__ tok_nd)
 {
-    const u32 p = blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= n_cp || !(cw[p] & TP_CLASS_WORD)) return;
-    const u32 k = tok_inc[p] - 1u;
-    const bool first = !(p > 0 && (cw[p - 1] & TP_CLASS_WORD));
-    if (first) tstart[k] = p;
-    if (!(p + 1 < n_cp && (cw[p + 1] & TP_CLASS_WORD))) tend[k] = p;
-    // (ordinary words: the first letter says it; a token that starts with digits hears it from its first other character)
-    if (!(cw[p] & TP_CLASS_DIGIT) && (first || (cw[p - 1] & TP_CLASS_DIGIT))) tok_nd[k] = 1u;
+    // (cw is allocated with TP_VEC bytes of padding behind n_cp and starts 16-byte aligned)
+    const u32 p0 = (blockIdx.x * BLOCK + threadIdx.x) * TP_VEC;
+    if (p0 >= n_cp) return;
+    const u64 c8 = *reinterpret_cast<const u64 *>(cw + p0);
+    if (!(c8 & 0x0101010101010101ull * TP_CLASS_WORD)) return;          // no word character among the eight
+    u32 prev = p0 > 0 ? cw[p0 - 1] : 0u;
+    const u32 after = p0 + TP_VEC < n_cp ? cw[p0 + TP_VEC] : 0u;
+#pragma unroll
+    for (int e = 0; e < TP_VEC; e++) {
+        const u32 p = p0 + e;
+        const u32 c = (u32)(c8 >> (8 * e)) & 0xFFu;
+        const u32 next = e + 1 < TP_VEC ? (u32)(c8 >> (8 * (e + 1))) & 0xFFu : after;
+        if (p < n_cp && (c & TP_CLASS_WORD)) {
+            const u32 k = tok_inc[p] - 1u;
+            const bool first = !(prev & TP_CLASS_WORD);
+            if (first) tstart[k] = p;
+            if (!(p + 1 < n_cp && (next & TP_CLASS_WORD))) tend[k] = p;
+            // (ordinary words: the first letter says it; a token that starts with digits hears it from its first other character)
+            if (!(c & TP_CLASS_DIGIT) && (first || (prev & TP_CLASS_DIGIT))) tok_nd[k] = 1u;
+        }
+        prev = c;
+    }
 }
 
 // keep[k] = len > 2 and not all digits (utils.py:63); klen[k] = kept length or 0
@@ -209,39 +244,48 @@ __global__ __launch_bounds__(BLOCK) void tp_token_out_kernel(const u32 *__restri
                                                              const u32 *__restrict__ doc_cp_off,
                                                              const u32 *__restrict__ first_tok,
                                                              const u32 *__restrict__ doc_sym_off, u32 n_docs, u32 n_tok,
-                                                             u32 *__restrict__ tok_out, u32 *__restrict__ tok_term)
+                                                             const u32 *__restrict__ tend,
+                                                             u32 *__restrict__ tok_out, u32 *__restrict__ tok_term,
+                                                             uint4 *__restrict__ tok_rec)
 {
+    // tok_rec[k] = {where the token's first symbol goes, its first code point, its terminator, its last code point}:
+    // everything tp_emit_kernel needs about a token in ONE 16-byte load
     const u32 k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n_tok) return;
-    if (keep_ex[k + 1u] == keep_ex[k]) { tok_out[k] = TP_DROPPED; tok_term[k] = 0; return; }
+    if (keep_ex[k + 1u] == keep_ex[k]) { tok_out[k] = TP_DROPPED; tok_term[k] = 0; tok_rec[k] = uint4{TP_DROPPED, 0u, 0u, 0u}; return; }
     const u32 d = tp_doc_of_cp(doc_cp_off, n_docs, tstart[k]);
     const u32 ft = first_tok[d], ft1 = first_tok[d + 1];
     const u32 kidx = keep_ex[k] - keep_ex[ft];               // index among the document's kept tokens
     const u32 kd = keep_ex[ft1] - keep_ex[ft];
     const u32 g = kidx / 3u;
-    tok_out[k] = doc_sym_off[d] + (klen_ex[k] - klen_ex[ft]) + g;
-    tok_term[k] = (kidx % 3u == 2u || kidx + 1u == kd) ? TP_TEXT_LIMIT + g : 0u;
+    const u32 out = doc_sym_off[d] + (klen_ex[k] - klen_ex[ft]) + g;
+    const u32 term = (kidx % 3u == 2u || kidx + 1u == kd) ? TP_TEXT_LIMIT + g : 0u;
+    tok_out[k] = out;
+    tok_term[k] = term;
+    tok_rec[k] = uint4{out, tstart[k], term, tend[k]};
 }
 
-// every code point of a kept token goes to its place; the last one of a group writes the terminator
-__global__ __launch_bounds__(BLOCK) void tp_emit_kernel(const u32 *__restrict__ cpu, const uint8_t *__restrict__ cw,
-                                                        const u32 *__restrict__ tok_inc,
-                                                        const u32 *__restrict__ tstart, const u32 *__restrict__ tend,
-                                                        const u32 *__restrict__ tok_out,
-                                                        const u32 *__restrict__ tok_term, u32 n_cp,
-                                                        u32 *__restrict__ sym, u32 *__restrict__ high)
+// every code point of a kept token goes to its place; the last one of a group writes the terminator.
+// One code point per thread (neighbouring lanes write neighbouring symbols); per code point one class byte, the token's
+// number and ONE 16-byte token record.  cpu == nullptr: every byte is a code point of its own -- the code point is
+// up256[byte].  (Eight consecutive code points per thread were measured: 0.71 against 0.45 ms -- the stores stride.)
+__global__ __launch_bounds__(BLOCK) void tp_emit_kernel(const u32 *__restrict__ cpu, const uint8_t *__restrict__ bytes,
+                                                        const u32 *__restrict__ up256, const uint8_t *__restrict__ cw,
+                                                        const u32 *__restrict__ tok_inc, const uint4 *__restrict__ tok_rec,
+                                                        u32 n_cp, u32 *__restrict__ sym, u32 *__restrict__ high)
 {
+    __shared__ u32 up[256];
+    if (!cpu) up[threadIdx.x] = up256[threadIdx.x];    // (BLOCK == 256)
+    __syncthreads();
     const u32 p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= n_cp || !(cw[p] & TP_CLASS_WORD)) return;
-    const u32 k = tok_inc[p] - 1u;
-    const u32 base = tok_out[k];
-    if (base == TP_DROPPED) return;                         // token dropped
-    const u32 out = base + (p - tstart[k]);
-    const u32 cp = cpu[p];
+    const uint4 rec = tok_rec[tok_inc[p] - 1u];
+    if (rec.x == TP_DROPPED) return;                        // token dropped
+    const u32 out = rec.x + (p - rec.y);
+    const u32 cp = cpu ? cpu[p] : up[bytes[p]];
     if (cp >= TP_TEXT_LIMIT) *high = 1u;                    // kept text at or above U+0A00: the build takes the tagged encoding
     sym[out] = cp;
-    const u32 term = tok_term[k];
-    if (term && p == tend[k]) sym[out + 1u] = term;
+    if (rec.z && p == rec.w) sym[out + 1u] = rec.z;
 }
 
 // Kept word characters at or above U+0A00 were found: the terminators are rewritten in the tagged encoding
