@@ -1206,7 +1206,10 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_restore_kernel(const u32 *__
     if (names_g) names_g[g] = starts(j);
 }
 
-// the members of large groups, compacted: the radix round's input
+// the members of large groups, compacted: the radix round's input.  Four consecutive domain positions per thread: their
+// keep bits come out of one word, and a thread none of whose positions is kept (half of them, in natural-language text)
+// is done after a single load.
+#define COMPACT_IPT 4
 template <class Starts>
 __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__restrict__ elem, Starts starts,
                                                                    const u32 *__restrict__ slot, BitIn keep,
@@ -1216,20 +1219,30 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__
                                                                    u32 *__restrict__ lcp_g = nullptr, int w = 0, int b = 0,
                                                                    int spare = 0)
 {
-    const u32 j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= m || !keep(j)) return;
-    const u32 k = idx(j);
-    const u32 st = starts(j);
-    slot_out[k] = slot ? slot[j] : j;
-    elem_out[k] = elem[j];
-    group_start[k] = st;
-    if constexpr (Starts::HAS_KEYS) {
-        // the keyed first domain: the first rank of a group left to the rounds gets its LCP entry here, from the
-        // two keys -- whichever member ends up there
-        if (lcp_g && st) {
-            bool whole;
-            lcp_g[j] = j > 0 ? lvl0_lcp_of_keys(starts, w, b, spare, j, whole) : 0u;
+    const u32 j0 = (blockIdx.x * BLOCK + threadIdx.x) * COMPACT_IPT;
+    if (j0 >= m) return;
+    const u64 word = keep.bits[j0 >> 6];
+    const u32 nib = (u32)(word >> (j0 & 63u)) & ((1u << COMPACT_IPT) - 1u);
+    if (!nib) return;
+    // (the rank of the first kept position among the kept ones; the others follow)
+    u32 k = idx.word_prefix[j0 >> 6] + (u32)__popcll(word & (((u64)1 << (j0 & 63u)) - 1ull));
+#pragma unroll
+    for (int e = 0; e < COMPACT_IPT; e++) {
+        const u32 j = j0 + e;
+        if (j >= m || !((nib >> e) & 1u)) continue;
+        const u32 st = starts(j);
+        slot_out[k] = slot ? slot[j] : j;
+        elem_out[k] = elem[j];
+        group_start[k] = st;
+        if constexpr (Starts::HAS_KEYS) {
+            // the keyed first domain: the first rank of a group left to the rounds gets its LCP entry here, from the
+            // two keys -- whichever member ends up there
+            if (lcp_g && st) {
+                bool whole;
+                lcp_g[j] = j > 0 ? lvl0_lcp_of_keys(starts, w, b, spare, j, whole) : 0u;
+            }
         }
+        k++;
     }
 }
 
@@ -1653,14 +1666,15 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // compact the members of large groups, number their groups, sort by (group, next window)
             const int e_c = (e_dom + 4) % 3, e_out = (e_dom + 5) % 3;      // the two buffers the domain is not in
             u32 *slot_c = sbuf[s_dom ^ 1];
+            const u32 gc = ceil_div_u32((u64)m + 1, BLOCK * COMPACT_IPT);
             if (!slot && fused)
-                LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<BitStarts>), gm, elem,
+                LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<BitStarts>), gc, elem,
                              BitStarts{gstart_bits}, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart);
             else if (!slot)
-                LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<KeyNeqWindowIn<K>>), gm, elem,
+                LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<KeyNeqWindowIn<K>>), gc, elem,
                              starts, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart, lcp_out, w, bt, spare);
             else
-                LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<FlagArrIn>), gm, elem,
+                LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<FlagArrIn>), gc, elem,
                              FlagArrIn{flag}, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart);
             m = m_next;
             bool have_group = false;                    // group[] = inclusive scan of gstart: the groups' numbers
@@ -1734,7 +1748,8 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 depth *= 2;
             } else {
                 // (13 bits: room for the group numbers inside a workgroup's tile of the in-LDS round)
-                const int w2 = std::min(12, (64 - std::max(gbits, 13)) / bt);
+                int w2 = std::min(12, (64 - std::max(gbits, 13)) / bt);
+                if (getenv("EAST_HIP_ROUND_W2")) w2 = std::max(1, std::min(w2, atoi(getenv("EAST_HIP_ROUND_W2"))));   // (experiments)
                 if (w2 < 1) break;
                 sort_round(false, w2, KeyNeqWindowIn<u64>::make(nullptr, w2, bt, 0, term_first));
                 depth += (u32)w2;
