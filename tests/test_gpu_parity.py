@@ -699,6 +699,33 @@ def test_build_from_resident_symbols_at_any_alignment(hip, oracle, shift):
         assert np.array_equal(t[name], getattr(o, name)), name
 
 
+@pytest.mark.parametrize("n", [1023, 1024, 1025, 2047, 2048, 2049, 3073, 65535, 65536, 65537, 66560, 70001])
+def test_sizes_around_the_stretches_of_the_placement_pass(hip, oracle, n):
+    """The fused finish works on stretches of 1 024 ranks with a halo to either side; the separate placement pass on
+    stretches of 1 024 as well: symbol counts right at, just below and just above multiples of the stretch, on both
+    sides of the 65 536-symbol border between the small-input limits and the ordinary ones, over a small alphabet (many
+    ties, buckets that run across stretch borders) -- all six tables against the oracle."""
+    from east import hip_backend
+    rng = np.random.default_rng(n)
+    for sigma, mean_len in ((3, 9), (20, 5)):
+        # strings of random letters until n symbols are used up exactly (terminators included)
+        parts, used, i = [], 0, 0
+        while used < n:
+            ln = int(min(max(1, rng.geometric(1.0 / mean_len)), n - used - 1)) if n - used > 1 else 0
+            parts.append(rng.integers(65, 65 + sigma, size=ln, dtype=np.uint32))
+            parts.append(np.array([0x0A00 + i], dtype=np.uint32))
+            used += ln + 1
+            i += 1
+        sym = np.concatenate(parts)
+        assert sym.size == n
+        index = hip_backend.HipIndex()
+        index.build(sym, np.array([0, n]), np.array([i]))
+        o = oracle.OracleEASA(symbols=sym, n_strings=i)
+        t = index.tables(0)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, n, sigma, index.info())
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_fused_finish_on_skewed_text(hip, oracle, seed):
     """The fused finish forced (knob 6) on text it is not planned for: natural-language-like documents with planted
