@@ -48,8 +48,11 @@ template <class K> struct PairSrc {
 // One more key for the wave's sub-histogram.  Keys that arrive sorted on their high bits (the group
 // numbers of the refinement rounds) put a whole wavefront on ONE bin, where 64 LDS atomics would queue
 // up: that case is a compare against the first active lane and a single add.
-__device__ __forceinline__ void radix_hist_add(u32 *mine, u32 digit)
+template <bool CHECK = true> __device__ __forceinline__ void radix_hist_add(u32 *mine, u32 digit)
 {
+    // (CHECK = false: the caller knows the digits of a wavefront are spread out -- the low digits of window keys in text
+    // order --, and the test for the one-bin case, two ballots per key, is saved)
+    if constexpr (!CHECK) { atomicAdd(&mine[digit], 1u); return; }
     const u32 first = __builtin_amdgcn_readfirstlane(digit);
     const u64 active = __ballot(1);
     if (__ballot(digit == first) == active) {
@@ -68,7 +71,7 @@ __device__ __forceinline__ void radix_hist_add(u32 *mine, u32 digit)
 #ifndef RS_HIST_BATCH
 #define RS_HIST_BATCH 8                // 16-byte loads a wave keeps in flight (8 KiB)
 #endif
-template <class K, class Src>
+template <class K, class Src, bool CHECK = true>
 __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u32 n, int shift, u32 mask, u32 n_tiles,
                                                                      u32 *__restrict__ hist, u32 *__restrict__ group_sum,
                                                                      u32 *__restrict__ digit_total)
@@ -99,23 +102,23 @@ __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u3
                     for (int j = 0; j < RS_HIST_BATCH; j++) {
                         if constexpr (sizeof(K) == 8) {
                             const u64 ka = ((u64)q[j].y << 32) | q[j].x, kb = ((u64)q[j].w << 32) | q[j].z;
-                            radix_hist_add(mine, (u32)(ka >> shift) & mask);
-                            radix_hist_add(mine, (u32)(kb >> shift) & mask);
+                            radix_hist_add<CHECK>(mine, (u32)(ka >> shift) & mask);
+                            radix_hist_add<CHECK>(mine, (u32)(kb >> shift) & mask);
                         } else {
-                            radix_hist_add(mine, (u32)(q[j].x >> shift) & mask);
-                            radix_hist_add(mine, (u32)(q[j].y >> shift) & mask);
-                            radix_hist_add(mine, (u32)(q[j].z >> shift) & mask);
-                            radix_hist_add(mine, (u32)(q[j].w >> shift) & mask);
+                            radix_hist_add<CHECK>(mine, (u32)(q[j].x >> shift) & mask);
+                            radix_hist_add<CHECK>(mine, (u32)(q[j].y >> shift) & mask);
+                            radix_hist_add<CHECK>(mine, (u32)(q[j].z >> shift) & mask);
+                            radix_hist_add<CHECK>(mine, (u32)(q[j].w >> shift) & mask);
                         }
                     }
                 }
             } else {
-                for (u32 i = lane; i < count; i += WAVE) radix_hist_add(mine, (u32)(src.keys[base + i] >> shift) & mask);
+                for (u32 i = lane; i < count; i += WAVE) radix_hist_add<CHECK>(mine, (u32)(src.keys[base + i] >> shift) & mask);
             }
         } else if constexpr (Src::MODE == 1) {
-            for (u32 i = lane; i < count; i += WAVE) radix_hist_add(mine, (u32)(src.key(base + i) >> shift) & mask);
+            for (u32 i = lane; i < count; i += WAVE) radix_hist_add<CHECK>(mine, (u32)(src.key(base + i) >> shift) & mask);
         } else {
-            src.hist_tile(mine, base, base + count, shift, mask);
+            src.template hist_tile<CHECK>(mine, base, base + count, shift, mask);
         }
     }
     syncthreads_after_lds_atomics();
@@ -392,8 +395,10 @@ static inline void radix_account(Ctx &ctx, size_t key_bytes, u32 n, bool generat
 // Sorts on key bits [begin_bit, bits).  Input in buffers [0] -- or, with a generator, produced on the
 // fly by the first pass, which then writes into buffers [0].  Returns the index (0/1) of the buffers
 // that hold the sorted pairs.
+// check_from_bit: the histogram passes at or above that bit test every key for "the whole wavefront on one bin" (keys
+// that arrive sorted on their high bits: group numbers, document numbers); the passes below take the digits as spread out.
 template <class K, class Gen = NoGen>
-static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin_bit = 0, Gen gen = Gen())
+static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin_bit = 0, Gen gen = Gen(), int check_from_bit = 0)
 {
     constexpr bool HAS_GEN = !std::is_same<Gen, NoGen>::value;
     if (n == 0 || bits <= begin_bit) return 0;
@@ -420,13 +425,20 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin
                                                   : (first ? "radix_scatter_kernel<u32,gen>" : "radix_scatter_kernel<u32>");
         if (!ctx.dry) {
             if (prof) ctx.prof->begin(name_hist, ctx.stream);
+            const bool check = shift + RS_DB > check_from_bit;
             if constexpr (HAS_GEN) {
-                if (first)
-                    hipLaunchKernelGGL((radix_hist_kernel<K, Gen>), dim3(n_groups), dim3(RS_HIST_THREADS), 0, ctx.stream, gen, n,
+                if (first && check)
+                    hipLaunchKernelGGL((radix_hist_kernel<K, Gen, true>), dim3(n_groups), dim3(RS_HIST_THREADS), 0, ctx.stream, gen, n,
+                                       shift, mask, n_tiles, hist, group_sum, tot);
+                else if (first)
+                    hipLaunchKernelGGL((radix_hist_kernel<K, Gen, false>), dim3(n_groups), dim3(RS_HIST_THREADS), 0, ctx.stream, gen, n,
                                        shift, mask, n_tiles, hist, group_sum, tot);
             }
-            if (!first)
-                hipLaunchKernelGGL((radix_hist_kernel<K, PairSrc<K>>), dim3(n_groups), dim3(RS_HIST_THREADS), 0, ctx.stream, src,
+            if (!first && check)
+                hipLaunchKernelGGL((radix_hist_kernel<K, PairSrc<K>, true>), dim3(n_groups), dim3(RS_HIST_THREADS), 0, ctx.stream, src,
+                                   n, shift, mask, n_tiles, hist, group_sum, tot);
+            else if (!first)
+                hipLaunchKernelGGL((radix_hist_kernel<K, PairSrc<K>, false>), dim3(n_groups), dim3(RS_HIST_THREADS), 0, ctx.stream, src,
                                    n, shift, mask, n_tiles, hist, group_sum, tot);
             HIP_CHECK(hipGetLastError());
             if (prof) ctx.prof->end(ctx.stream);

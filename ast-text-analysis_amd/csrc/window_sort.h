@@ -221,7 +221,7 @@ template <class K> struct TextWindowGen {
         }
     }
     // digit histogram of the positions [e0, e1) of a tile, by ONE wave
-    __device__ __forceinline__ void hist_tile(u32 *mine, u32 e0, u32 e1, int shift, u32 mask) const
+    template <bool CHECK = true> __device__ __forceinline__ void hist_tile(u32 *mine, u32 e0, u32 e1, int shift, u32 mask) const
     {
         const bool need_docs = docs.bits && w * b + spare < shift + 12;     // (a digit only sees the document number of short windows)
         for (u32 p0 = e0 + lane_id() * TW_RUN; p0 < e1; p0 += WAVE * TW_RUN) {
@@ -232,7 +232,7 @@ template <class K> struct TextWindowGen {
             if (need_docs) add_docs(p0, k);
 #pragma unroll
             for (int q = 0; q < TW_RUN; q++)
-                if (p0 + q < e1) radix_hist_add(mine, (u32)(k[q] >> shift) & mask);
+                if (p0 + q < e1) radix_hist_add<CHECK>(mine, (u32)(k[q] >> shift) & mask);
         }
     }
 };
@@ -1494,7 +1494,9 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     const int r = n0 ? radix_sort_pairs<K, WindowSrc<K>>(ctx, sb, n02, total_bits, 0,
                                                          WindowSrc<K>{s8, n0, w, bt, spare, term_first, docs})
                      : radix_sort_pairs<K, TextWindowGen<K>>(ctx, sb, n02, total_bits, low_bits,
-                                                             TextWindowGen<K>{s8, n02, w, bt, spare, term_first, docs});
+                                                             TextWindowGen<K>{s8, n02, w, bt, spare, term_first, docs},
+                                                             // (suffixes in text order: only the document number is sorted)
+                                                             docs.bits ? total_bits - docs.bits : total_bits + RS_DB);
     const KeyNeqWindowIn<K> starts = KeyNeqWindowIn<K>::make(sb.keys[r], w, bt, spare, term_first);
     const u32 *sorted_vals = sb.vals[r];
     u64 *keep = (u64 *)sb.keys[r ^ 1];                   // n02 + 1 bits, in the keys idle since the sort
