@@ -201,9 +201,16 @@ template <class K> struct TextWindowGen {
     {
         u32 lo = docs.tile_doc[p0 >> DOC_TILE_SHIFT];
         const int at = w * b + spare;
+        // (the document of the run's first position; inside the run the next document's offset is compared against, one
+        // load per run instead of one per position -- a run of 8 positions crosses a document border once in 10^5 runs)
+        while (lo + 1 < docs.n_docs && docs.doc_off[lo + 1] <= p0) lo++;
+        u32 next_off = lo + 1 < docs.n_docs ? docs.doc_off[lo + 1] : 0xFFFFFFFFu;
 #pragma unroll
         for (int q = 0; q < TW_RUN; q++) {
-            while (lo + 1 < docs.n_docs && docs.doc_off[lo + 1] <= p0 + q) lo++;
+            while (p0 + q >= next_off) {
+                lo++;
+                next_off = lo + 1 < docs.n_docs ? docs.doc_off[lo + 1] : 0xFFFFFFFFu;
+            }
             out[q] |= (K)lo << at;
         }
     }
