@@ -53,6 +53,7 @@ def short(name):
     name = name.split("(")[0].replace("void ", "")
     name = name.replace("unsigned long", "u64").replace("unsigned int", "u32").replace(", 1024", "")
     name = name.replace("> >", ">>")
+    name = name.replace(">, false>", ">>").replace(">, true>", ">>")       # (radix_hist_kernel's third parameter: the one-bin test on / off)
     for k in ("u32", "u64"):
         name = name.replace(", PairSrc<%s>>" % k, ">").replace(", WindowSrc<%s>>" % k, ",gen>")
         name = name.replace(", TextWindowGen<%s>>" % k, ",gen>")
