@@ -557,13 +557,32 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
                 }
             }
         }
-        bool all_final = j0 + PLACE_IPT <= m;
+        // every rank: final (its key differs from both neighbours'), a member of a large group (sorted keys: an equal key
+        // `limit` places away means more than `limit` equal keys around it -- natural-language text: half of the suffixes;
+        // flagged without the exact bounds), or one for phase 2
+        u32 fin_mask = 0, large_mask = 0;
 #pragma unroll
-        for (int e = 0; e < PLACE_IPT; e++) all_final = all_final && start[e] && start[e + 1];
-        if (all_final) {
-            uint4 o = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<uint4 *>(order_g + j0) = o;
-            if (names_g) *reinterpret_cast<uint4 *>(names_g + j0) = uint4{1u, 1u, 1u, 1u};
+        for (int e = 0; e < PLACE_IPT; e++) {
+            const u32 j = j0 + e;
+            if (j >= m) break;
+            if (start[e] && start[e + 1]) fin_mask |= 1u << e;
+            else if (k[e] == k[e + 1] && k[e + 2] == k[e + 1] &&                  // (tied on both sides: worth two more reads)
+                     ((j >= limit && f.keys[j - limit] == k[e + 1]) || (j + limit < m && f.keys[j + limit] == k[e + 1])))
+                large_mask |= 1u << e;
+        }
+        if (large_mask) {
+            const u32 local0 = threadIdx.x * PLACE_IPT;                           // (a thread's four bits lie in one word)
+            atomicOr(&keep_bits[local0 >> 5], large_mask << (local0 & 31u));
+            my_keep += (u32)__popc(large_mask);
+        }
+        if ((fin_mask | large_mask) == (1u << PLACE_IPT) - 1u) {
+            // 16-byte stores.  (The LCP entry of a member of a large group that is not the group's first rank is whatever
+            // the two keys say -- the rounds write every such entry when its group splits or is ordered; the first rank's
+            // entry is the right one already.)
+            *reinterpret_cast<uint4 *>(order_g + j0) = uint4{v[0], v[1], v[2], v[3]};
+            if (names_g)
+                *reinterpret_cast<uint4 *>(names_g + j0) = uint4{(fin_mask & 1u) ? 1u : (u32)start[0], (fin_mask & 2u) ? 1u : (u32)start[1],
+                                                                 (fin_mask & 4u) ? 1u : (u32)start[2], (fin_mask & 8u) ? 1u : (u32)start[3]};
             if (lcp_g) {
                 u32 h[PLACE_IPT];
 #pragma unroll
@@ -578,23 +597,16 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
             for (int e = 0; e < PLACE_IPT; e++) {
                 const u32 j = j0 + e;
                 if (j >= m) break;
-                if (start[e] && start[e + 1]) {
+                if ((fin_mask >> e) & 1u) {
                     order_g[j] = v[e];
                     if (names_g) names_g[j] = 1;
                     if (lcp_g) {
                         bool whole;
                         lcp_g[j] = j > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, k[e + 1], k[e], whole) : 0u;
                     }
-                } else if (k[e] == k[e + 1] && k[e + 2] == k[e + 1] &&           // (tied on both sides: worth two more reads)
-                           ((j >= limit && f.keys[j - limit] == k[e + 1]) ||
-                            (j + limit < m && f.keys[j + limit] == k[e + 1]))) {
-                    // sorted keys: an equal key `limit` places away means more than `limit` equal keys around j -- a large
-                    // group (natural-language text: half of the suffixes), flagged without the exact bounds
+                } else if ((large_mask >> e) & 1u) {
                     order_g[j] = v[e];
                     if (names_g) names_g[j] = start[e];
-                    const u32 local = threadIdx.x * PLACE_IPT + e;
-                    atomicOr(&keep_bits[local >> 5], 1u << (local & 31u));
-                    my_keep++;
                 } else {
                     work[atomicAdd(&n_work, 1u)] = j;    // phase 2
                 }
@@ -1006,15 +1018,13 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
             if (a.km.kg && first) kg_mark(j, k, kp);
             const K xt = k ^ a.top_rep_t;
             if (((K)(xt - a.top_ones) & ~xt & a.top_highs) != 0) return true;   // a constant bucket: final as it stands
-            a.order_g[j] = sa_o;
+            // (handed to the rounds: the suffix goes to its rank as it is, with the caller's 16-byte stores; the LCP entry is
+            // the right one for the group's first rank, and the rounds write every other one when the group splits)
             atomicOr(&keep_bits[i >> 5], 1u << (i & 31));
             my_keep++;
-            if (first) {
-                atomicOr(&gs_bits[i >> 5], 1u << (i & 31));
-                if (a.lcp_g) a.lcp_g[j] = lcp_o;
-            }
+            if (first) atomicOr(&gs_bits[i >> 5], 1u << (i & 31));
             if (a.kg_top && a.km.kg) *a.kg_bad = 1u;
-            return false;
+            return true;
         }
         if (a.km.kg) kg_mark(j, k, kp);
         const K x = k ^ f.rep_t;
@@ -1035,16 +1045,12 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
             if (!big && hi <= (int)(FIN_LEFT + FIN_CHUNK + FIN_G) && j + limit < m) big = kt[hi] == k;   // (staged up to there)
         }
         if (big) {
-            a.order_g[j] = sa_o;
             atomicOr(&keep_bits[i >> 5], 1u << (i & 31));
             my_keep++;
-            if (st) {
-                atomicOr(&gs_bits[i >> 5], 1u << (i & 31));
-                if (a.lcp_g) a.lcp_g[j] = lcp_o;
-            }
-        } else {
-            work[atomicAdd(&n_work, 1u)] = (uint16_t)i;
+            if (st) atomicOr(&gs_bits[i >> 5], 1u << (i & 31));
+            return true;                                // (as above: stored by the caller)
         }
+        work[atomicAdd(&n_work, 1u)] = (uint16_t)i;
         return false;
     };
     {
