@@ -566,9 +566,13 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
             const u32 j = j0 + e;
             if (j >= m) break;
             if (start[e] && start[e + 1]) fin_mask |= 1u << e;
+#ifdef PLACE_DIAG_NOLARGEREAD
+            else if (k[e] == k[e + 1] && k[e + 2] == k[e + 1]) large_mask |= 1u << e;
+#else
             else if (k[e] == k[e + 1] && k[e + 2] == k[e + 1] &&                  // (tied on both sides: worth two more reads)
                      ((j >= limit && f.keys[j - limit] == k[e + 1]) || (j + limit < m && f.keys[j + limit] == k[e + 1])))
                 large_mask |= 1u << e;
+#endif
         }
         if (large_mask) {
             const u32 local0 = threadIdx.x * PLACE_IPT;                           // (a thread's four bits lie in one word)
@@ -617,7 +621,11 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     // phase 2: the tied elements, one per thread, so that their text gathers run side by side
     // instead of one after the other inside the thread that met them.  First every one of them fetches the 8
     // symbols behind the window once (NextSymbols), then they rank themselves inside their groups.
+#ifdef PLACE_DIAG_NOPHASE2
+    const u32 todo = 0;
+#else
     const u32 todo = n_work;
+#endif
     const u32 stretch = blockIdx.x * (BLOCK * PLACE_IPT);
     for (u32 i = threadIdx.x; i < todo; i += BLOCK) {
         const u32 j = work[i];
