@@ -520,14 +520,14 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
             }
         }
     }
+    K k[PLACE_IPT + 2];
+    u32 v[PLACE_IPT];
     if (j0 < m) {
         // keys j0-1 .. j0+4 (the arrays carry 8 spare entries behind m), elements j0 .. j0+3
-        K k[PLACE_IPT + 2];
         k[0] = j0 > 0 ? f.keys[j0 - 1] : (K)0;
 #pragma unroll
         for (int e = 0; e < PLACE_IPT; e++) k[e + 1] = f.keys[j0 + e];
         k[PLACE_IPT + 1] = f.keys[j0 + PLACE_IPT];
-        u32 v[PLACE_IPT];
 #pragma unroll
         for (int e = 0; e < PLACE_IPT; e++) v[e] = vals[j0 + e];
 #pragma unroll
@@ -535,6 +535,9 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
             key_tile[PLACE_HALO + threadIdx.x * PLACE_IPT + e] = k[e + 1];
             val_tile[PLACE_HALO + threadIdx.x * PLACE_IPT + e] = v[e];
         }
+    }
+    __syncthreads();                                    // (the staged keys: the test for large groups reads them `limit` places away)
+    if (j0 < m) {
         bool start[PLACE_IPT + 1];
 #pragma unroll
         for (int e = 0; e <= PLACE_IPT; e++) {
@@ -569,9 +572,16 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
 #ifdef PLACE_DIAG_NOLARGEREAD
             else if (k[e] == k[e + 1] && k[e + 2] == k[e + 1]) large_mask |= 1u << e;
 #else
-            else if (k[e] == k[e + 1] && k[e + 2] == k[e + 1] &&                  // (tied on both sides: worth two more reads)
-                     ((j >= limit && f.keys[j - limit] == k[e + 1]) || (j + limit < m && f.keys[j + limit] == k[e + 1])))
-                large_mask |= 1u << e;
+            else if (k[e] == k[e + 1] && k[e + 2] == k[e + 1]) {                   // (tied on both sides: worth two more reads)
+                bool big;
+                if constexpr (limit <= PLACE_HALO) {                               // (out of the staged keys)
+                    const u32 at = PLACE_HALO + threadIdx.x * PLACE_IPT + e;
+                    big = (j >= limit && key_tile[at - limit] == k[e + 1]) || (j + limit < m && key_tile[at + limit] == k[e + 1]);
+                } else {
+                    big = (j >= limit && f.keys[j - limit] == k[e + 1]) || (j + limit < m && f.keys[j + limit] == k[e + 1]);
+                }
+                if (big) large_mask |= 1u << e;
+            }
 #endif
         }
         if (large_mask) {
