@@ -458,8 +458,12 @@ __device__ __forceinline__ u32 pyr_leftmost_argmin(const Pyramid &P, u32 a, u32 
 #define ANN_NEAR 8
 #define ANN_IPT 4                       // consecutive ranks per thread: 16-byte loads and stores
 #define ANN_TILE (BLOCK * ANN_IPT)
+#ifndef ANN_HALO
 #define ANN_HALO 32
+#endif
+#ifndef ANN_LOCAL
 #define ANN_LOCAL 24                    // phase 2 walks at most this far; what is wider goes to ann_wide_kernel
+#endif
 
 __global__ __launch_bounds__(BLOCK) void ann_stream_kernel(const u32 *__restrict__ lcp, const u32 *__restrict__ doc_off,
                                                            const u32 *__restrict__ n_strings, u32 n_docs, u32 n,
