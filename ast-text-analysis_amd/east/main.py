@@ -5,6 +5,13 @@ README.rst:27-63; the shipped reference main crashes with a NameError, SURVEY.md
     east [-s ast] [-a easa|easa_hip|ast_linear|ast_naive] [-d] [-f xml|csv] \\
          keyphrases table <keyphrases file> <directory with .txt files | single file>
     east [-c confidence] [-r relevance] [-p support] [-f edges|gml] keyphrases graph <keyphrases file> <texts>
+
+Several GPUs (one process per GPU, documents sharded over the ranks, one RCCL all-gather of the score blocks --
+east/parallel.py; the reference's loops relevance.py:41-53 / applications.py:43-52 are what is sharded):
+    east -g 8 keyphrases table ...          or   EAST_HIP_DEVICES=8 east keyphrases table ...
+        starts the 8 ranks itself (child processes under torch.distributed.run) and relays rank 0's output;
+    python -m torch.distributed.run --nproc-per-node 8 ... -m east.main keyphrases table ...
+        under a launcher (WORLD_SIZE > 1 in the environment) every rank runs this module, rank 0 prints.
 """
 import getopt
 import os
@@ -22,18 +29,75 @@ def _read(path):
         return f.read()
 
 
-def main(argv=None):
+def _world():
+    """(world size, rank) a launcher gave this process (torch.distributed.run exports both)."""
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+
+
+def launch_ranks(n_ranks, argv):
+    """The no-launcher spelling of a multi-GPU run (`-g N` / EAST_HIP_DEVICES=N): start N ranks of this module as
+    CHILD processes under torch.distributed.run, let their output through (only rank 0 prints) and return their exit
+    code.  Nothing in this process has touched a GPU at this point, and it never exec()s.  EAST_HIP_LAUNCHER replaces
+    the launcher command (tests)."""
+    import shlex
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    launcher = shlex.split(os.environ.get("EAST_HIP_LAUNCHER", "")) or [sys.executable, "-m", "torch.distributed.run"]
+    cmd = launcher + ["--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+                      "--master-port", str(port), "-m", "east.main"] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("EAST_HIP_DEVICES", None)                       # (the ranks must not start ranks of their own)
+    env.pop("EAST_HIP_DEVICE", None)                        # every rank takes the device of its LOCAL_RANK
+    pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = pkg + os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else pkg
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None, measure_factory=None):
+    """measure_factory: test hook of the multi-rank path (the per-shard scorer of DistributedASTRelevanceMeasure;
+    the collective logic then runs on gloo without a GPU)."""
     args = sys.argv[1:] if argv is None else list(argv)
     try:
-        opts, args = getopt.getopt(args, "s:a:w:v:l:f:c:r:p:dy")
+        opts, args = getopt.getopt(args, "s:a:w:v:l:f:c:r:p:g:dy")
     except getopt.GetoptError as e:
         print(e)
         return 1
     opts = dict(opts)
+    world, rank = _world()
+    if world == 1:
+        try:
+            n_ranks = int(opts.get("-g", os.environ.get("EAST_HIP_DEVICES", "1")))
+        except ValueError:
+            print("Invalid number of GPUs: '%s'." % opts.get("-g", os.environ.get("EAST_HIP_DEVICES")))
+            return 1
+        if n_ranks > 1:
+            # the same command line without -g: the ranks learn the world size from the launcher
+            child_argv = []
+            for key, value in opts.items():
+                if key != "-g":
+                    child_argv.extend([key, value] if value else [key])
+            child_argv.extend(args)
+            return launch_ranks(n_ranks, child_argv)
+    quiet = rank != 0                                       # under a launcher only rank 0 prints
     opts.setdefault("-l", consts.Language.ENGLISH)
     opts.setdefault("-s", consts.RelevanceMeasure.AST)
     opts.setdefault("-a", consts.ASTAlgorithm.EASA)
 
+    saved_stdout = sys.stdout
+    if quiet:
+        sys.stdout = open(os.devnull, "w")
+    try:
+        return _main(opts, args, world, measure_factory)
+    finally:
+        if quiet:
+            sys.stdout.close()
+            sys.stdout = saved_stdout
+
+
+def _main(opts, args, world, measure_factory):
     if len(args) < 2:
         print("Invalid syntax: EAST should be called as:\n\n"
               "    east [options] <command> <subcommand> args\n\n"
@@ -69,20 +133,44 @@ def main(argv=None):
             texts[os.path.basename(filename)[:-4]] = _read(filename)
 
     measure_name = opts["-s"]
-    if measure_name.lower() == "ast":
-        similarity_measure = relevance.ASTRelevanceMeasure(opts["-a"], "-d" not in opts)          # main.py:95-98
-    else:
+    if measure_name.lower() != "ast":
         print("Relevance measure '%s' is not available in the MI355X build (only 'ast')." % measure_name)
         return 1
     if "-y" in opts:
         print("Synonym extraction (-y) needs the external Tomita parser and is not available.")
         return 1
 
+    group_up = False
     try:
+        if world > 1 or os.environ.get("EAST_HIP_FORCE_DIST") == "1":     # (forced: the collective path with one rank)
+            # one rank per GPU: this rank indexes its share of the documents on the device of its LOCAL_RANK and
+            # the K x D table is assembled by one all-gather (east/parallel.py); every rank computes, rank 0 prints
+            import torch.distributed as dist
+            from east import parallel
+            backend = os.environ.get("EAST_HIP_DIST_BACKEND", "nccl")      # (gloo: the CPU-tier tests)
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                kwargs = {}
+                if backend == "nccl":
+                    import torch
+                    local = int(os.environ.get("LOCAL_RANK", "0"))
+                    torch.cuda.set_device(local)
+                    kwargs["device_id"] = torch.device("cuda", local)
+                dist.init_process_group(backend, **kwargs)
+                group_up = True
+            device = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else None
+            similarity_measure = parallel.DistributedASTRelevanceMeasure(opts["-a"], "-d" not in opts, device=device,
+                                                                         measure_factory=measure_factory)
+        else:
+            similarity_measure = relevance.ASTRelevanceMeasure(opts["-a"], "-d" not in opts)      # main.py:95-98
         return _run(subcommand, keyphrases, texts, similarity_measure, opts)
     except exceptions.EastException as e:       # (no device, a failed build ...): a message, not a traceback
         print(e)
         return 1
+    finally:
+        if group_up:
+            import torch.distributed as dist
+            dist.destroy_process_group()
 
 
 def _run(subcommand, keyphrases, texts, similarity_measure, opts):

@@ -98,8 +98,9 @@ class DistributedASTRelevanceMeasure(relevance.ASTRelevanceMeasure):
         the synonym dictionary), raised on EVERY rank before anyone looks at its shard: a rank with an empty shard
         would otherwise walk into the collective alone and wait there for the others."""
         if synonimizer:
-            for kp in prepared_keyphrases:
-                relevance.synonym_variants(kp, synonimizer)
+            for kp in prepared_keyphrases:                       # per word: no product over the alternatives here
+                if relevance.has_empty_variant(relevance.synonym_alternatives(kp, synonimizer)):
+                    raise ZeroDivisionError("float division by zero")
         elif not all(kp.replace(" ", "") for kp in prepared_keyphrases):
             raise ZeroDivisionError("float division by zero")
 

@@ -35,12 +35,24 @@ def synonym_variants(query, synonimizer):
     alternatives, synonyms first, each variant the concatenation of its words.  `synonimizer`
     is anything with get_synonyms() -> {word: [synonyms]}; a word missing from the mapping
     raises KeyError exactly as the reference's dictionary look-up does."""
-    synonyms = synonimizer.get_synonyms()
-    alternatives = [list(synonyms[word]) + [word] for word in utils.tokenize(query)]
-    variants = ["".join(words) for words in itertools.product(*alternatives)]
-    if not all(variants):
+    alternatives = synonym_alternatives(query, synonimizer)
+    if has_empty_variant(alternatives):
         raise ZeroDivisionError("float division by zero")              # easa.py:134 on an empty variant
-    return variants
+    return ["".join(words) for words in itertools.product(*alternatives)]
+
+
+def has_empty_variant(alternatives):
+    """Whether the product of the per-word alternatives holds an empty string: no words at all, or an empty
+    alternative for every word."""
+    return all("" in alts for alts in alternatives)
+
+
+def synonym_alternatives(query, synonimizer):
+    """Per word of the prepared keyphrase: its synonyms followed by the word itself (what synonym_variants forms the
+    product of).  Linear in the number of words: this is what the row cache is keyed by and what the multi-rank path
+    validates on every rank.  Raises KeyError for a word missing from the mapping."""
+    synonyms = synonimizer.get_synonyms()
+    return tuple(tuple(synonyms[word]) + (word,) for word in utils.tokenize(query))
 
 
 class _Shard(object):
@@ -55,14 +67,13 @@ class _Shard(object):
 
     def row(self, query, normalized, synonimizer=None):
         q = query.replace(" ", "")
-        # (the synonym row is keyed by the expanded variants themselves: a synonimizer whose mapping changes, or a new
-        # one at a collected one's address, must not get a stale row)
-        variants = tuple(synonym_variants(query, synonimizer)) if synonimizer is not None else None
-        key = (q, bool(normalized)) if synonimizer is None else ("synonyms", variants)
+        # (the synonym row is keyed by the per-word alternatives -- linear in the words, the product is only formed on a
+        # miss: a synonimizer whose mapping changes, or a new one at a collected one's address, must not get a stale row)
+        key = (q, bool(normalized)) if synonimizer is None else ("synonyms", synonym_alternatives(query, synonimizer))
         if self.row_cache[0] != key:
             if synonimizer is not None:
                 # easa.py:27-34: max over the variants, scored with normalized=True whatever was asked for
-                variants = list(variants)
+                variants = synonym_variants(query, synonimizer)
                 qs, qo = hip_backend.pack_queries(variants, keep_spaces=True)
                 row = self.index.score_table_grouped(qs, qo, [0, len(variants)], True)[0]
             else:

@@ -32,7 +32,8 @@ The JSON line also carries
   cpu_baseline   the CPU oracle (C port of the reference's easa.py) timed on this box's host cores on the
                  same 64 MiB document (one core) and over the documents of configs[2] (all cores)
 
-Launch:  python bench.py [--gpus N --steps K --warmup W]
+Launch:  python bench.py [--gpus N --steps K --warmup W]      (N > 1 without WORLD_SIZE in the environment: bench.py
+                                                               starts its N ranks itself, as child processes)
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -72,7 +73,29 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip build_from_host / child tables / probe count")
     ap.add_argument("--cpu-sample-mib", type=float, default=64.0,
                     help="size of the CPU-baseline document (64 = the bench document itself, about 15 s of one core)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # (never returns: the ranks are child processes)
+    return args
+
+
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: start the N ranks ourselves, as CHILD
+    processes under torch.distributed.run, relay what they print (rank 0's JSON line) and return their exit code.
+    Runs before torch is imported or anything else could touch a GPU -- this process never initialises one and never
+    exec()s (a process that has initialised the GPU must not be replaced on this pool).  EAST_BENCH_LAUNCHER replaces
+    the launcher command (tests: a stub that records its command line)."""
+    import shlex
+    import socket
+    import subprocess
+    with socket.socket() as sock:                            # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    launcher = shlex.split(os.environ.get("EAST_BENCH_LAUNCHER", "")) or [sys.executable, "-m", "torch.distributed.run"]
+    cmd = launcher + ["--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+                      "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode           # stdout / stderr inherited: the JSON line passes through
 
 
 def kernel_bytes(name, info, n, n_docs):
@@ -373,16 +396,19 @@ def main():
             # part of a step (build + score, no collective; max over ranks), the all-gather behind it, and how much of
             # the step the local part is -- the figure a perfectly scaling run keeps at 1.
             out["multi_gpu"] = {"step_local_ms": step_local_ms, "allgather_ms": allgather_ms,
-                                "weak_scaling_efficiency": step_local_ms / ms_per_step if ms_per_step else None,
+                                "local_fraction_of_step": step_local_ms / ms_per_step if ms_per_step else None,
                                 "rccl_world_size": rccl_world, "backend": dist.get_backend(),
                                 "same_shape_single_gpu_base": "config2.value of the N=1 line (256 x 1 MiB docs, 10000 keyphrases)",
-                                "note": "max over ranks; efficiency = local / whole step (1 = the collective is free)"}
+                                "note": "max over ranks; local_fraction_of_step = local / whole step (1 = the collective is free) -- NOT a "
+                                        "scaling efficiency: that is value(N) / (N x the same-shape N=1 value), which the "
+                                        "driver computes from the per-N lines"}
         else:
             out["scaling_base_note"] = ("--gpus N > 1 runs BASELINE configs[3]'s per-GPU shape (256 x 1 MiB documents, 10000 "
                                         "keyphrases per rank): its single-GPU base is this line's config2.value, not value")
-        if world == 1:
+        if world == 1 and not args.no_extras:
             out.update(first_build_leg(hip_backend, torch, local_rank, d_symbols, n, doc_offsets, n_strings, q_symbols,
                                        q_offsets, local_block, not args.denormalized, n_bytes))
+        if world == 1:
             out["value_note"] = ("value = steady state: the timed steps rebuild the same collection on one handle (guesses "
                                  "from the build before always hold); value_first_build = a fresh handle's first build")
         if not args.no_extras:

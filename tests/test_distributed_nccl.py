@@ -64,6 +64,43 @@ def test_bench_distributed_line_on_one_gpu(tmp_path):
     mg = out["multi_gpu"]
     assert mg["rccl_world_size"] == 1 and mg["backend"] == "nccl"
     assert 0 < mg["step_local_ms"] <= out["ms_per_step"] * 1.05 and mg["allgather_ms"] >= 0
-    assert 0 < mg["weak_scaling_efficiency"] <= 1.05
+    assert 0 < mg["local_fraction_of_step"] <= 1.05
     assert out["config"]["all_gather_bytes_per_rank"] == 200 * 8 * 8
     assert out["roofline"]["kernel"] and out["roofline"]["peak"] == 8000.0
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_cli_table_multi_gpu_equals_single_process(tmp_path, world):
+    """`east -g N keyphrases table` (N = 2: the CLI starts its own ranks) and, on the one-GPU box, the same rank code
+    under torch.distributed.run with the collective path forced (EAST_HIP_FORCE_DIST=1): the printed table is the
+    single-process CLI's, byte for byte."""
+    if _device_count() < world:
+        pytest.skip("needs %d GPUs, this box has %d" % (world, _device_count()))
+    from conftest import PKG, word_stream
+    rng = np.random.default_rng(77)
+    tdir = tmp_path / "texts"
+    tdir.mkdir()
+    for i, size in enumerate([30000, 600, 50000, 1200, 25000, 90000, 64]):
+        (tdir / ("doc%02d.txt" % i)).write_bytes(word_stream(rng, size))
+    kp = tmp_path / "keyphrases.txt"
+    kp.write_text("\n".join(word_stream(rng, int(rng.integers(6, 24))).decode() for _ in range(40)) + "\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=PKG)
+    for k in ("EAST_HIP_DEVICE", "EAST_HIP_DEVICES", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = ["-f", "csv", "keyphrases", "table", str(kp), str(tdir)]
+    single = subprocess.run([sys.executable, "-m", "east.main"] + tail, env=env, stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, timeout=600)
+    assert single.returncode == 0, single.stderr.decode(errors="replace")[-3000:]
+    if world == 1:
+        port = 29900 + os.getpid() % 90
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), "-m", "east.main"] + tail
+        env["EAST_HIP_FORCE_DIST"] = "1"
+    else:
+        cmd = [sys.executable, "-m", "east.main", "-g", str(world)] + tail
+    multi = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert multi.returncode == 0, multi.stderr.decode(errors="replace")[-3000:]
+    table = [ln for ln in single.stdout.decode().splitlines() if ln.strip()]
+    assert len(table) >= 41
+    got = [ln for ln in multi.stdout.decode().splitlines() if ln.strip()]
+    assert got[-len(table):] == table          # (RCCL may print a banner in front)
