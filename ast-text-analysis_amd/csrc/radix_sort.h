@@ -71,6 +71,12 @@ template <bool CHECK = true> __device__ __forceinline__ void radix_hist_add(u32 
 #ifndef RS_HIST_BATCH
 #define RS_HIST_BATCH 8                // 16-byte loads a wave keeps in flight (8 KiB)
 #endif
+// Copies of a tile's histogram, one per lane class (lane mod RS_HIST_COPIES): natural-language text puts several lanes
+// of a wavefront on the same few bins, and LDS atomics to one address are served one after the other -- the Zipf
+// stand-in counted at 2.0 TB/s where uniform text reaches 3.7.  Lanes of different classes never meet in a counter.
+#ifndef RS_HIST_COPIES
+#define RS_HIST_COPIES 4
+#endif
 template <class K, class Src, bool CHECK = true>
 __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u32 n, int shift, u32 mask, u32 n_tiles,
                                                                      u32 *__restrict__ hist, u32 *__restrict__ group_sum,
@@ -78,14 +84,16 @@ __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u3
 {
     constexpr int UW = RS_HIST_THREADS / WAVE;
     static_assert(RS_HIST_THREADS == RS_BINS, "thread d owns digit d");
-    __shared__ u32 bins[RS_GROUP][RS_BINS];
+    __shared__ u32 bins[RS_GROUP][RS_HIST_COPIES][RS_BINS];
 #pragma unroll
-    for (int k = 0; k < RS_GROUP; k++) bins[k][threadIdx.x] = 0;
+    for (int k = 0; k < RS_GROUP; k++)
+#pragma unroll
+        for (int c = 0; c < RS_HIST_COPIES; c++) bins[k][c][threadIdx.x] = 0;
     __syncthreads();
     const u32 g = blockIdx.x, lane = lane_id();
     const u32 t0 = g * RS_GROUP, t1 = t0 + RS_GROUP < n_tiles ? t0 + RS_GROUP : n_tiles;
     for (u32 tile = t0 + wave_id(); tile < t1; tile += UW) {
-        u32 *mine = bins[tile - t0];
+        u32 *mine = bins[tile - t0][lane & (RS_HIST_COPIES - 1)];
         const u32 base = tile * RS_TILE;
         const u32 count = n - base < (u32)RS_TILE ? n - base : (u32)RS_TILE;
         if constexpr (Src::MODE == 0) {
@@ -126,7 +134,8 @@ __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u3
 #pragma unroll
     for (int k = 0; k < RS_GROUP; k++) {
         if (t0 + k < t1) hist[(size_t)(t0 + k) * RS_BINS + threadIdx.x] = run;
-        run += bins[k][threadIdx.x];
+#pragma unroll
+        for (int c = 0; c < RS_HIST_COPIES; c++) run += bins[k][c][threadIdx.x];
     }
     group_sum[(size_t)g * RS_BINS + threadIdx.x] = run;     // one coalesced row per group
     // (RS_TOTAL_SHARDS copies of the totals: thousands of workgroups adding into one 1 KiB row queue up behind one another)
