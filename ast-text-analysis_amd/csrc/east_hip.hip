@@ -35,6 +35,7 @@
 
 static thread_local std::string g_last_error;
 static bool g_speculate = getenv("EAST_HIP_NO_SPECULATION") == nullptr;     // east_hip_debug_set_speculation (tests)
+static bool g_kg_pairs = getenv("EAST_HIP_NO_KG_PAIRS") == nullptr;         // east_hip_debug_set_score_path (tests, A/B timing)
 static u32 g_plan_epoch = 1;        // bumped by the test knobs that change what a build allocates
 
 // ------------------------------------------------------------ prep kernels --
@@ -445,6 +446,8 @@ struct east_hip_index {
     size_t q_cap = 0;
     u32 n_kp = 0, n_q = 0, score_chunk = 0;     // score_chunk: documents per stretch the scratch was sized for
     u32 *q_raw = nullptr, *q_code = nullptr, *q_end = nullptr, *q_off = nullptr, *group_off = nullptr;
+    u32 *q_blk = nullptr;        // whole keyphrases per workgroup of the score walk: [q_blk[i], q_blk[i + 1]), n_blk of them
+    u32 n_blk = 0;               // (0: a keyphrase is longer than a workgroup -- the walk writes per-suffix results, a second kernel sums)
     double *suffix = nullptr, *table = nullptr, *table_g = nullptr;
     // k-gram bucket tables for the score walk (own allocation, rebuilt after every build)
     u32 *kg = nullptr;
@@ -453,6 +456,8 @@ struct east_hip_index {
     u32 kg_A = 0, kg_bins = 0;
     bool kg_built = false;
     bool kg_marked = false;      // the bucket starts were written by the build (off the window keys): only the fill is due
+    bool kg_pairs = false;       // ... in the pair layout (score.h: KgTables); kg3 = the table of the levels above the last
+    u32 *kg3 = nullptr;
     float last_build_ms = -1.f, last_score_ms = -1.f, last_prep_ms = -1.f;
     // the caller's Unicode tables of the device text preparation (own allocation, re-uploaded when their hash changes)
     char *tp_tables = nullptr;
@@ -673,7 +678,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
             km.A = sigma_t + 2;
             u64 bins = 1;
             while (km.k < KGRAM_KEYS_MAX_K && bins * km.A <= KGRAM_KEYS_MAX_BINS && bins * km.A <= 2 * ((u64)n / n_docs) + 4096 &&
-                   (bins * km.A + 1) * n_docs * 4 <= ((u64)1 << 30)) {
+                   (bins * km.A + 1) * n_docs * 8 <= ((u64)1 << 31)) {
                 bins *= km.A;
                 km.k++;
             }
@@ -681,6 +686,9 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
                 km.kg = h->kg;
                 km.doc_off = h->doc_off;
                 km.n_docs = n_docs;
+                // (the pair layout: the level above the last in a table of its own, behind the 8-byte entries)
+                if (g_kg_pairs) km.kg3 = h->kg + 2 * (size_t)(bins + 1) * n_docs;
+                h->kg3 = km.kg3;
             } else {
                 km.k = 0;
             }
@@ -689,6 +697,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
                                            km.k > 0 ? &km : nullptr);
         if (window_sorted && km.k > 0) {                 // (km.k is 0 if the sort did not mark: small inputs)
             h->kg_marked = true;
+            h->kg_pairs = km.pairs != 0;
             h->kg_k = km.k;
             h->kg_A = km.A;
             h->kg_bins = km.bins;
@@ -1178,6 +1187,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
 // one-line documents would need hundreds of GB -- and the documents are scored a stretch at a time.
 #define SCORE_SCRATCH_BYTES ((size_t)1 << 30)
 static size_t g_score_scratch_bytes = SCORE_SCRATCH_BYTES;     // east_hip_debug_set_score_scratch (tests)
+static bool g_score_fused = getenv("EAST_HIP_SCORE_UNFUSED") == nullptr;   // east_hip_debug_set_score_path (tests, A/B timing)
 static u32 score_doc_chunk(u32 n_q, u32 n_docs)
 {
     const size_t per_doc = (size_t)n_q * 8;
@@ -1201,7 +1211,7 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
     const u32 n_q = (u32)S;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const u32 chunk = score_doc_chunk(n_q, h->n_docs);
-    const size_t bytes = 256 + al((size_t)n_q * 4) * 3 + al(((size_t)n_kp + 1) * 4) * 2 +
+    const size_t bytes = 256 + al((size_t)n_q * 4) * 3 + al(((size_t)n_kp + 1) * 4) * 3 +
                          al((size_t)n_q * chunk * 8) + al((size_t)n_kp * h->n_docs * 8) * 2;
     if (bytes > h->q_cap) {
         HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1219,6 +1229,7 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
     h->q_end = (u32 *)p;  p += al((size_t)n_q * 4);
     h->q_off = (u32 *)p;  p += al(((size_t)n_kp + 1) * 4);
     h->group_off = (u32 *)p; p += al(((size_t)n_kp + 1) * 4);      // synonym-expanded scoring: variants per keyphrase
+    h->q_blk = (u32 *)p;  p += al(((size_t)n_kp + 1) * 4);
     h->suffix = (double *)p; p += al((size_t)n_q * chunk * 8);
     h->table = (double *)p; p += al((size_t)n_kp * h->n_docs * 8);
     h->table_g = (double *)p;
@@ -1228,6 +1239,20 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
         for (i64 i = q_offsets[k]; i < q_offsets[k + 1]; i++) end[i] = (u32)q_offsets[k + 1];
     }
     off[n_kp] = n_q;
+    // the score walk's workgroups take whole keyphrases (score.h: score_walk_kernel, blk): consecutive keyphrases packed
+    // into stretches of at most BLOCK suffixes
+    std::vector<u32> blk;
+    blk.push_back(0);
+    bool fits = g_score_fused;
+    for (int32_t k = 0, used = 0; k < n_kp && fits; k++) {
+        const i64 len = q_offsets[k + 1] - q_offsets[k];
+        if (len > BLOCK) { fits = false; break; }
+        if (used + len > BLOCK) { blk.push_back((u32)k); used = 0; }
+        used += (int32_t)len;
+    }
+    blk.push_back((u32)n_kp);
+    h->n_blk = fits ? (u32)blk.size() - 1 : 0;
+    if (fits) HIP_CHECK(hipMemcpyAsync(h->q_blk, blk.data(), blk.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipMemcpyAsync(h->q_raw, q_symbols, (size_t)n_q * 4, hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipMemcpyAsync(h->q_end, end.data(), (size_t)n_q * 4, hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipMemcpyAsync(h->q_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, h->stream));
@@ -1240,8 +1265,10 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
 // device memory for n_docs rows of bins + 1 entries plus the fill's chunk scratch; false if it cannot be had
 static bool kgram_reserve(east_hip_index *h, u64 bins, u32 n_docs)
 {
+    // (room for the pair layout: 8-byte entries of the last level + the table of the level above; the filled 4-byte
+    // layout with its chunk scratch is smaller)
     const size_t chunks = (size_t)((bins + KGF_CHUNK - 1) / KGF_CHUNK);
-    const size_t bytes = ((size_t)(bins + 1) + 2 * chunks) * n_docs * 4 + 256;
+    const size_t bytes = (2 * (size_t)(bins + 1) + (size_t)(bins / 2 + 2) + 2 * chunks) * n_docs * 4 + 256;
     if (bytes <= h->kg_cap) return true;
     HIP_CHECK(hipStreamSynchronize(h->stream));
     if (h->kg) HIP_CHECK(hipFree(h->kg));
@@ -1258,6 +1285,14 @@ static bool kgram_reserve(east_hip_index *h, u64 bins, u32 n_docs)
 static void ensure_kgram(east_hip_index *h, Ctx &ctx)
 {
     if (h->kg_built) return;
+    if (h->kg_marked && h->kg_pairs) {
+        // the pair layout: the last level stays as the build marked it (+ its end entries), the small table above it is filled
+        const u32 bins3 = h->kg_bins / h->kg_A;
+        LAUNCH(ctx, kgram_pairs_end_kernel, ceil_div_u32(h->n_docs, BLOCK), (const u32 *)h->doc_off, h->n_docs, h->kg_bins, h->kg);
+        LAUNCH(ctx, kgram_fill_kernel, h->n_docs, (const u32 *)h->doc_off, bins3, h->kg3);
+        h->kg_built = true;
+        return;
+    }
     if (h->kg_marked) {
         // the build left the bucket starts in the table: suffix minimum per document, in chunks
         const u32 bins = h->kg_bins, n_chunks = ceil_div_u32(bins, KGF_CHUNK);
@@ -1270,6 +1305,7 @@ static void ensure_kgram(east_hip_index *h, Ctx &ctx)
         return;
     }
     h->kg_k = 0;
+    h->kg_pairs = false;
     h->kg_built = true;
     if (!h->use_s8 || h->n_docs > 65535) return;
     const u32 A = h->sigma_t + 2;
@@ -1322,23 +1358,32 @@ static void score_resident(east_hip_index *h, int normalized, unsigned long long
     LAUNCH(ctx, query_map_kernel, ceil_div_u32(h->n_q, BLOCK), (const u32 *)h->q_raw, h->n_q,
            (const u32 *)h->code_map, (const u32 *)h->hi_bits, (const u32 *)h->hi_rank,
            h->sigma_hi ? h->sigma_t - h->sigma_hi + 1u : 0u, h->q_code);
-    const u32 chunk = h->score_chunk;
+    KgTables kt;
+    kt.kg = h->kg; kt.kg3 = h->kg3; kt.k = h->kg_k; kt.pairs = h->kg_k > 0 && h->kg_pairs; kt.A = h->kg_A; kt.bins = h->kg_bins;
+    // whole keyphrases per workgroup, summed in the walk (no per-suffix results unless the caller wants them: then the
+    // documents go a stretch at a time, as far as the scratch reaches); otherwise per-suffix results + the reduction kernel
+    const bool fused = h->n_blk > 0;
+    const u32 chunk = fused && !suffix_host ? h->n_docs : h->score_chunk;
     for (u32 first = 0; first < h->n_docs; first += chunk) {
         const u32 count = std::min(chunk, h->n_docs - first);
         const int xcd_order = count >= 64;                // see score_walk_kernel
-        const u32 walk_grid = (xcd_order ? 8u * ceil_div_u32(count, 8) : count) * ceil_div_u32(h->n_q, BLOCK);
+        const u32 per_doc = fused ? h->n_blk : ceil_div_u32(h->n_q, BLOCK);
+        const u32 walk_grid = (xcd_order ? 8u * ceil_div_u32(count, 8) : count) * per_doc;
+        double *suffix = fused && !suffix_host ? (double *)nullptr : h->suffix;
+        const u32 *blk = fused ? (const u32 *)h->q_blk : (const u32 *)nullptr;
         if (h->use_s8)
             LAUNCH_NAMED(ctx, "score_walk_kernel", (score_walk_kernel<uint8_t>), walk_grid, (const uint8_t *)h->s8,
                          (const u32 *)h->sa, (const u32 *)h->doc_off, (const u32 *)h->n_strings, h->n_docs,
-                         (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, (const u32 *)h->kg, h->kg_k,
-                         h->kg_A, h->kg_bins, xcd_order, first, count, h->suffix, probe_count);
+                         (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, kt, xcd_order, first, count, suffix,
+                         probe_count, blk, h->n_blk, (const u32 *)h->q_off, h->table);
         else
             LAUNCH_NAMED(ctx, "score_walk_kernel", (score_walk_kernel<u32>), walk_grid, (const u32 *)h->s,
                          (const u32 *)h->sa, (const u32 *)h->doc_off, (const u32 *)h->n_strings, h->n_docs,
-                         (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, (const u32 *)h->kg, h->kg_k,
-                         h->kg_A, h->kg_bins, xcd_order, first, count, h->suffix, probe_count);
-        LAUNCH(ctx, score_reduce_kernel, ceil_div_u32((u64)h->n_kp * count, BLOCK), (const double *)h->suffix,
-               (const u32 *)h->q_off, h->n_kp, h->n_docs, h->n_q, first, count, h->table);
+                         (const u32 *)h->q_code, (const u32 *)h->q_end, h->n_q, normalized, kt, xcd_order, first, count, suffix,
+                         probe_count, blk, h->n_blk, (const u32 *)h->q_off, h->table);
+        if (!fused)
+            LAUNCH(ctx, score_reduce_kernel, ceil_div_u32((u64)h->n_kp * count, BLOCK), (const double *)h->suffix,
+                   (const u32 *)h->q_off, h->n_kp, h->n_docs, h->n_q, first, count, h->table);
         if (suffix_host)                                  // the per-suffix results of this stretch of documents (D x S, row-major)
             HIP_CHECK(hipMemcpyAsync(suffix_host + (size_t)first * h->n_q, h->suffix, (size_t)count * h->n_q * 8,
                                      hipMemcpyDeviceToHost, h->stream));
@@ -1827,13 +1872,26 @@ int east_hip_debug_set_window_sort(int enabled)
 
 int east_hip_debug_set_lds_rounds(int enabled)
 {
+    // 0: every round through the global sort; 1: the default (in-LDS rounds that also classify the next domain);
+    // 2: in-LDS rounds with the stand-alone classification pass
     g_lds_rounds = enabled != 0;
+    g_fused_classify = enabled != 2 && getenv("EAST_HIP_NO_FUSED_CLASSIFY") == nullptr;
     return EAST_HIP_OK;
 }
 
 int east_hip_debug_set_score_scratch(int64_t bytes)
 {
     g_score_scratch_bytes = bytes > 0 ? (size_t)bytes : SCORE_SCRATCH_BYTES;
+    return EAST_HIP_OK;
+}
+
+int east_hip_debug_set_score_path(int mode)
+{
+    // 1: the default; 0: the walk as rounds 1-3 ran it -- one filled k-gram table of 4-byte entries, per-suffix results in
+    // HBM and a reduction kernel; 2: pair tables, separate reduction; 3: filled table, the sums inside the walk.
+    // (takes effect with the next build / the next set of keyphrases)
+    g_kg_pairs = mode == 1 || mode == 2;
+    g_score_fused = mode == 1 || mode == 3;
     return EAST_HIP_OK;
 }
 

@@ -35,7 +35,7 @@ struct LgLds {
     u32 wave_cnt[LG_WAVES][128];            // per-wave digit counts (16-bit pairs), then wave bases
     u32 digit_start[256];
     u32 wsum[LG_WAVES];
-    u64 start_bits[LG_WORDS];               // bit q: domain position chunk_base + q starts a group
+    u64 start_bits[LG_WORDS + 1];           // bit q: domain position chunk_base + q starts a group; after the sort: the NEW starts, by tile position
     u32 word_prefix[LG_WORDS];              // group starts of the tile before the word
     u32 hdr[2];                             // first position of the tile (relative to the chunk), its elements
 };
@@ -185,6 +185,30 @@ __device__ __forceinline__ void lg_radix_pass(LgLds &lds, u64 (&key)[LG_IPT], u3
     }
 }
 
+// The classification of the NEXT domain, folded into the round (symbol windows only): the tile's sorted keys are still
+// in LDS when the write-back is done, so the new group bounds are a bit scan away -- a member of a new group of at
+// most `limit` suffixes fetches the 8 symbols behind the new depth once, ranks itself against the other members out of
+// LDS (window_sort.h: lvl0_place_tied does the same from global arrays) and is placed for good; a member of a larger
+// group sets its bit in keep[] (zeroed by the host; OR-ed into, the tile's positions do not start at a word).  What
+// dc3_refine_classify_kernel did for these positions in a pass of its own -- reading elements, flags and slots back
+// from HBM, a dozen scattered flag reads per tied element -- is gone; that kernel still runs for what the global sort
+// took, for prefix-doubling rounds (their names are updated in between) and for the endgame.
+// keep == nullptr: off.  A comparison longer than max_len raises *fail (the host restores the domain and repeats
+// the classification as mark + commit with the stand-alone kernel).
+struct LgClassify {
+    u64 *keep = nullptr;
+    u32 *fail = nullptr;
+    u32 limit = 0, max_len = 0;
+};
+
+// 64 bits of a bit array from bit `pos` on (the array carries one spare word)
+__device__ __forceinline__ u64 lg_bits_from(const u64 *bits, u32 pos)
+{
+    const u32 wi = pos >> 6, sh = pos & 63u;
+    const u64 lo = bits[wi] >> sh;
+    return sh ? lo | (bits[wi + 1] << (64u - sh)) : lo;
+}
+
 // elems / gstart / slots: the round's compacted domain (m elements; gstart[j] != 0: j starts a group).
 // Key of an element = (its group's number inside the tile << w2*b) | the w2 symbols at offset `depth` of its
 // suffix, as dc3_refine_keys_kernel builds them (zeros behind a terminator; rep_t / ones / highs: the
@@ -194,7 +218,7 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
     const uint8_t *__restrict__ s8, const u32 *__restrict__ elems, const u32 *__restrict__ gstart,
     const u32 *__restrict__ slots, u32 m, u32 n0, u32 depth, int w2, int b, u32 term_first, u64 rep_t, u64 ones, u64 highs,
     u32 *__restrict__ order_g, u32 *__restrict__ names_g, u32 *__restrict__ elem_out, u32 *__restrict__ flag_out,
-    u32 *__restrict__ lcp_g, uint2 *__restrict__ cover, const u32 *__restrict__ name_of)
+    u32 *__restrict__ lcp_g, uint2 *__restrict__ cover, const u32 *__restrict__ name_of, LgClassify cls)
 {
     __shared__ LgLds lds;
     const u32 lane = lane_id(), w = wave_id();
@@ -296,25 +320,144 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
     const u32 n_waves = (n_act + LG_IPT * WAVE - 1u) / (LG_IPT * WAVE);
     for (int shift = 0; shift < bits; shift += 8) lg_radix_pass(lds, key, val, shift, active, n_waves);
     // ---- what the round's write-back writes, for the tile ----
-    if (!active) return;
+    const bool fuse = cls.keep != nullptr && !name_of;  // (uniform over the workgroup)
+    if (!active && !fuse) return;
+    const u32 nd = depth + (u32)w2;                     // what the members of a new group share
+    u32 fbits = 0;                                      // bit j: the thread's element j starts a new group
+    u32 slot_of[LG_IPT];
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < LG_IPT; j++) {
+            const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+            slot_of[j] = 0;
+            if (local >= n_act) { fbits |= 1u << j; continue; }       // (position n_act counts as a start)
+            const u64 k = key[j], kp = local ? lds.keys[local - 1u] : 0ull;
+            const u64 x = k ^ rep_t;
+            const u64 tz = (x - ones) & ~x & highs;
+            const u32 r = base + begin_q + local, slot = slots[r], e = val[j];
+            const u32 f = (local == 0u || tz != 0ull || k != kp) ? 1u : 0u;
+            fbits |= f << j;
+            slot_of[j] = slot;
+            if (!fuse) order_g[slot] = e;               // (fused: below, once it is known who is placed elsewhere)
+            if (names_g) names_g[slot] = f;
+            elem_out[r] = e;
+            flag_out[r] = f;
+            if (lcp_g && f && local > 0u && (k >> wbits) == (kp >> wbits)) {       // a seam inside a group (see dc3_refine_writeback_kernel)
+                const u64 d = (k ^ kp) & (((u64)1 << wbits) - 1ull);
+                const u32 mism = d ? (u32)(w2 - 1 - (63 - __builtin_clzll(d)) / b) : (u32)w2;
+                const u32 term = tz ? (u32)(w2 - 1 - __builtin_ctzll(tz) / b) : (u32)w2;
+                lcp_g[slot] = depth + (mism < term ? mism : term);
+            }
+        }
+    }
+    if (!fuse) return;
+    // ---- the next domain's classification (LgClassify) ----
+#pragma unroll
+    for (int j = 0; j < LG_IPT; j++) {                  // the new starts as bits, by tile position (waves behind the tile: all ones)
+        const u64 bal = __ballot(!active || ((fbits >> j) & 1u));
+        if (lane == 0) lds.start_bits[w * LG_IPT + j] = bal;
+    }
+    if (threadIdx.x == 0) { lds.start_bits[LG_WORDS] = ~0ull; lds.hdr[0] = 0u; }     // (hdr[0]: the work list's length)
+    __syncthreads();                                    // (also: every read of the sorted keys above is done, lds.keys is free)
+    // Every element of the tile: untied or left to the next round (its suffix goes to its own slot; a member of a group of
+    // more than `limit` sets its keep bit), or a member of a small group: parked in a work list -- the per-wave counters
+    // of the sort are idle -- and ranked one member per thread below, so that their text gathers run side by side.
+    const u32 limit = cls.limit;
+    uint16_t *work = reinterpret_cast<uint16_t *>(&lds.wave_cnt[0][0]);
+    constexpr u32 WORK_CAP = sizeof(lds.wave_cnt) / sizeof(uint16_t);
+    // the new group [a, bnd) around tile position `local` if it has at most `limit` members, else false
+    auto small_group = [&](u32 local, u32 &a, u32 &bnd) -> bool {
+        const u32 lo = local >= limit ? local - limit : 0u;
+        const u64 left = lg_bits_from(lds.start_bits, lo) & (((u64)2 << (local - lo)) - 1ull);      // positions lo .. local
+        const u64 right = lg_bits_from(lds.start_bits, local + 1u) & (((u64)1 << limit) - 1ull);    // local + 1 .. local + limit
+        if (!left || !right) return false;
+        a = lo + 63u - (u32)__builtin_clzll(left);
+        bnd = local + 1u + (u32)__builtin_ctzll(right);
+        return bnd - a <= limit;
+    };
+    u32 pmask = 0;                                      // bit j: the thread's element j is in the work list
 #pragma unroll
     for (int j = 0; j < LG_IPT; j++) {
         const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
-        if (local >= n_act) continue;
-        const u64 k = key[j], kp = local ? lds.keys[local - 1u] : 0ull;
-        const u64 x = k ^ rep_t;
-        const u64 tz = (x - ones) & ~x & highs;
-        const u32 r = base + begin_q + local, slot = slots[r], e = val[j];
-        const u32 f = (local == 0u || tz != 0ull || k != kp) ? 1u : 0u;
-        order_g[slot] = e;
-        if (names_g) names_g[slot] = f;
-        elem_out[r] = e;
-        flag_out[r] = f;
-        if (lcp_g && f && local > 0u && (k >> wbits) == (kp >> wbits)) {       // a seam inside a group (see dc3_refine_writeback_kernel)
-            const u64 d = (k ^ kp) & (((u64)1 << wbits) - 1ull);
-            const u32 mism = d ? (u32)(w2 - 1 - (63 - __builtin_clzll(d)) / b) : (u32)w2;
-            const u32 term = tz ? (u32)(w2 - 1 - __builtin_ctzll(tz) / b) : (u32)w2;
-            lcp_g[slot] = depth + (mism < term ? mism : term);
+        bool large = false, parked = false;
+        if (active && local < n_act) {
+            u32 a = 0, bnd = 0;
+            if (!small_group(local, a, bnd)) large = true;
+            else parked = bnd - a > 1u;
         }
+        // (one LDS atomic per wavefront and row for the list positions)
+        const u64 pbal = __ballot(parked);
+        u32 at = 0;
+        if (pbal) {
+            if (lane == (u32)__builtin_ctzll(pbal)) at = atomicAdd(&lds.hdr[0], (u32)__popcll(pbal));
+            at = __shfl(at, __builtin_ctzll(pbal), WAVE) + __builtin_amdgcn_mbcnt_hi((u32)(pbal >> 32), __builtin_amdgcn_mbcnt_lo((u32)pbal, 0u));
+        }
+        if (parked) { pmask |= 1u << j; if (at < WORK_CAP) work[at] = (uint16_t)local; }
+        else if (active && local < n_act) order_g[slot_of[j]] = val[j];
+        const u64 bal = __ballot(large);                // one keep bit per position of the row
+        if (lane == 0 && bal) {
+            const u64 g0 = (u64)base + begin_q + w * (LG_IPT * WAVE) + j * WAVE;
+            const u32 sh = (u32)(g0 & 63u);
+            atomicOr((unsigned long long *)&cls.keep[g0 >> 6], (unsigned long long)(bal << sh));
+            if (sh) atomicOr((unsigned long long *)&cls.keep[(g0 >> 6) + 1], (unsigned long long)(bal >> (64u - sh)));
+        }
+    }
+    syncthreads_after_lds_atomics();
+    u32 todo = lds.hdr[0];
+    if (todo > WORK_CAP) {
+        // (more members of small groups than the list holds -- nearly the whole tile: all of them are left to the next
+        // round instead, as if their groups were large; a group is ordered here whole or not at all)
+#pragma unroll
+        for (int j = 0; j < LG_IPT; j++) {
+            const bool mine = (pmask >> j) & 1u;
+            if (mine) order_g[slot_of[j]] = val[j];
+            const u64 bal = __ballot(mine);
+            if (lane == 0 && bal) {
+                const u64 g0 = (u64)base + begin_q + w * (LG_IPT * WAVE) + j * WAVE;
+                const u32 sh = (u32)(g0 & 63u);
+                atomicOr((unsigned long long *)&cls.keep[g0 >> 6], (unsigned long long)(bal << sh));
+                if (sh) atomicOr((unsigned long long *)&cls.keep[(g0 >> 6) + 1], (unsigned long long)(bal >> (64u - sh)));
+            }
+        }
+        todo = 0;
+    }
+    for (u32 i = threadIdx.x; i < todo; i += LG_THREADS) {              // the 8 symbols behind the new depth, once per member
+        const u32 local = work[i];
+        lds.keys[local] = load_u64_unaligned(s8 + lvl0_pos(lds.vals[local], n0) + nd);
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < todo; i += LG_THREADS) {
+        const u32 local = work[i];
+        u32 a = 0, bnd = 0;
+        (void)small_group(local, a, bnd);
+        const u32 e = lds.vals[local], p = lvl0_pos(e, n0);
+        const u64 u0 = lds.keys[local];
+        u32 r = 0, best = 0;                            // best: longest common prefix with a smaller member
+        bool undecided = false;
+        for (u32 x = a; x < bnd; x++) {
+            if (x == local) continue;
+            const u32 p2 = lvl0_pos(lds.vals[x], n0);
+            bool decided = false, less = false;         // less: suffix p2 < suffix p
+            u32 h = nd;
+            for (; h < nd + cls.max_len && !decided; h += 8) {
+                const u64 u = h == nd ? u0 : load_u64_unaligned(s8 + p + h);
+                const u64 v = h == nd ? lds.keys[x] : load_u64_unaligned(s8 + p2 + h);
+                const u64 d = u ^ v, z = ~u;
+                const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+                const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+                const u32 term = tz ? (u32)__builtin_ctzll(tz) >> 3 : 8u;
+                if (term < mism) { less = p2 < p; decided = true; h += term; break; }     // both end in (different) terminators
+                if (mism < 8u) { less = ((v >> (8 * mism)) & 0xFFu) < ((u >> (8 * mism)) & 0xFFu); decided = true; h += mism; break; }
+            }
+            if (!decided) { undecided = true; break; }
+            if (less) { r++; best = h > best ? h : best; }
+        }
+        if (undecided) { atomicOr(cls.fail, 1u); continue; }   // (the host restores the domain and repeats the classification)
+        // groups keep their stretches of the global order: the slot of tile position a + r lies a + r - local behind this one's
+        const u32 slot = slots[base + begin_q + local];
+        const u32 at_g = slot + a + r - local;
+        order_g[at_g] = e;
+        if (names_g) names_g[slot] = 1;
+        if (lcp_g && r > 0) lcp_g[at_g] = best;          // (the first of the group keeps the entry it got when the group split off)
     }
 }

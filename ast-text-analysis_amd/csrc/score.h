@@ -266,58 +266,76 @@ __global__ __launch_bounds__(BLOCK) void query_map_kernel(const u32 *__restrict_
     q_code[i] = code;
 }
 
+// The k-gram tables of a walk.  pairs == 0: one filled table of 4-byte entries over all k levels (see above).
+// pairs != 0 (tables marked off the sorted window keys, window_sort.h: KgMark): kg3 = the filled table of the levels
+// 1 .. k - 1, kg = the UNFILLED table of level k with 8-byte entries {rank, text position of the suffix at that rank}
+// (0xFFFFFFFF: no suffix has this k-gram; entry [bins] = {n_d, -}) -- the end of a bucket is the rank of the next entry
+// that is not empty (the one right behind it, for text that fills most of the table), and a walk that arrives in a
+// bucket of ONE suffix goes on with that suffix's position out of the entry it has just read: one dependent gather
+// (the symbol) instead of two (suffix array entry, then the symbol).
+struct KgTables {
+    const u32 *kg = nullptr, *kg3 = nullptr;
+    int k = 0, pairs = 0;
+    u32 A = 0, bins = 0;
+};
+
+// One walk: the keyphrase suffix q_code[t0 .. end) down document d's annotated suffix array (sad / nd / root_ann).
 // SYM = uint8_t: the byte stream (a quarter of the footprint; 0xFF terminators sort above every
 // text code, which is all the binary search needs), SYM = u32: the dense symbol stream.
 template <class SYM>
-__global__ __launch_bounds__(BLOCK) void score_walk_kernel(
-    const SYM *__restrict__ s, const u32 *__restrict__ sa, const u32 *__restrict__ doc_off,
-    const u32 *__restrict__ n_strings, u32 n_docs, const u32 *__restrict__ q_code,
-    const u32 *__restrict__ q_end, u32 n_q, int normalized, const u32 *__restrict__ kg, int kg_k, u32 kg_A,
-    u32 kg_bins, int xcd_order, u32 doc_first, u32 doc_count, double *__restrict__ suffix_out,
-    unsigned long long *__restrict__ probe_count)
+__device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, const u32 *__restrict__ sad, u32 nd, u32 root_ann,
+                                                    const u32 *__restrict__ q_code, u32 t0, u32 end, int normalized,
+                                                    const KgTables &kt, u32 d, u32 &probes)
 {
-    // XCD-aware work order: workgroups go round-robin over the 8 XCDs, each with its own 4 MB L2.  All the
-    // keyphrase suffixes of ONE document are walked by ONE XCD (document d belongs to XCD d mod 8, which takes
-    // its documents one after the other), so the top of that document's binary searches stays in that L2.
-    // (Only with many documents -- xcd_order, host side: with a handful an XCD would sit idle.)
-    const u32 blocks_per_doc = (n_q + BLOCK - 1u) / BLOCK;
-    const u32 local = xcd_order ? blockIdx.x >> 3 : blockIdx.x;
-    // (the documents [doc_first, doc_first + doc_count) of this launch: the per-suffix scratch is bounded, see score_resident)
-    const u32 dl = xcd_order ? (local / blocks_per_doc) * 8u + (blockIdx.x & 7u) : local / blocks_per_doc;
-    const u32 si = (local % blocks_per_doc) * BLOCK + threadIdx.x;
-    if (dl >= doc_count || si >= n_q) return;
-    const u32 d = doc_first + dl;
-    u32 probes = 0;                     // table reads and binary-search probes of this walk (roofline accounting)
-    const u32 seg = doc_off[d];
-    const u32 nd = doc_off[d + 1] - seg;
-    const u32 root_ann = nd - n_strings[d];
-    const u32 *sad = sa + seg;
-    const u32 end = q_end[si];
-
     u32 lo = 0, hi = nd - 1, depth = 0, nodes = 0;
     double acc = 0.0;
-    u32 t = si;
-    if (kg_k > 0) {
-        // the first kg_k symbols: two table reads per symbol instead of two binary searches
-        const u32 *row = kg + (size_t)d * (kg_bins + 1);
-        u32 code = 0, stride = kg_bins;
-        for (; t < end && depth < (u32)kg_k; t++) {
+    u32 t = t0;
+    u32 p_lo = 0;                       // the text position of the suffix at rank lo, where known
+    bool have_p = false;
+    auto enter = [&](u32 a, u32 b) {    // the interval of the next symbol; a node is entered whenever the interval shrinks
+        if (b - a < hi - lo) {
+            const u32 parent = depth == 0 ? root_ann : hi - lo + 1;
+            acc += (double)(b - a + 1) / (double)parent;
+            nodes++;
+        }
+        lo = a; hi = b; depth++;
+    };
+    if (kt.k > 0) {
+        // the first k symbols: table reads instead of binary searches
+        const int k3 = kt.pairs ? kt.k - 1 : kt.k;
+        const u32 bins3 = kt.pairs ? kt.bins / kt.A : kt.bins;
+        const u32 *row = (kt.pairs ? kt.kg3 : kt.kg) + (size_t)d * (bins3 + 1);
+        u32 code = 0, stride = bins3;
+        bool ended = false;
+        for (; t < end && depth < (u32)k3; t++) {
             const u32 c = q_code[t];
-            if (c == Q_NOMATCH) break;
-            stride /= kg_A;
-            code = code * kg_A + c;
+            if (c == Q_NOMATCH) { ended = true; break; }
+            stride /= kt.A;
+            code = code * kt.A + c;
             const u32 a = row[code * stride], b1 = row[(code + 1u) * stride];
             probes += 2;
-            if (b1 <= a) break;                           // no suffix continues with c
-            const u32 b = b1 - 1u;
-            if (b - a < hi - lo) {
-                const u32 parent = depth == 0 ? root_ann : hi - lo + 1;
-                acc += (double)(b - a + 1) / (double)parent;
-                nodes++;
-            }
-            lo = a; hi = b; depth++;
+            if (b1 <= a) { ended = true; break; }         // no suffix continues with c
+            enter(a, b1 - 1u);
         }
-        if (depth < (u32)kg_k) t = end;                   // the walk ended inside the table levels
+        if (kt.pairs && !ended && t < end && depth == (u32)k3) {
+            const u32 c = q_code[t];
+            ended = true;
+            if (c != Q_NOMATCH) {
+                const uint2 *row2 = reinterpret_cast<const uint2 *>(kt.kg) + (size_t)d * (kt.bins + 1);
+                u32 g = code * kt.A + c;
+                const uint2 e0 = row2[g];
+                probes++;
+                if (e0.x != 0xFFFFFFFFu) {
+                    u32 b1;
+                    do { b1 = row2[++g].x; probes++; } while (b1 == 0xFFFFFFFFu);     // (entry [bins] is never empty)
+                    enter(e0.x, b1 - 1u);
+                    p_lo = e0.y; have_p = lo == hi;
+                    t++;
+                    ended = false;
+                }
+            }
+        }
+        if (ended || depth < (u32)kt.k) t = end;          // the walk ended inside the table levels
     }
     for (; t < end; t++) {
         const u32 c = q_code[t];
@@ -325,7 +343,8 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
         u32 a, b;
         if (lo == hi) {
             probes++;
-            if (s[sad[lo] + depth] != c) break;
+            if (!have_p) { p_lo = sad[lo]; have_p = true; }
+            if (s[p_lo + depth] != c) break;
             a = b = lo;
         } else {
             u32 x = lo, y = hi + 1;                       // lower bound of c at this depth
@@ -344,20 +363,74 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
             if (x == a) break;                            // no suffix continues with c
             b = x - 1;
         }
-        if (b - a < hi - lo) {                            // a child node was entered
-            const u32 parent = depth == 0 ? root_ann : hi - lo + 1;
-            acc += (double)(b - a + 1) / (double)parent;
-            nodes++;
-        }
-        lo = a; hi = b; depth++;
+        enter(a, b);
     }
     double r = 0.0;
     if (depth > 0) {
         r = (acc + (double)depth) - (double)nodes;        // easa.py:127
         if (normalized) r /= (double)depth;               // easa.py:128-129
     }
-    suffix_out[(u64)dl * n_q + si] = r;
-    if (probe_count) atomicAdd(probe_count, (unsigned long long)probes);   // (counting runs only: east_hip_score_probes)
+    return r;
+}
+
+// One thread per (keyphrase suffix, document).  Two work layouts:
+//   blk == nullptr  thread si of a document's workgroups takes suffix si; the results go to suffix_out (D_local x S) and
+//                   score_reduce_kernel sums them;
+//   blk != nullptr  a workgroup takes WHOLE keyphrases -- those numbered [blk[i], blk[i + 1]), at most BLOCK suffixes in
+//                   all, packed by the host when the keyphrases were set -- and sums their suffix results itself, in
+//                   suffix order, out of LDS: the same additions in the same order as the reduction kernel's, without
+//                   the round trip of the per-suffix results through HBM and without the second launch.
+template <class SYM>
+__global__ __launch_bounds__(BLOCK) void score_walk_kernel(
+    const SYM *__restrict__ s, const u32 *__restrict__ sa, const u32 *__restrict__ doc_off,
+    const u32 *__restrict__ n_strings, u32 n_docs, const u32 *__restrict__ q_code,
+    const u32 *__restrict__ q_end, u32 n_q, int normalized, KgTables kt, int xcd_order, u32 doc_first, u32 doc_count,
+    double *__restrict__ suffix_out, unsigned long long *__restrict__ probe_count, const u32 *__restrict__ blk, u32 n_blk,
+    const u32 *__restrict__ q_off, double *__restrict__ table)
+{
+    // XCD-aware work order: workgroups go round-robin over the 8 XCDs, each with its own 4 MB L2.  All the
+    // keyphrase suffixes of ONE document are walked by ONE XCD (document d belongs to XCD d mod 8, which takes
+    // its documents one after the other), so the top of that document's binary searches stays in that L2.
+    // (Only with many documents -- xcd_order, host side: with a handful an XCD would sit idle.)
+    __shared__ double res[BLOCK];
+    const u32 blocks_per_doc = blk ? n_blk : (n_q + BLOCK - 1u) / BLOCK;
+    const u32 local = xcd_order ? blockIdx.x >> 3 : blockIdx.x;
+    // (the documents [doc_first, doc_first + doc_count) of this launch: the per-suffix scratch is bounded, see score_resident)
+    const u32 dl = xcd_order ? (local / blocks_per_doc) * 8u + (blockIdx.x & 7u) : local / blocks_per_doc;
+    if (dl >= doc_count) return;                          // (the whole workgroup)
+    const u32 bi = local % blocks_per_doc;
+    u32 kp0 = 0, kp1 = 0, s0 = bi * BLOCK, s1 = n_q;
+    if (blk) { kp0 = blk[bi]; kp1 = blk[bi + 1]; s0 = q_off[kp0]; s1 = q_off[kp1]; }
+    const u32 si = s0 + threadIdx.x;
+    const u32 d = doc_first + dl;
+    double r = 0.0;
+    if (si < s1) {
+        u32 probes = 0;                 // table reads and binary-search probes of this walk (roofline accounting)
+        const u32 seg = doc_off[d];
+        const u32 nd = doc_off[d + 1] - seg;
+        r = score_walk_suffix<SYM>(s, sa + seg, nd, nd - n_strings[d], q_code, si, q_end[si], normalized, kt, d, probes);
+        if (suffix_out) suffix_out[(u64)dl * n_q + si] = r;
+        if (probe_count) atomicAdd(probe_count, (unsigned long long)probes);   // (counting runs only: east_hip_score_probes)
+    }
+    if (!blk) return;
+    res[threadIdx.x] = r;
+    __syncthreads();
+    if (threadIdx.x < kp1 - kp0) {
+        const u32 k = kp0 + threadIdx.x;
+        const u32 b = q_off[k] - s0, e = q_off[k + 1] - s0;
+        double total = 0.0;
+        for (u32 i = b; i < e; i++) total += res[i];      // easa.py:130, in suffix order
+        table[(u64)k * n_docs + d] = total / (double)(e - b);   // easa.py:134
+    }
+}
+
+// the level-k table of a pair layout (KgTables): entry [bins] of every document = {n_d, -}
+__global__ __launch_bounds__(BLOCK) void kgram_pairs_end_kernel(const u32 *__restrict__ doc_off, u32 n_docs, u32 bins,
+                                                                u32 *__restrict__ kg)
+{
+    const u32 d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d >= n_docs) return;
+    reinterpret_cast<uint2 *>(kg)[(size_t)d * (bins + 1) + bins] = uint2{doc_off[d + 1] - doc_off[d], 0u};
 }
 
 // out[k*D + d] = (sum of the keyphrase's suffix results, in suffix order) / |q|

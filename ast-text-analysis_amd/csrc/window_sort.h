@@ -26,6 +26,7 @@ __device__ __forceinline__ u32 dc3_sample_pos(u32 t, u32 n0)
 __device__ __forceinline__ u32 lvl0_pos(u32 t, u32 n0) { return n0 ? dc3_sample_pos(t, n0) : t; }
 #include "lds_group_sort.h"
 static bool g_lds_rounds = getenv("EAST_HIP_NO_LDS_ROUNDS") == nullptr;     // east_hip_debug_set_lds_rounds (tests, A/B timing)
+static bool g_fused_classify = getenv("EAST_HIP_NO_FUSED_CLASSIFY") == nullptr;   // ... (2): the in-LDS rounds with the stand-alone classification pass
 
 static const bool g_trace = getenv("EAST_HIP_TRACE") != nullptr;   // per-round progress on stderr
 static bool g_force_wide_keys = getenv("EAST_HIP_WIDE_KEYS") != nullptr;                      // east_hip_debug_set_window_sort(3) (tests)
@@ -64,13 +65,38 @@ struct DocKey {
 // differ from the key before -- exactly "k-gram class code differs", terminator class and the zeroes
 // behind it included.  The placement pass writes those entries (kg[d][code] = rank inside the document;
 // the table was preset to 0xFFFFFFFF), the score side only has to run the suffix-minimum fill.
+// pairs (k >= 2): the table of the last level holds 8-byte entries {rank, text position of the suffix at that rank} and
+// stays UNFILLED (empty buckets keep 0xFFFFFFFF; the walk of score.h looks for a bucket's end among the next entries),
+// and the levels above it get a table of their own, kg3 (k - 1 symbols, 4-byte entries, filled on the score side: it is
+// A times smaller).  A walk that arrives in a bucket of ONE suffix -- most do -- then has that suffix's position with
+// the entry it read anyway, instead of behind a dependent read of the suffix array; the position is only ever used for
+// such buckets, whose suffix is untied and therefore final when the mark is written.
 struct KgMark {
     u32 *kg = nullptr;              // n_docs rows of bins + 1 entries
     int k = 0;                      // on entry: the largest k the table has room for; on return: the k marked (<= w)
     u32 A = 0, bins = 0;            // alphabet of the class codes (sigma_text + 2), A^k
     const u32 *doc_off = nullptr;
     u32 n_docs = 1;
+    u32 *kg3 = nullptr;             // pairs: n_docs rows of bins / A + 1 entries
+    int pairs = 0;
 };
+
+// rank j (key k, the key before it kp, its suffix v) opens a k-gram bucket of its document?  Then write the mark(s).
+template <class K>
+__device__ __forceinline__ void kg_mark_key(const KgMark &km, int w, int b, int spare, u32 j, K k, K kp, u32 v)
+{
+    const int top = spare + (w - km.k) * b;
+    if (j != 0 && (K)(k >> top) == (K)(kp >> top)) return;
+    const u32 d = km.n_docs > 1 ? (u32)(k >> (w * b + spare)) : 0u;     // (one document: no bits above the window)
+    u32 code = 0;
+    for (int q = 0; q < km.k; q++) code = code * km.A + ((u32)(k >> (spare + (w - 1 - q) * b)) & ((1u << b) - 1u));
+    if (code >= km.bins) return;                        // (only in a speculative build that assumed the wrong alphabet)
+    const u32 jl = j - km.doc_off[d];
+    if (!km.pairs) { km.kg[(size_t)d * (km.bins + 1) + code] = jl; return; }
+    reinterpret_cast<uint2 *>(km.kg)[(size_t)d * (km.bins + 1) + code] = uint2{jl, v};
+    const int top3 = top + b;                           // the level above: k - 1 symbols
+    if (j == 0 || (K)(k >> top3) != (K)(kp >> top3)) km.kg3[(size_t)d * (km.bins / km.A + 1) + code / km.A] = jl;
+}
 
 __global__ __launch_bounds__(BLOCK) void doc_tiles_kernel(const u32 *__restrict__ doc_off, u32 n_docs, u32 n_tiles,
                                                           u32 *__restrict__ tile_doc)
@@ -546,19 +572,9 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
             start[e] = j0 + e == 0 || j0 + e >= m || has_term || k[e + 1] != k[e];
         }
         if (OPTIMISTIC && km.kg) {                      // k-gram bucket starts, read off the keys (see KgMark)
-            const int top = spare + (w - km.k) * b;
 #pragma unroll
-            for (int e = 0; e < PLACE_IPT; e++) {
-                const u32 j = j0 + e;
-                if (j < m && (j == 0 || (K)(k[e + 1] >> top) != (K)(k[e] >> top))) {
-                    const u32 d = km.n_docs > 1 ? (u32)(k[e + 1] >> (w * b + spare)) : 0u;     // (one document: no bits above the window)
-                    u32 code = 0;
-                    for (int i = 0; i < km.k; i++)
-                        code = code * km.A + ((u32)(k[e + 1] >> (spare + (w - 1 - i) * b)) & ((1u << b) - 1u));
-                    // (code < bins always, except in a speculative build that assumed the wrong alphabet)
-                    if (code < km.bins) km.kg[(size_t)d * (km.bins + 1) + code] = j - km.doc_off[d];
-                }
-            }
+            for (int e = 0; e < PLACE_IPT; e++)
+                if (j0 + e < m) kg_mark_key<K>(km, w, b, spare, j0 + e, k[e + 1], k[e], v[e]);
         }
         // every rank: final (its key differs from both neighbours'), a member of a large group (sorted keys: an equal key
         // `limit` places away means more than `limit` equal keys around it -- natural-language text: half of the suffixes;
@@ -1016,15 +1032,8 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     const KeyNeqWindowIn<K> f{a.keys, a.rep_t, a.ones, a.highs};   // (keys / vals: never read -- everything the tie code touches is staged; a null pointer here crashes hipcc 7.2)
     const int w = a.w, b = a.b, spare = a.spare;
     u32 my_keep = 0;                                    // suffixes this thread left to the rounds (summed per wavefront at the end)
-    auto kg_mark = [&](u32 j, K k, K kp) {              // k-gram bucket starts, read off the keys (see KgMark)
-        const int top = spare + (w - a.km.k) * b;
-        if (j == 0 || (K)(k >> top) != (K)(kp >> top)) {
-            const u32 d = a.km.n_docs > 1 ? (u32)(k >> (w * b + spare)) : 0u;
-            u32 code = 0;
-            for (int q = 0; q < a.km.k; q++)
-                code = code * a.km.A + ((u32)(k >> (spare + (w - 1 - q) * b)) & ((1u << b) - 1u));
-            if (code < a.km.bins) a.km.kg[(size_t)d * (a.km.bins + 1) + code] = j - a.km.doc_off[d];
-        }
+    auto kg_mark = [&](u32 j, K k, K kp, u32 v) {       // k-gram bucket starts, read off the keys (see KgMark)
+        kg_mark_key<K>(a.km, w, b, spare, j, k, kp, v);
     };
     // rank `base + i` (one of this workgroup's): returns true when it is final here (suffix and LCP entry in sa_o / lcp_o,
     // to be stored by the caller); a rank handed to the rounds or a member of a small tie group is dealt with inside
@@ -1033,7 +1042,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
         sa_o = v;
         lcp_o = j > 0 ? fin_lcp_of_key_pair(a, k, kp) : 0u;
         if (is_hot) {
-            if (a.km.kg && first) kg_mark(j, k, kp);
+            if (a.km.kg && first) kg_mark(j, k, kp, v);
             const K xt = k ^ a.top_rep_t;
             if (((K)(xt - a.top_ones) & ~xt & a.top_highs) != 0) return true;   // a constant bucket: final as it stands
             // (handed to the rounds: the suffix goes to its rank as it is, with the caller's 16-byte stores; the LCP entry is
@@ -1044,7 +1053,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
             if (a.kg_top && a.km.kg) *a.kg_bad = 1u;
             return true;
         }
-        if (a.km.kg) kg_mark(j, k, kp);
+        if (a.km.kg) kg_mark(j, k, kp, v);
         const K x = k ^ f.rep_t;
         const bool st = j == 0 || ((K)(x - f.ones) & ~x & f.highs) != 0 || k != kp;
         bool st_next = j + 1 >= m;
@@ -1205,14 +1214,18 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
                                                                     u32 *__restrict__ order_g, u32 *__restrict__ names_g,
                                                                     u64 *__restrict__ keep, u32 *__restrict__ fail,
                                                                     u32 limit, u32 max_len, u32 *__restrict__ name_of,
-                                                                    LongRepeats lr, u32 *__restrict__ lcp_g)
+                                                                    LongRepeats lr, u32 *__restrict__ lcp_g,
+                                                                    const uint2 *__restrict__ only_rest = nullptr)
 {
     // (as in the placement pass: every tied element of the workgroup's stretch fetches the 8 symbols behind the common
     // depth once, and the members of a group rank themselves against those instead of gathering each other's text)
+    // only_rest != nullptr: the in-LDS round classified its own tiles (lds_group_sort.h: LgClassify) -- only the positions
+    // the global sort took are looked at, and the keep bits are OR-ed into words the host has zeroed
     __shared__ u64 next8[BLOCK];
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
     u32 my_keep = 0;
-    const bool tied = j < m && ((j > 0 && !starts(j)) || (j + 1 < m && !starts(j + 1)));
+    const bool mine = !only_rest || LgUncovered{only_rest, m}(j);       // (a group lies wholly inside or outside the tiles)
+    const bool tied = mine && j < m && ((j > 0 && !starts(j)) || (j + 1 < m && !starts(j + 1)));
     if (tied) next8[threadIdx.x] = load_u64_unaligned(s8 + lvl0_pos(elem[j], n0) + depth);
     __syncthreads();
     if (tied)
@@ -1220,7 +1233,10 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
                                   name_of, lr, NextSymbols{next8, blockIdx.x * BLOCK, (u32)BLOCK});
     // keep[]: one bit per element (entries m.. of the last word are 0: the exclusive scan over m + 1 yields the total)
     const u64 bal = __ballot(my_keep != 0);
-    if (lane_id() == 0) keep[j >> 6] = bal;
+    if (lane_id() == 0) {
+        if (!only_rest) keep[j >> 6] = bal;
+        else if (bal) atomicOr((unsigned long long *)&keep[j >> 6], (unsigned long long)bal);
+    }
 }
 
 // A repeat too long for the direct ordering leaves its group half written: put the whole domain back
@@ -1554,7 +1570,9 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         km.k = std::min(km.k, w);
         km.bins = 1;
         for (int i = 0; i < km.k; i++) km.bins *= km.A;
-        HIP_CHECK(hipMemsetAsync(km.kg, 0xFF, (size_t)(km.bins + 1) * km.n_docs * sizeof(u32), ctx.stream));
+        km.pairs = km.kg3 && km.k >= 2;
+        HIP_CHECK(hipMemsetAsync(km.kg, 0xFF, (size_t)(km.bins + 1) * km.n_docs * (km.pairs ? 8 : 4), ctx.stream));
+        if (km.pairs) HIP_CHECK(hipMemsetAsync(km.kg3, 0xFF, (size_t)(km.bins / km.A + 1) * km.n_docs * sizeof(u32), ctx.stream));
         *kg_mark = km;
     }
     u32 m = n02, m_next = n02, h_fail = 0;              // (sizing run: as if everything were tied)
@@ -1723,15 +1741,22 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // (prefix doubling) the name of the suffix `depth` symbols further on.  Groups that fit a workgroup's LDS are
             // sorted there, keys, sort and write-back in one launch (lds_group_sort.h); the rest is compacted and takes
             // the global radix sort by (group, key).
+            // (the classification of the next domain rides along with the in-LDS round, see LgClassify: symbol windows, the
+            // usual limits, no groups with long repeats known)
+            const bool endgame = m <= REFINE_ENDGAME_DOMAIN;
+            const bool fuse_cls = g_lds_rounds && g_fused_classify && !doubling && !endgame && !long_repeats;
+            u32 round_left = m;                         // what the in-LDS round left to the global sort
             auto sort_round = [&](bool names, int w2, const KeyNeqWindowIn<u64> &f) {
                 const int kbits = names ? 32 : w2 * bt;
                 u32 *lcp_r = names ? (u32 *)nullptr : lcp_out;
                 u32 m_left = m;
                 if (g_lds_rounds) {
+                    if (fuse_cls) HIP_CHECK(hipMemsetAsync(keep, 0, (((size_t)m >> 6) + 2) * sizeof(u64), ctx.stream));
                     LAUNCH_BLOCK(ctx, refine_lds_sort_kernel, ceil_div_u32(m, LG_CHUNK), LG_THREADS, s8, (const u32 *)ebuf[e_c],
                                  (const u32 *)gstart, (const u32 *)slot_c, m, n0, depth, w2, bt, term_first, (u64)f.rep_t,
                                  (u64)f.ones, (u64)f.highs, sa12, names_g, ebuf[e_out], fbuf[f_dom ^ 1], lcp_r, cover,
-                                 names ? (const u32 *)name_of : (const u32 *)nullptr);
+                                 names ? (const u32 *)name_of : (const u32 *)nullptr,
+                                 fuse_cls ? LgClassify{keep, fail, (u32)REFINE_SMALL_GROUP, (u32)RESOLVE_MAX_LEN} : LgClassify());
                     // what is left: counted per chunk from cover[] (no pass over the elements)
                     const u32 n_chunks = ceil_div_u32(m, LG_CHUNK);
                     LAUNCH(ctx, lg_rest_count_kernel, ceil_div_u32(n_chunks + 1, BLOCK), (const uint2 *)cover, m, n_chunks, rest_cnt);
@@ -1741,6 +1766,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                     if (ctx.stats) ctx.stats->lds_sorted += m - m_left;
                     if (g_trace) fprintf(stderr, "[east_hip]   round %d: %u of %u sorted in LDS\n", round, m - m_left, m);
                 }
+                round_left = m_left;
                 if (m_left == 0) return;
                 const u32 *elems_s = ebuf[e_c];             // what goes through the global sort: the domain, or its rest
                 const u32 *full = nullptr;
@@ -1793,12 +1819,12 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // the new, smaller domain: place what is untied or in small groups now, count the rest
             // a small domain is finished by direct ordering of much larger groups (a round costs ~60 launches
             // however few suffixes are left); the comparisons are kept short so that the work stays bounded
-            const bool endgame = m <= REFINE_ENDGAME_DOMAIN;
-            auto classify = [&](int mode) {
-                LAUNCH(ctx, dc3_refine_classify_kernel, gt, elem, FlagArrIn{flag}, slot, m, s8, n0, depth, sa12, names_g, keep,
-                       fail, endgame ? (u32)REFINE_ENDGAME_GROUP : (u32)REFINE_SMALL_GROUP,
-                       endgame ? (u32)REFINE_ENDGAME_LEN : (u32)RESOLVE_MAX_LEN, doubling ? name_of : (u32 *)nullptr,
-                       LongRepeats{bad, mode}, lcp_out);
+            auto classify = [&](int mode, bool rest_only = false) {
+                if (!rest_only || round_left > 0)       // (rest_only: the in-LDS round has classified its own tiles)
+                    LAUNCH(ctx, dc3_refine_classify_kernel, gt, elem, FlagArrIn{flag}, slot, m, s8, n0, depth, sa12, names_g, keep,
+                           fail, endgame ? (u32)REFINE_ENDGAME_GROUP : (u32)REFINE_SMALL_GROUP,
+                           endgame ? (u32)REFINE_ENDGAME_LEN : (u32)RESOLVE_MAX_LEN, doubling ? name_of : (u32 *)nullptr,
+                           LongRepeats{bad, mode}, lcp_out, rest_only ? (const uint2 *)cover : (const uint2 *)nullptr);
                 if (mode == 1) return;
                 device_scan<PopIn, false>(ctx, PopIn{keep, (m >> 6) + 1u}, (m >> 6) + 2u, idx);
                 have_idx = true;
@@ -1809,7 +1835,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                     fprintf(stderr, "[east_hip]   round %d: domain %u, %u still in large groups, depth %u%s\n", round, m, m_next,
                             depth, h_fail ? ", a repeat too long to order directly" : "");
             };
-            if (!long_repeats) classify(0);             // (once such groups are known to exist: mark + place right away)
+            if (!long_repeats) classify(0, fuse_cls);   // (once such groups are known to exist: mark + place right away)
             if (h_fail || long_repeats) {               // as in the first domain: restore, mark, place the rest
                 if (h_fail) LAUNCH(ctx, (dc3_refine_restore_kernel<FlagArrIn>), gt, elem, FlagArrIn{flag}, slot, m, sa12, names_g);
                 HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
@@ -1914,12 +1940,17 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
                                            kg_mark, allow_fused, docs.bits ? longest : n);
     };
     bool ok;
+    const Stats stats_in = ctx.stats ? *ctx.stats : Stats();
     try {
         ok = level0(true);
     } catch (const FusedAbort &) {
         if (g_trace) fprintf(stderr, "[east_hip] fused finish gave up (a repeat too long to order directly): full sort\n");
         ar.release(mark);
         if (kg_mark) kg_mark->k = kg_k_in;
+        // nothing of the abandoned attempt is left behind: its pass counts (the bench's byte model reads them), and the
+        // "k-gram marks incomplete" flag it may have raised -- the full sort's placement pass marks every bucket start
+        if (ctx.stats) *ctx.stats = stats_in;
+        if (ctx.kg_bad && !ctx.dry) HIP_CHECK(hipMemsetAsync(ctx.kg_bad, 0, sizeof(u32), ctx.stream));
         ok = level0(false);
     }
     ar.release(mark);

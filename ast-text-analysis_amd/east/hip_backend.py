@@ -70,6 +70,7 @@ SIGNATURES = {
     "east_hip_debug_set_lds_rounds": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_debug_set_speculation": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_debug_set_score_scratch": (ctypes.c_int, [ctypes.c_int64]),
+    "east_hip_debug_set_score_path": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "east_hip_profile_only": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
     "east_hip_profile_report": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),

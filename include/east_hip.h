@@ -15,7 +15,9 @@
  *   - plain pointers and sizes only; the caller owns every host buffer
  *     (C-contiguous), the library owns device memory behind the opaque handle
  *   - calls are blocking unless the name ends in _async; a handle is not
- *     thread-safe, distinct handles are; one HIP stream per handle; every call runs on
+ *     thread-safe, distinct handles are -- EXCEPT with respect to the east_hip_debug_* setters, which change
+ *     process-wide test knobs and must only be called while no build or score call is in flight on any handle;
+ *     one HIP stream per handle; every call runs on
  *     the handle's device and restores the calling thread's current HIP device before it returns
  *   - indices are int32 on the device (n_total < 2^31 - 8); the Python side
  *     widens to int64 to match the reference's np.int tables
@@ -289,7 +291,7 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes);
 int east_hip_debug_set_window_sort(int enabled);
 /* Test knob: 0 = the tie-refinement rounds sort every group with the global radix sort; 1 (default) = groups
  * that fit a workgroup's LDS are sorted there (csrc/lds_group_sort.h), the global sort takes the rest. */
-int east_hip_debug_set_lds_rounds(int enabled);
+int east_hip_debug_set_lds_rounds(int enabled);   /* 0 / 1 (default: the in-LDS rounds also classify the next domain) / 2 (in-LDS rounds + the stand-alone classification pass) */
 /* Test knob: 0 = every build waits for the device's answers (alphabet size, tie groups) as a handle's
  * first build does; 1 (default) = later builds on a handle are queued without waiting, on the strength
  * of what the build before found, and checked by the one read-back at their end. */
@@ -298,6 +300,11 @@ int east_hip_debug_set_speculation(int enabled);
  * more documents than fit is scored a stretch of documents at a time.  Takes effect at the next
  * east_hip_set_keyphrases / east_hip_score_table. */
 int east_hip_debug_set_score_scratch(int64_t bytes);
+/* Test knob (process-wide): which form of the score path runs (easa.py:91-139).  1 (default) = pair k-gram tables marked
+ * off the window keys + the per-keyphrase sums inside the walk kernel; 0 = one filled table, per-suffix results in HBM
+ * and a reduction kernel (rounds 1-3); 2 = pair tables with the reduction kernel; 3 = filled table with the sums in the
+ * walk.  Takes effect at the next build (tables) / the next east_hip_set_keyphrases (sums). */
+int east_hip_debug_set_score_path(int mode);
 /* Host-only: bytes of device arena a build of n_total symbols / n_docs documents
  * reserves (worst case over inputs).  Needs no device. */
 int64_t east_hip_plan_arena_bytes(int64_t n_total, int32_t n_docs);

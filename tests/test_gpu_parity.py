@@ -598,13 +598,13 @@ def test_small_vocabulary_text_tie_refinement_vs_oracle(hip, oracle, seed):
             assert np.array_equal(t[name], getattr(o, name)), (name, d, index.info())
 
 
-@pytest.mark.parametrize("lds_rounds", [1, 0])
+@pytest.mark.parametrize("lds_rounds", [1, 2, 0])
 @pytest.mark.parametrize("seed", range(4))
 def test_refinement_rounds_in_lds_and_by_the_global_sort(hip, oracle, suffix_sort_path, seed, lds_rounds):
     """The rounds order tie groups that fit a workgroup's LDS there (csrc/lds_group_sort.h) and leave longer ones to
     the global radix sort: word text over small vocabularies gives both kinds in one domain -- groups of a few
     dozen members next to groups of tens of thousands --, single documents and several, with the in-LDS path on
-    (default) and off.  All six tables bit-exact against the oracle, the LCP entries the rounds write included."""
+    (1, the default: the in-LDS round also classifies the next domain; 2: with the stand-alone classification pass) and off.  All six tables bit-exact against the oracle, the LCP entries the rounds write included."""
     from east import hip_backend, synthetic
     lib = hip.load()
     rng = np.random.default_rng(7700 + seed)
