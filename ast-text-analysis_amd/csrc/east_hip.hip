@@ -598,8 +598,10 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
             for (u32 d = 1; d < n_docs; d++)
                 if (off32[d + 1] - off32[d] > off32[dl + 1] - off32[dl]) dl = d;
             const u32 len = off32[dl + 1] - off32[dl], cnt = std::min<u32>(SAMPLE_N, len);
-            LAUNCH_BLOCK(ctx, sample_prefix_kernel, SAMPLE_MAX_L, SAMPLE_THREADS, d_sym, n, off32[dl] + (len - cnt) / 2, cnt,
-                         flags + FLAG_SAMPLE);
+            // (many short documents: a sample of a few dozen suffixes decides nothing -- no sample, the uniform estimates)
+            if (cnt >= SAMPLE_N / 4)
+                LAUNCH_BLOCK(ctx, sample_prefix_kernel, SAMPLE_MAX_L, SAMPLE_THREADS, d_sym, n, off32[dl] + (len - cnt) / 2, cnt,
+                             flags + FLAG_SAMPLE);
         }
         if (!ctx.dry) {
             if (ctx.spec) {
@@ -943,6 +945,11 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     // (hardly anything tied behind the wide window -- another kind of text on the same handle: back to the estimate)
     if (ctx.did_wide && h->stats.first_n > 0 && h->stats.first_kept * 50 < h->stats.first_n) h->plan_wide = -1;
     h->plan_fused = h->stats.window_sorted ? ctx.did_fused : -1;
+    // (the same for the fused finish: it handed more than a few per cent of the suffixes to the rounds, or the separate
+    // placement pass left next to nothing -- another kind of text than the plan was made for: the next build decides anew)
+    if (h->stats.first_n > 0 && ((ctx.did_fused && h->stats.first_kept * 20 > h->stats.first_n) ||
+                                 (!ctx.did_fused && h->stats.first_kept * 50 < h->stats.first_n)))
+        h->plan_fused = -1;
     h->hint_no_rounds = h->stats.window_sorted && h->stats.refine_rounds == 0 && !h->stats.long_repeats;
     h->prof.collect();
     HIP_CHECK(hipEventElapsedTime(&h->last_build_ms, h->ev0, h->ev1));

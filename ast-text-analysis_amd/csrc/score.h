@@ -301,40 +301,62 @@ __device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, c
         lo = a; hi = b; depth++;
     };
     if (kt.k > 0) {
-        // the first k symbols: table reads instead of binary searches
+        // The first k symbols: table reads instead of binary searches.  Where the entries lie follows from the query
+        // symbols alone, so ALL of them -- every level's pair, the last level's entry with its successor -- are requested
+        // before the first one is looked at: one memory round trip for the table levels instead of one per level (the
+        // walk is bound by latency: a level's reads used to wait for the verdict of the level before).
         const int k3 = kt.pairs ? kt.k - 1 : kt.k;
         const u32 bins3 = kt.pairs ? kt.bins / kt.A : kt.bins;
         const u32 *row = (kt.pairs ? kt.kg3 : kt.kg) + (size_t)d * (bins3 + 1);
-        u32 code = 0, stride = bins3;
-        bool ended = false;
-        for (; t < end && depth < (u32)k3; t++) {
-            const u32 c = q_code[t];
-            if (c == Q_NOMATCH) { ended = true; break; }
-            stride /= kt.A;
-            code = code * kt.A + c;
-            const u32 a = row[code * stride], b1 = row[(code + 1u) * stride];
-            probes += 2;
-            if (b1 <= a) { ended = true; break; }         // no suffix continues with c
-            enter(a, b1 - 1u);
+        const uint2 *row2 = reinterpret_cast<const uint2 *>(kt.kg) + (size_t)d * (kt.bins + 1);
+        u32 cs[KGRAM_KEYS_MAX_K];
+        int L = 0;                                        // query symbols the table levels can take
+#pragma unroll
+        for (int i = 0; i < KGRAM_KEYS_MAX_K; i++) {
+            const u32 c = (i < kt.k && t0 + (u32)i < end) ? q_code[t0 + i] : Q_NOMATCH;
+            cs[i] = c;
+            if (c != Q_NOMATCH && L == i) L = i + 1;
         }
-        if (kt.pairs && !ended && t < end && depth == (u32)k3) {
-            const u32 c = q_code[t];
-            ended = true;
-            if (c != Q_NOMATCH) {
-                const uint2 *row2 = reinterpret_cast<const uint2 *>(kt.kg) + (size_t)d * (kt.bins + 1);
-                u32 g = code * kt.A + c;
-                const uint2 e0 = row2[g];
-                probes++;
-                if (e0.x != 0xFFFFFFFFu) {
-                    u32 b1;
-                    do { b1 = row2[++g].x; probes++; } while (b1 == 0xFFFFFFFFu);     // (entry [bins] is never empty)
-                    enter(e0.x, b1 - 1u);
-                    p_lo = e0.y; have_p = lo == hi;
-                    t++;
-                    ended = false;
-                }
+        u32 ta[KGRAM_KEYS_MAX_K], tb[KGRAM_KEYS_MAX_K];
+        u32 code = 0, stride = bins3;
+#pragma unroll
+        for (int i = 0; i < KGRAM_KEYS_MAX_K; i++) {
+            ta[i] = tb[i] = 0;
+            if (i < k3 && i < L) {
+                stride /= kt.A;
+                code = code * kt.A + cs[i];
+                ta[i] = row[code * stride];
+                tb[i] = row[(code + 1u) * stride];
             }
         }
+        uint2 e0 = uint2{0xFFFFFFFFu, 0u};
+        u32 e1 = 0, g = 0;
+        const bool last = kt.pairs && L == kt.k;           // (then k3 = k - 1 levels were taken above)
+        if (last) {
+            g = code * kt.A + cs[kt.k - 1];
+            e0 = row2[g];
+            e1 = row2[g + 1u].x;
+        }
+        bool ended = false;
+#pragma unroll
+        for (int i = 0; i < KGRAM_KEYS_MAX_K; i++) {
+            if (i < k3 && i < L && !ended) {
+                probes += 2;
+                if (tb[i] <= ta[i]) ended = true;          // no suffix continues with c
+                else enter(ta[i], tb[i] - 1u);
+            }
+        }
+        if (last && !ended) {
+            probes += 2;
+            if (e0.x == 0xFFFFFFFFu) ended = true;
+            else {
+                g++;
+                while (e1 == 0xFFFFFFFFu) { e1 = row2[++g].x; probes++; }     // (entry [bins] is never empty)
+                enter(e0.x, e1 - 1u);
+                p_lo = e0.y; have_p = lo == hi;
+            }
+        }
+        t = t0 + depth;
         if (ended || depth < (u32)kt.k) t = end;          // the walk ended inside the table levels
     }
     for (; t < end; t++) {

@@ -350,8 +350,11 @@ def main():
         value = world * n_bytes / (elapsed / args.steps)
         default_shape = (D, doc_mib, K, args.mode, args.corpus) == (1, 64.0, 1000, "text", "words") and not args.duplicate_docs
         zipf_shape = (D, doc_mib, K, args.mode, args.corpus) == (100, 1.0, 1000, "text", "zipf") and not args.duplicate_docs
-        # (the counters were collected on these two workloads: tools/profile_round.sh, tools/profile_zipf.sh)
-        traffic = load_traffic("traffic.json") if default_shape else load_traffic("traffic_zipf.json") if zipf_shape else {}
+        config2_shape = (D, doc_mib, K, args.mode, args.corpus) == (256, 1.0, 10000, "text", "words") and not args.duplicate_docs
+        # (the counters were collected on these workloads: tools/profile_round.sh, profile_zipf.sh, profile_config2.sh)
+        traffic_file = ("traffic.json" if default_shape else "traffic_zipf.json" if zipf_shape else
+                        "traffic_config2.json" if config2_shape else None)
+        traffic = load_traffic(traffic_file) if traffic_file else {}
         roofline, by_kernel, per_step = roofline_of(prof, info, n, D, profile_steps, traffic)
         live = prof_timed.get(dom_name)
         if live and live[0]:                             # the dominant kernel as measured inside the timed region
@@ -363,6 +366,9 @@ def main():
                 roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
             roofline["avg_launch_ms_profiling_pass"] = prof[dom_name][1] / prof[dom_name][0]
         roofline["rocprof_hbm_fraction"] = hbm_fraction(prof, traffic)
+        roofline["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this "
+                                      "workload (tools/profile_*.sh + summarize_profiles.py), committed with the code -- not "
+                                      "measured by this run" % traffic_file) if traffic_file else None
         out = {
             "metric": "corpus chars/sec (SA+annotation build + keyphrase score table)",
             "value": value, "unit": "chars/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -445,9 +451,9 @@ def extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D, 
     walk = prof.get("score_walk_kernel")
     if walk:
         probes = index.score_probes(not args.denormalized)
-        # 8 B per table read / probe (suffix-array entry + symbol), the per-suffix results written by the walk
-        # and read by the reduction (8 B each way), 8 B per score
-        b = 8 * probes + 16 * n_q * D + 8 * K * D
+        # 8 B per table read / probe (suffix-array entry + symbol), 8 B per score; the per-suffix results written by the
+        # walk and read by the reduction (8 B each way) only where the reduction kernel still runs
+        b = 8 * probes + (16 * n_q * D if "score_reduce_kernel" in prof else 0) + 8 * K * D
         ms = walk[1] / walk[0]
         res["roofline_score"] = {"kernel": "score_walk_kernel", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "probes": probes, "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms,
@@ -644,7 +650,9 @@ def config2_leg(args, hip_backend, synthetic, torch, dev, local_rank):
     prof = index.profile_report()
     index.profile_enable(False)
     info = index.info()
-    roofline, by_kernel, per_step = roofline_of(prof, info, n, D, steps, {})
+    traffic = load_traffic("traffic_config2.json")          # PMC passes of this workload (tools/profile_config2.sh)
+    roofline, by_kernel, per_step = roofline_of(prof, info, n, D, steps, traffic)
+    roofline["traffic_source"] = "profiles/traffic_config2.json (tools/profile_config2.sh), committed counters of an earlier run"
     res = {"workload": "256 synthetic 1 MiB random-ASCII word-stream docs (text mode), 10000 keyphrases, normalized",
            "steps": steps, "ms_per_step": elapsed * 1e3 / steps, "value": D * (1 << 20) / (elapsed / steps),
            "unit": "chars/s", "symbols": n, "build_ms": float(np.mean(build_ms)), "score_ms": float(np.mean(score_ms)),
@@ -654,11 +662,14 @@ def config2_leg(args, hip_backend, synthetic, torch, dev, local_rank):
     walk = prof.get("score_walk_kernel")
     if walk and not args.no_extras:
         probes = index.score_probes(True)
-        b = 8 * probes + 16 * int(qo[-1]) * D + 8 * K * D
+        b = 8 * probes + (16 * int(qo[-1]) * D if "score_reduce_kernel" in prof else 0) + 8 * K * D
         ms = walk[1] / walk[0]
         res["roofline_score"] = {"kernel": "score_walk_kernel", "probes": probes, "algorithmic_bytes_per_launch": b,
                                  "avg_launch_ms": ms, "achieved": b / (ms * 1e-3) / 1e9, "unit": "GB/s",
-                                 "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                 "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic.get("score_walk_kernel"),
+                                 "traffic_note": "PMC bytes per launch (64-byte sectors, fetch correction 1), profiles/traffic_config2.json"}
+        res["score_kernels_ms_per_step"] = {k: round(v[1] / steps, 4) for k, v in prof.items()
+                                            if k.startswith(("score_", "kgram_", "query_"))}
     index.close()
     return res
 

@@ -395,6 +395,9 @@ def test_config2_256_documents_10000_keyphrases_vs_oracle(hip, oracle):
         for norm in (True, False):
             want = np.array([o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=True) for k in range(10000)])
             assert np.array_equal(tables[norm][:, d], want), (d, norm)
+        if d == 37:     # ... and the reference's own walk over the sibling chains (easa.py:91-139, not the interval walk) on 200 of them
+            for k in range(0, 10000, 50):
+                assert tables[True][k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=False), (d, k)
     # every keyphrase copied from a document scores > 0 there (keyphrases() takes the even ones from the corpus)
     assert (tables[True].max(axis=1)[0::2] > 0).all()
 
@@ -1443,6 +1446,62 @@ def test_score_in_stretches_of_documents(hip, oracle):
     o = oracle.OracleEASA(symbols=docs[77][0], n_strings=docs[77][1])
     for k in range(40):
         assert want[k, 77] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=True)
+
+
+@pytest.mark.parametrize("mode", [1, 0, 2, 3])
+def test_score_path_variants(hip, oracle, mode):
+    """The score walk's two choices (east_hip_debug_set_score_path): k-gram tables in the pair layout (last level
+    unfilled, 8-byte entries with the suffix position; the level above in a table of its own) or as one filled table,
+    and the per-keyphrase sums inside the walk kernel or by the reduction kernel -- every combination bit-equal to the
+    oracle, normalized and -d, the per-suffix results included; documents of very different sizes (tables of 1 to 4
+    levels), natural-language-like text (mostly empty last-level tables), a keyphrase longer than a workgroup (the sums
+    fall back to the reduction kernel), absent symbols, and scoring a stretch of documents at a time."""
+    from east import hip_backend, synthetic
+    lib = hip.load()
+    rng = np.random.default_rng(8800)
+    vocab = synthetic.zipf_vocabulary(np.random.default_rng(5), size=800, exponent=1.0)
+    docs = []
+    for i in range(21):
+        size = int(rng.choice([300, 5000, 70000, 400000]))
+        if i % 3 == 2:
+            docs.append(synthetic.zipf_document(rng, size, vocab))
+        else:
+            docs.append(synthetic.word_stream_document(rng, size, want_text=False)[1:])
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    ms = np.array([d[1] for d in docs])
+    qs, qo = synthetic.keyphrases(rng, sym, 300)
+    parts = [qs[qo[k]:qo[k + 1]] for k in range(300)]
+    parts[7] = np.concatenate([parts[7], np.array([ord("9")], dtype=np.uint32), parts[8]])      # a symbol absent from the corpus
+    long_kp = sym[1000:1400][sym[1000:1400] < 0x0A00]
+    assert lib.east_hip_debug_set_score_path(mode) == 0
+    try:
+        index = hip_backend.HipIndex()
+        index.build(sym, off, ms)
+        oracles = {d: oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1]) for d in (0, 2, 5, 11, 20)}
+        for with_long in (False, True):
+            ps = parts + [long_kp] if with_long else parts
+            q = np.concatenate(ps)
+            o = np.concatenate([[0], np.cumsum([p.size for p in ps])]).astype(np.int64)
+            for norm in (True, False):
+                table, suf = index.score_table(q, o, norm, want_suffix=True)
+                plain = index.score_table(q, o, norm)
+                assert np.array_equal(table, plain)
+                index.set_keyphrases(q, o)
+                index.score_resident(norm)
+                for d, orc in oracles.items():
+                    for k in range(0, len(ps), 1 if d == 5 else 7):
+                        want, want_suf = orc.score_symbols(ps[k], norm, fast=True, want_suffix=True)
+                        assert table[k, d] == want, (mode, d, k, norm)
+                        assert np.array_equal(suf[d, o[k]:o[k + 1]], want_suf), (mode, d, k, norm)
+        assert lib.east_hip_debug_set_score_scratch(int(qo[-1]) * 8 * 4) == 0       # four documents at a time
+        t2, s2 = index.score_table(q, o, True, want_suffix=True)
+        t1, s1 = index.score_table(q, o, False, want_suffix=True)
+        assert np.array_equal(t1, table) and np.array_equal(s1, suf)
+        assert np.array_equal(t2, index.score_table(q, o, True))
+    finally:
+        assert lib.east_hip_debug_set_score_scratch(0) == 0
+        assert lib.east_hip_debug_set_score_path(1) == 0
 
 
 def test_half_gib_symbols(hip):
