@@ -456,8 +456,9 @@ struct east_hip_index {
     u32 kg_A = 0, kg_bins = 0;
     bool kg_built = false;
     bool kg_marked = false;      // the bucket starts were written by the build (off the window keys): only the fill is due
-    bool kg_pairs = false;       // ... in the pair layout (score.h: KgTables); kg3 = the table of the levels above the last
-    u32 *kg3 = nullptr;
+    bool kg_pairs = false;       // ... in the pair layout (score.h: KgTables); kg3 = the table of the levels above the last,
+    u32 *kg3 = nullptr, *kg_up = nullptr;        // kg_up = the small tables of the levels above kg3's own
+    u32 kg_up_stride = 0;
     float last_build_ms = -1.f, last_score_ms = -1.f, last_prep_ms = -1.f;
     // the caller's Unicode tables of the device text preparation (own allocation, re-uploaded when their hash changes)
     char *tp_tables = nullptr;
@@ -691,6 +692,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
                 // (the pair layout: the level above the last in a table of its own, behind the 8-byte entries)
                 if (g_kg_pairs) km.kg3 = h->kg + 2 * (size_t)(bins + 1) * n_docs;
                 h->kg3 = km.kg3;
+                h->kg_up = km.kg3 ? km.kg3 + (size_t)(bins / km.A + 1) * n_docs : nullptr;
             } else {
                 km.k = 0;
             }
@@ -1275,7 +1277,7 @@ static bool kgram_reserve(east_hip_index *h, u64 bins, u32 n_docs)
     // (room for the pair layout: 8-byte entries of the last level + the table of the level above; the filled 4-byte
     // layout with its chunk scratch is smaller)
     const size_t chunks = (size_t)((bins + KGF_CHUNK - 1) / KGF_CHUNK);
-    const size_t bytes = (2 * (size_t)(bins + 1) + (size_t)(bins / 2 + 2) + 2 * chunks) * n_docs * 4 + 256;
+    const size_t bytes = (2 * (size_t)(bins + 1) + (size_t)(bins / 2 + 2) + (size_t)(bins / 4 + 8) + 2 * chunks) * n_docs * 4 + 256;
     if (bytes <= h->kg_cap) return true;
     HIP_CHECK(hipStreamSynchronize(h->stream));
     if (h->kg) HIP_CHECK(hipFree(h->kg));
@@ -1297,6 +1299,12 @@ static void ensure_kgram(east_hip_index *h, Ctx &ctx)
         const u32 bins3 = h->kg_bins / h->kg_A;
         LAUNCH(ctx, kgram_pairs_end_kernel, ceil_div_u32(h->n_docs, BLOCK), (const u32 *)h->doc_off, h->n_docs, h->kg_bins, h->kg);
         LAUNCH(ctx, kgram_fill_kernel, h->n_docs, (const u32 *)h->doc_off, bins3, h->kg3);
+        // (levels 1 .. k - 2 as tables of their own: A + 1, A^2 + 1, ... entries per document)
+        h->kg_up_stride = 0;
+        u32 len = h->kg_A;
+        for (int l = 1; l < h->kg_k - 1; l++) { h->kg_up_stride += len + 1; len *= h->kg_A; }
+        if (h->kg_up_stride && h->kg_up)
+            LAUNCH(ctx, kgram_upper_kernel, h->n_docs, (const u32 *)h->kg3, bins3, h->kg_A, h->kg_k - 1, h->kg_up_stride, h->kg_up);
         h->kg_built = true;
         return;
     }
@@ -1367,6 +1375,7 @@ static void score_resident(east_hip_index *h, int normalized, unsigned long long
            h->sigma_hi ? h->sigma_t - h->sigma_hi + 1u : 0u, h->q_code);
     KgTables kt;
     kt.kg = h->kg; kt.kg3 = h->kg3; kt.k = h->kg_k; kt.pairs = h->kg_k > 0 && h->kg_pairs; kt.A = h->kg_A; kt.bins = h->kg_bins;
+    if (kt.pairs && h->kg_up_stride && h->kg_up) { kt.up = h->kg_up; kt.up_stride = h->kg_up_stride; }
     // whole keyphrases per workgroup, summed in the walk (no per-suffix results unless the caller wants them: then the
     // documents go a stretch at a time, as far as the scratch reaches); otherwise per-suffix results + the reduction kernel
     const bool fused = h->n_blk > 0;

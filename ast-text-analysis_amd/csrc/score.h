@@ -273,11 +273,22 @@ __global__ __launch_bounds__(BLOCK) void query_map_kernel(const u32 *__restrict_
 // that is not empty (the one right behind it, for text that fills most of the table), and a walk that arrives in a
 // bucket of ONE suffix goes on with that suffix's position out of the entry it has just read: one dependent gather
 // (the symbol) instead of two (suffix array entry, then the symbol).
+// The levels 1 .. k - 2 of a pair layout also exist as small tables of their own (`up`: per document the tables of A + 1,
+// A^2 + 1, ... entries one after the other, copied out of kg3 once it is filled), so that EVERY level's interval is two
+// adjacent entries -- one 8-byte load per level.  (The walk is bound by the number of address-divergent loads a
+// wavefront issues -- every lane another sector --, not by bytes and not by the length of its dependency chain.)
 struct KgTables {
-    const u32 *kg = nullptr, *kg3 = nullptr;
+    const u32 *kg = nullptr, *kg3 = nullptr, *up = nullptr;
     int k = 0, pairs = 0;
-    u32 A = 0, bins = 0;
+    u32 A = 0, bins = 0, up_stride = 0;
 };
+
+__device__ __forceinline__ uint2 load_pair_u32(const u32 *p)       // two adjacent 4-byte entries (4-byte aligned)
+{
+    uint2 v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
 
 // One walk: the keyphrase suffix q_code[t0 .. end) down document d's annotated suffix array (sad / nd / root_ann).
 // SYM = uint8_t: the byte stream (a quarter of the footprint; 0xFF terminators sort above every
@@ -318,15 +329,23 @@ __device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, c
             if (c != Q_NOMATCH && L == i) L = i + 1;
         }
         u32 ta[KGRAM_KEYS_MAX_K], tb[KGRAM_KEYS_MAX_K];
-        u32 code = 0, stride = bins3;
+        u32 code = 0, stride = bins3, up_off = 0, up_len = kt.A;
+        const u32 *up = kt.up ? kt.up + (size_t)d * kt.up_stride : nullptr;
 #pragma unroll
         for (int i = 0; i < KGRAM_KEYS_MAX_K; i++) {
             ta[i] = tb[i] = 0;
             if (i < k3 && i < L) {
                 stride /= kt.A;
                 code = code * kt.A + cs[i];
-                ta[i] = row[code * stride];
-                tb[i] = row[(code + 1u) * stride];
+                if (stride == 1u || up) {                  // two adjacent entries: one load
+                    const uint2 ab = load_pair_u32(stride == 1u ? row + code : up + up_off + code);
+                    ta[i] = ab.x; tb[i] = ab.y;
+                } else {
+                    ta[i] = row[code * stride];
+                    tb[i] = row[(code + 1u) * stride];
+                }
+                up_off += up_len + 1u;
+                up_len *= kt.A;
             }
         }
         uint2 e0 = uint2{0xFFFFFFFFu, 0u};
@@ -334,8 +353,10 @@ __device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, c
         const bool last = kt.pairs && L == kt.k;           // (then k3 = k - 1 levels were taken above)
         if (last) {
             g = code * kt.A + cs[kt.k - 1];
-            e0 = row2[g];
-            e1 = row2[g + 1u].x;
+            uint4 ee;                                      // the entry and its successor: one 16-byte load (8-byte aligned)
+            __builtin_memcpy(&ee, row2 + g, 16);
+            e0 = uint2{ee.x, ee.y};
+            e1 = ee.z;
         }
         bool ended = false;
 #pragma unroll
@@ -443,6 +464,22 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
         double total = 0.0;
         for (u32 i = b; i < e; i++) total += res[i];      // easa.py:130, in suffix order
         table[(u64)k * n_docs + d] = total / (double)(e - b);   // easa.py:134
+    }
+}
+
+// the small tables of the levels above kg3's own (KgTables::up), out of the filled kg3: level l entry g = kg3[g * A^(k3 - l)]
+__global__ __launch_bounds__(BLOCK) void kgram_upper_kernel(const u32 *__restrict__ kg3, u32 bins3, u32 A, int k3, u32 up_stride,
+                                                            u32 *__restrict__ up)
+{
+    const u32 d = blockIdx.x;
+    const u32 *row = kg3 + (size_t)d * (bins3 + 1);
+    u32 *out = up + (size_t)d * up_stride;
+    u32 len = A, stride = bins3 / A;
+    for (int l = 1; l < k3; l++) {
+        for (u32 g = threadIdx.x; g <= len; g += BLOCK) out[g] = row[g * stride];
+        out += len + 1u;
+        len *= A;
+        stride /= A;
     }
 }
 
