@@ -79,6 +79,7 @@ struct Stats {
     i64 lds_sorted = 0;         // elements the refinement rounds ordered inside a workgroup's LDS (lds_group_sort.h)
     i64 first_kept = 0, first_n = 0;    // all-suffix window sort: suffixes the placement pass left in large groups, of how many
     i64 fused_finish = 0;       // the last radix digit and the placement ran as one pass in LDS (lvl0_finish_kernel)
+    i64 ht_keys = 0;            // the first-level keys held variable-length code words (ht_code.h)
 };
 
 // Optional per-kernel timing with HIP events on the handle's own stream (the
@@ -156,6 +157,13 @@ struct Ctx {
     u32 sample_n = 0, sample_dup2[9] = {0}, sample_dup4[9] = {0};
     int plan_wide = -1, plan_fused = -1;    // -1 = decide from the sample / the estimates; 0 / 1 = as the build before did
     int did_wide = 0, did_fused = 0;        // out: what the all-suffix window sort did (the next speculative build's plan)
+    // An order-preserving variable-length code for the text's symbols is at hand (ht_code.h; ht_max_len > 0): the device
+    // tables, the longest code word and the mean code word length over the text (bits per symbol)
+    const u32 *ht_enc = nullptr;
+    const uint16_t *ht_dec = nullptr;
+    int ht_max_len = 0;
+    double ht_mean_len = 0.0;
+    int plan_ht = -1, did_ht = 0;           // first-level keys of variable-length code words: plan (as plan_wide) / what was done
     Stats *stats = nullptr;
     Profiler *prof = nullptr;
 };

@@ -437,6 +437,14 @@ struct east_hip_index {
     // what the last successful build found, the guesses of the next (speculative) one
     bool hint_valid = false, hint_no_rounds = false, hint_window = false;
     int plan_wide = -1, plan_fused = -1;   // what the last build's window sort did (wide first window, fused finish): a speculative build does the same
+    int plan_ht = -1;                      // ... (first-level keys of variable-length code words)
+    // the order-preserving variable-length code of the last build that made one (ht_code.h): device tables (own
+    // allocation: 256 x u32 enc, 4096 x u16 dec), valid for text with ht_sigma text symbols
+    char *ht_tab = nullptr;
+    bool ht_valid = false;
+    u32 ht_sigma = 0;
+    int ht_max_len = 0;
+    double ht_mean_len = 0.0;
     u32 hint_sigma = 0;
     u32 plan_n = 0, plan_docs = 0, plan_epoch = 0;
     bool plan_tagged = false;   // shape of the last sizing run (and test-knob epoch), its result
@@ -516,6 +524,78 @@ static void annotate(east_hip_index *h, Ctx &ctx)
     LAUNCH(ctx, ann_wide_kernel, ceil_div_u32(n_tiles, BLOCK / ANN_WIDE_SLOTS), pyr, n, n_tiles, (const u32 *)wide_list,
            (const u32 *)wide_count, h->ann);
     ar.release(mark);
+}
+
+// symbol counts of the byte stream (the weights of the variable-length code, ht_code.h): 16 bytes per thread and step,
+// per-lane-class counters in LDS
+__global__ __launch_bounds__(BLOCK) void byte_hist_kernel(const uint8_t *__restrict__ s8, u32 n, u32 *__restrict__ counts)
+{
+    __shared__ u32 bins[4][256];
+    for (int c = 0; c < 4; c++) bins[c][threadIdx.x] = 0;
+    __syncthreads();
+    u32 *mine = bins[threadIdx.x & 3u];
+    for (u64 i = ((u64)blockIdx.x * BLOCK + threadIdx.x) * 16u; i < n; i += (u64)gridDim.x * BLOCK * 16u) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(s8 + i);          // (the stream is padded to 16 bytes behind n)
+        const u32 wds[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            if (i + q < n) atomicAdd(&mine[(wds[q >> 2] >> ((q & 3) * 8)) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    const u32 t = bins[0][threadIdx.x] + bins[1][threadIdx.x] + bins[2][threadIdx.x] + bins[3][threadIdx.x];
+    if (t) atomicAdd(&counts[threadIdx.x], t);
+}
+
+// The variable-length code of this build's text (ht_code.h), for the window sort to use if it pays: made from the symbol
+// counts on a build that waits for the device anyway, taken over from the build before on a speculative one (same
+// alphabet -- any alphabetic code orders correctly, a stale one is merely less compact).
+static void prepare_ht_code(east_hip_index *h, Ctx &ctx, u32 n, u32 sigma_t, u32 m_total)
+{
+    ctx.ht_max_len = 0;
+    if (ctx.dry || !h->use_s8 || !g_window_sort || g_ht_mode == 0) return;
+    if (ctx.spec) {
+        if (!h->ht_valid || h->ht_sigma != sigma_t) return;
+    } else {
+        h->ht_valid = false;
+        // (an alphabet of at most 5 bits -- letters only -- has nothing to gain: at best a fraction of a symbol per key)
+        if (sigma_t + 1 < 4 || (g_ht_mode != 1 && (bit_width_u32(sigma_t + 1) < 6 || n < 65536)) || n < 64) return;
+        Arena &ar = *ctx.arena;
+        const size_t mark = ar.mark();
+        u32 *d_counts = ar.alloc<u32>(256);
+        HIP_CHECK(hipMemsetAsync(d_counts, 0, 256 * sizeof(u32), ctx.stream));
+        LAUNCH(ctx, byte_hist_kernel, std::min<u32>(ceil_div_u32(n, BLOCK * 16), 2048), (const uint8_t *)h->s8, n, d_counts);
+        u32 h_counts[256];
+        HIP_CHECK(hipMemcpyAsync(h_counts, d_counts, sizeof(h_counts), hipMemcpyDeviceToHost, ctx.stream));
+        HIP_CHECK(sync_stream(ctx.stream));
+        ar.release(mark);
+        std::vector<u64> counts(256);
+        for (int c = 0; c < 256; c++) counts[c] = h_counts[c];
+        std::vector<u32> enc;
+        std::vector<uint16_t> dec;
+        double mean_len = 0.0;
+        if (!ht_make_tables(counts, sigma_t, m_total, enc, dec, &mean_len)) return;
+        if (!h->ht_tab) {
+            void *p = nullptr;
+            if (hipMalloc(&p, 256 * 4 + HT_DEC_SIZE * 2) != hipSuccess) { (void)hipGetLastError(); return; }
+            h->ht_tab = (char *)p;
+        }
+        // (pageable host buffers: the copies are staged before the calls return)
+        HIP_CHECK(hipMemcpyAsync(h->ht_tab, enc.data(), 256 * 4, hipMemcpyHostToDevice, ctx.stream));
+        HIP_CHECK(hipMemcpyAsync(h->ht_tab + 256 * 4, dec.data(), HT_DEC_SIZE * 2, hipMemcpyHostToDevice, ctx.stream));
+        HIP_CHECK(sync_stream(ctx.stream));
+        int longest = 0;
+        for (u32 c = 0; c < 256; c++) longest = std::max(longest, (int)(enc[c] & 0xFFu));
+        h->ht_valid = true;
+        h->ht_sigma = sigma_t;
+        h->ht_max_len = longest;
+        h->ht_mean_len = mean_len;
+        if (g_trace) fprintf(stderr, "[east_hip] variable-length code: %u symbols, %.2f bits per symbol on average, longest code word %d\n",
+                             sigma_t + 1, mean_len, longest);
+    }
+    ctx.ht_enc = (const u32 *)h->ht_tab;
+    ctx.ht_dec = (const uint16_t *)(h->ht_tab + 256 * 4);
+    ctx.ht_max_len = h->ht_max_len;
+    ctx.ht_mean_len = h->ht_mean_len;
 }
 
 // The build proper.  With ctx.dry it only measures the arena high-water mark
@@ -671,6 +751,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     bool window_sorted = false;
     const int doc_bits = n_docs > 1 ? bit_width_u32(n_docs - 1) : 0;
     h->kg_marked = false;
+    prepare_ht_code(h, ctx, n, sigma_t, m_total);
     if ((h->use_s8 || ctx.dry) && g_window_sort) {       // (the sizing run prices it with 64-bit keys)
         DocKey docs;
         if (n_docs > 1) { docs.doc_off = h->doc_off; docs.n_docs = n_docs; docs.bits = doc_bits; }
@@ -901,6 +982,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
         ctx.spec_rounds = spec && spec_rounds;
         ctx.plan_wide = spec ? h->plan_wide : -1;        // (a build that waits for the alphabet plans from its own sample)
         ctx.plan_fused = spec ? h->plan_fused : -1;
+        ctx.plan_ht = spec ? h->plan_ht : -1;
         try {
             build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings, h->hint_sigma, tagged);
         } catch (const SpecAbort &) {
@@ -947,6 +1029,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     // (hardly anything tied behind the wide window -- another kind of text on the same handle: back to the estimate)
     if (ctx.did_wide && h->stats.first_n > 0 && h->stats.first_kept * 50 < h->stats.first_n) h->plan_wide = -1;
     h->plan_fused = h->stats.window_sorted ? ctx.did_fused : -1;
+    h->plan_ht = h->stats.window_sorted ? ctx.did_ht : -1;
     // (the same for the fused finish: it handed more than a few per cent of the suffixes to the rounds, or the separate
     // placement pass left next to nothing -- another kind of text than the plan was made for: the next build decides anew)
     if (h->stats.first_n > 0 && ((ctx.did_fused && h->stats.first_kept * 20 > h->stats.first_n) ||
@@ -1482,6 +1565,7 @@ void east_hip_destroy(east_hip_handle_t h)
     if (h->kg) (void)hipFree(h->kg);
     if (h->prep_sym) (void)hipFree(h->prep_sym);
     if (h->tp_tables) (void)hipFree(h->tp_tables);
+    if (h->ht_tab) (void)hipFree(h->ht_tab);
     if (h->guess) (void)hipFree(h->guess);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1722,7 +1806,8 @@ int east_hip_reset(east_hip_handle_t h)
         h->sigma_hi = 0;
         h->prof.enabled = false;
         h->prof.only.clear();
-        h->plan_wide = h->plan_fused = -1;
+        h->plan_wide = h->plan_fused = h->plan_ht = -1;
+        h->ht_valid = false;
         h->stats = Stats();
         // a recycled handle keeps its stream and a small arena, not gigabytes of side allocations
         const size_t keep = (size_t)64 << 20;
@@ -1746,15 +1831,15 @@ void *east_hip_stream(east_hip_handle_t h) { return h ? (void *)h->stream : null
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap)
 {
     if (!h || !out) return EAST_HIP_ERR_INVALID;
-    const int64_t v[23] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
+    const int64_t v[24] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
                            (int64_t)h->arena.cap, (int64_t)h->arena.high, h->stats.radix_passes,
                            h->stats.radix_elems, h->stats.radix_elem_bytes, h->stats.radix_passes_u32,
                            h->stats.radix_elems_u32, h->stats.radix_passes_u64, h->stats.radix_elems_u64,
                            h->stats.levels_resolved, h->stats.merge_elems, h->stats.refine_rounds,
                            h->stats.window_sorted, h->stats.lds_sorted, h->stats.fused_finish, h->stats.first_kept,
-                           h->stats.first_n};
-    for (int i = 0; i < 23 && i < cap; i++) out[i] = v[i];
-    return 23;
+                           h->stats.first_n, h->stats.ht_keys};
+    for (int i = 0; i < 24 && i < cap; i++) out[i] = v[i];
+    return 24;
 }
 
 int east_hip_profile_enable(east_hip_handle_t h, int on)
@@ -1882,7 +1967,21 @@ int east_hip_debug_set_window_sort(int enabled)
     g_force_wide_keys = enabled == 3 || enabled == 5;
     g_fused_finish = enabled != 4 && enabled != 5 && getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;
     g_force_fused = enabled == 6;                        // 6: as 1, the fused finish whatever the plan says (skewed text through it)
+    // 7: as 1, first-level keys of variable-length code words wherever a code can be made (ht_code.h); 8: never
+    g_ht_mode = enabled == 7 ? 1 : enabled == 8 ? 0 : (getenv("EAST_HIP_HT") ? atoi(getenv("EAST_HIP_HT")) : -1);
     g_plan_epoch++;
+    return EAST_HIP_OK;
+}
+
+int east_hip_debug_alphabetic_code(const uint64_t *weights, int32_t n, uint32_t *code, int32_t *len)
+{
+    // host only: the order-preserving variable-length code of csrc/ht_code.h for n symbols with the given weights
+    if (!weights || !code || !len || n < 1) return EAST_HIP_ERR_INVALID;
+    std::vector<u64> w(weights, weights + n);
+    std::vector<u32> c;
+    std::vector<int> l;
+    if (!ht_build_code(w, c, l)) return EAST_HIP_ERR_DOMAIN;
+    for (int i = 0; i < n; i++) { code[i] = c[i]; len[i] = l[i]; }
     return EAST_HIP_OK;
 }
 

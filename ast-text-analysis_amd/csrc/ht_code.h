@@ -112,7 +112,7 @@ static bool ht_make_tables(const std::vector<u64> &byte_counts, u32 sigma_t, u64
     std::vector<u32> code;
     std::vector<int> len;
     if (!ht_build_code(w, code, len)) return false;
-    enc.assign(256, 0);
+    enc.assign(256, HT_MIN_LEN);                        // (bytes that never occur: a harmless code word)
     dec.assign(HT_DEC_SIZE, 0);
     double bits = 0, tot = 0;
     for (u32 i = 0; i <= sigma_t; i++) {

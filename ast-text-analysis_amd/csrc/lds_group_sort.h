@@ -199,6 +199,9 @@ struct LgClassify {
     u64 *keep = nullptr;
     u32 *fail = nullptr;
     u32 limit = 0, max_len = 0;
+    // (not part of the classification, but it travels with it: what the group of a domain position shares beyond `depth`
+    // -- first-level keys of variable-length code words, window_sort.h -- or nullptr)
+    const uint8_t *xdep = nullptr;
 };
 
 // 64 bits of a bit array from bit `pos` on (the array carries one spare word)
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
                 if (name_of) {
                     k = (k << 32) | (u64)name_of[e + depth];
                 } else {
-                    const u32 p = lvl0_pos(e, n0) + depth;
+                    const u32 p = lvl0_pos(e, n0) + depth + (cls.xdep ? (u32)cls.xdep[base + q] : 0u);
                     u64 lo8, hi8;
                     __builtin_memcpy(&lo8, s8 + p, 8);
                     __builtin_memcpy(&hi8, s8 + p + 8, 8);
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
                 const u64 d = (k ^ kp) & (((u64)1 << wbits) - 1ull);
                 const u32 mism = d ? (u32)(w2 - 1 - (63 - __builtin_clzll(d)) / b) : (u32)w2;
                 const u32 term = tz ? (u32)(w2 - 1 - __builtin_ctzll(tz) / b) : (u32)w2;
-                lcp_g[slot] = depth + (mism < term ? mism : term);
+                lcp_g[slot] = depth + (cls.xdep ? (u32)cls.xdep[r] : 0u) + (mism < term ? mism : term);
             }
         }
     }
@@ -423,7 +426,8 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
     }
     for (u32 i = threadIdx.x; i < todo; i += LG_THREADS) {              // the 8 symbols behind the new depth, once per member
         const u32 local = work[i];
-        lds.keys[local] = load_u64_unaligned(s8 + lvl0_pos(lds.vals[local], n0) + nd);
+        const u32 nde = nd + (cls.xdep ? (u32)cls.xdep[base + begin_q + local] : 0u);
+        lds.keys[local] = load_u64_unaligned(s8 + lvl0_pos(lds.vals[local], n0) + nde);
     }
     __syncthreads();
     for (u32 i = threadIdx.x; i < todo; i += LG_THREADS) {
@@ -432,16 +436,17 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
         (void)small_group(local, a, bnd);
         const u32 e = lds.vals[local], p = lvl0_pos(e, n0);
         const u64 u0 = lds.keys[local];
+        const u32 nde = nd + (cls.xdep ? (u32)cls.xdep[base + begin_q + local] : 0u);     // (the members of a group share it)
         u32 r = 0, best = 0;                            // best: longest common prefix with a smaller member
         bool undecided = false;
         for (u32 x = a; x < bnd; x++) {
             if (x == local) continue;
             const u32 p2 = lvl0_pos(lds.vals[x], n0);
             bool decided = false, less = false;         // less: suffix p2 < suffix p
-            u32 h = nd;
-            for (; h < nd + cls.max_len && !decided; h += 8) {
-                const u64 u = h == nd ? u0 : load_u64_unaligned(s8 + p + h);
-                const u64 v = h == nd ? lds.keys[x] : load_u64_unaligned(s8 + p2 + h);
+            u32 h = nde;
+            for (; h < nde + cls.max_len && !decided; h += 8) {
+                const u64 u = h == nde ? u0 : load_u64_unaligned(s8 + p + h);
+                const u64 v = h == nde ? lds.keys[x] : load_u64_unaligned(s8 + p2 + h);
                 const u64 d = u ^ v, z = ~u;
                 const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
                 const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u3
     constexpr int UW = RS_HIST_THREADS / WAVE;
     static_assert(RS_HIST_THREADS == RS_BINS, "thread d owns digit d");
     __shared__ u32 bins[RS_GROUP][RS_HIST_COPIES][RS_BINS];
+    if constexpr (Src::MODE == 2) src.prepare();
 #pragma unroll
     for (int k = 0; k < RS_GROUP; k++)
 #pragma unroll
@@ -238,6 +239,7 @@ __device__ __forceinline__ void radix_scatter_tile(ScatterLds<K> &lds, const Src
     }
     if constexpr (Src::MODE == 2) {
         // the generator fills s_keys with the tile's keys in input order
+        src.prepare();
         src.fill_tile(lds.s_keys, tile_base, tile_count);
         __syncthreads();
     }

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "radix_sort.h"
 #include "scan.h"
+#include "ht_code.h"
 #include <math.h>
 #include <algorithm>
 
@@ -34,6 +35,9 @@ static bool g_force_lean = false;                           // east_hip_debug_se
 static bool g_window_sort = true;                            // east_hip_debug_set_window_sort (tests)
 static bool g_fused_finish = getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;    // east_hip_debug_set_window_sort(4 / 5) (tests, A/B timing)
 static bool g_force_fused = false;                           // east_hip_debug_set_window_sort(6): the fused finish whatever the plan says (tests: skewed text through it)
+// variable-length first-level keys (ht_code.h): -1 = where the text's symbol statistics promise a symbol more per key,
+// 0 = never, 1 = whenever a code exists (east_hip_debug_set_window_sort(7) / EAST_HIP_HT: tests, A/B timing)
+static int g_ht_mode = getenv("EAST_HIP_HT") ? atoi(getenv("EAST_HIP_HT")) : -1;
 struct FusedAbort {};           // the fused finish met a repeat too long to order directly: the level is redone with the full sort
 
 #define RESOLVE_MAX_LEN 2048            // longest direct comparison of two suffixes (symbols)
@@ -199,6 +203,7 @@ template <class K> struct TextWindowGen {
     u32 term_first;
     DocKey docs;
 
+    __device__ __forceinline__ void prepare() const {}
     // keys of the positions p0 .. p0 + 7 (p0 a multiple of 8) from x = the bytes s8[p0 .. p0 + 24)
     __device__ __forceinline__ void keys_of_run(const u32 (&x)[6], K (&out)[TW_RUN]) const
     {
@@ -270,6 +275,93 @@ template <class K> struct TextWindowGen {
     }
 };
 
+// The same for keys of VARIABLE-LENGTH code words (ht_code.h): the key of position q is the first `sb` bits of the coded
+// suffix -- stream(q) = code(x[q]) on top of stream(q + 1) moved down by its length, nothing behind a terminator's code
+// word --, under the document number.  Code words have at least HT_MIN_LEN = 2 bits, so 16 symbols fill any key: the run
+// of 8 positions is rolled out of its 24 loaded bytes from the right.  enc[] (byte -> code << 8 | length) is staged in
+// LDS by prepare(), which the two kernels of the first radix pass call once, workgroup-wide.
+__device__ __forceinline__ u32 *ht_enc_lds()
+{
+    __shared__ u32 t[256];
+    return t;
+}
+template <class K> struct HtWindowGen {
+    static constexpr int MODE = 2;
+    const uint8_t *s8;                          // byte stream; readable (any content) up to 24 bytes behind the last symbol
+    u32 n;
+    int sb;                                     // stream bits of a key (key bits below the document number)
+    const u32 *enc;
+    DocKey docs;
+
+    __device__ __forceinline__ void prepare() const
+    {
+        u32 *t = ht_enc_lds();
+        for (u32 i = threadIdx.x; i < 256u; i += blockDim.x) t[i] = enc[i];
+        __syncthreads();
+    }
+    __device__ __forceinline__ void keys_of_run(const u32 (&x)[6], K (&out)[TW_RUN]) const
+    {
+        const u32 *t = ht_enc_lds();
+        K st = 0;
+#pragma unroll
+        for (int q = 23; q >= 0; q--) {
+            const u32 c = (x[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+            const u32 e = t[c];
+            const int len = (int)(e & 0xFFu);
+            const K rest = c == 0xFFu ? (K)0 : (K)(st >> len);
+            st = ((K)(e >> 8) << (sb - len)) | rest;
+            if (q < TW_RUN) out[q] = st;
+        }
+    }
+    __device__ __forceinline__ void load_run(u32 p0, u32 (&x)[6]) const
+    {
+        const uint2 *src = reinterpret_cast<const uint2 *>(s8 + p0);
+        const uint2 a = src[0], c = src[1], e = src[2];
+        x[0] = a.x; x[1] = a.y; x[2] = c.x; x[3] = c.y; x[4] = e.x; x[5] = e.y;
+    }
+    __device__ __forceinline__ void add_docs(u32 p0, K (&out)[TW_RUN]) const
+    {
+        u32 lo = docs.tile_doc[p0 >> DOC_TILE_SHIFT];
+        while (lo + 1 < docs.n_docs && docs.doc_off[lo + 1] <= p0) lo++;
+        u32 next_off = lo + 1 < docs.n_docs ? docs.doc_off[lo + 1] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < TW_RUN; q++) {
+            while (p0 + q >= next_off) {
+                lo++;
+                next_off = lo + 1 < docs.n_docs ? docs.doc_off[lo + 1] : 0xFFFFFFFFu;
+            }
+            out[q] |= (K)lo << sb;
+        }
+    }
+    __device__ __forceinline__ void fill_tile(K *s_keys, u32 tile_base, u32 tile_count) const
+    {
+        for (u32 r = threadIdx.x; r < (u32)RS_TILE / TW_RUN; r += RS_THREADS) {
+            if (r * TW_RUN >= tile_count) break;
+            u32 x[6];
+            K k[TW_RUN];
+            load_run(tile_base + r * TW_RUN, x);
+            keys_of_run(x, k);
+            if (docs.bits) add_docs(tile_base + r * TW_RUN, k);
+#pragma unroll
+            for (int q = 0; q < TW_RUN; q++) s_keys[r * TW_RUN + q] = k[q];
+        }
+    }
+    template <bool CHECK = true> __device__ __forceinline__ void hist_tile(u32 *mine, u32 e0, u32 e1, int shift, u32 mask) const
+    {
+        const bool need_docs = docs.bits && sb < shift + 12;
+        for (u32 p0 = e0 + lane_id() * TW_RUN; p0 < e1; p0 += WAVE * TW_RUN) {
+            u32 x[6];
+            K k[TW_RUN];
+            load_run(p0, x);
+            keys_of_run(x, k);
+            if (need_docs) add_docs(p0, k);
+#pragma unroll
+            for (int q = 0; q < TW_RUN; q++)
+                if (p0 + q < e1) radix_hist_add<CHECK>(mine, (u32)(k[q] >> shift) & mask);
+        }
+    }
+};
+
 // Layout of a window key of `used` = w * bits + document bits: whole radix passes are paid for anyway, so
 // the key is filled up to a whole number of digits (of the width the sort will pick) with the top bits of
 // one more symbol.  Returns the spare bits taken from symbol w + 1.
@@ -279,10 +371,35 @@ static int lvl0_spare_bits(int used, int key_bits, int bt, int w)
     return w < 12 ? std::min(total - used, bt - 1) : 0;
 }
 
+// ht_sb != 0: the keys hold variable-length code words (HtWindowGen): ht_sb stream bits under the document number,
+// ht_dec = the decode table (global memory; kernels that read many keys stage it in LDS), ht_wmin = the whole symbols
+// every key without a terminator holds at least.
 template <class K> struct KeyNeqWindowIn {
     static constexpr bool HAS_KEYS = true;
     const K *keys;
     K rep_t, ones, highs;       // terminator code / 1 / top bit replicated into every full-symbol field
+    int ht_sb = 0, ht_wmin = 0;
+    const uint16_t *ht_dec = nullptr;
+    // the coded stream of a key, left-aligned in 32 bits (at most 32 of its bits are ever looked at)
+    __device__ __forceinline__ u32 ht_stream(K k) const
+    {
+        if constexpr (sizeof(K) == 4) return ht_sb >= 32 ? (u32)k : (u32)k << (32 - ht_sb);
+        else return ht_sb >= 32 ? (u32)(k >> (ht_sb - 32)) : (u32)k << (32 - ht_sb);
+    }
+    // bits the streams of k and kp have in common (ht_sb if the keys are equal; -1: different documents)
+    __device__ __forceinline__ int ht_common_bits(K k, K kp) const
+    {
+        const K d = k ^ kp;
+        if (!d) return ht_sb;
+        int hb;
+        if constexpr (sizeof(K) == 4) hb = 31 - __clz((u32)d); else hb = 63 - __clzll((u64)d);
+        return hb >= ht_sb ? -1 : ht_sb - 1 - hb;
+    }
+    template <class Table> __device__ __forceinline__ HtScan ht_read(K k, K kp, const Table &dec) const
+    {
+        const int cb = ht_common_bits(k, kp);
+        return ht_scan(ht_stream(k), ht_sb < 32 ? ht_sb : 32, dec, cb < 0 ? 0 : cb);
+    }
     // "does any of the w full symbols equal the terminator code": xor turns such a field into zero,
     // then the zero-field test (x - ones) & ~x & highs (exact for "any field is zero")
     static KeyNeqWindowIn make(const K *keys, int w, int b, int spare, u32 term_first)
@@ -298,6 +415,7 @@ template <class K> struct KeyNeqWindowIn {
     __device__ __forceinline__ u32 operator()(u32 i) const
     {
         const K k = keys[i];
+        if (ht_sb) return (i == 0 || k != keys[i - 1] || ht_read(k, k, ht_dec).term) ? 1u : 0u;
         const K x = k ^ rep_t;
         const bool has_term = ((x - ones) & ~x & highs) != 0;
         return (i == 0 || has_term || k != keys[i - 1]) ? 1u : 0u;
@@ -371,6 +489,11 @@ template <class K>
 __device__ __forceinline__ u32 lvl0_lcp_of_key_pair(const KeyNeqWindowIn<K> &f, int w, int b, int spare, K k, K kp,
                                                     bool &whole)
 {
+    if (f.ht_sb) {
+        const HtScan r = f.ht_read(k, kp, f.ht_dec);
+        whole = k == kp && !r.term;
+        return r.common;
+    }
     const u64 d = (u64)(k ^ kp);
     u32 mism = (u32)w;                                   // leading symbol fields in common
     if (d) {
@@ -425,14 +548,20 @@ template <class K> struct TileStarts {
     KeyNeqWindowIn<K> f;
     const K *kt;                    // kt[i - first] = keys[i] for first <= i < first + count
     u32 first, count;
+    const u32 *tbits = nullptr;     // variable-length keys: bit (i - first + tskip) = "the key at i holds a terminator" (staged range)
+    u32 tskip = 0;
     __device__ __forceinline__ K key(u32 i) const { return i - first < count ? kt[i - first] : f.keys[i]; }
     __device__ __forceinline__ u32 operator()(u32 i) const
     {
         if (i == 0) return 1u;
         const K k = key(i);
+        if (k != key(i - 1)) return 1u;
+        if (f.ht_sb) {
+            if (i - first < count) return (tbits[(i - first + tskip) >> 5] >> ((i - first + tskip) & 31u)) & 1u;
+            return f.ht_read(k, k, f.ht_dec).term ? 1u : 0u;
+        }
         const K x = k ^ f.rep_t;
-        const bool has_term = ((x - f.ones) & ~x & f.highs) != 0;
-        return (has_term || k != key(i - 1)) ? 1u : 0u;
+        return ((x - f.ones) & ~x & f.highs) != 0 ? 1u : 0u;
     }
 };
 struct TileElems {
@@ -512,7 +641,11 @@ struct NoLcp {
 // from the two keys, no text is read) are written at once; tied ones go through lvl0_place_tied.
 // keep[]: one bit per element, set for members of large groups; block_keep: their number per workgroup.
 #define PLACE_IPT 4
-template <class K, bool ENDGAME_LIMITS, bool OPTIMISTIC>  // (OPTIMISTIC: the first attempt, LongRepeats mode 0 folded in)
+// HT: the keys hold variable-length code words (KeyNeqWindowIn::ht_sb): the decode table is staged in LDS, every thread
+// reads its keys once with it (terminator inside? whole symbols? symbols shared with the key before = the LCP entry),
+// and a tied suffix is compared with the other members of its group from the depth its own key holds (`w` is then the
+// least number of symbols any key holds).
+template <class K, bool ENDGAME_LIMITS, bool OPTIMISTIC, bool HT = false>  // (OPTIMISTIC: the first attempt, LongRepeats mode 0 folded in)
 __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, const u32 *__restrict__ vals, u32 m,
                                                           const uint8_t *__restrict__ s8, u32 n0, int w, int b,
                                                           int spare, u32 *__restrict__ order_g,
@@ -529,8 +662,16 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     __shared__ __attribute__((aligned(16))) K key_tile[BLOCK * PLACE_IPT + 2 * PLACE_HALO];   // TileStarts
     __shared__ __attribute__((aligned(16))) u32 val_tile[BLOCK * PLACE_IPT + 2 * PLACE_HALO];  // TileElems
     __shared__ u32 n_keep, n_work;
+    constexpr int TB_WORDS = (BLOCK * PLACE_IPT + 2 * PLACE_HALO + 31) / 32 + 1;
+    __shared__ uint16_t dec_lds[HT ? HT_DEC_SIZE : 1];  // the decode table
+    __shared__ u32 term_bits[HT ? TB_WORDS : 1];        // by staged index: the key holds a terminator
+    __shared__ uint8_t dep_tile[HT ? BLOCK * PLACE_IPT : 1];   // whole symbols of the stretch's keys
     if (threadIdx.x < BLOCK * PLACE_IPT / 32) keep_bits[threadIdx.x] = 0;
     if (threadIdx.x == 0) { n_keep = 0; n_work = 0; }
+    if constexpr (HT) {
+        for (u32 i = threadIdx.x; i < HT_DEC_SIZE; i += BLOCK) dec_lds[i] = f.ht_dec[i];
+        if (threadIdx.x < TB_WORDS) term_bits[threadIdx.x] = 0;
+    }
     __syncthreads();
     const u32 j0 = (blockIdx.x * BLOCK + threadIdx.x) * PLACE_IPT;
     u32 my_keep = 0;                                    // suffixes this thread left to the rounds
@@ -541,8 +682,12 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
             const u32 q = left ? threadIdx.x : threadIdx.x - PLACE_HALO;
             const u64 g = left ? (u64)stretch0 + q - PLACE_HALO : (u64)stretch0 + BLOCK * PLACE_IPT + q;    // (wraps below 0: skipped)
             if ((!left || stretch0 >= PLACE_HALO) && g < (u64)m + 8) {
-                key_tile[left ? q : PLACE_HALO + BLOCK * PLACE_IPT + q] = f.keys[g];
-                val_tile[left ? q : PLACE_HALO + BLOCK * PLACE_IPT + q] = vals[g];
+                const K hk = f.keys[g];
+                const u32 at = left ? q : PLACE_HALO + BLOCK * PLACE_IPT + q;
+                key_tile[at] = hk;
+                val_tile[at] = vals[g];
+                if constexpr (HT)
+                    if (g < m && f.ht_read(hk, hk, dec_lds).term) atomicOr(&term_bits[at >> 5], 1u << (at & 31u));
             }
         }
     }
@@ -562,13 +707,36 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
             val_tile[PLACE_HALO + threadIdx.x * PLACE_IPT + e] = v[e];
         }
     }
+    HtScan sc[PLACE_IPT + 1];                           // (HT) what the thread's keys hold; [PLACE_IPT]: the key behind them
+    if constexpr (HT) {
+        if (j0 < m) {
+            u32 tb = 0;
+#pragma unroll
+            for (int e = 0; e <= PLACE_IPT; e++) {
+                sc[e] = f.ht_read(k[e + 1], k[e], dec_lds);
+                if (e < PLACE_IPT) {
+                    if (sc[e].term && j0 + e < m) tb |= 1u << e;
+                    dep_tile[threadIdx.x * PLACE_IPT + e] = (uint8_t)sc[e].whole;
+                }
+            }
+            const u32 at0 = PLACE_HALO + threadIdx.x * PLACE_IPT;
+            if (tb) {
+                atomicOr(&term_bits[at0 >> 5], tb << (at0 & 31u));
+                if ((at0 & 31u) + PLACE_IPT > 32u) atomicOr(&term_bits[(at0 >> 5) + 1], tb >> (32u - (at0 & 31u)));
+            }
+        }
+    }
     __syncthreads();                                    // (the staged keys: the test for large groups reads them `limit` places away)
     if (j0 < m) {
         bool start[PLACE_IPT + 1];
 #pragma unroll
         for (int e = 0; e <= PLACE_IPT; e++) {
-            const K x = k[e + 1] ^ f.rep_t;
-            const bool has_term = ((x - f.ones) & ~x & f.highs) != 0;
+            bool has_term;
+            if constexpr (HT) has_term = sc[e].term;
+            else {
+                const K x = k[e + 1] ^ f.rep_t;
+                has_term = ((x - f.ones) & ~x & f.highs) != 0;
+            }
             start[e] = j0 + e == 0 || j0 + e >= m || has_term || k[e + 1] != k[e];
         }
         if (OPTIMISTIC && km.kg) {                      // k-gram bucket starts, read off the keys (see KgMark)
@@ -618,7 +786,8 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
 #pragma unroll
                 for (int e = 0; e < PLACE_IPT; e++) {
                     bool whole;
-                    h[e] = j0 + e > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, k[e + 1], k[e], whole) : 0u;
+                    if constexpr (HT) h[e] = j0 + e > 0 ? sc[e].common : 0u;
+                    else h[e] = j0 + e > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, k[e + 1], k[e], whole) : 0u;
                 }
                 *reinterpret_cast<uint4 *>(lcp_g + j0) = uint4{h[0], h[1], h[2], h[3]};
             }
@@ -632,7 +801,8 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
                     if (names_g) names_g[j] = 1;
                     if (lcp_g) {
                         bool whole;
-                        lcp_g[j] = j > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, k[e + 1], k[e], whole) : 0u;
+                        if constexpr (HT) lcp_g[j] = j > 0 ? sc[e].common : 0u;
+                        else lcp_g[j] = j > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, k[e + 1], k[e], whole) : 0u;
                     }
                 } else if ((large_mask >> e) & 1u) {
                     order_g[j] = v[e];
@@ -655,7 +825,8 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     const u32 stretch = blockIdx.x * (BLOCK * PLACE_IPT);
     for (u32 i = threadIdx.x; i < todo; i += BLOCK) {
         const u32 j = work[i];
-        next8[j - stretch] = load_u64_unaligned(s8 + lvl0_pos(val_tile[PLACE_HALO + j - stretch], n0) + (u32)w);
+        const u32 dep = HT ? (u32)dep_tile[j - stretch] : (u32)w;       // (the members of a group hold the same key)
+        next8[j - stretch] = load_u64_unaligned(s8 + lvl0_pos(val_tile[PLACE_HALO + j - stretch], n0) + dep);
     }
     __syncthreads();
     const NextSymbols ns{next8, stretch, (u32)(BLOCK * PLACE_IPT)};
@@ -664,15 +835,17 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     const u32 t_skip = stretch >= PLACE_HALO ? 0u : (u32)PLACE_HALO;               // (no left halo in the first stretch)
     const u64 t_end = std::min<u64>((u64)stretch + BLOCK * PLACE_IPT + PLACE_HALO, (u64)m + 8);
     const u32 t_count = (u32)(t_end - t_first);
-    const TileStarts<K> tstarts{f, key_tile + t_skip, t_first, t_count};
+    const TileStarts<K> tstarts{f, key_tile + t_skip, t_first, t_count, HT ? term_bits : (const u32 *)nullptr, t_skip};
     const TileElems telems{vals, val_tile + t_skip, t_first, t_count};
     for (u32 i = threadIdx.x; i < todo; i += BLOCK) {
         const u32 j = work[i];
         auto lcp_first = [&](u32 at) -> u32 {
             bool whole;
-            return at > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, tstarts.key(at), tstarts.key(at - 1), whole) : 0u;
+            if constexpr (HT) return at > 0 ? f.ht_read(tstarts.key(at), tstarts.key(at - 1), dec_lds).common : 0u;
+            else return at > 0 ? lvl0_lcp_of_key_pair(f, w, b, spare, tstarts.key(at), tstarts.key(at - 1), whole) : 0u;
         };
-        if (lvl0_place_tied(j, telems, tstarts, (const u32 *)nullptr, m, s8, n0, (u32)w, order_g, names_g, lcp_g, lcp_first, fail,
+        const u32 dep = HT ? (u32)dep_tile[j - stretch] : (u32)w;
+        if (lvl0_place_tied(j, telems, tstarts, (const u32 *)nullptr, m, s8, n0, dep, order_g, names_g, lcp_g, lcp_first, fail,
                             limit, max_len, (u32 *)nullptr, lr, ns)) {
             const u32 local = j - blockIdx.x * (BLOCK * PLACE_IPT);
             atomicOr(&keep_bits[local >> 5], 1u << (local & 31u));
@@ -1215,7 +1388,8 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
                                                                     u64 *__restrict__ keep, u32 *__restrict__ fail,
                                                                     u32 limit, u32 max_len, u32 *__restrict__ name_of,
                                                                     LongRepeats lr, u32 *__restrict__ lcp_g,
-                                                                    const uint2 *__restrict__ only_rest = nullptr)
+                                                                    const uint2 *__restrict__ only_rest = nullptr,
+                                                                    const uint8_t *__restrict__ xdep = nullptr)
 {
     // (as in the placement pass: every tied element of the workgroup's stretch fetches the 8 symbols behind the common
     // depth once, and the members of a group rank themselves against those instead of gathering each other's text)
@@ -1226,6 +1400,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
     u32 my_keep = 0;
     const bool mine = !only_rest || LgUncovered{only_rest, m}(j);       // (a group lies wholly inside or outside the tiles)
     const bool tied = mine && j < m && ((j > 0 && !starts(j)) || (j + 1 < m && !starts(j + 1)));
+    if (tied && xdep) depth += (u32)xdep[j];            // (the members of a group share it)
     if (tied) next8[threadIdx.x] = load_u64_unaligned(s8 + lvl0_pos(elem[j], n0) + depth);
     __syncthreads();
     if (tied)
@@ -1264,8 +1439,11 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__
                                                                    u32 *__restrict__ slot_out, u32 *__restrict__ elem_out,
                                                                    u32 *__restrict__ group_start,
                                                                    u32 *__restrict__ lcp_g = nullptr, int w = 0, int b = 0,
-                                                                   int spare = 0)
+                                                                   int spare = 0, const uint8_t *__restrict__ xdep_in = nullptr,
+                                                                   uint8_t *__restrict__ xdep_out = nullptr)
 {
+    // xdep (variable-length first-level keys): what the group of a position shares BEYOND the rounds' common depth --
+    // first domain: the whole symbols of its key less the least any key holds; later domains: copied along
     const u32 j0 = (blockIdx.x * BLOCK + threadIdx.x) * COMPACT_IPT;
     if (j0 >= m) return;
     const u64 word = keep.bits[j0 >> 6];
@@ -1281,6 +1459,16 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__
         slot_out[k] = slot ? slot[j] : j;
         elem_out[k] = elem[j];
         group_start[k] = st;
+        if (xdep_out) {
+            u32 x = xdep_in ? xdep_in[j] : 0u;
+            if constexpr (Starts::HAS_KEYS) {
+                if (starts.ht_sb) {
+                    const u32 whole = starts.ht_read(starts.keys[j], starts.keys[j], starts.ht_dec).whole;
+                    x = whole > (u32)starts.ht_wmin ? whole - (u32)starts.ht_wmin : 0u;
+                }
+            }
+            xdep_out[k] = (uint8_t)x;
+        }
         if constexpr (Starts::HAS_KEYS) {
             // the keyed first domain: the first rank of a group left to the rounds gets its LCP entry here, from the
             // two keys -- whichever member ends up there
@@ -1298,11 +1486,13 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_keys_kernel(const uint8_t *_
                                                                 const u32 *__restrict__ elems,
                                                                 const u32 *__restrict__ group, u32 n_tied, u32 n0,
                                                                 u32 depth, int w2, int b, u32 term_first,
-                                                                u64 *__restrict__ keys, u32 *__restrict__ vals)
+                                                                u64 *__restrict__ keys, u32 *__restrict__ vals,
+                                                                const uint8_t *__restrict__ xdep = nullptr,
+                                                                const u32 *__restrict__ full_idx = nullptr)
 {
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
     if (j >= n_tied) return;
-    const u32 p = lvl0_pos(elems[j], n0) + depth;
+    const u32 p = lvl0_pos(elems[j], n0) + depth + (xdep ? (u32)xdep[full_idx ? full_idx[j] : j] : 0u);
     u64 lo8, hi8;
     __builtin_memcpy(&lo8, s8 + p, 8);
     __builtin_memcpy(&hi8, s8 + p + 8, 8);
@@ -1376,7 +1566,8 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_writeback_kernel(const u64 *
                                                                      u32 *__restrict__ elem_out, u32 *__restrict__ flag_out,
                                                                      u32 *__restrict__ lcp_g = nullptr, u32 depth = 0,
                                                                      int w2 = 0, int b = 0,
-                                                                     const u32 *__restrict__ full_idx = nullptr)
+                                                                     const u32 *__restrict__ full_idx = nullptr,
+                                                                     const uint8_t *__restrict__ xdep = nullptr)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n_tied) return;
@@ -1402,7 +1593,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_writeback_kernel(const u64 *
         const u64 d = (k ^ kp) & (((u64)1 << gshift) - 1u);
         const u32 mism = d ? (u32)(w2 - 1 - (63 - __builtin_clzll(d)) / b) : (u32)w2;
         const u32 term = tz ? (u32)(w2 - 1 - __builtin_ctzll(tz) / b) : (u32)w2;
-        lcp_g[slot] = depth + (mism < term ? mism : term);
+        lcp_g[slot] = depth + (xdep ? (u32)xdep[at] : 0u) + (mism < term ? mism : term);
     }
 }
 
@@ -1485,23 +1676,33 @@ __global__ __launch_bounds__(BLOCK) void spec_counts_kernel(const u32 *__restric
 // or the caller falls back to DC3 (all-suffix mode, s12 == nullptr).
 #define FIN_LOW_BITS 8                   // key bits the fused finish orders in LDS (one global radix pass less)
 #define FIN_MAX_EXPECTED 32.0            // ... when a bucket of the top part is expected to hold at most this many suffixes
+// ht != nullptr (all-suffix mode, 32-bit keys): the first-level keys are the first bits of the suffixes coded with
+// variable-length code words (ht_code.h); w = the least number of whole symbols a key holds -- the depth the rounds start
+// from, every position carrying what its group shares beyond it (xdep).
+struct HtKeys {
+    const u32 *enc = nullptr;           // device: byte -> code << 8 | length
+    const uint16_t *dec = nullptr;      // device: 12 stream bits -> symbol << 8 | terminator << 7 | length
+    int wmin = 0;
+};
 template <class K>
 static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w, int bt, u32 term_first, u32 *sa12,
                              u32 *s12, u32 &n_names, u32 *lcp_out = nullptr, u32 *lcp_capped = nullptr,
-                             DocKey docs = DocKey(), KgMark *kg_mark = nullptr, bool allow_fused = false, u32 longest = 0)
+                             DocKey docs = DocKey(), KgMark *kg_mark = nullptr, bool allow_fused = false, u32 longest = 0,
+                             const HtKeys *ht = nullptr)
 {
     Arena &ar = *ctx.arena;
     const u32 g02 = ceil_div_u32((u64)n02 + 1, BLOCK);
+    const int ht_sb = ht ? (int)sizeof(K) * 8 - docs.bits : 0;
     // whole passes are paid for anyway: fill the last digit with the top bits of the next symbol
     // (the document number, if any, sits above window and spare bits)
-    const int spare = lvl0_spare_bits(w * bt + docs.bits, (int)sizeof(K) * 8, bt, w);
+    const int spare = ht ? 0 : lvl0_spare_bits(w * bt + docs.bits, (int)sizeof(K) * 8, bt, w);
     // The fused finish (lvl0_finish_kernel): the global passes stop above the low FIN_LOW_BITS key bits.  depth0 = the
     // symbols that lie wholly inside the top part -- what the members of a bucket are known to share.
-    const int total_bits = w * bt + spare + docs.bits;
+    const int total_bits = ht ? (int)sizeof(K) * 8 : w * bt + spare + docs.bits;
     int depth0 = 0;
     for (int j = 0; j < w; j++)
         if (spare + j * bt >= FIN_LOW_BITS) depth0++;
-    bool fused = allow_fused && g_fused_finish && n0 == 0 && total_bits >= 2 * FIN_LOW_BITS && depth0 >= 1;
+    bool fused = !ht && allow_fused && g_fused_finish && n0 == 0 && total_bits >= 2 * FIN_LOW_BITS && depth0 >= 1;
     bool fin_small_halo = false;                        // buckets of at most ten suffixes expected: the kernel with the halo of 32
     if (fused && !ctx.dry) {
         if (g_force_fused) {
@@ -1540,11 +1741,15 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     }
     const int r = n0 ? radix_sort_pairs<K, WindowSrc<K>>(ctx, sb, n02, total_bits, 0,
                                                          WindowSrc<K>{s8, n0, w, bt, spare, term_first, docs})
+                : ht ? radix_sort_pairs<K, HtWindowGen<K>>(ctx, sb, n02, total_bits, 0,
+                                                           HtWindowGen<K>{s8, n02, ht_sb, ht->enc, docs},
+                                                           docs.bits ? total_bits - docs.bits : total_bits + RS_DB)
                      : radix_sort_pairs<K, TextWindowGen<K>>(ctx, sb, n02, total_bits, low_bits,
                                                              TextWindowGen<K>{s8, n02, w, bt, spare, term_first, docs},
                                                              // (suffixes in text order: only the document number is sorted)
                                                              docs.bits ? total_bits - docs.bits : total_bits + RS_DB);
-    const KeyNeqWindowIn<K> starts = KeyNeqWindowIn<K>::make(sb.keys[r], w, bt, spare, term_first);
+    KeyNeqWindowIn<K> starts = KeyNeqWindowIn<K>::make(sb.keys[r], ht ? 0 : w, bt, spare, term_first);
+    if (ht) { starts.ht_sb = ht_sb; starts.ht_wmin = ht->wmin; starts.ht_dec = ht->dec; }
     const u32 *sorted_vals = sb.vals[r];
     u64 *keep = (u64 *)sb.keys[r ^ 1];                   // n02 + 1 bits, in the keys idle since the sort
     u64 *gstart_bits = ar.alloc<u64>(((size_t)n02 >> 6) + 2);  // fused finish: the first rank of every group left to the rounds
@@ -1564,7 +1769,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     // (a small input is better off with the direct ordering of much larger groups than with a round of ~50 launches)
     KgMark km;                                          // k-gram bucket starts ride along with the first placement pass
     const bool small_input = n02 <= REFINE_SMALL_INPUT;
-    if (kg_mark) kg_mark->k = kg_mark->kg && n0 == 0 && !ctx.dry && !small_input ? kg_mark->k : 0;
+    if (kg_mark) kg_mark->k = kg_mark->kg && n0 == 0 && !ctx.dry && !small_input && !ht ? kg_mark->k : 0;   // (variable-length keys: the score side builds its tables itself)
     if (kg_mark && kg_mark->k > 0) {
         km = *kg_mark;
         km.k = std::min(km.k, w);
@@ -1604,7 +1809,16 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             if (small_input) LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, true, 64>), gp, fa);
             else if (fin_small_halo) LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, false, 32>), gp, fa);
             else LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, false, 64>), gp, fa);
-        } else if (small_input)
+        } else if (ht && small_input)
+            LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, true, false, true>), gp, starts, sorted_vals, n02, s8, n0, w,
+                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
+        else if (ht && mode == 0)
+            LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, false, true, true>), gp, starts, sorted_vals, n02, s8, n0, w,
+                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
+        else if (ht)
+            LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, false, false, true>), gp, starts, sorted_vals, n02, s8, n0, w,
+                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
+        else if (small_input)
             LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, true, false>), gp, starts, sorted_vals, n02, s8, n0, w,
                          bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
         else if (mode == 0)
@@ -1676,6 +1890,11 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         SortBufs<u64> rb;
         for (int k = 0; k < 2; k++) { rb.keys[k] = ar.alloc<u64>(cap); rb.vals[k] = ar.alloc<u32>(cap); }
         u32 *name_of = n0 == 0 ? ar.alloc<u32>(n02) : nullptr;      // all-suffix mode: names for prefix doubling
+        // variable-length first-level keys: what the group of a domain position shares beyond `depth` (see HtKeys)
+        uint8_t *xbuf[2] = {nullptr, nullptr};
+        if (ht || ctx.dry) for (auto &x : xbuf) x = ar.alloc<uint8_t>((size_t)cap + 16);
+        int x_dom = 0;
+        bool have_x = false;                            // xbuf[x_dom] describes the current domain
         // the in-LDS round (lds_group_sort.h): what each workgroup took, and the compaction of the rest
         uint2 *cover = ar.alloc<uint2>((size_t)cap / LG_CHUNK + 2);
         u32 *sub_idx = ar.alloc<u32>((size_t)cap + 1), *full_idx = ar.alloc<u32>(cap);
@@ -1718,15 +1937,23 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             const int e_c = (e_dom + 4) % 3, e_out = (e_dom + 5) % 3;      // the two buffers the domain is not in
             u32 *slot_c = sbuf[s_dom ^ 1];
             const u32 gc = ceil_div_u32((u64)m + 1, BLOCK * COMPACT_IPT);
+            // (xdep: computed from the keys by the first compaction, copied along by the later ones; prefix doubling rounds
+            // go by the common depth alone)
+            const uint8_t *x_in = have_x ? (const uint8_t *)xbuf[x_dom] : (const uint8_t *)nullptr;
+            uint8_t *x_out = ht && !doubling ? xbuf[x_dom ^ 1] : (uint8_t *)nullptr;
             if (!slot && fused)
                 LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<BitStarts>), gc, elem,
                              BitStarts{gstart_bits}, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart);
             else if (!slot)
                 LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<KeyNeqWindowIn<K>>), gc, elem,
-                             starts, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart, lcp_out, w, bt, spare);
+                             starts, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart, lcp_out, w, bt, spare,
+                             x_in, x_out);
             else
                 LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<FlagArrIn>), gc, elem,
-                             FlagArrIn{flag}, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart);
+                             FlagArrIn{flag}, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart,
+                             (u32 *)nullptr, 0, 0, 0, x_in, x_out);
+            if (x_out) { x_dom ^= 1; have_x = true; } else have_x = false;
+            const uint8_t *xdep = have_x ? (const uint8_t *)xbuf[x_dom] : (const uint8_t *)nullptr;
             m = m_next;
             bool have_group = false;                    // group[] = inclusive scan of gstart: the groups' numbers
             auto number_groups = [&]() {
@@ -1756,7 +1983,8 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                                  (const u32 *)gstart, (const u32 *)slot_c, m, n0, depth, w2, bt, term_first, (u64)f.rep_t,
                                  (u64)f.ones, (u64)f.highs, sa12, names_g, ebuf[e_out], fbuf[f_dom ^ 1], lcp_r, cover,
                                  names ? (const u32 *)name_of : (const u32 *)nullptr,
-                                 fuse_cls ? LgClassify{keep, fail, (u32)REFINE_SMALL_GROUP, (u32)RESOLVE_MAX_LEN} : LgClassify());
+                                 fuse_cls ? LgClassify{keep, fail, (u32)REFINE_SMALL_GROUP, (u32)RESOLVE_MAX_LEN, names ? nullptr : xdep}
+                                          : LgClassify{nullptr, nullptr, 0u, 0u, names ? nullptr : xdep});
                     // what is left: counted per chunk from cover[] (no pass over the elements)
                     const u32 n_chunks = ceil_div_u32(m, LG_CHUNK);
                     LAUNCH(ctx, lg_rest_count_kernel, ceil_div_u32(n_chunks + 1, BLOCK), (const uint2 *)cover, m, n_chunks, rest_cnt);
@@ -1790,11 +2018,11 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                            rb.keys[0], rb.vals[0]);
                 else
                     LAUNCH(ctx, dc3_refine_keys_kernel, gl, s8, elems_s, (const u32 *)group, m_left, n0, depth, w2, bt, term_first,
-                           rb.keys[0], rb.vals[0]);
+                           rb.keys[0], rb.vals[0], xdep, full);
                 const int rr = radix_sort_pairs<u64>(ctx, rb, m_left, gb + kbits);
                 LAUNCH(ctx, dc3_refine_writeback_kernel, gl, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr], (const u32 *)slot_c,
                        (const u32 *)ebuf[e_c], m_left, f.rep_t, f.ones, f.highs, sa12, names_g, ebuf[e_out], fbuf[f_dom ^ 1], lcp_r,
-                       depth, w2, bt, full);
+                       depth, w2, bt, full, names ? (const uint8_t *)nullptr : xdep);
             };
             if (doubling) {
                 sort_round(true, 0, KeyNeqWindowIn<u64>{nullptr, 0, 0, 0});
@@ -1824,7 +2052,8 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                     LAUNCH(ctx, dc3_refine_classify_kernel, gt, elem, FlagArrIn{flag}, slot, m, s8, n0, depth, sa12, names_g, keep,
                            fail, endgame ? (u32)REFINE_ENDGAME_GROUP : (u32)REFINE_SMALL_GROUP,
                            endgame ? (u32)REFINE_ENDGAME_LEN : (u32)RESOLVE_MAX_LEN, doubling ? name_of : (u32 *)nullptr,
-                           LongRepeats{bad, mode}, lcp_out, rest_only ? (const uint2 *)cover : (const uint2 *)nullptr);
+                           LongRepeats{bad, mode}, lcp_out, rest_only ? (const uint2 *)cover : (const uint2 *)nullptr,
+                           doubling ? (const uint8_t *)nullptr : xdep);
                 if (mode == 1) return;
                 device_scan<PopIn, false>(ctx, PopIn{keep, (m >> 6) + 1u}, (m >> 6) + 2u, idx);
                 have_idx = true;
@@ -1927,12 +2156,30 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
     if (ctx.plan_wide >= 0) wide = ctx.plan_wide != 0;
     else if (ctx.sample_n && w < w_wide && w * bt + docs.bits <= 32)
         wide = (u64)ctx.sample_dup2[std::min(w, 8)] * 2u > ctx.sample_n;
+    // Variable-length code words in a 32-bit key (ht_code.h): taken where they put at least one symbol more into the key
+    // than the fixed width does -- text over a large alphabet in which a few symbols make up most of it (prose: 7 bits a
+    // symbol fixed, under 5 coded).  They go before the wide window: the narrow sort is half the passes on two thirds of
+    // the bytes, and with 5-6 symbols in the key the rounds have no more to do than behind the 8 symbols of the wide one.
+    bool use_ht = false;
+    const int ht_sb = 32 - docs.bits;
+    if (ctx.ht_max_len > 0 && !ctx.dry && ht_sb >= 20 && !g_force_wide_keys && g_ht_mode != 0) {
+        if (g_ht_mode == 1) use_ht = true;
+        else if (ctx.plan_ht >= 0) use_ht = ctx.plan_ht != 0;
+        else use_ht = (double)ht_sb / ctx.ht_mean_len >= (double)ht_sb / bt + 1.0;
+    }
+    ctx.did_ht = use_ht;
+    if (ctx.stats) ctx.stats->ht_keys = use_ht;
+    if (use_ht) wide = false;
     if (wide) w = std::max(w, w_wide);
     ctx.did_wide = wide;
     // (experiments, DESIGN.md 5.2: EAST_HIP_WINDOW=<symbols> overrides the width of the first window)
     if (getenv("EAST_HIP_WINDOW")) w = std::max(3, std::min(atoi(getenv("EAST_HIP_WINDOW")), std::min(12, (64 - docs.bits) / bt)));
     u32 n_names = 0;
+    const HtKeys hk{ctx.ht_enc, ctx.ht_dec, use_ht ? ht_sb / ctx.ht_max_len : 0};
     auto level0 = [&](bool allow_fused) {
+        if (use_ht)
+            return dc3_level0_bytes<u32>(ctx, s8, 0, n, hk.wmin, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
+                                         kg_mark, false, docs.bits ? longest : n, &hk);
         return w * bt + docs.bits <= 32 && !g_force_wide_keys
                    ? dc3_level0_bytes<u32>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
                                            kg_mark, allow_fused, docs.bits ? longest : n)

@@ -71,6 +71,8 @@ SIGNATURES = {
     "east_hip_debug_set_speculation": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_debug_set_score_scratch": (ctypes.c_int, [ctypes.c_int64]),
     "east_hip_debug_set_score_path": (ctypes.c_int, [ctypes.c_int]),
+    "east_hip_debug_alphabetic_code": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int32,
+                                                      ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int32)]),
     "east_hip_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "east_hip_profile_only": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
     "east_hip_profile_report": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
@@ -80,7 +82,7 @@ BUILD_INFO_FIELDS = ("n_total", "n_docs", "n_strings", "sigma_text", "bits_level
                      "arena_high_water", "radix_passes", "radix_elements", "radix_element_bytes",
                      "radix_passes_u32", "radix_elements_u32", "radix_passes_u64", "radix_elements_u64",
                      "dc3_levels_resolved", "merge_elements", "refine_rounds", "window_sorted", "lds_sorted",
-                     "fused_finish", "first_kept", "first_n")
+                     "fused_finish", "first_kept", "first_n", "ht_keys")
 
 _lib = None
 

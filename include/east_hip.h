@@ -242,7 +242,8 @@ void *east_hip_stream(east_hip_handle_t h);
  * tie refinement by further windows, [18] 1 if the all-suffix window sort produced the suffix array
  * (no DC3 level ran; [5] is 0 then), [19] elements the refinement rounds ordered inside a workgroup's LDS,
  * [20] 1 when the last radix digit and the placement ran as one pass in LDS (the fused finish), [21] suffixes the
- * first placement left in large tie groups, [22] of how many.
+ * first placement left in large tie groups, [22] of how many, [23] 1 when the first-level keys held variable-length
+ * (order-preserving) code words instead of fixed-width symbol fields (csrc/ht_code.h).
  */
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap);
 
@@ -285,7 +286,8 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes);
  * 64-bit window keys even where 32 bits suffice (the code path of large inputs, on small ones);
  * 4 / 5 = as 1 / 3 with every radix pass global and the separate placement pass (the fused finish,
  * csrc/window_sort.h: lvl0_finish_kernel, switched off); 6 = as 1 with the fused finish whatever the build's
- * plan says (skewed text, whose large buckets it hands to the refinement rounds).
+ * plan says (skewed text, whose large buckets it hands to the refinement rounds); 7 = as 1 with first-level keys of
+ * variable-length code words wherever a code can be made (csrc/ht_code.h), 8 = as 1 without them.
  * The test knobs of this section are PROCESS-WIDE (they exist to steer a test run through every code path):
  * set them while no build is in flight on any handle. */
 int east_hip_debug_set_window_sort(int enabled);
@@ -300,6 +302,10 @@ int east_hip_debug_set_speculation(int enabled);
  * more documents than fit is scored a stretch of documents at a time.  Takes effect at the next
  * east_hip_set_keyphrases / east_hip_score_table. */
 int east_hip_debug_set_score_scratch(int64_t bytes);
+/* Host only (needs no device): the order-preserving variable-length code csrc/ht_code.h makes for n symbols (in their
+ * order) with the given weights -- code[i] = the len[i] bits of symbol i's code word, right-aligned.  EAST_HIP_ERR_DOMAIN
+ * if no code with word lengths in [2, 12] exists for them (n < 4, n > 256). */
+int east_hip_debug_alphabetic_code(const uint64_t *weights, int32_t n, uint32_t *code, int32_t *len);
 /* Test knob (process-wide): which form of the score path runs (easa.py:91-139).  1 (default) = pair k-gram tables marked
  * off the window keys + the per-keyphrase sums inside the walk kernel; 0 = one filled table, per-suffix results in HBM
  * and a reduction kernel (rounds 1-3); 2 = pair tables with the reduction kernel; 3 = filled table with the sums in the

@@ -16,21 +16,23 @@ from conftest import load_golden, word_stream
 pytestmark = pytest.mark.gpu
 
 
-_PATH_KNOB = {"window_sort": 1, "window_sort_unfused": 4, "dc3_only": 0}
+_PATH_KNOB = {"window_sort": 1, "window_sort_unfused": 4, "window_sort_ht": 7, "dc3_only": 0}
 _CURRENT = {"knob": 1}          # the knob of the running test (tests that check which path a build took)
 
 
-@pytest.fixture(autouse=True, params=["window_sort", "window_sort_unfused", "dc3_only"])
+@pytest.fixture(autouse=True, params=["window_sort", "window_sort_unfused", "window_sort_ht", "dc3_only"])
 def suffix_sort_path(request, hip):
-    """Every parity test runs three times: through the all-suffix window sort as it ships (the last radix
+    """Every parity test runs four times: through the all-suffix window sort as it ships (the last radix
     digit ordered in LDS by the fused finish), through the same sort with every pass global and the separate
-    placement pass, and with the window sort switched off, so that DC3 -- the fallback for repetitive
-    inputs -- stays covered on every input as well.  (Tests that read `suffix_sort_path` get "window_sort"
-    for both window-sort variants.)"""
+    placement pass, through the window sort with first-level keys of variable-length code words wherever a code can
+    be made (csrc/ht_code.h; by itself the build only takes them for text they pay on), and with the window sort
+    switched off, so that DC3 -- the fallback for repetitive inputs -- stays covered on every input as well.
+    (Tests that read `suffix_sort_path` get "window_sort" for the first two.)"""
     lib = hip.load()
     assert lib.east_hip_debug_set_window_sort(_PATH_KNOB[request.param]) == 0
     _CURRENT["knob"] = _PATH_KNOB[request.param]
-    yield "window_sort" if request.param.startswith("window_sort") else request.param
+    # (the variant with variable-length keys gets its own name: the checks of WHICH passes ran do not apply to it)
+    yield "window_sort" if request.param in ("window_sort", "window_sort_unfused") else request.param
     assert lib.east_hip_debug_set_window_sort(1) == 0
     _CURRENT["knob"] = 1
 

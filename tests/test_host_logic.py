@@ -224,3 +224,57 @@ def test_synonym_variants():
         relevance.synonym_variants("QUICK WOLF", Syn())
     with pytest.raises(ZeroDivisionError):
         relevance.synonym_variants(" ", Syn())
+
+
+def test_order_preserving_variable_length_code():
+    """csrc/ht_code.h (host side, no device): the code words of the first-level keys' variable-length code are ordered like
+    the symbols, prefix-free, fill the code space exactly (Kraft sum 1), have 2 .. 12 bits, and -- where no length limit
+    interferes -- cost what the optimal alphabetic tree costs (interval dynamic programme as the checker)."""
+    from east import hip_backend
+    lib = hip_backend.load()
+    rng = np.random.default_rng(31)
+
+    def code_of(weights):
+        w = np.ascontiguousarray(weights, dtype=np.uint64)
+        code = np.zeros(w.size, dtype=np.uint32)
+        length = np.zeros(w.size, dtype=np.int32)
+        rc = lib.east_hip_debug_alphabetic_code(w.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), w.size,
+                                                code.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                                length.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        return rc, code, length
+
+    def optimal_alphabetic_cost(w):
+        n = len(w)
+        pre = np.concatenate([[0], np.cumsum(w)])
+        cost = [[0] * (n + 1) for _ in range(n + 1)]
+        for span in range(2, n + 1):
+            for i in range(0, n - span + 1):
+                j = i + span
+                cost[i][j] = min(cost[i][s] + cost[s][j] for s in range(i + 1, j)) + int(pre[j] - pre[i])
+        return cost[0][n]
+
+    cases = []
+    for n in (4, 5, 9, 27, 28, 57, 113, 255, 256):
+        cases.append(rng.integers(1, 1000, size=n))
+        cases.append(np.sort(rng.integers(1, 10**6, size=n))[::-1] ** 2)                 # steep
+        zipf = (1e7 / np.arange(1, n + 1) ** 1.3).astype(np.int64) + 1
+        cases.append(rng.permutation(zipf))
+        cases.append(np.ones(n, dtype=np.int64))
+    cases.append(np.array([10**9, 1, 1, 1, 1, 1]))                                        # one symbol carries the text
+    cases.append(np.array([1] * 200 + [10**12]))
+    for w in cases:
+        rc, code, length = code_of(w)
+        assert rc == 0, (rc, len(w))
+        assert length.min() >= 2 and length.max() <= 12
+        left = [(int(c) << (12 - int(l))) for c, l in zip(code, length)]
+        for i in range(len(w) - 1):
+            assert left[i] + (1 << (12 - int(length[i]))) <= left[i + 1]               # ordered and prefix-free
+        assert sum(1 << (12 - int(l)) for l in length) == 1 << 12                       # no hole in the code space
+        if len(w) <= 57:
+            want = optimal_alphabetic_cost(np.asarray(w, dtype=np.int64))
+            got = int(sum(int(x) * int(l) for x, l in zip(w, length)))
+            # (a case that runs into the 2 / 12 bit limits has its weights adjusted and may cost a little more: the steep
+            # ones; flat weights never do)
+            flat = int(np.max(w)) <= 1000
+            assert got >= want and (got == want or not flat), (len(w), got, want)
+    assert code_of(np.array([1, 2, 3]))[0] != 0                                           # too few symbols: no code
