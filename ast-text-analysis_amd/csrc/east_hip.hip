@@ -558,7 +558,7 @@ static void prepare_ht_code(east_hip_index *h, Ctx &ctx, u32 n, u32 sigma_t, u32
     } else {
         h->ht_valid = false;
         // (an alphabet of at most 5 bits -- letters only -- has nothing to gain: at best a fraction of a symbol per key)
-        if (sigma_t + 1 < 4 || (g_ht_mode != 1 && (bit_width_u32(sigma_t + 1) < 6 || n < 65536)) || n < 64) return;
+        if (sigma_t + 1 < 8 || (g_ht_mode != 1 && (bit_width_u32(sigma_t + 1) < 6 || n < 65536)) || n < 64) return;
         Arena &ar = *ctx.arena;
         const size_t mark = ar.mark();
         u32 *d_counts = ar.alloc<u32>(256);
@@ -1965,10 +1965,11 @@ int east_hip_debug_set_window_sort(int enabled)
     g_window_sort = enabled != 0;
     g_force_lean = enabled == 2;
     g_force_wide_keys = enabled == 3 || enabled == 5;
-    g_fused_finish = enabled != 4 && enabled != 5 && getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;
+    g_fused_finish = enabled != 4 && enabled != 5 && enabled != 9 && getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;
     g_force_fused = enabled == 6;                        // 6: as 1, the fused finish whatever the plan says (skewed text through it)
-    // 7: as 1, first-level keys of variable-length code words wherever a code can be made (ht_code.h); 8: never
-    g_ht_mode = enabled == 7 ? 1 : enabled == 8 ? 0 : (getenv("EAST_HIP_HT") ? atoi(getenv("EAST_HIP_HT")) : -1);
+    // 7: as 1, first-level keys of variable-length code words wherever a code can be made (ht_code.h); 9: the same
+    // without the fused finish; 8: as 1 without such keys
+    g_ht_mode = enabled == 7 || enabled == 9 ? 1 : enabled == 8 ? 0 : (getenv("EAST_HIP_HT") ? atoi(getenv("EAST_HIP_HT")) : -1);
     g_plan_epoch++;
     return EAST_HIP_OK;
 }

@@ -18,7 +18,8 @@
 #include <algorithm>
 
 #define HT_MAX_LEN 12                   // longest code word (bits): the decode table is indexed by 12 bits
-#define HT_MIN_LEN 2                    // shortest: a key of 32 bits then holds at most 16 symbols (HtWindowGen looks 16 ahead)
+#define HT_MIN_LEN 3                    // shortest: a stream of 48 bits then holds at most 16 symbols (HtWindowGen looks 16 ahead)
+#define HT_MAX_STREAM 48                // ... which is the most stream bits a key may carry
 #define HT_DEC_SIZE (1u << HT_MAX_LEN)
 
 // ---- host: the code -----------------------------------------------------------------------------------------------
@@ -63,7 +64,7 @@ static std::vector<int> ht_garsia_wachs(const std::vector<u64> &w)
 static bool ht_build_code(const std::vector<u64> &w_in, std::vector<u32> &code, std::vector<int> &len)
 {
     const int n = (int)w_in.size();
-    if (n < 4 || n > 256) return false;
+    if (n < (1 << HT_MIN_LEN) || n > 256) return false;   // (fewer symbols cannot fill the code space with words this long)
     std::vector<u64> w = w_in;
     u64 total = 0;
     for (u64 x : w) total += x;
@@ -80,7 +81,7 @@ static bool ht_build_code(const std::vector<u64> &w_in, std::vector<u32> &code, 
             // one symbol carries nearly half of the text: its weight is capped
             u64 t2 = 0;
             for (u64 x : w) t2 += x;
-            for (int i = 0; i < n; i++) w[i] = std::min(w[i], std::max<u64>(1, t2 / 5));
+            for (int i = 0; i < n; i++) w[i] = std::min(w[i], std::max<u64>(1, t2 / 10));
         }
         if (attempt == 23) return false;
     }
@@ -131,24 +132,26 @@ static bool ht_make_tables(const std::vector<u64> &byte_counts, u32 sigma_t, u64
 struct HtScan {
     u32 whole;      // whole code words of text in front of the first terminator / the cut of the key
     u32 common;     // ... of them inside the first `cb` bits (the LCP with a key that shares exactly cb bits)
+    u32 top;        // ... of them inside the first `tb` bits
     bool term;      // a whole terminator code word follows those `whole` symbols (the key is unique)
+    bool term_top;  // ... and it ends inside the first `tb` bits
 };
 
-// stream: the coded suffix, left-aligned in 32 bits, sb of them valid; dec: the decode table (LDS or global)
-template <class Table> __device__ __forceinline__ HtScan ht_scan(u32 stream, int sb, const Table &dec, int cb)
+// stream: the coded suffix, left-aligned in S (u32 / u64), sb of its bits valid; dec: the decode table (LDS or global;
+// entries of 8 or 16 bits: length in bits 0-6, "terminator" in bit 7)
+template <class S, class Table> __device__ __forceinline__ HtScan ht_scan(S stream, int sb, const Table &dec, int cb, int tb = 0)
 {
-    HtScan r{0u, 0u, false};
+    HtScan r{0u, 0u, 0u, false, false};
     int pos = 0;
-    bool counting = true;
     while (pos < sb) {
-        const u32 e = dec[(stream << pos) >> (32 - HT_MAX_LEN)];
+        const u32 e = dec[(u32)((S)(stream << pos) >> (sizeof(S) * 8 - HT_MAX_LEN))];
         const int len = (int)(e & 0x7Fu);
         if (len == 0 || pos + len > sb) break;          // (a hole of the code space only turns up in the zero padding)
-        if (pos + len > cb) counting = false;
-        if (e & 0x80u) { r.term = true; break; }
+        if (e & 0x80u) { r.term = true; r.term_top = pos + len <= tb; break; }
         r.whole++;
-        if (counting) r.common++;
         pos += len;
+        if (pos <= cb) r.common++;
+        if (pos <= tb) r.top++;
     }
     return r;
 }

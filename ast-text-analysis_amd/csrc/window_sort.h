@@ -380,11 +380,10 @@ template <class K> struct KeyNeqWindowIn {
     K rep_t, ones, highs;       // terminator code / 1 / top bit replicated into every full-symbol field
     int ht_sb = 0, ht_wmin = 0;
     const uint16_t *ht_dec = nullptr;
-    // the coded stream of a key, left-aligned in 32 bits (at most 32 of its bits are ever looked at)
-    __device__ __forceinline__ u32 ht_stream(K k) const
+    // the coded stream of a key, left-aligned (the document number shifted out at the top)
+    __device__ __forceinline__ K ht_stream(K k) const
     {
-        if constexpr (sizeof(K) == 4) return ht_sb >= 32 ? (u32)k : (u32)k << (32 - ht_sb);
-        else return ht_sb >= 32 ? (u32)(k >> (ht_sb - 32)) : (u32)k << (32 - ht_sb);
+        return ht_sb >= (int)sizeof(K) * 8 ? k : (K)(k << ((int)sizeof(K) * 8 - ht_sb));
     }
     // bits the streams of k and kp have in common (ht_sb if the keys are equal; -1: different documents)
     __device__ __forceinline__ int ht_common_bits(K k, K kp) const
@@ -395,10 +394,12 @@ template <class K> struct KeyNeqWindowIn {
         if constexpr (sizeof(K) == 4) hb = 31 - __clz((u32)d); else hb = 63 - __clzll((u64)d);
         return hb >= ht_sb ? -1 : ht_sb - 1 - hb;
     }
-    template <class Table> __device__ __forceinline__ HtScan ht_read(K k, K kp, const Table &dec) const
+    // what the key k holds; common = the symbols it shares with kp (the LCP of the two suffixes, if the keys differ);
+    // tb: see HtScan::top
+    template <class Table> __device__ __forceinline__ HtScan ht_read(K k, K kp, const Table &dec, int tb = 0) const
     {
         const int cb = ht_common_bits(k, kp);
-        return ht_scan(ht_stream(k), ht_sb < 32 ? ht_sb : 32, dec, cb < 0 ? 0 : cb);
+        return ht_scan<K>(ht_stream(k), ht_sb, dec, cb < 0 ? 0 : cb, tb);
     }
     // "does any of the w full symbols equal the terminator code": xor turns such a field into zero,
     // then the zero-field test (x - ones) & ~x & highs (exact for "any field is zero")
@@ -651,7 +652,8 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
                                                           int spare, u32 *__restrict__ order_g,
                                                           u32 *__restrict__ names_g, u32 *__restrict__ lcp_g,
                                                           u64 *__restrict__ keep, u32 *__restrict__ block_keep,
-                                                          u32 *__restrict__ fail, LongRepeats lr_arg, KgMark km)
+                                                          u32 *__restrict__ fail, LongRepeats lr_arg, KgMark km,
+                                                          uint8_t *__restrict__ xdep0 = nullptr)
 {
     const LongRepeats lr = OPTIMISTIC ? LongRepeats() : lr_arg;
     constexpr u32 limit = ENDGAME_LIMITS ? REFINE_ENDGAME_GROUP : REFINE_SMALL_GROUP;
@@ -718,6 +720,17 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
                     if (sc[e].term && j0 + e < m) tb |= 1u << e;
                     dep_tile[threadIdx.x * PLACE_IPT + e] = (uint8_t)sc[e].whole;
                 }
+            }
+            // (per rank: what its key holds beyond the least any key does -- the extra depth of its tie group, should the
+            // rounds get it; j0 is a multiple of 4 and the array is padded: one 4-byte store)
+            if (xdep0) {
+                u32 x4 = 0;
+#pragma unroll
+                for (int e = 0; e < PLACE_IPT; e++) {
+                    const u32 x = sc[e].whole > (u32)f.ht_wmin ? sc[e].whole - (u32)f.ht_wmin : 0u;
+                    x4 |= (x > 255u ? 255u : x) << (8 * e);
+                }
+                *reinterpret_cast<u32 *>(xdep0 + j0) = x4;
             }
             const u32 at0 = PLACE_HALO + threadIdx.x * PLACE_IPT;
             if (tb) {
@@ -910,6 +923,12 @@ template <class K> struct FinishArgs {
     u64 *keep, *gstart;                     // one bit per rank (zeroed; OR-ed into): left to the rounds / first of its group
     u32 *block_keep, *fail, *kg_bad;
     KgMark km;
+    // variable-length code words in the keys (ht_code.h; ht_sb = 0: fixed-width fields): stream bits, the least whole
+    // symbols the TOP part of a key holds (the depth the rounds start from), the decode table, and per rank handed to the
+    // rounds what its group shares beyond that depth
+    int ht_sb = 0, ht_wmin = 0;
+    const uint16_t *ht_dec = nullptr;
+    uint8_t *xdep0 = nullptr;
 };
 
 // highest set bit of fl[] in [lo, i] / lowest in [i, hi]; -1 if none (the ranges span at most G + 4 bits)
@@ -979,13 +998,16 @@ __device__ __forceinline__ u32 fin_lcp_of_key_pair(const FinishArgs<K> &a, K k, 
 // so everything touched is staged (staged indices throughout); next4[] holds the 4 symbols behind the window of every
 // tied pair (enough to tell nearly all of them apart; longer comparisons go on reading the text, 8 symbols a step).
 // Returns 1 when the group has more than `limit` members (left to the rounds).
+// (dec8 / depth_i: variable-length keys -- the decode table in LDS and the whole symbols the member's key holds: the depth
+// the comparisons start from.  A tied member's key holds no terminator, and the members of its group hold the same key.)
 template <class K>
 __device__ __forceinline__ u32 fin_place_tied(const FinishArgs<K> &a, int i, const K *kt, const u32 *vt, const u32 *next4,
-                                              u32 base, u32 limit, u32 max_len)
+                                              u32 base, u32 limit, u32 max_len, const uint8_t *dec8 = nullptr, u32 depth_i = 0)
 {
     auto starts = [&](int x) -> bool {
         if (base + (u32)x == 0) return true;
         const K k = kt[x], xx = k ^ a.rep_t;
+        if (a.ht_sb) return k != kt[x - 1];
         return ((K)(xx - a.ones) & ~xx & a.highs) != 0 || k != kt[x - 1];
     };
     int lo = i, hi = i + 1;
@@ -993,7 +1015,7 @@ __device__ __forceinline__ u32 fin_place_tied(const FinishArgs<K> &a, int i, con
     while (base + (u32)hi < a.m && !starts(hi) && (u32)(hi - i) <= limit) hi++;
     if ((u32)(hi - lo) > limit) return 1;
     const uint8_t *s8 = a.s8;
-    const u32 depth = (u32)a.w, p = vt[i];
+    const u32 depth = a.ht_sb ? depth_i : (u32)a.w, p = vt[i];
     const u32 u0 = next4[i];
     u32 r = 0, best = 0;                                // best: longest common prefix with a smaller member
     for (int x = lo; x < hi; x++) {
@@ -1026,11 +1048,21 @@ __device__ __forceinline__ u32 fin_place_tied(const FinishArgs<K> &a, int i, con
     const int at = lo + (int)r;
     const u32 at_g = base + (u32)at;
     a.order_g[at_g] = p;
-    if (a.lcp_g) a.lcp_g[at_g] = r > 0 ? best : (at_g > 0 ? fin_lcp_of_key_pair(a, kt[at], kt[at - 1]) : 0u);
+    if (a.lcp_g) {
+        u32 h = best;
+        if (r == 0) {
+            if (at_g == 0) h = 0;
+            else if (a.ht_sb) {
+                const KeyNeqWindowIn<K> hf{nullptr, 0, 0, 0, a.ht_sb, a.ht_wmin, a.ht_dec};
+                h = hf.ht_read(kt[at], kt[at - 1], dec8).common;
+            } else h = fin_lcp_of_key_pair(a, kt[at], kt[at - 1]);
+        }
+        a.lcp_g[at_g] = h;
+    }
     return 0;
 }
 
-template <class K, bool ENDGAME_LIMITS, int FIN_G>
+template <class K, bool ENDGAME_LIMITS, int FIN_G, bool HT = false>
 __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
 {
     using GE = FinGeom<FIN_G>;
@@ -1046,6 +1078,11 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     __shared__ u32 fl[FIN_WORDS];                       // bucket starts, by staged index
     __shared__ u32 keep_bits[FIN_WORDS], gs_bits[FIN_WORDS];
     __shared__ u32 n_keep, n_work;
+    __shared__ uint8_t dec8[HT ? HT_DEC_SIZE : 1];      // variable-length keys: the decode table (length, terminator bit)
+    __shared__ uint8_t wdep[HT ? FIN_CHUNK + FIN_G : 1];   // ... the whole symbols of the tied members' keys, by work list index
+    if constexpr (HT)
+        for (u32 i = threadIdx.x; i < HT_DEC_SIZE; i += BLOCK) dec8[i] = (uint8_t)(a.ht_dec[i] & 0xFFu);
+    const KeyNeqWindowIn<K> hf{a.keys, a.rep_t, a.ones, a.highs, a.ht_sb, a.ht_wmin, a.ht_dec};
     u32 *comp = next4;                                  // (bucket start, low key bits, staged index) of every pair; next4 is used after the ranking
     const u32 m = a.m;
     const u32 c0 = blockIdx.x * FIN_CHUNK;
@@ -1213,11 +1250,24 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     auto place_one = [&](int i, bool is_hot, bool first, K k, K kp, K kn, u32 v, u32 &sa_o, u32 &lcp_o) -> bool {
         const u32 j = base + (u32)i;
         sa_o = v;
-        lcp_o = j > 0 ? fin_lcp_of_key_pair(a, k, kp) : 0u;
+        HtScan sc{0u, 0u, 0u, false, false};
+        if constexpr (HT) sc = hf.ht_read(k, kp, dec8, a.ht_sb - L);             // (one reading of the key says it all)
+        if constexpr (HT) lcp_o = j > 0 ? sc.common : 0u;
+        else lcp_o = j > 0 ? fin_lcp_of_key_pair(a, k, kp) : 0u;
+        // (a rank left to the rounds: what its group shares beyond the depth the rounds start from)
+        auto note_depth = [&](u32 shared) {
+            if constexpr (HT) a.xdep0[j] = (uint8_t)(shared > (u32)a.ht_wmin ? (shared - (u32)a.ht_wmin > 255u ? 255u : shared - (u32)a.ht_wmin) : 0u);
+        };
         if (is_hot) {
             if (a.km.kg && first) kg_mark(j, k, kp, v);
-            const K xt = k ^ a.top_rep_t;
-            if (((K)(xt - a.top_ones) & ~xt & a.top_highs) != 0) return true;   // a constant bucket: final as it stands
+            bool constant;
+            if constexpr (HT) constant = sc.term_top;
+            else {
+                const K xt = k ^ a.top_rep_t;
+                constant = ((K)(xt - a.top_ones) & ~xt & a.top_highs) != 0;
+            }
+            if (constant) return true;                  // a constant bucket: final as it stands
+            note_depth(sc.top);
             // (handed to the rounds: the suffix goes to its rank as it is, with the caller's 16-byte stores; the LCP entry is
             // the right one for the group's first rank, and the rounds write every other one when the group splits)
             atomicOr(&keep_bits[i >> 5], 1u << (i & 31));
@@ -1227,12 +1277,17 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
             return true;
         }
         if (a.km.kg) kg_mark(j, k, kp, v);
-        const K x = k ^ f.rep_t;
-        const bool st = j == 0 || ((K)(x - f.ones) & ~x & f.highs) != 0 || k != kp;
-        bool st_next = j + 1 >= m;
-        if (!st_next) {
-            const K xn = kn ^ f.rep_t;
-            st_next = ((K)(xn - f.ones) & ~xn & f.highs) != 0 || kn != k;
+        bool st, st_next = j + 1 >= m;
+        if constexpr (HT) {
+            st = j == 0 || sc.term || k != kp;
+            st_next = st_next || kn != k || sc.term;    // (an equal key holds a terminator exactly if this one does)
+        } else {
+            const K x = k ^ f.rep_t;
+            st = j == 0 || ((K)(x - f.ones) & ~x & f.highs) != 0 || k != kp;
+            if (!st_next) {
+                const K xn = kn ^ f.rep_t;
+                st_next = ((K)(xn - f.ones) & ~xn & f.highs) != 0 || kn != k;
+            }
         }
         if (st && st_next) return true;
         // tied: a group of equal keys inside this bucket (all of it is staged).  More than `limit` equal keys around
@@ -1248,9 +1303,12 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
             atomicOr(&keep_bits[i >> 5], 1u << (i & 31));
             my_keep++;
             if (st) atomicOr(&gs_bits[i >> 5], 1u << (i & 31));
+            note_depth(sc.whole);
             return true;                                // (as above: stored by the caller)
         }
-        work[atomicAdd(&n_work, 1u)] = (uint16_t)i;
+        const u32 wi = atomicAdd(&n_work, 1u);
+        work[wi] = (uint16_t)i;
+        if constexpr (HT) wdep[wi] = (uint8_t)sc.whole;
         return false;
     };
     {
@@ -1309,21 +1367,29 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     for (u32 q = tid; q < todo; q += BLOCK) {
         const u32 i = work[q];
         u32 x4;
-        __builtin_memcpy(&x4, a.s8 + vt[i] + (u32)w, 4);
+        __builtin_memcpy(&x4, a.s8 + vt[i] + (HT ? (u32)wdep[q] : (u32)w), 4);
         next4[i] = x4;
     }
     __syncthreads();
     for (u32 q = tid; q < todo; q += BLOCK) {
         const int i = (int)work[q];
-        if (fin_place_tied(a, i, kt, vt, next4, base, limit, max_len)) {
+        if (fin_place_tied(a, i, kt, vt, next4, base, limit, max_len, HT ? dec8 : (const uint8_t *)nullptr, HT ? (u32)wdep[q] : 0u)) {
             const u32 j = base + (u32)i;
             a.order_g[j] = vt[i];
             atomicOr(&keep_bits[i >> 5], 1u << (i & 31));
             my_keep++;
+            if constexpr (HT) {
+                const u32 shared = (u32)wdep[q];
+                a.xdep0[j] = (uint8_t)(shared > (u32)a.ht_wmin ? (shared - (u32)a.ht_wmin > 255u ? 255u : shared - (u32)a.ht_wmin) : 0u);
+            }
             const K k = kt[i], x = k ^ a.rep_t;
-            if (j == 0 || ((K)(x - a.ones) & ~x & a.highs) != 0 || k != kt[i - 1]) {     // the first of its group
+            const bool has_term = HT ? false : ((K)(x - a.ones) & ~x & a.highs) != 0;       // (a tied key holds none)
+            if (j == 0 || has_term || k != kt[i - 1]) {     // the first of its group
                 atomicOr(&gs_bits[i >> 5], 1u << (i & 31));
-                if (a.lcp_g) a.lcp_g[j] = j > 0 ? fin_lcp_of_key_pair(a, k, kt[i - 1]) : 0u;
+                if (a.lcp_g) {
+                    if constexpr (HT) a.lcp_g[j] = j > 0 ? hf.ht_read(k, kt[i - 1], dec8).common : 0u;
+                    else a.lcp_g[j] = j > 0 ? fin_lcp_of_key_pair(a, k, kt[i - 1]) : 0u;
+                }
             }
         }
     }
@@ -1443,7 +1509,8 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__
                                                                    uint8_t *__restrict__ xdep_out = nullptr)
 {
     // xdep (variable-length first-level keys): what the group of a position shares BEYOND the rounds' common depth --
-    // first domain: the whole symbols of its key less the least any key holds; later domains: copied along
+    // first domain: written per rank by the placement pass (the whole symbols of the key less the least any key holds);
+    // later domains: copied along
     const u32 j0 = (blockIdx.x * BLOCK + threadIdx.x) * COMPACT_IPT;
     if (j0 >= m) return;
     const u64 word = keep.bits[j0 >> 6];
@@ -1459,16 +1526,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__
         slot_out[k] = slot ? slot[j] : j;
         elem_out[k] = elem[j];
         group_start[k] = st;
-        if (xdep_out) {
-            u32 x = xdep_in ? xdep_in[j] : 0u;
-            if constexpr (Starts::HAS_KEYS) {
-                if (starts.ht_sb) {
-                    const u32 whole = starts.ht_read(starts.keys[j], starts.keys[j], starts.ht_dec).whole;
-                    x = whole > (u32)starts.ht_wmin ? whole - (u32)starts.ht_wmin : 0u;
-                }
-            }
-            xdep_out[k] = (uint8_t)x;
-        }
+        if (xdep_out) xdep_out[k] = xdep_in ? xdep_in[j] : (uint8_t)0;
         if constexpr (Starts::HAS_KEYS) {
             // the keyed first domain: the first rank of a group left to the rounds gets its LCP entry here, from the
             // two keys -- whichever member ends up there
@@ -1682,7 +1740,8 @@ __global__ __launch_bounds__(BLOCK) void spec_counts_kernel(const u32 *__restric
 struct HtKeys {
     const u32 *enc = nullptr;           // device: byte -> code << 8 | length
     const uint16_t *dec = nullptr;      // device: 12 stream bits -> symbol << 8 | terminator << 7 | length
-    int wmin = 0;
+    int max_len = 0;                    // the longest code word
+    int sb = 0;                         // stream bits of a key (<= HT_MAX_STREAM), under the document number
 };
 template <class K>
 static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w, int bt, u32 term_first, u32 *sa12,
@@ -1692,24 +1751,27 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
 {
     Arena &ar = *ctx.arena;
     const u32 g02 = ceil_div_u32((u64)n02 + 1, BLOCK);
-    const int ht_sb = ht ? (int)sizeof(K) * 8 - docs.bits : 0;
+    const int ht_sb = ht ? ht->sb : 0;
     // whole passes are paid for anyway: fill the last digit with the top bits of the next symbol
     // (the document number, if any, sits above window and spare bits)
     const int spare = ht ? 0 : lvl0_spare_bits(w * bt + docs.bits, (int)sizeof(K) * 8, bt, w);
     // The fused finish (lvl0_finish_kernel): the global passes stop above the low FIN_LOW_BITS key bits.  depth0 = the
     // symbols that lie wholly inside the top part -- what the members of a bucket are known to share.
-    const int total_bits = ht ? (int)sizeof(K) * 8 : w * bt + spare + docs.bits;
+    const int total_bits = ht ? ht_sb + docs.bits : w * bt + spare + docs.bits;
     int depth0 = 0;
     for (int j = 0; j < w; j++)
         if (spare + j * bt >= FIN_LOW_BITS) depth0++;
-    bool fused = !ht && allow_fused && g_fused_finish && n0 == 0 && total_bits >= 2 * FIN_LOW_BITS && depth0 >= 1;
+    if (ht) depth0 = (ht_sb - FIN_LOW_BITS) / ht->max_len;          // the whole symbols any top part holds at least
+    bool fused = allow_fused && g_fused_finish && n0 == 0 && total_bits >= 2 * FIN_LOW_BITS && depth0 >= 1;
     bool fin_small_halo = false;                        // buckets of at most ten suffixes expected: the kernel with the halo of 32
     if (fused && !ctx.dry) {
         if (g_force_fused) {
             // (test knob: buckets of any size -- the large ones go to the rounds)
         } else if (ctx.plan_fused >= 0) {
             fused = ctx.plan_fused != 0;                 // (speculative build: as the build before)
-            fin_small_halo = ctx.plan_fused == 2;
+            fin_small_halo = ctx.plan_fused == 2 && !ht;
+        } else if (ht) {
+            // (variable-length keys come with a wide window: few suffixes per bucket of the top part)
         } else {
             // expected members of a bucket, were the text uniform
             double top_codes = pow((double)term_first, depth0);
@@ -1726,6 +1788,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         }
     }
     const int low_bits = fused ? FIN_LOW_BITS : 0;
+    if (ht) w = fused ? depth0 : ht_sb / ht->max_len;     // the depth the rounds start from: what every key (its top part) holds at least
     if (n0 == 0) ctx.did_fused = fused ? (fin_small_halo ? 2 : 1) : 0;
     if (ctx.stats && n0 == 0) ctx.stats->fused_finish = fused;
     SortBufs<K> sb;
@@ -1741,7 +1804,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     }
     const int r = n0 ? radix_sort_pairs<K, WindowSrc<K>>(ctx, sb, n02, total_bits, 0,
                                                          WindowSrc<K>{s8, n0, w, bt, spare, term_first, docs})
-                : ht ? radix_sort_pairs<K, HtWindowGen<K>>(ctx, sb, n02, total_bits, 0,
+                : ht ? radix_sort_pairs<K, HtWindowGen<K>>(ctx, sb, n02, total_bits, low_bits,
                                                            HtWindowGen<K>{s8, n02, ht_sb, ht->enc, docs},
                                                            docs.bits ? total_bits - docs.bits : total_bits + RS_DB)
                      : radix_sort_pairs<K, TextWindowGen<K>>(ctx, sb, n02, total_bits, low_bits,
@@ -1749,7 +1812,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                                                              // (suffixes in text order: only the document number is sorted)
                                                              docs.bits ? total_bits - docs.bits : total_bits + RS_DB);
     KeyNeqWindowIn<K> starts = KeyNeqWindowIn<K>::make(sb.keys[r], ht ? 0 : w, bt, spare, term_first);
-    if (ht) { starts.ht_sb = ht_sb; starts.ht_wmin = ht->wmin; starts.ht_dec = ht->dec; }
+    if (ht) { starts.ht_sb = ht_sb; starts.ht_wmin = w; starts.ht_dec = ht->dec; }
     const u32 *sorted_vals = sb.vals[r];
     u64 *keep = (u64 *)sb.keys[r ^ 1];                   // n02 + 1 bits, in the keys idle since the sort
     u64 *gstart_bits = ar.alloc<u64>(((size_t)n02 >> 6) + 2);  // fused finish: the first rank of every group left to the rounds
@@ -1763,6 +1826,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     const u32 nb = ceil_div_u32(gp, SCAN_TILE);
     u32 *block_sums = ar.alloc<u32>(nb);
     u32 *bad = ar.alloc<u32>(((size_t)n02 >> 5) + 2);   // groups with a repeat too long to compare directly (rare)
+    uint8_t *xdep0 = ht || ctx.dry ? ar.alloc<uint8_t>((size_t)n02 + 16) : nullptr;   // variable-length keys: extra depth per rank
     if (!ctx.dry && !fail_is_zero) HIP_CHECK(hipMemsetAsync(fail, 0, sizeof(u32), ctx.stream));
 
     // ---- the whole sorted input as the first domain --------------------------------------
@@ -1798,6 +1862,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         fa.order_g = sa12; fa.lcp_g = lcp_out; fa.keep = keep; fa.gstart = gstart_bits;
         fa.block_keep = block_keep; fa.fail = fail; fa.kg_bad = ctx.kg_bad ? ctx.kg_bad : fail;
         fa.km = small_input ? KgMark() : km;
+        if (ht) { fa.ht_sb = ht_sb; fa.ht_wmin = w; fa.ht_dec = ht->dec; fa.xdep0 = xdep0; }
         if (!ctx.dry) {
             HIP_CHECK(hipMemsetAsync(keep, 0, (((size_t)n02 >> 6) + 2) * sizeof(u64), ctx.stream));
             HIP_CHECK(hipMemsetAsync(gstart_bits, 0, (((size_t)n02 >> 6) + 2) * sizeof(u64), ctx.stream));
@@ -1806,18 +1871,20 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     auto place = [&](int mode) {
         if (fused) {
             if (mode != 0) throw FusedAbort();
-            if (small_input) LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, true, 64>), gp, fa);
+            if (ht && small_input) LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, true, 64, true>), gp, fa);
+            else if (ht) LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, false, 64, true>), gp, fa);
+            else if (small_input) LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, true, 64>), gp, fa);
             else if (fin_small_halo) LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, false, 32>), gp, fa);
             else LAUNCH_NAMED(ctx, "lvl0_finish_kernel", (lvl0_finish_kernel<K, false, 64>), gp, fa);
         } else if (ht && small_input)
             LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, true, false, true>), gp, starts, sorted_vals, n02, s8, n0, w,
-                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
+                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark(), xdep0);
         else if (ht && mode == 0)
             LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, false, true, true>), gp, starts, sorted_vals, n02, s8, n0, w,
-                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
+                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark(), xdep0);
         else if (ht)
             LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, false, false, true>), gp, starts, sorted_vals, n02, s8, n0, w,
-                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
+                         bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark(), xdep0);
         else if (small_input)
             LAUNCH_NAMED(ctx, "lvl0_place_kernel", (lvl0_place_kernel<K, true, false>), gp, starts, sorted_vals, n02, s8, n0, w,
                          bt, spare, sa12, names_g, lcp_out, keep, block_keep, fail, LongRepeats{bad, mode}, KgMark());
@@ -1939,11 +2006,12 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             const u32 gc = ceil_div_u32((u64)m + 1, BLOCK * COMPACT_IPT);
             // (xdep: computed from the keys by the first compaction, copied along by the later ones; prefix doubling rounds
             // go by the common depth alone)
-            const uint8_t *x_in = have_x ? (const uint8_t *)xbuf[x_dom] : (const uint8_t *)nullptr;
+            const uint8_t *x_in = have_x ? (const uint8_t *)xbuf[x_dom] : !slot && ht ? (const uint8_t *)xdep0 : (const uint8_t *)nullptr;
             uint8_t *x_out = ht && !doubling ? xbuf[x_dom ^ 1] : (uint8_t *)nullptr;
             if (!slot && fused)
                 LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<BitStarts>), gc, elem,
-                             BitStarts{gstart_bits}, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart);
+                             BitStarts{gstart_bits}, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart,
+                             (u32 *)nullptr, 0, 0, 0, x_in, x_out);
             else if (!slot)
                 LAUNCH_NAMED(ctx, "dc3_refine_compact_kernel", (dc3_refine_compact_kernel<KeyNeqWindowIn<K>>), gc, elem,
                              starts, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart, lcp_out, w, bt, spare,
@@ -2160,26 +2228,37 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
     // than the fixed width does -- text over a large alphabet in which a few symbols make up most of it (prose: 7 bits a
     // symbol fixed, under 5 coded).  They go before the wide window: the narrow sort is half the passes on two thirds of
     // the bytes, and with 5-6 symbols in the key the rounds have no more to do than behind the 8 symbols of the wide one.
-    bool use_ht = false;
-    const int ht_sb = 32 - docs.bits;
-    if (ctx.ht_max_len > 0 && !ctx.dry && ht_sb >= 20 && !g_force_wide_keys && g_ht_mode != 0) {
-        if (g_ht_mode == 1) use_ht = true;
-        else if (ctx.plan_ht >= 0) use_ht = ctx.plan_ht != 0;
-        else use_ht = (double)ht_sb / ctx.ht_mean_len >= (double)ht_sb / bt + 1.0;
+    // They are worth their decoding where the text pays far more bits per symbol than it needs AND the wide window is
+    // the plan anyway: the same 64-bit pairs, sorted on fewer bits (48 stream bits: a pass less), holding half as many
+    // symbols again.  (Behind a narrow 32-bit key they were measured and lose to the wide fixed-width window: 6.75 against
+    // 6.1 ms on 64 x 1 MiB of prose -- twice the suffixes in the rounds.  Forced -- mode 1 -- they take the key width the
+    // fixed-width plan would have taken: the tests go through both.)
+    bool use_ht = false, ht_wide = false;
+    if (ctx.ht_max_len > 0 && !ctx.dry && g_ht_mode != 0) {
+        if (g_ht_mode == 1) { use_ht = true; ht_wide = wide || g_force_wide_keys || w * bt + docs.bits > 32; }
+        else if (ctx.plan_ht >= 0) { use_ht = ctx.plan_ht != 0; ht_wide = ctx.plan_ht == 2; }
+        else { use_ht = ht_wide = wide && ctx.ht_mean_len <= (double)bt - 1.5; }
+        if (use_ht && !ht_wide && (32 - docs.bits < 20 || g_force_wide_keys)) ht_wide = true;
+        if (use_ht && ht_wide && 64 - docs.bits < 20) use_ht = false;
     }
-    ctx.did_ht = use_ht;
-    if (ctx.stats) ctx.stats->ht_keys = use_ht;
-    if (use_ht) wide = false;
+    int ht_sb = !use_ht ? 0 : ht_wide ? std::min(HT_MAX_STREAM, 64 - docs.bits) : std::min(HT_MAX_STREAM, 32 - docs.bits);
+    // (experiments: EAST_HIP_HT_SB=<bits> overrides the stream bits of a wide key -- 42 next to 6 document bits is a pass less than 48)
+    if (use_ht && ht_wide && getenv("EAST_HIP_HT_SB")) ht_sb = std::max(20, std::min(ht_sb, atoi(getenv("EAST_HIP_HT_SB"))));
+    ctx.did_ht = use_ht ? (ht_wide ? 2 : 1) : 0;
+    if (ctx.stats) ctx.stats->ht_keys = ctx.did_ht;
     if (wide) w = std::max(w, w_wide);
     ctx.did_wide = wide;
     // (experiments, DESIGN.md 5.2: EAST_HIP_WINDOW=<symbols> overrides the width of the first window)
     if (getenv("EAST_HIP_WINDOW")) w = std::max(3, std::min(atoi(getenv("EAST_HIP_WINDOW")), std::min(12, (64 - docs.bits) / bt)));
     u32 n_names = 0;
-    const HtKeys hk{ctx.ht_enc, ctx.ht_dec, use_ht ? ht_sb / ctx.ht_max_len : 0};
+    const HtKeys hk{ctx.ht_enc, ctx.ht_dec, ctx.ht_max_len, ht_sb};
     auto level0 = [&](bool allow_fused) {
+        if (use_ht && ht_wide)
+            return dc3_level0_bytes<u64>(ctx, s8, 0, n, 0, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
+                                         kg_mark, allow_fused, docs.bits ? longest : n, &hk);
         if (use_ht)
-            return dc3_level0_bytes<u32>(ctx, s8, 0, n, hk.wmin, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
-                                         kg_mark, false, docs.bits ? longest : n, &hk);
+            return dc3_level0_bytes<u32>(ctx, s8, 0, n, 0, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
+                                         kg_mark, allow_fused, docs.bits ? longest : n, &hk);
         return w * bt + docs.bits <= 32 && !g_force_wide_keys
                    ? dc3_level0_bytes<u32>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
                                            kg_mark, allow_fused, docs.bits ? longest : n)

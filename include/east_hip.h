@@ -287,7 +287,8 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes);
  * 4 / 5 = as 1 / 3 with every radix pass global and the separate placement pass (the fused finish,
  * csrc/window_sort.h: lvl0_finish_kernel, switched off); 6 = as 1 with the fused finish whatever the build's
  * plan says (skewed text, whose large buckets it hands to the refinement rounds); 7 = as 1 with first-level keys of
- * variable-length code words wherever a code can be made (csrc/ht_code.h), 8 = as 1 without them.
+ * variable-length code words wherever a code can be made (csrc/ht_code.h), 9 = the same without the fused finish,
+ * 8 = as 1 without such keys.
  * The test knobs of this section are PROCESS-WIDE (they exist to steer a test run through every code path):
  * set them while no build is in flight on any handle. */
 int east_hip_debug_set_window_sort(int enabled);
@@ -304,7 +305,7 @@ int east_hip_debug_set_speculation(int enabled);
 int east_hip_debug_set_score_scratch(int64_t bytes);
 /* Host only (needs no device): the order-preserving variable-length code csrc/ht_code.h makes for n symbols (in their
  * order) with the given weights -- code[i] = the len[i] bits of symbol i's code word, right-aligned.  EAST_HIP_ERR_DOMAIN
- * if no code with word lengths in [2, 12] exists for them (n < 4, n > 256). */
+ * if no code with word lengths in [3, 12] exists for them (n < 8, n > 256). */
 int east_hip_debug_alphabetic_code(const uint64_t *weights, int32_t n, uint32_t *code, int32_t *len);
 /* Test knob (process-wide): which form of the score path runs (easa.py:91-139).  1 (default) = pair k-gram tables marked
  * off the window keys + the per-keyphrase sums inside the walk kernel; 0 = one filled table, per-suffix results in HBM

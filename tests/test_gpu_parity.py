@@ -16,16 +16,17 @@ from conftest import load_golden, word_stream
 pytestmark = pytest.mark.gpu
 
 
-_PATH_KNOB = {"window_sort": 1, "window_sort_unfused": 4, "window_sort_ht": 7, "dc3_only": 0}
+_PATH_KNOB = {"window_sort": 1, "window_sort_unfused": 4, "window_sort_ht": 7, "window_sort_ht_unfused": 9, "dc3_only": 0}
 _CURRENT = {"knob": 1}          # the knob of the running test (tests that check which path a build took)
 
 
-@pytest.fixture(autouse=True, params=["window_sort", "window_sort_unfused", "window_sort_ht", "dc3_only"])
+@pytest.fixture(autouse=True, params=["window_sort", "window_sort_unfused", "window_sort_ht", "window_sort_ht_unfused", "dc3_only"])
 def suffix_sort_path(request, hip):
-    """Every parity test runs four times: through the all-suffix window sort as it ships (the last radix
+    """Every parity test runs five times: through the all-suffix window sort as it ships (the last radix
     digit ordered in LDS by the fused finish), through the same sort with every pass global and the separate
     placement pass, through the window sort with first-level keys of variable-length code words wherever a code can
-    be made (csrc/ht_code.h; by itself the build only takes them for text they pay on), and with the window sort
+    be made (csrc/ht_code.h; by itself the build only takes them for text they pay on) with and without the fused
+    finish, and with the window sort
     switched off, so that DC3 -- the fallback for repetitive inputs -- stays covered on every input as well.
     (Tests that read `suffix_sort_path` get "window_sort" for the first two.)"""
     lib = hip.load()
@@ -626,6 +627,9 @@ def test_refinement_rounds_in_lds_and_by_the_global_sort(hip, oracle, suffix_sor
         if suffix_sort_path == "window_sort":
             assert info["window_sorted"] == 1 and info["refine_rounds"] >= 1, info
             assert (info["lds_sorted"] > 0) == bool(lds_rounds), info
+        if suffix_sort_path.startswith("window_sort_ht"):
+            assert info["window_sorted"] == 1 and info["ht_keys"] >= 1, info      # variable-length keys really ran
+            assert info["fused_finish"] == int(suffix_sort_path == "window_sort_ht"), info
         for d in range(n_docs):
             o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
             t = index.tables(d)

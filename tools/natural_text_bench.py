@@ -52,8 +52,10 @@ def main():
     print("symbols %d, strings %d, distinct text symbols %d, bits/symbol %d" % (info["n_total"], info["n_strings"],
                                                                                info["sigma_text"], info["bits_level0"]))
     print("build %.2f ms (%.2e chars/s), text preparation %.2f ms, wall %.1f ms; window sort %s, refinement rounds %d, "
-          "DC3 levels %d" % (index.last_build_ms, len(raw) / (index.last_build_ms * 1e-3), index.last_prep_ms, wall * 1e3,
-                             "succeeded" if info["window_sorted"] else "gave up", info["refine_rounds"], info["dc3_levels"]))
+          "DC3 levels %d, variable-length keys %d, fused finish %d, 64-bit passes %d"
+          % (index.last_build_ms, len(raw) / (index.last_build_ms * 1e-3), index.last_prep_ms, wall * 1e3,
+             "succeeded" if info["window_sorted"] else "gave up", info["refine_rounds"], info["dc3_levels"], info.get("ht_keys", 0),
+             info["fused_finish"], info["radix_passes_u64"]))
     if os.environ.get("EAST_PROFILE"):
         index.profile_enable(True)
         index.build(sym, off, ms)
