@@ -554,7 +554,11 @@ static void prepare_ht_code(east_hip_index *h, Ctx &ctx, u32 n, u32 sigma_t, u32
     ctx.ht_max_len = 0;
     if (ctx.dry || !h->use_s8 || !g_window_sort || g_ht_mode == 0) return;
     if (ctx.spec) {
-        if (!h->ht_valid || h->ht_sigma != sigma_t) return;
+        if (!h->ht_valid || h->ht_sigma != sigma_t) {
+            // (no code from the build before.  Forced -- the tests -- the build starts over with its read-backs in place and makes one)
+            if (g_ht_mode == 1 && sigma_t + 1 >= 8 && n >= 64) throw SpecAbort();
+            return;
+        }
     } else {
         h->ht_valid = false;
         // (an alphabet of at most 5 bits -- letters only -- has nothing to gain: at best a fraction of a symbol per key)

@@ -155,3 +155,43 @@ template <class S, class Table> __device__ __forceinline__ HtScan ht_scan(S stre
     }
     return r;
 }
+
+// Reading the keys of CONSECUTIVE ranks: neighbours in the sorted order share most of their bits, and with the bits the
+// code word boundaries inside them.  The walk keeps the boundaries of the current key as a bit mask (bit p - 1: a text
+// code word ends behind bit p of the stream); moving on to the next key keeps what lies inside the common bits and goes on
+// decoding from there -- and only as far as somebody needs: the LCP entry of a rank wants the boundaries inside the bits it
+// shares with its neighbours, the whole key is read only where a tie group or a hot bucket is at stake.
+template <class S> struct HtWalk {
+    u64 bounds = 0;
+    int pos = 0;            // the last boundary found so far (bits decoded)
+    int term_end = 0;       // where the terminator's code word ends (0: none met)
+    bool done = false;      // the rest of the key holds no further whole code word
+
+    static __device__ __forceinline__ u64 upto(int bits) { return bits >= 64 ? ~0ull : ((u64)1 << bits) - 1ull; }
+    // the walk of a key that shares its first `cb` bits with the key walked so far
+    __device__ __forceinline__ void inherit(int cb)
+    {
+        bounds &= upto(cb);
+        if (term_end > cb) term_end = 0;
+        pos = bounds ? 64 - __clzll((long long)bounds) : 0;
+        done = term_end != 0;
+    }
+    // decode on until every boundary inside the first `need` bits is known
+    template <class Table> __device__ __forceinline__ void extend(S stream, int sb, const Table &dec, int need)
+    {
+        while (!done && pos < need) {
+            const u32 e = dec[(u32)((S)(stream << pos) >> (sizeof(S) * 8 - HT_MAX_LEN))];
+            const int len = (int)(e & 0x7Fu);
+            if (len == 0 || pos + len > sb) { done = true; break; }
+            if (e & 0x80u) { term_end = pos + len; done = true; break; }
+            pos += len;
+            bounds |= (u64)1 << (pos - 1);
+        }
+    }
+    __device__ __forceinline__ u32 symbols_within(int bits) const { return (u32)__popcll(bounds & upto(bits)); }
+    // (valid once extend() ran with need = sb)
+    __device__ __forceinline__ HtScan result(int cb, int tb) const
+    {
+        return HtScan{(u32)__popcll(bounds), symbols_within(cb), symbols_within(tb), term_end != 0, term_end != 0 && term_end <= tb};
+    }
+};

@@ -713,9 +713,18 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     if constexpr (HT) {
         if (j0 < m) {
             u32 tb = 0;
+            HtWalk<K> walk;                             // (one walk over the five keys: see HtWalk)
 #pragma unroll
             for (int e = 0; e <= PLACE_IPT; e++) {
-                sc[e] = f.ht_read(k[e + 1], k[e], dec_lds);
+                int cb = f.ht_common_bits(k[e + 1], k[e]);
+                cb = cb < 0 ? 0 : cb;
+                if (e > 0) walk.inherit(cb);
+                // (the whole key only where the rank may be tied; else the boundaries its own and the next LCP entry need)
+                const bool all = k[e + 1] == k[e] || (e < PLACE_IPT && k[e + 2] == k[e + 1]);
+                int cbn = e < PLACE_IPT ? f.ht_common_bits(k[e + 2], k[e + 1]) : 0;
+                cbn = cbn < 0 ? 0 : cbn;
+                walk.extend(f.ht_stream(k[e + 1]), f.ht_sb, dec_lds, all ? f.ht_sb : (cb > cbn ? cb : cbn));
+                sc[e] = walk.result(cb, 0);
                 if (e < PLACE_IPT) {
                     if (sc[e].term && j0 + e < m) tb |= 1u << e;
                     dep_tile[threadIdx.x * PLACE_IPT + e] = (uint8_t)sc[e].whole;
@@ -1247,11 +1256,11 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     };
     // rank `base + i` (one of this workgroup's): returns true when it is final here (suffix and LCP entry in sa_o / lcp_o,
     // to be stored by the caller); a rank handed to the rounds or a member of a small tie group is dealt with inside
-    auto place_one = [&](int i, bool is_hot, bool first, K k, K kp, K kn, u32 v, u32 &sa_o, u32 &lcp_o) -> bool {
+    // (sc: variable-length keys -- what the key holds, as far as this rank needs it: the symbols shared with the key before
+    // always, the rest where the rank is in a hot bucket or tied with a neighbour)
+    auto place_one = [&](int i, bool is_hot, bool first, K k, K kp, K kn, u32 v, u32 &sa_o, u32 &lcp_o, const HtScan &sc) -> bool {
         const u32 j = base + (u32)i;
         sa_o = v;
-        HtScan sc{0u, 0u, 0u, false, false};
-        if constexpr (HT) sc = hf.ht_read(k, kp, dec8, a.ht_sb - L);             // (one reading of the key says it all)
         if constexpr (HT) lcp_o = j > 0 ? sc.common : 0u;
         else lcp_o = j > 0 ? fin_lcp_of_key_pair(a, k, kp) : 0u;
         // (a rank left to the rounds: what its group shares beyond the depth the rounds start from)
@@ -1332,10 +1341,31 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
             vq[0] = q.x; vq[1] = q.y; vq[2] = q.z; vq[3] = q.w;
         }
 #ifndef FIN_DIAG_NOPLACE
+        // variable-length keys: the four keys are read in one walk (HtWalk) -- the boundaries inside the bits a key shares
+        // with the one before are inherited, the rest is decoded only as far as it is needed
+        HtScan sc4[FIN_IPT];
+        if constexpr (HT) {
+            HtWalk<K> walk;
+            const int tb = a.ht_sb - L;
+#pragma unroll
+            for (int e = 0; e < FIN_IPT; e++) {
+                const K k = kq[e + 1];
+                int cb = hf.ht_common_bits(k, kq[e]);
+                const int cb_next = hf.ht_common_bits(kq[e + 2], k);
+                if (e == 0) cb = cb < 0 ? 0 : cb; else { cb = cb < 0 ? 0 : cb; walk.inherit(cb); }
+                const bool all = ((hot >> e) & 1u) || k == kq[e] || kq[e + 2] == k;       // a hot bucket, or tied with a neighbour
+                const int need = all ? a.ht_sb : (cb > cb_next ? cb : cb_next);
+                walk.extend(hf.ht_stream(k), a.ht_sb, dec8, need);
+                sc4[e] = walk.result(cb, tb);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < FIN_IPT; e++) sc4[e] = HtScan{0u, 0u, 0u, false, false};
+        }
 #pragma unroll
         for (int e = 0; e < FIN_IPT; e++)
             if (((todo4 >> e) & 1u) &&
-                place_one(i0 + e, (hot >> e) & 1u, (myfl >> e) & 1u, kq[e + 1], kq[e], kq[e + 2], vq[e], sa4[e], lc4[e]))
+                place_one(i0 + e, (hot >> e) & 1u, (myfl >> e) & 1u, kq[e + 1], kq[e], kq[e + 2], vq[e], sa4[e], lc4[e], sc4[e]))
                 fin |= 1u << e;
 #else
 #pragma unroll
@@ -1355,7 +1385,9 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
         }
         if (own & 16u) {                                // the overhang of the last bucket that starts in the stretch
             u32 sa1, lc1;
-            if (place_one(ih, false, false, kt[ih], kt[ih - 1], kt[ih + 1], vt[ih], sa1, lc1)) {
+            HtScan sc1{0u, 0u, 0u, false, false};
+            if constexpr (HT) sc1 = hf.ht_read(kt[ih], kt[ih - 1], dec8, a.ht_sb - L);
+            if (place_one(ih, false, false, kt[ih], kt[ih - 1], kt[ih + 1], vt[ih], sa1, lc1, sc1)) {
                 a.order_g[base + (u32)ih] = sa1;
                 if (a.lcp_g) a.lcp_g[base + (u32)ih] = lc1;
             }
