@@ -2274,6 +2274,9 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
         if (use_ht && ht_wide && 64 - docs.bits < 20) use_ht = false;
     }
     int ht_sb = !use_ht ? 0 : ht_wide ? std::min(HT_MAX_STREAM, 64 - docs.bits) : std::min(HT_MAX_STREAM, 32 - docs.bits);
+    // (a wide key is cut to whole radix digits: 42 stream bits next to 6 document bits sort in five global passes where
+    // 48 take six -- measured on 64 x 1 MiB of prose: 5.77 against 5.82 ms, the 8.6 symbols of the shorter key are enough)
+    if (use_ht && ht_wide) ht_sb -= (ht_sb + docs.bits) % RS_DB;
     // (experiments: EAST_HIP_HT_SB=<bits> overrides the stream bits of a wide key -- 42 next to 6 document bits is a pass less than 48)
     if (use_ht && ht_wide && getenv("EAST_HIP_HT_SB")) ht_sb = std::max(20, std::min(ht_sb, atoi(getenv("EAST_HIP_HT_SB"))));
     ctx.did_ht = use_ht ? (ht_wide ? 2 : 1) : 0;
