@@ -99,8 +99,11 @@ def main():
     paths = {}
     while time.time() < t_end:
         docs = random_collection(rng, args.max_symbols)
-        knob = int(rng.choice([1, 1, 1, 0, 3, 2, 4, 5]))
+        # (7 / 9: first-level keys of variable-length code words, with / without the fused finish)
+        knob = int(rng.choice([1, 1, 1, 0, 3, 2, 4, 5, 7, 7, 9, 9]))
         lib.east_hip_debug_set_window_sort(knob)
+        lib.east_hip_debug_set_lds_rounds(int(rng.choice([1, 1, 2, 0])))
+        lib.east_hip_debug_set_score_path(int(rng.choice([1, 1, 0, 2, 3])))
         parts = [to_symbols(sc) for sc in docs]
         sym = np.concatenate(parts)
         off = np.concatenate([[0], np.cumsum([p.size for p in parts])])
@@ -124,7 +127,7 @@ def main():
             index.build(dev_sym, off, np.array([len(sc) for sc in docs], dtype=np.int32))
             info = index.info()
             key = (knob, info["window_sorted"], min(info["dc3_levels"], 3), min(info["refine_rounds"], 3), int(lifted),
-                   info["fused_finish"])
+                   info["fused_finish"], info["ht_keys"])
             paths[key] = paths.get(key, 0) + 1
             queries = []
             for sc in docs[:2]:
@@ -157,7 +160,10 @@ def main():
             index.close()
         cases += 1
     lib.east_hip_debug_set_window_sort(1)
-    print("fuzz ok: %d collections, %d documents, %d symbols checked; paths (knob, window_sorted, dc3_levels, rounds, lifted, fused):"
+    lib.east_hip_debug_set_lds_rounds(1)
+    lib.east_hip_debug_set_score_path(1)
+    print("fuzz ok: %d collections, %d documents, %d symbols checked; paths (knob, window_sorted, dc3_levels, rounds, lifted, fused, "
+          "variable-length keys):"
           % (cases, docs_checked, symbols))
     for k in sorted(paths):
         print("   ", k, paths[k])
