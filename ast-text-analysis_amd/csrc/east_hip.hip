@@ -23,6 +23,8 @@
 #include "score.h"
 #include "tables.h"
 #include "textprep.h"
+#include <atomic>
+#include <thread>
 
 #include <algorithm>
 #include <string.h>
@@ -473,6 +475,9 @@ struct east_hip_index {
     size_t tp_tables_bytes = 0;
     u64 tp_tables_hash = 0;
     std::vector<uint8_t> tp_host_tables;
+    // the streamed text preparation: a copy stream of its own and one event per chunk
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> copy_events;
     // symbols prepared on the device by east_hip_build_texts (own allocation)
     u32 *prep_sym = nullptr;
     size_t prep_cap = 0;
@@ -1053,6 +1058,223 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
 // ---------------------------------------------------------------- text prep --
 #define TP_WORD_HI_WORDS ((0x110000u - TP_TEXT_LIMIT + 31u) / 32u)
 
+// ---- the streamed preparation (textprep.h, "the streamed preparation") --------------------------------------------
+// -1: streamed for inputs of TP_STREAM_MIN bytes or more, in about TP_STREAM_CHUNKS chunks; 0: never; > 0: always, in chunks
+// of about that many bytes (east_hip_debug_set_text_stream: the tests push the fixtures through chunks of a few dozen bytes)
+static i64 g_tp_stream = getenv("EAST_HIP_TEXT_STREAM") ? atoll(getenv("EAST_HIP_TEXT_STREAM")) : -1;
+#define TP_STREAM_MIN ((u32)8 << 20)
+#define TP_STREAM_CHUNKS 5
+
+struct TpChunk {
+    u32 b0 = 0, b1 = 0;             // bytes [b0, b1) of the concatenated stream (separators included)
+    u32 doc_first = 0, n_docs = 0;  // the documents it touches
+    bool cont_in = false, cont_out = false;
+    std::vector<u32> text_off;      // n_docs + 1: where they start, relative to b0 (the last entry = b1 - b0)
+};
+
+// byte p of the concatenated stream (document d holds it)
+static inline u32 tp_byte_at(const uint8_t *bytes, const uint8_t *const *texts, const i64 *text_offsets, u32 d, u32 p)
+{
+    if (p + 1 == (u32)text_offsets[d + 1]) return 0xFFu;              // the separator
+    return texts ? texts[d][p - (u32)text_offsets[d]] : bytes[p];
+}
+
+// Cuts of the stream where neither a token nor a UTF-8 unit can span them: behind a separator, or behind an ASCII byte
+// that is no word character (looked for in the 4 KiB in front of where the chunk would end; a document without one there
+// -- one endless token, binary junk -- stays whole).
+static std::vector<TpChunk> tp_plan_chunks(const uint8_t *bytes, const uint8_t *const *texts, const i64 *text_offsets, u32 D,
+                                           u32 n_bytes, u32 chunk_bytes, const uint8_t *cls256)
+{
+    std::vector<TpChunk> chunks;
+    u32 pos = 0, d = 0;                                  // d: the document that holds byte pos
+    while (pos < n_bytes) {
+        u32 cut = n_bytes;
+        if ((u64)pos + chunk_bytes < n_bytes) {
+            const u32 target = pos + chunk_bytes;
+            u32 dt = d;
+            while ((u32)text_offsets[dt + 1] < target) dt++;         // the document that holds byte target - 1
+            cut = (u32)text_offsets[dt + 1];                         // (its end, unless a cut inside it is found)
+            const u32 lowest = std::max(pos + 1, target > 4096u ? target - 4096u : 0u);
+            for (u32 q = target; q-- > lowest;) {
+                if (q < (u32)text_offsets[dt]) { cut = (u32)text_offsets[dt]; break; }     // (the document starts in the window: cut in front of it)
+                const u32 c = tp_byte_at(bytes, texts, text_offsets, dt, q);
+                if (c == 0xFFu || (c < 0x80u && !(cls256[c] & TP_CLASS_WORD))) { cut = q + 1; break; }
+            }
+        }
+        TpChunk ch;
+        ch.b0 = pos; ch.b1 = cut;
+        while ((u32)text_offsets[d + 1] <= pos) d++;
+        ch.doc_first = d;
+        ch.cont_in = pos > (u32)text_offsets[d];
+        u32 dl = d;
+        ch.text_off.push_back(0);
+        while ((u32)text_offsets[dl + 1] < cut) { ch.text_off.push_back((u32)text_offsets[dl + 1] - pos); dl++; }
+        ch.text_off.push_back(cut - pos);
+        ch.n_docs = dl - d + 1;
+        ch.cont_out = cut < (u32)text_offsets[dl + 1];
+        chunks.push_back(std::move(ch));
+        pos = cut;
+    }
+    return chunks;
+}
+
+// Prepares the collection chunk by chunk; the symbols end up in h->prep_sym, the per-document offsets and string counts in
+// h_off / h_m.  Returns false when the monolithic preparation has to take over: kept text at or above U+0A00 (the tagged
+// encoding rewrites terminators the chunks no longer remember).  d_bytes: n_bytes + 32 bytes of the arena, nothing uploaded yet.
+static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *bytes, const uint8_t *const *texts,
+                                   const i64 *text_offsets, u32 D, u32 n_bytes, u32 chunk_bytes, uint8_t *d_bytes,
+                                   const TpTables &tables, const uint8_t *d_cls256, const u32 *d_up256,
+                                   std::vector<u32> &h_off, std::vector<u32> &h_m)
+{
+    Arena &ar = *ctx.arena;
+    const std::vector<TpChunk> chunks = tp_plan_chunks(bytes, texts, text_offsets, D, n_bytes, chunk_bytes, h->tp_host_tables.data());
+    const u32 C = (u32)chunks.size();
+    u32 nb_max = 0, dl_max = 0;
+    for (const TpChunk &c : chunks) { nb_max = std::max(nb_max, c.b1 - c.b0); dl_max = std::max(dl_max, c.n_docs); }
+    if (!h->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    while (h->copy_events.size() < C) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->copy_events.push_back(e);
+    }
+    // the symbols: every kept code point one, every string of three tokens (of three code points or more) a terminator,
+    // an empty document two
+    const size_t sym_cap = (size_t)n_bytes + (size_t)n_bytes / 9 + 2 * (size_t)D + 64;
+    if (sym_cap * 4 > h->prep_cap) {
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->prep_sym) HIP_CHECK(hipFree(h->prep_sym));
+        h->prep_sym = nullptr;
+        h->prep_cap = 0;
+        void *p = nullptr;
+        if (hipMalloc(&p, sym_cap * 4) != hipSuccess) east_throw(EAST_HIP_ERR_OOM, "hipMalloc of the prepared symbols failed");
+        h->prep_sym = (u32 *)p;
+        h->prep_cap = sym_cap * 4;
+    }
+    // ---- the uploads: a thread of their own (a copy out of pageable memory returns when it is staged) ----
+    std::atomic<int> uploaded{0}, upload_failed{0};
+    const int device = h->device;
+    hipStream_t copy_stream = h->copy_stream;
+    const std::vector<hipEvent_t> &events = h->copy_events;
+    std::thread uploader([&, device, copy_stream]() {
+        bool ok = hipSetDevice(device) == hipSuccess;
+        if (ok && texts) ok = hipMemsetAsync(d_bytes, 0xFF, n_bytes, copy_stream) == hipSuccess;       // the separators
+        if (ok) ok = hipMemsetAsync(d_bytes + n_bytes, 0, 32, copy_stream) == hipSuccess;
+        for (u32 c = 0; c < C && ok; c++) {
+            const TpChunk &ch = chunks[c];
+            if (texts) {
+                for (u32 i = 0; i < ch.n_docs && ok; i++) {
+                    const u32 d = ch.doc_first + i;
+                    const u32 lo = std::max(ch.b0, (u32)text_offsets[d]), hi = std::min(ch.b1, (u32)text_offsets[d + 1] - 1u);    // (without the separator)
+                    if (hi > lo)
+                        ok = hipMemcpyAsync(d_bytes + lo, texts[d] + (lo - (u32)text_offsets[d]), hi - lo, hipMemcpyHostToDevice,
+                                            copy_stream) == hipSuccess;
+                }
+            } else {
+                ok = hipMemcpyAsync(d_bytes + ch.b0, bytes + ch.b0, ch.b1 - ch.b0, hipMemcpyHostToDevice, copy_stream) == hipSuccess;
+            }
+            if (ok) ok = hipEventRecord(events[c], copy_stream) == hipSuccess;
+            if (ok) uploaded.store((int)c + 1, std::memory_order_release);
+        }
+        if (!ok) { (void)hipGetLastError(); upload_failed.store(1, std::memory_order_release); }
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};
+
+    // ---- device state shared by the chunks ----
+    TpCarry *carry = ar.alloc<TpCarry>(2);
+    u32 *d_high = ar.alloc<u32>(1);
+    u32 *doc_sym_off_all = ar.alloc<u32>((size_t)D + 1), *m_all = ar.alloc<u32>(D);
+    HIP_CHECK(hipMemsetAsync(carry, 0, 2 * sizeof(TpCarry), h->stream));
+    HIP_CHECK(hipMemsetAsync(d_high, 0, 4, h->stream));
+    // per-chunk scratch (sized for the largest chunk, used by one chunk after the other)
+    const u32 ub_tok = nb_max / 2 + 2;                   // a token needs a character and something behind it
+    u32 *d_text_off = ar.alloc<u32>((size_t)dl_max + 1);
+    u32 *cp_index = ar.alloc<u32>((size_t)nb_max + 1);
+    const u32 nb_cp_max = ceil_div_u32((u64)nb_max + 1, SCAN_TILE);
+    u32 *cp_sums = ar.alloc<u32>(nb_cp_max);
+    u32 *cpu = ar.alloc<u32>(nb_max);
+    uint8_t *cw = ar.alloc<uint8_t>((size_t)nb_max + 32);
+    u32 *doc_cp_off = ar.alloc<u32>((size_t)dl_max + 1);
+    u32 *tok_inc = ar.alloc<u32>((size_t)nb_max + 1);
+    u32 *tstart = ar.alloc<u32>(ub_tok), *tend = ar.alloc<u32>(ub_tok), *tok_nd = ar.alloc<u32>(ub_tok);
+    u32 *keep = ar.alloc<u32>((size_t)ub_tok + 1), *klen = ar.alloc<u32>((size_t)ub_tok + 1);
+    u32 *keep_ex = ar.alloc<u32>((size_t)ub_tok + 1), *klen_ex = ar.alloc<u32>((size_t)ub_tok + 1);
+    uint4 *tok_rec = ar.alloc<uint4>(ub_tok);
+    u32 *first_tok = ar.alloc<u32>((size_t)dl_max + 1), *n_loc = ar.alloc<u32>((size_t)dl_max + 1);
+    u32 *off_loc = ar.alloc<u32>((size_t)dl_max + 1), *kept_tot = ar.alloc<u32>(dl_max), *chars_tot = ar.alloc<u32>(dl_max);
+    std::vector<u32> h_cp_sums(nb_cp_max);
+
+    for (u32 c = 0; c < C; c++) {
+        const TpChunk &ch = chunks[c];
+        const u32 nb = ch.b1 - ch.b0, Dl = ch.n_docs;
+        const uint8_t *b = d_bytes + ch.b0;
+        // the chunk's bytes: recorded by the uploader, waited for by the compute stream
+        while (uploaded.load(std::memory_order_acquire) <= (int)c) {
+            if (upload_failed.load(std::memory_order_acquire)) east_throw(EAST_HIP_ERR_HIP, "upload of the raw text failed");
+            std::this_thread::yield();
+        }
+        HIP_CHECK(hipStreamWaitEvent(h->stream, events[c], 0));
+        HIP_CHECK(hipMemcpyAsync(d_text_off, ch.text_off.data(), ((size_t)Dl + 1) * 4, hipMemcpyHostToDevice, h->stream));
+        // bytes -> code points (the count first: a chunk in which every byte is a code point of its own needs no index)
+        const u32 nb_cp = ceil_div_u32((u64)nb + 1, SCAN_TILE);
+        LAUNCH(ctx, (scan_reduce_kernel<TpStartIn>), nb_cp, TpStartIn{b, nb}, nb + 1, cp_sums);
+        HIP_CHECK(hipMemcpyAsync(h_cp_sums.data(), cp_sums, (size_t)nb_cp * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        u32 n_cp = 0;
+        for (u32 i = 0; i < nb_cp; i++) n_cp += h_cp_sums[i];
+        const bool bytewise = n_cp == nb;
+        if (bytewise) {
+            LAUNCH(ctx, tp_classify_bytes_kernel, ceil_div_u32(nb, BLOCK * 16), b, nb, d_cls256, cw);
+        } else {
+            device_scan<ArrIn, false>(ctx, ArrIn{cp_sums}, nb_cp, cp_sums);
+            LAUNCH(ctx, (scan_apply_kernel<TpStartIn, false>), nb_cp, TpStartIn{b, nb}, nb + 1, (const u32 *)cp_sums, cp_index);
+            LAUNCH(ctx, tp_decode_kernel, ceil_div_u32(nb, BLOCK), b, nb, (const u32 *)cp_index, tables, cpu, cw);
+        }
+        LAUNCH(ctx, tp_doc_cp_offsets_kernel, ceil_div_u32(Dl + 1, BLOCK), bytewise ? (const u32 *)nullptr : (const u32 *)cp_index,
+               (const u32 *)d_text_off, Dl, doc_cp_off);
+        // code points -> tokens (their number stays on the device: tok_inc[n_cp - 1])
+        device_scan<TpTokStartIn, true>(ctx, TpTokStartIn{cw, n_cp}, n_cp, tok_inc);
+        const u32 *n_tok_dev = tok_inc + (n_cp - 1);
+        const u32 ub = n_cp / 2 + 2;
+        HIP_CHECK(hipMemsetAsync(tok_nd, 0, (size_t)ub * 4, h->stream));
+        HIP_CHECK(hipMemsetAsync(keep, 0, ((size_t)ub + 1) * 4, h->stream));
+        HIP_CHECK(hipMemsetAsync(klen, 0, ((size_t)ub + 1) * 4, h->stream));
+        LAUNCH(ctx, tp_token_bounds_kernel, ceil_div_u32(n_cp, BLOCK * TP_VEC), (const uint8_t *)cw, (const u32 *)tok_inc, n_cp, tstart,
+               tend, tok_nd);
+        LAUNCH(ctx, tp_token_keep_kernel, ceil_div_u32(ub, BLOCK), (const u32 *)tstart, (const u32 *)tend, (const u32 *)tok_nd, ub, keep,
+               klen, n_tok_dev);
+        device_scan<ArrIn, false>(ctx, ArrIn{keep}, ub + 1, keep_ex);
+        device_scan<ArrIn, false>(ctx, ArrIn{klen}, ub + 1, klen_ex);
+        // tokens -> the documents' strings and symbols, with what earlier chunks emitted of the first document
+        const TpCarry *cin = carry + (c & 1u);
+        TpCarry *cout = carry + ((c + 1u) & 1u);
+        LAUNCH(ctx, tp_stream_docs_kernel, ceil_div_u32(Dl + 1, BLOCK), (const u32 *)doc_cp_off, (const u32 *)tok_inc, (const u32 *)keep_ex,
+               (const u32 *)klen_ex, Dl, (u32)ch.cont_in, (u32)ch.cont_out, cin, first_tok, n_loc, kept_tot, chars_tot);
+        device_scan<ArrIn, false>(ctx, ArrIn{n_loc}, Dl + 1, off_loc);
+        LAUNCH(ctx, tp_stream_token_out_kernel, ceil_div_u32(ub, BLOCK), (const u32 *)tstart, (const u32 *)tend, (const u32 *)keep_ex,
+               (const u32 *)klen_ex, (const u32 *)doc_cp_off, (const u32 *)first_tok, (const u32 *)off_loc, (const u32 *)kept_tot, Dl,
+               (u32)ch.cont_in, (u32)ch.cont_out, cin, n_tok_dev, tok_rec);
+        LAUNCH(ctx, tp_emit_kernel, ceil_div_u32(n_cp, BLOCK), bytewise ? (const u32 *)nullptr : (const u32 *)cpu, b, d_up256,
+               (const uint8_t *)cw, (const u32 *)tok_inc, (const uint4 *)tok_rec, n_cp, h->prep_sym, d_high);
+        LAUNCH(ctx, tp_stream_close_docs_kernel, ceil_div_u32(Dl, BLOCK), (const u32 *)off_loc, (const u32 *)n_loc, (const u32 *)kept_tot,
+               (const u32 *)chars_tot, Dl, ch.doc_first, (u32)ch.cont_in, (u32)ch.cont_out, cin, cout, doc_sym_off_all, m_all,
+               h->prep_sym);
+    }
+    uploader.join();
+    // the total, the per-document offsets and string counts, "kept text at or above U+0A00"
+    h_off.resize((size_t)D + 1);
+    h_m.resize(D);
+    u32 high = 0;
+    TpCarry last;
+    HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    HIP_CHECK(hipMemcpyAsync(h_off.data(), doc_sym_off_all, (size_t)D * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(h_m.data(), m_all, (size_t)D * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(&last, carry + (C & 1u), sizeof(last), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(&high, d_high, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h_off[D] = last.sym_base;
+    return high == 0;
+}
+
 // bytes: the texts concatenated, each followed by one 0xFF byte (host pointer).
 // (texts != nullptr: the texts lie apart in host memory -- text d = texts[d], text_offsets as if they were
 // concatenated with their separators; they are uploaded one by one and never joined on the host)
@@ -1076,7 +1298,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     use_device(h);
     h->built = false;
     const u32 n_bytes = (u32)n_bytes64, D = (u32)n_docs;
-    ensure_arena(h, (size_t)n_bytes * 44 + (size_t)D * 64 + (8u << 20));
+    ensure_arena(h, (size_t)n_bytes * 46 + (size_t)D * 96 + (8u << 20));
     Arena &ar = h->arena;
     ar.release(0);
     ar.high = 0;
@@ -1092,16 +1314,22 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     u32 *d_high = ar.alloc<u32>(1);
     std::vector<u32> off32((size_t)D + 1);
     for (u32 d = 0; d <= D; d++) off32[d] = (u32)text_offsets[d];
-    if (texts) {
-        HIP_CHECK(hipMemsetAsync(d_bytes, 0xFF, n_bytes, h->stream));              // the separators
-        for (u32 d = 0; d < D; d++) {
-            const size_t len = (size_t)(text_offsets[d + 1] - text_offsets[d] - 1);
-            if (len) HIP_CHECK(hipMemcpyAsync(d_bytes + text_offsets[d], texts[d], len, hipMemcpyHostToDevice, h->stream));
+    // (large inputs: the text goes up chunk by chunk and is prepared as it arrives, see prepare_texts_streamed)
+    const u32 stream_chunk = g_tp_stream > 0 ? (u32)std::min<i64>(g_tp_stream, 0x40000000)
+                             : g_tp_stream < 0 && n_bytes >= TP_STREAM_MIN ? std::max<u32>(n_bytes / TP_STREAM_CHUNKS + 1, 1u << 20) : 0u;
+    auto upload_all = [&]() {
+        if (texts) {
+            HIP_CHECK(hipMemsetAsync(d_bytes, 0xFF, n_bytes, h->stream));              // the separators
+            for (u32 d = 0; d < D; d++) {
+                const size_t len = (size_t)(text_offsets[d + 1] - text_offsets[d] - 1);
+                if (len) HIP_CHECK(hipMemcpyAsync(d_bytes + text_offsets[d], texts[d], len, hipMemcpyHostToDevice, h->stream));
+            }
+        } else {
+            HIP_CHECK(hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, h->stream));
         }
-    } else {
-        HIP_CHECK(hipMemcpyAsync(d_bytes, bytes, n_bytes, hipMemcpyHostToDevice, h->stream));
-    }
-    HIP_CHECK(hipMemsetAsync(d_bytes + n_bytes, 0, 32, h->stream));
+        HIP_CHECK(hipMemsetAsync(d_bytes + n_bytes, 0, 32, h->stream));
+    };
+    if (!stream_chunk) upload_all();
     HIP_CHECK(hipMemcpyAsync(d_text_off, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, h->stream));
     // The caller's Unicode tables (290 KB) stay on the device between calls (own allocation): they are uploaded again only
     // when their content changes -- a 64-bit hash over all of them, taken while the text is on its way.  With them go the two
@@ -1165,6 +1393,25 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
               *d_hi_to = (const u32 *)(h->tp_tables + tb_to), *d_up256 = (const u32 *)(h->tp_tables + tb_up256);
     HIP_CHECK(hipMemsetAsync(d_high, 0, 4, h->stream));
     const TpTables tables{d_class, d_upper, d_word_hi, d_digit_hi, d_hi_from, d_hi_to, (u32)n_hi_upper};
+    if (stream_chunk) {
+        std::vector<u32> s_off, s_m;
+        const size_t mark = ar.mark();
+        const bool done = prepare_texts_streamed(h, ctx, bytes, texts, text_offsets, D, n_bytes, stream_chunk, d_bytes, tables,
+                                                 d_cls256, d_up256, s_off, s_m);
+        ar.release(mark);
+        if (done) {
+            HIP_CHECK(hipEventElapsedTime(&h->last_prep_ms, h->ev0, h->ev1));
+            h->prep_tagged = false;
+            h->prep_n = s_off[D];
+            h->prep_doc_off.resize((size_t)D + 1);
+            h->prep_n_strings.resize(D);
+            for (u32 d = 0; d <= D; d++) h->prep_doc_off[d] = s_off[d];
+            for (u32 d = 0; d < D; d++) h->prep_n_strings[d] = (int32_t)s_m[d];
+            build_common(h, h->prep_sym, false, s_off[D], h->prep_doc_off.data(), h->prep_n_strings.data(), n_docs, false);
+            return;
+        }
+        upload_all();                                   // (kept text at or above U+0A00: the preparation in one piece, tagged encoding)
+    }
 
     // bytes -> code points
     // (first only the count: text in which every byte is a code point of its own -- ASCII, Latin-1 junk -- needs no
@@ -1570,6 +1817,8 @@ void east_hip_destroy(east_hip_handle_t h)
     if (h->prep_sym) (void)hipFree(h->prep_sym);
     if (h->tp_tables) (void)hipFree(h->tp_tables);
     if (h->ht_tab) (void)hipFree(h->ht_tab);
+    for (auto e : h->copy_events) (void)hipEventDestroy(e);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->guess) (void)hipFree(h->guess);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -2002,6 +2251,14 @@ int east_hip_debug_set_lds_rounds(int enabled)
 int east_hip_debug_set_score_scratch(int64_t bytes)
 {
     g_score_scratch_bytes = bytes > 0 ? (size_t)bytes : SCORE_SCRATCH_BYTES;
+    return EAST_HIP_OK;
+}
+
+int east_hip_debug_set_text_stream(int64_t chunk_bytes)
+{
+    // -1: the default (inputs of 8 MiB or more go up and are prepared in about five chunks); 0: the raw text goes up and
+    // is prepared in one piece; > 0: always in chunks of about that many bytes
+    g_tp_stream = chunk_bytes;
     return EAST_HIP_OK;
 }
 

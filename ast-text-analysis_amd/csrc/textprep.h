@@ -131,7 +131,8 @@ __global__ __launch_bounds__(BLOCK) void tp_classify_bytes_kernel(const uint8_t 
     __syncthreads();
     const u32 i = (blockIdx.x * BLOCK + threadIdx.x) * 16u;
     if (i >= n_bytes) return;
-    const uint4 x = *reinterpret_cast<const uint4 *>(b + i);
+    uint4 x;                                            // (a chunk of the streamed preparation starts at any byte)
+    __builtin_memcpy(&x, b + i, 16);
     auto four = [&](u32 v) -> u32 {
         return (u32)cls[v & 0xFFu] | ((u32)cls[(v >> 8) & 0xFFu] << 8) | ((u32)cls[(v >> 16) & 0xFFu] << 16) | ((u32)cls[v >> 24] << 24);
     };
@@ -189,12 +190,15 @@ __global__ __launch_bounds__(BLOCK) void tp_token_bounds_kernel(const uint8_t *_
 }
 
 // keep[k] = len > 2 and not all digits (utils.py:63); klen[k] = kept length or 0
+// (n_tok_dev != nullptr: the number of tokens is still on the device -- the streamed preparation launches over an upper bound)
 __global__ __launch_bounds__(BLOCK) void tp_token_keep_kernel(const u32 *__restrict__ tstart,
                                                               const u32 *__restrict__ tend,
                                                               const u32 *__restrict__ tok_nd, u32 n_tok,
-                                                              u32 *__restrict__ keep, u32 *__restrict__ klen)
+                                                              u32 *__restrict__ keep, u32 *__restrict__ klen,
+                                                              const u32 *__restrict__ n_tok_dev = nullptr)
 {
     const u32 k = blockIdx.x * BLOCK + threadIdx.x;
+    if (n_tok_dev) n_tok = *n_tok_dev;
     if (k >= n_tok) return;
     const u32 a = tstart[k], e = tend[k];
     const u32 len = e - a + 1u;
@@ -320,5 +324,104 @@ __global__ __launch_bounds__(BLOCK) void tp_empty_docs_kernel(const u32 *__restr
     if (keep_ex[first_tok[d + 1]] == keep_ex[first_tok[d]]) {
         sym[doc_sym_off[d]] = 32u;                          // [" "]
         sym[doc_sym_off[d] + 1u] = TP_TEXT_LIMIT;
+    }
+}
+
+// ---- the streamed preparation: a chunk of the byte stream at a time --------------------------------------------------
+// The raw text reaches the device in chunks (a copy stream, fed by a thread of its own: copies out of pageable memory block
+// their caller) and every chunk is prepared while the next one is on its way.  The host cuts the stream where no token
+// and no UTF-8 unit can span the cut -- behind a document's separator, or behind an ASCII byte that is no word character --,
+// so a chunk is prepared exactly like a small collection of its own: the kernels above on chunk-local code point and token
+// numbers.  What crosses a cut is carried on the device: where the document under way starts in the symbol stream, and
+// how many kept tokens and symbols of it earlier chunks have emitted (TpCarry; two slots used in turn) -- they decide
+// which of a chunk's tokens close a string of three and where its symbols go.  Nothing comes back to the host before the end.
+struct TpCarry {
+    u32 sym_base;       // first symbol of the document the next chunk starts in (or continues)
+    u32 kept, chars;    // kept tokens / symbols (without terminators) of that document emitted so far
+    u32 pad;
+};
+
+// per local document i of the chunk (i <= n_docs: one entry more for the bounds): its first token, the kept tokens and
+// symbols of the WHOLE document so far, and -- if the document ends in this chunk -- its length in the symbol stream
+__global__ __launch_bounds__(BLOCK) void tp_stream_docs_kernel(const u32 *__restrict__ doc_cp_off,
+                                                               const u32 *__restrict__ tok_inc,
+                                                               const u32 *__restrict__ keep_ex,
+                                                               const u32 *__restrict__ klen_ex, u32 n_docs, u32 cont_in,
+                                                               u32 cont_out, const TpCarry *__restrict__ carry,
+                                                               u32 *__restrict__ first_tok, u32 *__restrict__ n_loc,
+                                                               u32 *__restrict__ kept_tot, u32 *__restrict__ chars_tot)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i > n_docs) return;
+    const u32 c = doc_cp_off[i];
+    const u32 ft = c == 0 ? 0u : tok_inc[c - 1u];
+    first_tok[i] = ft;
+    if (i == n_docs) { n_loc[i] = 0; return; }
+    const u32 c1 = doc_cp_off[i + 1];
+    const u32 ft1 = c1 == 0 ? 0u : tok_inc[c1 - 1u];
+    u32 kd = keep_ex[ft1] - keep_ex[ft], ch = klen_ex[ft1] - klen_ex[ft];
+    if (i == 0 && cont_in) { kd += carry->kept; ch += carry->chars; }
+    kept_tot[i] = kd;
+    chars_tot[i] = ch;
+    const bool complete = !(i + 1 == n_docs && cont_out);
+    n_loc[i] = complete ? (kd ? ch + (kd + 2u) / 3u : 2u) : 0u;    // utils.py:76-77: an empty collection becomes [" "]
+}
+
+// tp_token_out_kernel for a chunk (off_loc: exclusive scan of n_loc)
+__global__ __launch_bounds__(BLOCK) void tp_stream_token_out_kernel(const u32 *__restrict__ tstart, const u32 *__restrict__ tend,
+                                                                    const u32 *__restrict__ keep_ex,
+                                                                    const u32 *__restrict__ klen_ex,
+                                                                    const u32 *__restrict__ doc_cp_off,
+                                                                    const u32 *__restrict__ first_tok,
+                                                                    const u32 *__restrict__ off_loc,
+                                                                    const u32 *__restrict__ kept_tot, u32 n_docs, u32 cont_in,
+                                                                    u32 cont_out, const TpCarry *__restrict__ carry,
+                                                                    const u32 *__restrict__ n_tok_dev,
+                                                                    uint4 *__restrict__ tok_rec)
+{
+    const u32 k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= *n_tok_dev) return;
+    if (keep_ex[k + 1u] == keep_ex[k]) { tok_rec[k] = uint4{TP_DROPPED, 0u, 0u, 0u}; return; }
+    const u32 d = tp_doc_of_cp(doc_cp_off, n_docs, tstart[k]);
+    const u32 ft = first_tok[d];
+    const bool carried = d == 0 && cont_in;
+    const u32 kidx = keep_ex[k] - keep_ex[ft] + (carried ? carry->kept : 0u);    // index among the document's kept tokens
+    const u32 g = kidx / 3u;
+    const u32 out = carry->sym_base + off_loc[d] + (klen_ex[k] - klen_ex[ft]) + (carried ? carry->chars : 0u) + g;
+    const bool complete = !(d + 1 == n_docs && cont_out);
+    const u32 term = (kidx % 3u == 2u || (complete && kidx + 1u == kept_tot[d])) ? TP_TEXT_LIMIT + g : 0u;
+    tok_rec[k] = uint4{out, tstart[k], term, tend[k]};
+}
+
+// the documents that end in the chunk: their number of strings, an empty one's [" "], the terminator of a last string
+// whose tokens all lie in earlier chunks; every document that starts in the chunk: its offset; and the carry for the next chunk
+__global__ __launch_bounds__(BLOCK) void tp_stream_close_docs_kernel(const u32 *__restrict__ off_loc, const u32 *__restrict__ n_loc,
+                                                                     const u32 *__restrict__ kept_tot,
+                                                                     const u32 *__restrict__ chars_tot, u32 n_docs,
+                                                                     u32 doc_first, u32 cont_in, u32 cont_out,
+                                                                     const TpCarry *__restrict__ carry,
+                                                                     TpCarry *__restrict__ carry_next,
+                                                                     u32 *__restrict__ doc_sym_off_all, u32 *__restrict__ m_all,
+                                                                     u32 *__restrict__ sym)
+{
+    const u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_docs) return;
+    const u32 base = carry->sym_base + off_loc[i];
+    const u32 kd = kept_tot[i];
+    const bool carried = i == 0 && cont_in, complete = !(i + 1 == n_docs && cont_out);
+    if (!carried) doc_sym_off_all[doc_first + i] = base;
+    if (complete) {
+        m_all[doc_first + i] = kd ? (kd + 2u) / 3u : 1u;
+        if (kd == 0) {
+            sym[base] = 32u;                                    // [" "]
+            sym[base + 1u] = TP_TEXT_LIMIT;
+        } else if (carried && kd == carry->kept && kd % 3u != 0u) {
+            // (no kept token of the document in this chunk: the last string's terminator is still to be written)
+            sym[base + n_loc[i] - 1u] = TP_TEXT_LIMIT + (kd + 2u) / 3u - 1u;
+        }
+    }
+    if (i + 1 == n_docs) {
+        if (complete) *carry_next = TpCarry{base + n_loc[i], 0u, 0u, 0u};
+        else *carry_next = TpCarry{base, kd, chars_tot[i], 0u};
     }
 }

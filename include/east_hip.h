@@ -303,6 +303,11 @@ int east_hip_debug_set_speculation(int enabled);
  * more documents than fit is scored a stretch of documents at a time.  Takes effect at the next
  * east_hip_set_keyphrases / east_hip_score_table. */
 int east_hip_debug_set_score_scratch(int64_t bytes);
+/* Test knob: how east_hip_build_texts[_v] brings the raw text to the device.  -1 (default) = inputs of 8 MiB or more are
+ * uploaded in about five chunks (cut where no token spans the cut) and every chunk is prepared while the next one is on its
+ * way; 0 = one upload, one preparation; > 0 = always in chunks of about that many bytes (a few dozen: every fixture goes
+ * through the chunk-to-chunk carries). */
+int east_hip_debug_set_text_stream(int64_t chunk_bytes);
 /* Host only (needs no device): the order-preserving variable-length code csrc/ht_code.h makes for n symbols (in their
  * order) with the given weights -- code[i] = the len[i] bits of symbol i's code word, right-aligned.  EAST_HIP_ERR_DOMAIN
  * if no code with word lengths in [3, 12] exists for them (n < 8, n > 256). */

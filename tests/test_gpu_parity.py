@@ -1143,7 +1143,18 @@ def _check_device_prep(hip, texts):
     return index
 
 
-def test_device_text_preparation_fixtures(hip):
+@pytest.fixture(params=[-1, 0, 23, 600])
+def text_stream(request, hip):
+    """How the raw text reaches the device (east_hip_debug_set_text_stream): the default (chunks from 8 MiB on), in one
+    piece, and in chunks of about 23 / 600 bytes -- every fixture then crosses cuts inside tokens' strings of three,
+    inside documents and between them, with the counts carried from chunk to chunk on the device."""
+    lib = hip.load()
+    assert lib.east_hip_debug_set_text_stream(request.param) == 0
+    yield request.param
+    assert lib.east_hip_debug_set_text_stream(-1) == 0
+
+
+def test_device_text_preparation_fixtures(hip, text_stream):
     """east_hip_build_texts == prepare_text + tokenize + text_to_strings_collection + make_unique_endings
     on the reference-derived vectors and the HSE corpus."""
     g = load_golden("utils_vectors.json")
@@ -1156,7 +1167,7 @@ def test_device_text_preparation_fixtures(hip):
     _check_device_prep(hip, ["str input: no decoding, just upper", "ß stays ß, ŉ stays ŉ"])
 
 
-def test_device_text_preparation_fuzz(hip):
+def test_device_text_preparation_fuzz(hip, text_stream):
     """Random mixtures of ASCII, Latin-1, Greek, Cyrillic, Arabic-Indic digits, superscripts, fractions,
     apostrophes, underscores, non-word characters beyond U+0A00 (emoji, dashes, BOM) and malformed
     UTF-8 (stray continuations, truncated and overlong sequences, surrogates, > U+10FFFF)."""
@@ -1182,15 +1193,37 @@ def test_device_text_preparation_fuzz(hip):
         _check_device_prep(hip, texts)
 
 
-def test_device_text_preparation_large(hip):
-    from east import synthetic
+@pytest.mark.parametrize("chunk", [-1, 0, 1 << 20, 3333333])
+def test_device_text_preparation_large(hip, chunk):
+    """16 MiB + three small documents, in one piece, in the default chunks and in chunks of 1 MiB / 3.3 MB; then the same
+    words with non-ASCII characters sprinkled in (the chunks then take the general UTF-8 path) against the host chain."""
+    from east import synthetic, utils
+    from east.asts import utils as ast_utils
+    lib = hip.load()
     rng = np.random.default_rng(3)
     text, sym, m = synthetic.word_stream_document(rng, 16 << 20)
-    index = hip.HipIndex()
-    index.build_texts([text, text[: 1 << 20], b"", b"12 345 ab"])
-    got, off, ms = index.prepared()
-    assert ms[0] == m and np.array_equal(got[: off[1]], sym)
-    assert got[off[2]:off[3]].tolist() == [32, 0x0A00] and got[off[3]:].tolist() == [32, 0x0A00]
+    assert lib.east_hip_debug_set_text_stream(chunk) == 0
+    try:
+        index = hip.HipIndex()
+        index.build_texts([text, text[: 1 << 20], b"", b"12 345 ab"])
+        got, off, ms = index.prepared()
+        assert ms[0] == m and np.array_equal(got[: off[1]], sym)
+        assert got[off[2]:off[3]].tolist() == [32, 0x0A00] and got[off[3]:].tolist() == [32, 0x0A00]
+        # four documents of 300 KB with accented letters, Greek and stray bytes at random places
+        docs = []
+        for d in range(4):
+            raw = bytearray(text[d * 300000:(d + 1) * 300000])
+            for pos in rng.integers(0, len(raw) - 4, size=400):
+                ins = [b"\xc3\xa9", b"\xce\xbb", b"\xff", b"\xe2\x80\x94", b"\xc3"][int(rng.integers(0, 5))]
+                raw[pos:pos + len(ins)] = ins
+            docs.append(bytes(raw))
+        index.build_texts(docs)
+        got, off, ms = index.prepared()
+        for d, raw in enumerate(docs):
+            want = ast_utils.strings_to_symbols(utils.text_to_strings_collection(raw))
+            assert np.array_equal(got[off[d]:off[d + 1]], want), d
+    finally:
+        assert lib.east_hip_debug_set_text_stream(-1) == 0
 
 
 def test_host_and_device_text_preparation_give_the_same_table(hip, monkeypatch):

@@ -60,12 +60,15 @@ def main():
     cases = texts_n = total = tagged = 0
     while time.time() < t_end:
         texts = [random_text(rng, rng.choice([200, 5000, 50000])) for _ in range(rng.randint(1, 8))]
+        # (how the text goes up: in one piece, or in chunks of a few dozen bytes to tens of kilobytes -- the streamed preparation)
+        hip_backend.load().east_hip_debug_set_text_stream(rng.choice([0, 0, 17, 64, 700, 9000, 40000]))
         index = T._check_device_prep(hip_backend, texts)
         tagged += hip_backend.load().east_hip_prepared_encoding(index._h)
         index.close()
         cases += 1
         texts_n += len(texts)
         total += sum(len(t) for t in texts)
+    hip_backend.load().east_hip_debug_set_text_stream(-1)
     print("text preparation fuzz ok: %d collections (%d of them with kept text at or above U+0A00: tagged encoding), "
           "%d texts, %d bytes" % (cases, tagged, texts_n, total))
 
