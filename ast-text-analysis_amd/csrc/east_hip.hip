@@ -476,7 +476,7 @@ struct east_hip_index {
     u64 tp_tables_hash = 0;
     std::vector<uint8_t> tp_host_tables;
     // the streamed text preparation: a copy stream of its own and one event per chunk
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr, aux_stream = nullptr;    // (aux: the chunks' code point counts, beside the preparation of the chunk before)
     std::vector<hipEvent_t> copy_events;
     // symbols prepared on the device by east_hip_build_texts (own allocation)
     u32 *prep_sym = nullptr;
@@ -1063,7 +1063,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
 // of about that many bytes (east_hip_debug_set_text_stream: the tests push the fixtures through chunks of a few dozen bytes)
 static i64 g_tp_stream = getenv("EAST_HIP_TEXT_STREAM") ? atoll(getenv("EAST_HIP_TEXT_STREAM")) : -1;
 #define TP_STREAM_MIN ((u32)8 << 20)
-#define TP_STREAM_CHUNKS 5
+#define TP_STREAM_CHUNKS 4
 
 struct TpChunk {
     u32 b0 = 0, b1 = 0;             // bytes [b0, b1) of the concatenated stream (separators included)
@@ -1089,8 +1089,10 @@ static std::vector<TpChunk> tp_plan_chunks(const uint8_t *bytes, const uint8_t *
     u32 pos = 0, d = 0;                                  // d: the document that holds byte pos
     while (pos < n_bytes) {
         u32 cut = n_bytes;
-        if ((u64)pos + chunk_bytes < n_bytes) {
-            const u32 target = pos + chunk_bytes;
+        // (the first chunk is a quarter of the others: the preparation -- the slower side -- starts that much earlier)
+        const u32 want = pos == 0 && chunk_bytes >= 4096u ? chunk_bytes / 4u : chunk_bytes;
+        if ((u64)pos + want < n_bytes) {
+            const u32 target = pos + want;
             u32 dt = d;
             while ((u32)text_offsets[dt + 1] < target) dt++;         // the document that holds byte target - 1
             cut = (u32)text_offsets[dt + 1];                         // (its end, unless a cut inside it is found)
@@ -1132,6 +1134,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     u32 nb_max = 0, dl_max = 0;
     for (const TpChunk &c : chunks) { nb_max = std::max(nb_max, c.b1 - c.b0); dl_max = std::max(dl_max, c.n_docs); }
     if (!h->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!h->aux_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
     while (h->copy_events.size() < C) {
         hipEvent_t e;
         HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1191,12 +1194,14 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     u32 *cp_index = ar.alloc<u32>((size_t)nb_max + 1);
     const u32 nb_cp_max = ceil_div_u32((u64)nb_max + 1, SCAN_TILE);
     u32 *cp_sums = ar.alloc<u32>(nb_cp_max);
+    u32 *cp_sums_aux = ar.alloc<u32>(nb_cp_max);        // (the count runs on a stream of its own, ahead of the chunk's turn)
     u32 *cpu = ar.alloc<u32>(nb_max);
     uint8_t *cw = ar.alloc<uint8_t>((size_t)nb_max + 32);
     u32 *doc_cp_off = ar.alloc<u32>((size_t)dl_max + 1);
     u32 *tok_inc = ar.alloc<u32>((size_t)nb_max + 1);
-    u32 *tstart = ar.alloc<u32>(ub_tok), *tend = ar.alloc<u32>(ub_tok), *tok_nd = ar.alloc<u32>(ub_tok);
-    u32 *keep = ar.alloc<u32>((size_t)ub_tok + 1), *klen = ar.alloc<u32>((size_t)ub_tok + 1);
+    u32 *tstart = ar.alloc<u32>(ub_tok), *tend = ar.alloc<u32>(ub_tok);
+    // (tok_nd, keep and klen side by side: one fill per chunk)
+    u32 *tok_nd = ar.alloc<u32>(3 * ((size_t)ub_tok + 1)), *keep = tok_nd + ((size_t)ub_tok + 1), *klen = keep + ((size_t)ub_tok + 1);
     u32 *keep_ex = ar.alloc<u32>((size_t)ub_tok + 1), *klen_ex = ar.alloc<u32>((size_t)ub_tok + 1);
     uint4 *tok_rec = ar.alloc<uint4>(ub_tok);
     u32 *first_tok = ar.alloc<u32>((size_t)dl_max + 1), *n_loc = ar.alloc<u32>((size_t)dl_max + 1);
@@ -1214,17 +1219,22 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         }
         HIP_CHECK(hipStreamWaitEvent(h->stream, events[c], 0));
         HIP_CHECK(hipMemcpyAsync(d_text_off, ch.text_off.data(), ((size_t)Dl + 1) * 4, hipMemcpyHostToDevice, h->stream));
-        // bytes -> code points (the count first: a chunk in which every byte is a code point of its own needs no index)
+        // bytes -> code points (the count first: a chunk in which every byte is a code point of its own needs no index).
+        // The count only needs the chunk's bytes: it runs on a stream of its own, so that the host has the answer -- and
+        // queues the chunk's kernels -- while the chunk before is still being prepared.
         const u32 nb_cp = ceil_div_u32((u64)nb + 1, SCAN_TILE);
-        LAUNCH(ctx, (scan_reduce_kernel<TpStartIn>), nb_cp, TpStartIn{b, nb}, nb + 1, cp_sums);
-        HIP_CHECK(hipMemcpyAsync(h_cp_sums.data(), cp_sums, (size_t)nb_cp * 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_CHECK(hipStreamSynchronize(h->stream));
+        HIP_CHECK(hipStreamWaitEvent(h->aux_stream, events[c], 0));
+        hipLaunchKernelGGL((scan_reduce_kernel<TpStartIn>), dim3(nb_cp), dim3(BLOCK), 0, h->aux_stream, TpStartIn{b, nb}, nb + 1, cp_sums_aux);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(h_cp_sums.data(), cp_sums_aux, (size_t)nb_cp * 4, hipMemcpyDeviceToHost, h->aux_stream));
+        HIP_CHECK(hipStreamSynchronize(h->aux_stream));
         u32 n_cp = 0;
         for (u32 i = 0; i < nb_cp; i++) n_cp += h_cp_sums[i];
         const bool bytewise = n_cp == nb;
         if (bytewise) {
             LAUNCH(ctx, tp_classify_bytes_kernel, ceil_div_u32(nb, BLOCK * 16), b, nb, d_cls256, cw);
         } else {
+            LAUNCH(ctx, (scan_reduce_kernel<TpStartIn>), nb_cp, TpStartIn{b, nb}, nb + 1, cp_sums);
             device_scan<ArrIn, false>(ctx, ArrIn{cp_sums}, nb_cp, cp_sums);
             LAUNCH(ctx, (scan_apply_kernel<TpStartIn, false>), nb_cp, TpStartIn{b, nb}, nb + 1, (const u32 *)cp_sums, cp_index);
             LAUNCH(ctx, tp_decode_kernel, ceil_div_u32(nb, BLOCK), b, nb, (const u32 *)cp_index, tables, cpu, cw);
@@ -1235,9 +1245,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         device_scan<TpTokStartIn, true>(ctx, TpTokStartIn{cw, n_cp}, n_cp, tok_inc);
         const u32 *n_tok_dev = tok_inc + (n_cp - 1);
         const u32 ub = n_cp / 2 + 2;
-        HIP_CHECK(hipMemsetAsync(tok_nd, 0, (size_t)ub * 4, h->stream));
-        HIP_CHECK(hipMemsetAsync(keep, 0, ((size_t)ub + 1) * 4, h->stream));
-        HIP_CHECK(hipMemsetAsync(klen, 0, ((size_t)ub + 1) * 4, h->stream));
+        HIP_CHECK(hipMemsetAsync(tok_nd, 0, (size_t)(klen + ub + 1 - tok_nd) * 4, h->stream));
         LAUNCH(ctx, tp_token_bounds_kernel, ceil_div_u32(n_cp, BLOCK * TP_VEC), (const uint8_t *)cw, (const u32 *)tok_inc, n_cp, tstart,
                tend, tok_nd);
         LAUNCH(ctx, tp_token_keep_kernel, ceil_div_u32(ub, BLOCK), (const u32 *)tstart, (const u32 *)tend, (const u32 *)tok_nd, ub, keep,
@@ -1819,6 +1827,7 @@ void east_hip_destroy(east_hip_handle_t h)
     if (h->ht_tab) (void)hipFree(h->ht_tab);
     for (auto e : h->copy_events) (void)hipEventDestroy(e);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     if (h->guess) (void)hipFree(h->guess);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
