@@ -1476,6 +1476,32 @@ __global__ __launch_bounds__(BLOCK) void lvl0_lcp_text_kernel(const uint8_t *__r
     lcp[r] = h;
 }
 
+// ... of a LIST of ranks: the members of the groups that were still open when the rounds went over to prefix doubling
+// (their slots, kept when that round compacted its domain) -- a few per cent of all ranks, no pass over the others
+__global__ __launch_bounds__(BLOCK) void lvl0_lcp_text_list_kernel(const uint8_t *__restrict__ s8, const u32 *__restrict__ sa,
+                                                                   const u32 *__restrict__ ranks, u32 count,
+                                                                   u32 *__restrict__ lcp, u32 *__restrict__ capped)
+{
+    const u32 t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= count) return;
+    const u32 r = ranks[t];
+    if (r == 0) { lcp[0] = 0; return; }
+    const u32 i = sa[r - 1], j = sa[r];
+    u32 h = 0;
+    while (true) {
+        const u64 xa = load_u64_unaligned(s8 + i + h), xb = load_u64_unaligned(s8 + j + h);
+        const u64 dd = xa ^ xb, z = ~xa;
+        const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+        const u32 mm = dd ? (u32)__builtin_ctzll(dd) >> 3 : 8u;
+        const u32 tt = tz ? (u32)__builtin_ctzll(tz) >> 3 : 8u;
+        const u32 step = mm < tt ? mm : tt;
+        h += step;
+        if (step < 8u || h >= LCP_DIRECT_CAP) break;
+    }
+    if (h >= LCP_DIRECT_CAP) { h = LCP_CAP_MARK; atomicOr(capped, 1u); }
+    lcp[r] = h;
+}
+
 // A later, compacted domain of m elements (slot[] = where each sits in the global order): untied
 // elements already have their place (written by the previous round's write-back); small groups are
 // placed by lvl0_place_tied; members of large groups are marked in keep[] (one bit each).
@@ -1975,7 +2001,10 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     // the placement pass's verdict is kept: the LCP entries of everything it placed are final (lvl0_lcp_keys_kernel)
     // (the ranks whose entries the rounds do NOT write -- those that go through prefix-doubling rounds, whose keys are
     // names -- are marked when the rounds switch over, and only they are computed at the end)
-    u64 *lcp_redo = lcp_out ? ar.alloc<u64>(((size_t)n02 >> 6) + 2) : nullptr;
+    // (the ranks whose entries have to be computed at the end: the slots of the domain of the round that switched over)
+    u32 *lcp_redo = lcp_out ? ar.alloc<u32>((size_t)n02 + 1) : nullptr;
+    u32 redo_n = 0;
+    bool redo_pending = false;
     bool done = false;
     bool lcp_from_rounds = true;                        // the rounds write the LCP entries of what they place (symbol windows)
     if (!ctx.lean) {
@@ -2020,10 +2049,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 // slow shrinking = long repeats: from here on the depth doubles every round (see above)
                 doubling = true;
                 lcp_from_rounds = false;                // (names instead of symbols: the seams' entries are computed at the end)
-                if (lcp_redo) {
-                    HIP_CHECK(hipMemsetAsync(lcp_redo, 0, (((size_t)n02 >> 6) + 2) * sizeof(u64), ctx.stream));
-                    LAUNCH(ctx, lvl0_mark_slots_kernel, gm, slot, BitIn{keep}, m, reinterpret_cast<u32 *>(lcp_redo));
-                }
+                redo_pending = lcp_redo != nullptr;     // (the compaction below lists the slots of the members still open)
                 LAUNCH(ctx, dc3_names_init_kernel, ceil_div_u32(n02, BLOCK), (const u32 *)sa12, n02, name_of);
                 device_scan<ArrIn, true>(ctx, ArrIn{flag}, m, group);
                 LAUNCH(ctx, dc3_group_starts_kernel, gm, flag, (const u32 *)group, slot, m, gstart);
@@ -2053,6 +2079,11 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                              FlagArrIn{flag}, slot, BitIn{keep}, BitRank{keep, idx}, m, slot_c, ebuf[e_c], gstart,
                              (u32 *)nullptr, 0, 0, 0, x_in, x_out);
             if (x_out) { x_dom ^= 1; have_x = true; } else have_x = false;
+            if (redo_pending) {
+                HIP_CHECK(hipMemcpyAsync(lcp_redo, slot_c, (size_t)m_next * 4, hipMemcpyDeviceToDevice, ctx.stream));
+                redo_n = m_next;
+                redo_pending = false;
+            }
             const uint8_t *xdep = have_x ? (const uint8_t *)xbuf[x_dom] : (const uint8_t *)nullptr;
             m = m_next;
             bool have_group = false;                    // group[] = inclusive scan of gstart: the groups' numbers
@@ -2185,12 +2216,9 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     }
     if (done) {
         if (ctx.stats) ctx.stats->levels_resolved++;
-        if (lcp_out && !lcp_from_rounds && fused)       // (prefix doubling: the entries of everything the rounds placed)
-            LAUNCH(ctx, lvl0_lcp_text_kernel, ceil_div_u32(n02, BLOCK), s8, (const u32 *)sa12, n02, (const u64 *)lcp_redo,
+        if (lcp_out && !lcp_from_rounds && redo_n)      // (prefix doubling: the entries of everything those rounds placed)
+            LAUNCH(ctx, lvl0_lcp_text_list_kernel, ceil_div_u32(redo_n, BLOCK), s8, (const u32 *)sa12, (const u32 *)lcp_redo, redo_n,
                    lcp_out, lcp_capped);
-        else if (lcp_out && !lcp_from_rounds)
-            LAUNCH_NAMED(ctx, "lvl0_lcp_keys_kernel", (lvl0_lcp_keys_kernel<K>), ceil_div_u32(n02, BLOCK), starts, w, bt,
-                         spare, s8, (const u32 *)sa12, n02, (const u64 *)lcp_redo, lcp_out, lcp_capped);
         return true;
     }
     if (!s12) return false;                            // all-suffix mode: the caller falls back to DC3

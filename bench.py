@@ -124,6 +124,9 @@ def kernel_bytes(name, info, n, n_docs):
         # the fused finish (last radix digit in LDS + placement): the pair read once (4 B key + 4 B element), 4 B SA + 4 B LCP
         # written per suffix; the tied ones add one 4 B text gather each
         "lvl0_finish_kernel": first * 16,
+        # the in-LDS refinement round (all launches of a build: lds_sorted elements): element, group flag and slot read
+        # (12 B), one 16-byte text gather, suffix + next domain's element + flag written (12 B)
+        "refine_lds_sort_kernel": info.get("lds_sorted", 0) * 40,
         # 4 B LCP read + 4 B annotation write per rank + pyramid level 1 (4 B per 16 ranks)
         "ann_stream_kernel": n * 8 + n // 4,
         # 4 B read per symbol

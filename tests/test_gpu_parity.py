@@ -688,6 +688,38 @@ def test_first_build_plans_the_window_from_its_own_text(hip, oracle, suffix_sort
             assert np.array_equal(t[name], getattr(o, name)), (name, d)
 
 
+def test_plan_follows_the_text_on_one_handle(hip, oracle, suffix_sort_path):
+    """A handle whose kind of text changes: the plan a speculative build takes over from the build before (wide window,
+    fused finish) is dropped when that build's own counts say it was made for other text -- a random word stream after
+    natural-language-like text fuses the end of its sort again after one build, not never.  Tables bit-exact throughout."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(909)
+    vocab = synthetic.zipf_vocabulary(rng, size=300, exponent=1.0)
+
+    def collection(kind):
+        if kind == "words":
+            docs = [synthetic.word_stream_document(rng, 300000, want_text=False)[1:] for _ in range(2)]
+        else:
+            docs = [synthetic.zipf_document(rng, 400000, vocab) for _ in range(2)]
+        return (docs, np.concatenate([d[0] for d in docs]), np.concatenate([[0], np.cumsum([d[0].size for d in docs])]),
+                np.array([d[1] for d in docs]))
+
+    index = hip_backend.HipIndex()
+    fused = []
+    for kind in ("words", "zipf", "words", "words", "words"):
+        docs, sym, off, m = collection(kind)
+        index.build(sym, off, m)
+        info = index.info()
+        fused.append(info["fused_finish"])
+        for d in range(2):
+            o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+            t = index.tables(d)
+            for name in TABLES:
+                assert np.array_equal(t[name], getattr(o, name)), (kind, name, d, info)
+    if suffix_sort_path == "window_sort" and _CURRENT["knob"] == 1:
+        assert fused[0] == 1 and fused[-1] == 1, fused        # back to the fused finish once the text is a word stream again
+
+
 @pytest.mark.parametrize("shift", [0, 1, 2, 3])
 def test_build_from_resident_symbols_at_any_alignment(hip, oracle, shift):
     """east_hip_build_device on a symbol array that starts 0..3 words into a device buffer (a view of
