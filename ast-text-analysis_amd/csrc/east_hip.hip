@@ -476,7 +476,7 @@ struct east_hip_index {
     u64 tp_tables_hash = 0;
     std::vector<uint8_t> tp_host_tables;
     // the streamed text preparation: a copy stream of its own and one event per chunk
-    hipStream_t copy_stream = nullptr, aux_stream = nullptr;    // (aux: the chunks' code point counts, beside the preparation of the chunk before)
+    hipStream_t copy_stream = nullptr;     // (created with the handle: creating a stream costs milliseconds)
     std::vector<hipEvent_t> copy_events;
     // symbols prepared on the device by east_hip_build_texts (own allocation)
     u32 *prep_sym = nullptr;
@@ -1134,7 +1134,6 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     u32 nb_max = 0, dl_max = 0;
     for (const TpChunk &c : chunks) { nb_max = std::max(nb_max, c.b1 - c.b0); dl_max = std::max(dl_max, c.n_docs); }
     if (!h->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    if (!h->aux_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
     while (h->copy_events.size() < C) {
         hipEvent_t e;
         HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1153,6 +1152,37 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         h->prep_sym = (u32 *)p;
         h->prep_cap = sym_cap * 4;
     }
+    // ---- device state shared by the chunks ----
+    TpCarry *carry = ar.alloc<TpCarry>(2);
+    u32 *d_high = ar.alloc<u32>(1);
+    u32 *doc_sym_off_all = ar.alloc<u32>((size_t)D + 1), *m_all = ar.alloc<u32>(D);
+    HIP_CHECK(hipMemsetAsync(carry, 0, 2 * sizeof(TpCarry), h->stream));
+    HIP_CHECK(hipMemsetAsync(d_high, 0, 4, h->stream));
+    // per-chunk scratch (sized for the largest chunk, used by one chunk after the other)
+    const u32 ub_tok = nb_max / 2 + 2;                   // a token needs a character and something behind it
+    u32 *d_text_off = ar.alloc<u32>((size_t)dl_max + 1);
+    u32 *cp_index = ar.alloc<u32>((size_t)nb_max + 1);
+    const u32 nb_cp_max = ceil_div_u32((u64)nb_max + 1, SCAN_TILE);
+    u32 *cp_sums = ar.alloc<u32>(nb_cp_max);
+    // (the counts of the chunks: on the copy stream, each into a stretch of its own -- the host reads chunk c's while
+    // chunk c + 1's may already be written)
+    std::vector<u32> cnt_off(C + 1, 0);
+    for (u32 c = 0; c < C; c++) cnt_off[c + 1] = cnt_off[c] + ceil_div_u32((u64)(chunks[c].b1 - chunks[c].b0) + 1, SCAN_TILE);
+    u32 *cp_sums_aux = ar.alloc<u32>(cnt_off[C]);
+    std::vector<std::vector<u32>> h_counts(C);
+    for (u32 c = 0; c < C; c++) h_counts[c].resize(cnt_off[c + 1] - cnt_off[c]);
+    u32 *cpu = ar.alloc<u32>(nb_max);
+    uint8_t *cw = ar.alloc<uint8_t>((size_t)nb_max + 32);
+    u32 *doc_cp_off = ar.alloc<u32>((size_t)dl_max + 1);
+    u32 *tok_inc = ar.alloc<u32>((size_t)nb_max + 1);
+    u32 *tstart = ar.alloc<u32>(ub_tok), *tend = ar.alloc<u32>(ub_tok);
+    // (tok_nd, keep and klen side by side: one fill per chunk)
+    u32 *tok_nd = ar.alloc<u32>(3 * ((size_t)ub_tok + 1)), *keep = tok_nd + ((size_t)ub_tok + 1), *klen = keep + ((size_t)ub_tok + 1);
+    u32 *keep_ex = ar.alloc<u32>((size_t)ub_tok + 1), *klen_ex = ar.alloc<u32>((size_t)ub_tok + 1);
+    uint4 *tok_rec = ar.alloc<uint4>(ub_tok);
+    u32 *first_tok = ar.alloc<u32>((size_t)dl_max + 1), *n_loc = ar.alloc<u32>((size_t)dl_max + 1);
+    u32 *off_loc = ar.alloc<u32>((size_t)dl_max + 1), *kept_tot = ar.alloc<u32>(dl_max), *chars_tot = ar.alloc<u32>(dl_max);
+
     // ---- the uploads: a thread of their own (a copy out of pageable memory returns when it is staged) ----
     std::atomic<int> uploaded{0}, upload_failed{0};
     const int device = h->device;
@@ -1175,38 +1205,21 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
             } else {
                 ok = hipMemcpyAsync(d_bytes + ch.b0, bytes + ch.b0, ch.b1 - ch.b0, hipMemcpyHostToDevice, copy_stream) == hipSuccess;
             }
+            if (ok) {
+                // the chunk's code point count (per tile of the scan; the host adds them up), behind its bytes
+                const u32 nb = ch.b1 - ch.b0, nb_cp = ceil_div_u32((u64)nb + 1, SCAN_TILE);
+                hipLaunchKernelGGL((scan_reduce_kernel<TpStartIn>), dim3(nb_cp), dim3(BLOCK), 0, copy_stream,
+                                   TpStartIn{d_bytes + ch.b0, nb}, nb + 1, cp_sums_aux + cnt_off[c]);
+                ok = hipGetLastError() == hipSuccess &&
+                     hipMemcpyAsync(h_counts[c].data(), cp_sums_aux + cnt_off[c], (size_t)nb_cp * 4, hipMemcpyDeviceToHost,
+                                    copy_stream) == hipSuccess;
+            }
             if (ok) ok = hipEventRecord(events[c], copy_stream) == hipSuccess;
             if (ok) uploaded.store((int)c + 1, std::memory_order_release);
         }
         if (!ok) { (void)hipGetLastError(); upload_failed.store(1, std::memory_order_release); }
     });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};
-
-    // ---- device state shared by the chunks ----
-    TpCarry *carry = ar.alloc<TpCarry>(2);
-    u32 *d_high = ar.alloc<u32>(1);
-    u32 *doc_sym_off_all = ar.alloc<u32>((size_t)D + 1), *m_all = ar.alloc<u32>(D);
-    HIP_CHECK(hipMemsetAsync(carry, 0, 2 * sizeof(TpCarry), h->stream));
-    HIP_CHECK(hipMemsetAsync(d_high, 0, 4, h->stream));
-    // per-chunk scratch (sized for the largest chunk, used by one chunk after the other)
-    const u32 ub_tok = nb_max / 2 + 2;                   // a token needs a character and something behind it
-    u32 *d_text_off = ar.alloc<u32>((size_t)dl_max + 1);
-    u32 *cp_index = ar.alloc<u32>((size_t)nb_max + 1);
-    const u32 nb_cp_max = ceil_div_u32((u64)nb_max + 1, SCAN_TILE);
-    u32 *cp_sums = ar.alloc<u32>(nb_cp_max);
-    u32 *cp_sums_aux = ar.alloc<u32>(nb_cp_max);        // (the count runs on a stream of its own, ahead of the chunk's turn)
-    u32 *cpu = ar.alloc<u32>(nb_max);
-    uint8_t *cw = ar.alloc<uint8_t>((size_t)nb_max + 32);
-    u32 *doc_cp_off = ar.alloc<u32>((size_t)dl_max + 1);
-    u32 *tok_inc = ar.alloc<u32>((size_t)nb_max + 1);
-    u32 *tstart = ar.alloc<u32>(ub_tok), *tend = ar.alloc<u32>(ub_tok);
-    // (tok_nd, keep and klen side by side: one fill per chunk)
-    u32 *tok_nd = ar.alloc<u32>(3 * ((size_t)ub_tok + 1)), *keep = tok_nd + ((size_t)ub_tok + 1), *klen = keep + ((size_t)ub_tok + 1);
-    u32 *keep_ex = ar.alloc<u32>((size_t)ub_tok + 1), *klen_ex = ar.alloc<u32>((size_t)ub_tok + 1);
-    uint4 *tok_rec = ar.alloc<uint4>(ub_tok);
-    u32 *first_tok = ar.alloc<u32>((size_t)dl_max + 1), *n_loc = ar.alloc<u32>((size_t)dl_max + 1);
-    u32 *off_loc = ar.alloc<u32>((size_t)dl_max + 1), *kept_tot = ar.alloc<u32>(dl_max), *chars_tot = ar.alloc<u32>(dl_max);
-    std::vector<u32> h_cp_sums(nb_cp_max);
 
     for (u32 c = 0; c < C; c++) {
         const TpChunk &ch = chunks[c];
@@ -1218,18 +1231,15 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
             std::this_thread::yield();
         }
         HIP_CHECK(hipStreamWaitEvent(h->stream, events[c], 0));
+        HIP_CHECK(hipEventSynchronize(events[c]));         // (the host reads the chunk's counts)
         HIP_CHECK(hipMemcpyAsync(d_text_off, ch.text_off.data(), ((size_t)Dl + 1) * 4, hipMemcpyHostToDevice, h->stream));
         // bytes -> code points (the count first: a chunk in which every byte is a code point of its own needs no index).
-        // The count only needs the chunk's bytes: it runs on a stream of its own, so that the host has the answer -- and
-        // queues the chunk's kernels -- while the chunk before is still being prepared.
+        // The count only needs the chunk's bytes: the uploader queues it on the copy stream right behind them (and records
+        // the event behind it), so that the host has the answer -- and queues the chunk's kernels -- while the chunk
+        // before is still being prepared.
         const u32 nb_cp = ceil_div_u32((u64)nb + 1, SCAN_TILE);
-        HIP_CHECK(hipStreamWaitEvent(h->aux_stream, events[c], 0));
-        hipLaunchKernelGGL((scan_reduce_kernel<TpStartIn>), dim3(nb_cp), dim3(BLOCK), 0, h->aux_stream, TpStartIn{b, nb}, nb + 1, cp_sums_aux);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(h_cp_sums.data(), cp_sums_aux, (size_t)nb_cp * 4, hipMemcpyDeviceToHost, h->aux_stream));
-        HIP_CHECK(hipStreamSynchronize(h->aux_stream));
         u32 n_cp = 0;
-        for (u32 i = 0; i < nb_cp; i++) n_cp += h_cp_sums[i];
+        for (u32 i = 0; i < nb_cp; i++) n_cp += h_counts[c][i];
         const bool bytewise = n_cp == nb;
         if (bytewise) {
             LAUNCH(ctx, tp_classify_bytes_kernel, ceil_div_u32(nb, BLOCK * 16), b, nb, d_cls256, cw);
@@ -1797,6 +1807,7 @@ int east_hip_create(int device, int64_t reserve_symbols, east_hip_handle_t *out)
         try {
             use_device_ordinal(device);
             HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+            HIP_CHECK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));      // (the streamed text preparation's uploads)
             HIP_CHECK(hipEventCreate(&h->ev0));
             HIP_CHECK(hipEventCreate(&h->ev1));
             void *g = nullptr;
@@ -1827,7 +1838,6 @@ void east_hip_destroy(east_hip_handle_t h)
     if (h->ht_tab) (void)hipFree(h->ht_tab);
     for (auto e : h->copy_events) (void)hipEventDestroy(e);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
-    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     if (h->guess) (void)hipFree(h->guess);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
