@@ -38,6 +38,7 @@
 static thread_local std::string g_last_error;
 static bool g_speculate = getenv("EAST_HIP_NO_SPECULATION") == nullptr;     // east_hip_debug_set_speculation (tests)
 static bool g_kg_pairs = getenv("EAST_HIP_NO_KG_PAIRS") == nullptr;         // east_hip_debug_set_score_path (tests, A/B timing)
+static bool g_kg_pairs_forced = false;                                      // ... (4): the pair layout whatever the number of documents
 static u32 g_plan_epoch = 1;        // bumped by the test knobs that change what a build allocates
 
 // ------------------------------------------------------------ prep kernels --
@@ -780,7 +781,9 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
                 km.doc_off = h->doc_off;
                 km.n_docs = n_docs;
                 // (the pair layout: the level above the last in a table of its own, behind the 8-byte entries)
-                if (g_kg_pairs) km.kg3 = h->kg + 2 * (size_t)(bins + 1) * n_docs;
+                // (... where the score table has many columns: with a handful of long documents the 8-byte marks cost the
+                // build more than the few thousand walks of a score call get back; forced by the test knob)
+                if (g_kg_pairs && (n_docs >= 16 || g_kg_pairs_forced)) km.kg3 = h->kg + 2 * (size_t)(bins + 1) * n_docs;
                 h->kg3 = km.kg3;
                 h->kg_up = km.kg3 ? km.kg3 + (size_t)(bins / km.A + 1) * n_docs : nullptr;
             } else {
@@ -2286,8 +2289,9 @@ int east_hip_debug_set_score_path(int mode)
     // 1: the default; 0: the walk as rounds 1-3 ran it -- one filled k-gram table of 4-byte entries, per-suffix results in
     // HBM and a reduction kernel; 2: pair tables, separate reduction; 3: filled table, the sums inside the walk.
     // (takes effect with the next build / the next set of keyphrases)
-    g_kg_pairs = mode == 1 || mode == 2;
-    g_score_fused = mode == 1 || mode == 3;
+    g_kg_pairs = mode == 1 || mode == 2 || mode == 4;
+    g_kg_pairs_forced = mode == 4;                      // 4: as 1, the pair tables also for collections of fewer than 16 documents
+    g_score_fused = mode == 1 || mode == 3 || mode == 4;
     return EAST_HIP_OK;
 }
 

@@ -315,7 +315,9 @@ int east_hip_debug_alphabetic_code(const uint64_t *weights, int32_t n, uint32_t 
 /* Test knob (process-wide): which form of the score path runs (easa.py:91-139).  1 (default) = pair k-gram tables marked
  * off the window keys + the per-keyphrase sums inside the walk kernel; 0 = one filled table, per-suffix results in HBM
  * and a reduction kernel (rounds 1-3); 2 = pair tables with the reduction kernel; 3 = filled table with the sums in the
- * walk.  Takes effect at the next build (tables) / the next east_hip_set_keyphrases (sums). */
+ * walk; 4 = as 1 with the pair tables also for collections of fewer than 16 documents (which by default keep the filled
+ * table: the 8-byte marks cost their build more than a few thousand walks get back).  Takes effect at the next build
+ * (tables) / the next east_hip_set_keyphrases (sums). */
 int east_hip_debug_set_score_path(int mode);
 /* Host-only: bytes of device arena a build of n_total symbols / n_docs documents
  * reserves (worst case over inputs).  Needs no device. */

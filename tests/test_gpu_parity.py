@@ -1519,7 +1519,7 @@ def test_score_in_stretches_of_documents(hip, oracle):
         assert want[k, 77] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=True)
 
 
-@pytest.mark.parametrize("mode", [1, 0, 2, 3])
+@pytest.mark.parametrize("mode", [1, 0, 2, 3, 4])
 def test_score_path_variants(hip, oracle, mode):
     """The score walk's two choices (east_hip_debug_set_score_path): k-gram tables in the pair layout (last level
     unfilled, 8-byte entries with the suffix position; the level above in a table of its own) or as one filled table,

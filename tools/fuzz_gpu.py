@@ -103,7 +103,7 @@ def main():
         knob = int(rng.choice([1, 1, 1, 0, 3, 2, 4, 5, 7, 7, 9, 9]))
         lib.east_hip_debug_set_window_sort(knob)
         lib.east_hip_debug_set_lds_rounds(int(rng.choice([1, 1, 2, 0])))
-        lib.east_hip_debug_set_score_path(int(rng.choice([1, 1, 0, 2, 3])))
+        lib.east_hip_debug_set_score_path(int(rng.choice([1, 4, 4, 0, 2, 3])))
         parts = [to_symbols(sc) for sc in docs]
         sym = np.concatenate(parts)
         off = np.concatenate([[0], np.cumsum([p.size for p in parts])])
