@@ -1046,6 +1046,10 @@ def test_config5_zipf_100_documents_full_size(hip, oracle):
         for norm in (True, False):
             want = np.array([o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=True) for k in range(400)])
             assert np.array_equal(tables[norm][:, d], want) and np.abs(tables[norm][:, d] - want).max() <= TOL, (d, norm)
+        if d == 42:     # ... and the reference's own walk over the sibling chains (easa.py:91-139) on half of them, normalized and -d
+            for norm in (True, False):
+                for k in range(0, 400, 2):
+                    assert tables[norm][k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=False), (d, k, norm)
 
 
 def test_speculative_builds_on_one_handle(hip, oracle):
