@@ -1093,7 +1093,8 @@ static std::vector<TpChunk> tp_plan_chunks(const uint8_t *bytes, const uint8_t *
     while (pos < n_bytes) {
         u32 cut = n_bytes;
         // (the first chunk is a quarter of the others: the preparation -- the slower side -- starts that much earlier)
-        const u32 want = pos == 0 && chunk_bytes >= 4096u ? chunk_bytes / 4u : chunk_bytes;
+        const u32 first_div = getenv("EAST_HIP_TP_FIRST_DIV") ? (u32)std::max(1, atoi(getenv("EAST_HIP_TP_FIRST_DIV"))) : 4u;   // (experiments)
+        const u32 want = pos == 0 && chunk_bytes >= 4096u ? chunk_bytes / first_div : chunk_bytes;
         if ((u64)pos + want < n_bytes) {
             const u32 target = pos + want;
             u32 dt = d;
@@ -1164,9 +1165,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     // per-chunk scratch (sized for the largest chunk, used by one chunk after the other)
     const u32 ub_tok = nb_max / 2 + 2;                   // a token needs a character and something behind it
     u32 *d_text_off = ar.alloc<u32>((size_t)dl_max + 1);
-    u32 *cp_index = ar.alloc<u32>((size_t)nb_max + 1);
-    const u32 nb_cp_max = ceil_div_u32((u64)nb_max + 1, SCAN_TILE);
-    u32 *cp_sums = ar.alloc<u32>(nb_cp_max);
+    u32 *byte_prefix = ar.alloc<u32>((size_t)nb_max / TP_RANK_BLOCK + 2), *tok_prefix = ar.alloc<u32>((size_t)nb_max / TP_RANK_BLOCK + 2);
     // (the counts of the chunks: on the copy stream, each into a stretch of its own -- the host reads chunk c's while
     // chunk c + 1's may already be written)
     std::vector<u32> cnt_off(C + 1, 0);
@@ -1177,7 +1176,6 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     u32 *cpu = ar.alloc<u32>(nb_max);
     uint8_t *cw = ar.alloc<uint8_t>((size_t)nb_max + 32);
     u32 *doc_cp_off = ar.alloc<u32>((size_t)dl_max + 1);
-    u32 *tok_inc = ar.alloc<u32>((size_t)nb_max + 1);
     u32 *tstart = ar.alloc<u32>(ub_tok), *tend = ar.alloc<u32>(ub_tok);
     // (tok_nd, keep and klen side by side: one fill per chunk)
     u32 *tok_nd = ar.alloc<u32>(3 * ((size_t)ub_tok + 1)), *keep = tok_nd + ((size_t)ub_tok + 1), *klen = keep + ((size_t)ub_tok + 1);
@@ -1247,19 +1245,21 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         if (bytewise) {
             LAUNCH(ctx, tp_classify_bytes_kernel, ceil_div_u32(nb, BLOCK * 16), b, nb, d_cls256, cw);
         } else {
-            LAUNCH(ctx, (scan_reduce_kernel<TpStartIn>), nb_cp, TpStartIn{b, nb}, nb + 1, cp_sums);
-            device_scan<ArrIn, false>(ctx, ArrIn{cp_sums}, nb_cp, cp_sums);
-            LAUNCH(ctx, (scan_apply_kernel<TpStartIn, false>), nb_cp, TpStartIn{b, nb}, nb + 1, (const u32 *)cp_sums, cp_index);
-            LAUNCH(ctx, tp_decode_kernel, ceil_div_u32(nb, BLOCK), b, nb, (const u32 *)cp_index, tables, cpu, cw);
+            const u32 n_bblk = ceil_div_u32(nb, TP_RANK_BLOCK);
+            LAUNCH(ctx, (tp_block_counts_kernel<TpStartIn>), ceil_div_u32((u64)n_bblk + 1, 8), TpStartIn{b, nb}, nb, n_bblk, byte_prefix);
+            device_scan<ArrIn, false>(ctx, ArrIn{byte_prefix}, n_bblk + 1, byte_prefix);
+            LAUNCH(ctx, tp_decode_kernel, ceil_div_u32(nb, BLOCK), b, nb, (const u32 *)byte_prefix, tables, cpu, cw);
         }
-        LAUNCH(ctx, tp_doc_cp_offsets_kernel, ceil_div_u32(Dl + 1, BLOCK), bytewise ? (const u32 *)nullptr : (const u32 *)cp_index,
+        LAUNCH(ctx, tp_doc_cp_offsets_kernel, ceil_div_u32(Dl + 1, BLOCK), b, nb, bytewise ? (const u32 *)nullptr : (const u32 *)byte_prefix,
                (const u32 *)d_text_off, Dl, doc_cp_off);
-        // code points -> tokens (their number stays on the device: tok_inc[n_cp - 1])
-        device_scan<TpTokStartIn, true>(ctx, TpTokStartIn{cw, n_cp}, n_cp, tok_inc);
-        const u32 *n_tok_dev = tok_inc + (n_cp - 1);
+        // code points -> tokens (their number stays on the device: the last entry of the blocks' prefix sums)
+        const u32 n_tblk = ceil_div_u32(n_cp, TP_RANK_BLOCK);
+        LAUNCH(ctx, (tp_block_counts_kernel<TpTokStartIn>), ceil_div_u32((u64)n_tblk + 1, 8), TpTokStartIn{cw, n_cp}, n_cp, n_tblk, tok_prefix);
+        device_scan<ArrIn, false>(ctx, ArrIn{tok_prefix}, n_tblk + 1, tok_prefix);
+        const u32 *n_tok_dev = tok_prefix + n_tblk;
         const u32 ub = n_cp / 2 + 2;
         HIP_CHECK(hipMemsetAsync(tok_nd, 0, (size_t)(klen + ub + 1 - tok_nd) * 4, h->stream));
-        LAUNCH(ctx, tp_token_bounds_kernel, ceil_div_u32(n_cp, BLOCK * TP_VEC), (const uint8_t *)cw, (const u32 *)tok_inc, n_cp, tstart,
+        LAUNCH(ctx, tp_token_bounds_kernel, ceil_div_u32(n_cp, BLOCK * TP_VEC), (const uint8_t *)cw, (const u32 *)tok_prefix, n_cp, tstart,
                tend, tok_nd);
         LAUNCH(ctx, tp_token_keep_kernel, ceil_div_u32(ub, BLOCK), (const u32 *)tstart, (const u32 *)tend, (const u32 *)tok_nd, ub, keep,
                klen, n_tok_dev);
@@ -1268,14 +1268,14 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         // tokens -> the documents' strings and symbols, with what earlier chunks emitted of the first document
         const TpCarry *cin = carry + (c & 1u);
         TpCarry *cout = carry + ((c + 1u) & 1u);
-        LAUNCH(ctx, tp_stream_docs_kernel, ceil_div_u32(Dl + 1, BLOCK), (const u32 *)doc_cp_off, (const u32 *)tok_inc, (const u32 *)keep_ex,
+        LAUNCH(ctx, tp_stream_docs_kernel, ceil_div_u32(Dl + 1, BLOCK), (const u32 *)doc_cp_off, (const uint8_t *)cw, n_cp, (const u32 *)tok_prefix, (const u32 *)keep_ex,
                (const u32 *)klen_ex, Dl, (u32)ch.cont_in, (u32)ch.cont_out, cin, first_tok, n_loc, kept_tot, chars_tot);
         device_scan<ArrIn, false>(ctx, ArrIn{n_loc}, Dl + 1, off_loc);
         LAUNCH(ctx, tp_stream_token_out_kernel, ceil_div_u32(ub, BLOCK), (const u32 *)tstart, (const u32 *)tend, (const u32 *)keep_ex,
                (const u32 *)klen_ex, (const u32 *)doc_cp_off, (const u32 *)first_tok, (const u32 *)off_loc, (const u32 *)kept_tot, Dl,
                (u32)ch.cont_in, (u32)ch.cont_out, cin, n_tok_dev, tok_rec);
         LAUNCH(ctx, tp_emit_kernel, ceil_div_u32(n_cp, BLOCK), bytewise ? (const u32 *)nullptr : (const u32 *)cpu, b, d_up256,
-               (const uint8_t *)cw, (const u32 *)tok_inc, (const uint4 *)tok_rec, n_cp, h->prep_sym, d_high);
+               (const uint8_t *)cw, (const u32 *)tok_prefix, (const uint4 *)tok_rec, n_cp, h->prep_sym, d_high);
         LAUNCH(ctx, tp_stream_close_docs_kernel, ceil_div_u32(Dl, BLOCK), (const u32 *)off_loc, (const u32 *)n_loc, (const u32 *)kept_tot,
                (const u32 *)chars_tot, Dl, ch.doc_first, (u32)ch.cont_in, (u32)ch.cont_out, cin, cout, doc_sym_off_all, m_all,
                h->prep_sym);
@@ -1437,25 +1437,19 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     // bytes -> code points
     // (first only the count: text in which every byte is a code point of its own -- ASCII, Latin-1 junk -- needs no
     // index at all, and the count has to come back to the host anyway)
-    u32 *cp_index = ar.alloc<u32>((size_t)n_bytes + 1);
-    const u32 nb_cp = ceil_div_u32(n_bytes + 1, SCAN_TILE);
-    u32 *cp_sums = ar.alloc<u32>(nb_cp);
-    LAUNCH(ctx, (scan_reduce_kernel<TpStartIn>), nb_cp, TpStartIn{d_bytes, n_bytes}, n_bytes + 1, cp_sums);
-    std::vector<u32> h_cp_sums(nb_cp);
-    HIP_CHECK(hipMemcpyAsync(h_cp_sums.data(), cp_sums, (size_t)nb_cp * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));          // also covers off32
+    // (unit starts in front of every block of 256 bytes -- textprep.h, "ranks without a per-element index" --; the last
+    // entry is their total)
+    const u32 n_bblk = ceil_div_u32(n_bytes, TP_RANK_BLOCK);
+    u32 *byte_prefix = ar.alloc<u32>((size_t)n_bblk + 1);
+    LAUNCH(ctx, (tp_block_counts_kernel<TpStartIn>), ceil_div_u32((u64)n_bblk + 1, 8), TpStartIn{d_bytes, n_bytes}, n_bytes, n_bblk,
+           byte_prefix);
+    device_scan<ArrIn, false>(ctx, ArrIn{byte_prefix}, n_bblk + 1, byte_prefix);
     u32 n_cp = 0;
-    for (u32 x : h_cp_sums) n_cp += x;
-    if (n_cp == n_bytes) {
-        cp_index = nullptr;
-    } else {
-        device_scan<ArrIn, false>(ctx, ArrIn{cp_sums}, nb_cp, cp_sums);
-        LAUNCH(ctx, (scan_apply_kernel<TpStartIn, false>), nb_cp, TpStartIn{d_bytes, n_bytes}, n_bytes + 1, (const u32 *)cp_sums,
-               cp_index);
-    }
+    HIP_CHECK(hipMemcpyAsync(&n_cp, byte_prefix + n_bblk, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));          // also covers off32
     // (every byte a code point of its own: no code point array -- classes from a byte table, the kept bytes are mapped when
     // they are emitted)
-    const bool bytewise = cp_index == nullptr;
+    const bool bytewise = n_cp == n_bytes;
     u32 *cpu = bytewise ? nullptr : ar.alloc<u32>(n_cp);
     uint8_t *cw = ar.alloc<uint8_t>((size_t)n_cp + 32);
     u32 *doc_cp_off = ar.alloc<u32>((size_t)D + 1);
@@ -1463,18 +1457,20 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
         LAUNCH(ctx, tp_classify_bytes_kernel, ceil_div_u32(n_bytes, BLOCK * 16), (const uint8_t *)d_bytes, n_bytes,
                (const uint8_t *)d_cls256, cw);
     } else {
-        LAUNCH(ctx, tp_decode_kernel, ceil_div_u32(n_bytes, BLOCK), (const uint8_t *)d_bytes, n_bytes, (const u32 *)cp_index,
+        LAUNCH(ctx, tp_decode_kernel, ceil_div_u32(n_bytes, BLOCK), (const uint8_t *)d_bytes, n_bytes, (const u32 *)byte_prefix,
                tables, cpu, cw);
     }
-    LAUNCH(ctx, tp_doc_cp_offsets_kernel, ceil_div_u32(D + 1, BLOCK), (const u32 *)cp_index, (const u32 *)d_text_off, D,
-           doc_cp_off);
+    LAUNCH(ctx, tp_doc_cp_offsets_kernel, ceil_div_u32(D + 1, BLOCK), (const uint8_t *)d_bytes, n_bytes,
+           bytewise ? (const u32 *)nullptr : (const u32 *)byte_prefix, (const u32 *)d_text_off, D, doc_cp_off);
 
-    // code points -> tokens
-    u32 *tok_inc = ar.alloc<u32>(n_cp);
-    device_scan<TpTokStartIn, true>(ctx, TpTokStartIn{cw, n_cp}, n_cp, tok_inc);
+    // code points -> tokens (token starts in front of every block of 256 code points; the last entry: their number)
+    const u32 n_tblk = ceil_div_u32(n_cp, TP_RANK_BLOCK);
+    u32 *tok_prefix = ar.alloc<u32>((size_t)n_tblk + 1);
+    LAUNCH(ctx, (tp_block_counts_kernel<TpTokStartIn>), ceil_div_u32((u64)n_tblk + 1, 8), TpTokStartIn{cw, n_cp}, n_cp, n_tblk, tok_prefix);
+    device_scan<ArrIn, false>(ctx, ArrIn{tok_prefix}, n_tblk + 1, tok_prefix);
     u32 n_tok = 0;
     u32 high = 0;
-    HIP_CHECK(hipMemcpyAsync(&n_tok, tok_inc + (n_cp - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(&n_tok, tok_prefix + n_tblk, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
     u32 *tstart = ar.alloc<u32>((size_t)n_tok + 1), *tend = ar.alloc<u32>((size_t)n_tok + 1);
     u32 *keep = ar.alloc<u32>((size_t)n_tok + 1), *klen = ar.alloc<u32>((size_t)n_tok + 1);
@@ -1484,7 +1480,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     HIP_CHECK(hipMemsetAsync(keep + n_tok, 0, 4, h->stream));
     HIP_CHECK(hipMemsetAsync(klen + n_tok, 0, 4, h->stream));
     if (n_tok) {
-        LAUNCH(ctx, tp_token_bounds_kernel, ceil_div_u32(n_cp, BLOCK * TP_VEC), (const uint8_t *)cw, (const u32 *)tok_inc, n_cp,
+        LAUNCH(ctx, tp_token_bounds_kernel, ceil_div_u32(n_cp, BLOCK * TP_VEC), (const uint8_t *)cw, (const u32 *)tok_prefix, n_cp,
                tstart, tend, tok_nd);
         LAUNCH(ctx, tp_token_keep_kernel, ceil_div_u32(n_tok, BLOCK), (const u32 *)tstart, (const u32 *)tend,
                (const u32 *)tok_nd, n_tok, keep, klen);
@@ -1496,7 +1492,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     u32 *first_tok = ar.alloc<u32>((size_t)D + 1), *m_d = ar.alloc<u32>(D), *n_d = ar.alloc<u32>((size_t)D + 1);
     u32 *doc_sym_off = ar.alloc<u32>((size_t)D + 1);
     HIP_CHECK(hipMemsetAsync(n_d + D, 0, 4, h->stream));
-    LAUNCH(ctx, tp_doc_counts_kernel, ceil_div_u32(D + 1, BLOCK), (const u32 *)doc_cp_off, (const u32 *)tok_inc,
+    LAUNCH(ctx, tp_doc_counts_kernel, ceil_div_u32(D + 1, BLOCK), (const u32 *)doc_cp_off, (const uint8_t *)cw, n_cp, (const u32 *)tok_prefix,
            (const u32 *)keep_ex, (const u32 *)klen_ex, D, first_tok, m_d, n_d);
     device_scan<ArrIn, false>(ctx, ArrIn{n_d}, D + 1, doc_sym_off);
     std::vector<u32> h_off((size_t)D + 1), h_m(D);
@@ -1520,7 +1516,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
                (const u32 *)klen_ex, (const u32 *)doc_cp_off, (const u32 *)first_tok, (const u32 *)doc_sym_off, D, n_tok,
                (const u32 *)tend, tok_out, tok_term, tok_rec);
         LAUNCH(ctx, tp_emit_kernel, ceil_div_u32(n_cp, BLOCK), (const u32 *)cpu, (const uint8_t *)d_bytes,
-               (const u32 *)d_up256, (const uint8_t *)cw, (const u32 *)tok_inc, (const uint4 *)tok_rec, n_cp, h->prep_sym, d_high);
+               (const u32 *)d_up256, (const uint8_t *)cw, (const u32 *)tok_prefix, (const uint4 *)tok_rec, n_cp, h->prep_sym, d_high);
     }
     LAUNCH(ctx, tp_empty_docs_kernel, ceil_div_u32(D, BLOCK), (const u32 *)first_tok, (const u32 *)keep_ex,
            (const u32 *)doc_sym_off, D, h->prep_sym);

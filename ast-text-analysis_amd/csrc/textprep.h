@@ -88,15 +88,63 @@ struct TpTables {
     u32 n_hi;
 };
 
+// ---- ranks without a per-element index --------------------------------------------------------------------------------
+// "The how-manyth code point is this byte", "the how-manyth token is this code point": rounds 2-3 wrote such numbers out
+// for EVERY element (4 bytes per byte of text, written once and read two or three times -- the heaviest arrays of the whole
+// preparation).  Now only the number of set positions in front of every BLOCK of 256 positions is kept
+// (tp_block_counts_kernel + a scan over n / 256 entries); a consumer finds the rest among its own block's positions with a
+// ballot or a few shuffles, and the handful of per-document look-ups count the up to 255 positions in front of theirs.
+#define TP_RANK_BLOCK 256
+template <class Pred>
+__global__ __launch_bounds__(BLOCK) void tp_block_counts_kernel(Pred pred, u32 n, u32 n_blocks, u32 *__restrict__ counts)
+{
+    // 8 positions per thread, 32 threads (half a wavefront) per block of 256; counts[n_blocks] = 0 (the scan's last entry: the total)
+    const u32 t = blockIdx.x * BLOCK + threadIdx.x;
+    u32 cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const u64 p = (u64)t * 8u + e;
+        if (p < n) cnt += pred((u32)p);
+    }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, WAVE);
+    const u32 b = t >> 5;
+    if ((threadIdx.x & 31u) == 0 && b <= n_blocks) counts[b] = b < n_blocks ? cnt : 0u;
+}
+
+// set positions in [0, pos), from the blocks' prefix sums
+template <class Pred> __device__ __forceinline__ u32 tp_rank_before(const Pred &pred, const u32 *__restrict__ prefix, u32 pos)
+{
+    u32 r = prefix[pos / TP_RANK_BLOCK];
+    for (u32 p = pos & ~(u32)(TP_RANK_BLOCK - 1); p < pos; p++) r += pred(p);
+    return r;
+}
+
+// one position per thread, workgroup = one block of 256: the set positions of the block in front of this thread's
+// (lds4: 4 words; a barrier inside -- every thread of the workgroup calls it)
+__device__ __forceinline__ u32 tp_rank_in_block(bool set, u32 *lds4)
+{
+    const u64 bal = __ballot(set);
+    if (lane_id() == 0) lds4[wave_id()] = (u32)__popcll(bal);
+    __syncthreads();
+    u32 before = (u32)__popcll(bal & (((u64)1 << lane_id()) - 1ull));
+    for (u32 w = 0; w < wave_id(); w++) before += lds4[w];
+    return before;
+}
+
 // per start byte: decode, upper, classify; cpu[idx] = code point after upper, cw[idx] = class
+// (byte_prefix: unit starts in front of every block of 256 bytes -- the code point index of a start byte is that plus the
+// starts in front of it inside its block)
 __global__ __launch_bounds__(BLOCK) void tp_decode_kernel(const uint8_t *__restrict__ b, u32 n_bytes,
-                                                          const u32 *__restrict__ cp_index, TpTables T,
+                                                          const u32 *__restrict__ byte_prefix, TpTables T,
                                                           u32 *__restrict__ cpu, uint8_t *__restrict__ cw)
 {
+    __shared__ u32 lds4[WAVES_PER_BLOCK];
     const u32 i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n_bytes) return;
     const TpStartIn st{b, n_bytes};
-    if (!st(i)) return;
+    const bool is_start = i < n_bytes && st(i);
+    const u32 idx = byte_prefix[blockIdx.x] + tp_rank_in_block(is_start, lds4);
+    if (!is_start) return;
     u32 cp;
     (void)tp_unit(b, i, n_bytes, cp);
     if (cp < TP_TEXT_LIMIT) {
@@ -113,7 +161,6 @@ __global__ __launch_bounds__(BLOCK) void tp_decode_kernel(const uint8_t *__restr
         const u32 k = cp - TP_TEXT_LIMIT;
         cls = ((T.word_hi[k >> 5] >> (k & 31u)) & 1u) | (((T.digit_hi[k >> 5] >> (k & 31u)) & 1u) << 1);
     }
-    const u32 idx = cp_index ? cp_index[i] : i;     // (nullptr: every byte is a code point of its own)
     cpu[idx] = cp;
     cw[idx] = (uint8_t)cls;
 }
@@ -140,12 +187,14 @@ __global__ __launch_bounds__(BLOCK) void tp_classify_bytes_kernel(const uint8_t 
 }
 
 // code-point index of every document's first byte
-__global__ __launch_bounds__(BLOCK) void tp_doc_cp_offsets_kernel(const u32 *__restrict__ cp_index,
+// (byte_prefix == nullptr: every byte is a code point of its own)
+__global__ __launch_bounds__(BLOCK) void tp_doc_cp_offsets_kernel(const uint8_t *__restrict__ b, u32 n_bytes,
+                                                                  const u32 *__restrict__ byte_prefix,
                                                                   const u32 *__restrict__ text_off, u32 n_docs,
                                                                   u32 *__restrict__ doc_cp_off)
 {
     const u32 d = blockIdx.x * BLOCK + threadIdx.x;
-    if (d <= n_docs) doc_cp_off[d] = cp_index ? cp_index[text_off[d]] : text_off[d];      // cp_index has n_bytes + 1 entries
+    if (d <= n_docs) doc_cp_off[d] = byte_prefix ? tp_rank_before(TpStartIn{b, n_bytes}, byte_prefix, text_off[d]) : text_off[d];
 }
 
 struct TpTokStartIn {                            // 1 at the first code point of a token; defined on [0, n]
@@ -157,29 +206,49 @@ struct TpTokStartIn {                            // 1 at the first code point of
     }
 };
 
-// tok_inc[p] = inclusive count of token starts: a word position p belongs to token tok_inc[p]-1
+// A word position p belongs to token (token starts in [0, p]) - 1; tok_prefix: the token starts in front of every block
+// of 256 code points (TP_RANK_BLOCK): a thread's eight positions lie in one block, the starts in front of them inside
+// the block come from the 32 threads of that block (half a wavefront) by shuffles.
 // tok_nd[k] (zeroed by the caller) becomes 1 when token k holds a character that is not a digit
 #define TP_VEC 8                                  // code points per thread in the two per-code-point passes (8-byte class loads)
 __global__ __launch_bounds__(BLOCK) void tp_token_bounds_kernel(const uint8_t *__restrict__ cw,
-                                                                const u32 *__restrict__ tok_inc, u32 n_cp,
+                                                                const u32 *__restrict__ tok_prefix, u32 n_cp,
                                                                 u32 *__restrict__ tstart, u32 *__restrict__ tend,
                                                                 u32 *__restrict__ tok_nd)
 {
     // (cw is allocated with TP_VEC bytes of padding behind n_cp and starts 16-byte aligned)
     const u32 p0 = (blockIdx.x * BLOCK + threadIdx.x) * TP_VEC;
-    if (p0 >= n_cp) return;
-    const u64 c8 = *reinterpret_cast<const u64 *>(cw + p0);
-    if (!(c8 & 0x0101010101010101ull * TP_CLASS_WORD)) return;          // no word character among the eight
-    u32 prev = p0 > 0 ? cw[p0 - 1] : 0u;
-    const u32 after = p0 + TP_VEC < n_cp ? cw[p0 + TP_VEC] : 0u;
+    const bool live = p0 < n_cp;
+    const u64 c8 = live ? *reinterpret_cast<const u64 *>(cw + p0) : 0ull;
+    u32 prev = live && p0 > 0 ? cw[p0 - 1] : 0u;
+    const u32 after = live && p0 + TP_VEC < n_cp ? cw[p0 + TP_VEC] : 0u;
+    u32 starts = 0;                                // token starts among the thread's positions
+    {
+        u32 pv = prev;
+#pragma unroll
+        for (int e = 0; e < TP_VEC; e++) {
+            const u32 c = (u32)(c8 >> (8 * e)) & 0xFFu;
+            if (p0 + e < n_cp && (c & TP_CLASS_WORD) && !(pv & TP_CLASS_WORD)) starts++;
+            pv = c;
+        }
+    }
+    u32 inc = starts;                              // inclusive prefix over the lanes of the same half-wavefront (= block of 256)
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const u32 y = __shfl_up(inc, o, WAVE);
+        if ((lane_id() & 31u) >= (u32)o) inc += y;
+    }
+    if (!live || !(c8 & 0x0101010101010101ull * TP_CLASS_WORD)) return;          // no word character among the eight
+    u32 seen = tok_prefix[p0 / TP_RANK_BLOCK] + inc - starts;          // token starts in front of position p0
 #pragma unroll
     for (int e = 0; e < TP_VEC; e++) {
         const u32 p = p0 + e;
         const u32 c = (u32)(c8 >> (8 * e)) & 0xFFu;
         const u32 next = e + 1 < TP_VEC ? (u32)(c8 >> (8 * (e + 1))) & 0xFFu : after;
         if (p < n_cp && (c & TP_CLASS_WORD)) {
-            const u32 k = tok_inc[p] - 1u;
             const bool first = !(prev & TP_CLASS_WORD);
+            if (first) seen++;
+            const u32 k = seen - 1u;
             if (first) tstart[k] = p;
             if (!(p + 1 < n_cp && (next & TP_CLASS_WORD))) tend[k] = p;
             // (ordinary words: the first letter says it; a token that starts with digits hears it from its first other character)
@@ -209,7 +278,8 @@ __global__ __launch_bounds__(BLOCK) void tp_token_keep_kernel(const u32 *__restr
 
 // per document: first token, kept tokens, strings m_d, symbols n_d
 __global__ __launch_bounds__(BLOCK) void tp_doc_counts_kernel(const u32 *__restrict__ doc_cp_off,
-                                                              const u32 *__restrict__ tok_inc,
+                                                              const uint8_t *__restrict__ cw, u32 n_cp,
+                                                              const u32 *__restrict__ tok_prefix,
                                                               const u32 *__restrict__ keep_ex,
                                                               const u32 *__restrict__ klen_ex, u32 n_docs,
                                                               u32 *__restrict__ first_tok, u32 *__restrict__ m_d,
@@ -217,12 +287,11 @@ __global__ __launch_bounds__(BLOCK) void tp_doc_counts_kernel(const u32 *__restr
 {
     const u32 d = blockIdx.x * BLOCK + threadIdx.x;
     if (d > n_docs) return;
-    const u32 c = doc_cp_off[d];
-    const u32 ft = c == 0 ? 0u : tok_inc[c - 1u];           // tokens that start before the document
+    const TpTokStartIn ts{cw, n_cp};
+    const u32 ft = tp_rank_before(ts, tok_prefix, doc_cp_off[d]);      // tokens that start before the document
     first_tok[d] = ft;
     if (d == n_docs) return;
-    const u32 c1 = doc_cp_off[d + 1];
-    const u32 ft1 = c1 == 0 ? 0u : tok_inc[c1 - 1u];
+    const u32 ft1 = tp_rank_before(ts, tok_prefix, doc_cp_off[d + 1]);
     const u32 kd = keep_ex[ft1] - keep_ex[ft];
     const u32 chars = klen_ex[ft1] - klen_ex[ft];
     m_d[d] = kd ? (kd + 2u) / 3u : 1u;                       // utils.py:76-77: an empty collection becomes [" "]
@@ -273,17 +342,23 @@ __global__ __launch_bounds__(BLOCK) void tp_token_out_kernel(const u32 *__restri
 // One code point per thread (neighbouring lanes write neighbouring symbols); per code point one class byte, the token's
 // number and ONE 16-byte token record.  cpu == nullptr: every byte is a code point of its own -- the code point is
 // up256[byte].  (Eight consecutive code points per thread were measured: 0.71 against 0.45 ms -- the stores stride.)
+// (the token of a code point: the token starts in front of its block of 256 -- tok_prefix -- plus those of the block up
+// to the code point itself, by ballot)
 __global__ __launch_bounds__(BLOCK) void tp_emit_kernel(const u32 *__restrict__ cpu, const uint8_t *__restrict__ bytes,
                                                         const u32 *__restrict__ up256, const uint8_t *__restrict__ cw,
-                                                        const u32 *__restrict__ tok_inc, const uint4 *__restrict__ tok_rec,
+                                                        const u32 *__restrict__ tok_prefix, const uint4 *__restrict__ tok_rec,
                                                         u32 n_cp, u32 *__restrict__ sym, u32 *__restrict__ high)
 {
     __shared__ u32 up[256];
+    __shared__ u32 lds4[WAVES_PER_BLOCK];
     if (!cpu) up[threadIdx.x] = up256[threadIdx.x];    // (BLOCK == 256)
-    __syncthreads();
     const u32 p = blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= n_cp || !(cw[p] & TP_CLASS_WORD)) return;
-    const uint4 rec = tok_rec[tok_inc[p] - 1u];
+    const u32 c = p < n_cp ? cw[p] : 0u;
+    const bool word = (c & TP_CLASS_WORD) != 0;
+    const bool start = word && !(p > 0 && (cw[p - 1] & TP_CLASS_WORD));
+    const u32 before = tp_rank_in_block(start, lds4);   // (its barrier also covers up[])
+    if (!word) return;
+    const uint4 rec = tok_rec[tok_prefix[blockIdx.x] + before + (start ? 1u : 0u) - 1u];
     if (rec.x == TP_DROPPED) return;                        // token dropped
     const u32 out = rec.x + (p - rec.y);
     const u32 cp = cpu ? cpu[p] : up[bytes[p]];
@@ -344,7 +419,8 @@ struct TpCarry {
 // per local document i of the chunk (i <= n_docs: one entry more for the bounds): its first token, the kept tokens and
 // symbols of the WHOLE document so far, and -- if the document ends in this chunk -- its length in the symbol stream
 __global__ __launch_bounds__(BLOCK) void tp_stream_docs_kernel(const u32 *__restrict__ doc_cp_off,
-                                                               const u32 *__restrict__ tok_inc,
+                                                               const uint8_t *__restrict__ cw, u32 n_cp,
+                                                               const u32 *__restrict__ tok_prefix,
                                                                const u32 *__restrict__ keep_ex,
                                                                const u32 *__restrict__ klen_ex, u32 n_docs, u32 cont_in,
                                                                u32 cont_out, const TpCarry *__restrict__ carry,
@@ -353,12 +429,11 @@ __global__ __launch_bounds__(BLOCK) void tp_stream_docs_kernel(const u32 *__rest
 {
     const u32 i = blockIdx.x * BLOCK + threadIdx.x;
     if (i > n_docs) return;
-    const u32 c = doc_cp_off[i];
-    const u32 ft = c == 0 ? 0u : tok_inc[c - 1u];
+    const TpTokStartIn ts{cw, n_cp};
+    const u32 ft = tp_rank_before(ts, tok_prefix, doc_cp_off[i]);
     first_tok[i] = ft;
     if (i == n_docs) { n_loc[i] = 0; return; }
-    const u32 c1 = doc_cp_off[i + 1];
-    const u32 ft1 = c1 == 0 ? 0u : tok_inc[c1 - 1u];
+    const u32 ft1 = tp_rank_before(ts, tok_prefix, doc_cp_off[i + 1]);
     u32 kd = keep_ex[ft1] - keep_ex[ft], ch = klen_ex[ft1] - klen_ex[ft];
     if (i == 0 && cont_in) { kd += carry->kept; ch += carry->chars; }
     kept_tot[i] = kd;
