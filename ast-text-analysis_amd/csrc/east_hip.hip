@@ -24,6 +24,7 @@
 #include "tables.h"
 #include "textprep.h"
 #include <atomic>
+#include <chrono>
 #include <thread>
 
 #include <algorithm>
@@ -1185,7 +1186,13 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     u32 *off_loc = ar.alloc<u32>((size_t)dl_max + 1), *kept_tot = ar.alloc<u32>(dl_max), *chars_tot = ar.alloc<u32>(dl_max);
 
     // ---- the uploads: a thread of their own (a copy out of pageable memory returns when it is staged) ----
+    // (ONE uploader: two threads with a copy stream each, the chunks' halves side by side, were measured and are slower --
+    // 2.9 against 1.95 ms for 64 MiB: the staging copies of the runtime do not run side by side.  More, smaller chunks
+    // towards the end -- a shorter tail behind the last upload -- lose to their launches and read-backs: 2.3 ms with six.)
     std::atomic<int> uploaded{0}, upload_failed{0};
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    std::vector<double> t_up(C, 0.0), t_cnt(C, 0.0), t_queued(C, 0.0);     // (EAST_HIP_TRACE: when a chunk was staged / counted / queued)
     const int device = h->device;
     hipStream_t copy_stream = h->copy_stream;
     const std::vector<hipEvent_t> &events = h->copy_events;
@@ -1216,6 +1223,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
                                     copy_stream) == hipSuccess;
             }
             if (ok) ok = hipEventRecord(events[c], copy_stream) == hipSuccess;
+            t_up[c] = since();
             if (ok) uploaded.store((int)c + 1, std::memory_order_release);
         }
         if (!ok) { (void)hipGetLastError(); upload_failed.store(1, std::memory_order_release); }
@@ -1233,6 +1241,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         }
         HIP_CHECK(hipStreamWaitEvent(h->stream, events[c], 0));
         HIP_CHECK(hipEventSynchronize(events[c]));         // (the host reads the chunk's counts)
+        t_cnt[c] = since();
         HIP_CHECK(hipMemcpyAsync(d_text_off, ch.text_off.data(), ((size_t)Dl + 1) * 4, hipMemcpyHostToDevice, h->stream));
         // bytes -> code points (the count first: a chunk in which every byte is a code point of its own needs no index).
         // The count only needs the chunk's bytes: the uploader queues it on the copy stream right behind them (and records
@@ -1279,6 +1288,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         LAUNCH(ctx, tp_stream_close_docs_kernel, ceil_div_u32(Dl, BLOCK), (const u32 *)off_loc, (const u32 *)n_loc, (const u32 *)kept_tot,
                (const u32 *)chars_tot, Dl, ch.doc_first, (u32)ch.cont_in, (u32)ch.cont_out, cin, cout, doc_sym_off_all, m_all,
                h->prep_sym);
+        t_queued[c] = since();
     }
     uploader.join();
     // the total, the per-document offsets and string counts, "kept text at or above U+0A00"
@@ -1292,6 +1302,11 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     HIP_CHECK(hipMemcpyAsync(&last, carry + (C & 1u), sizeof(last), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(&high, d_high, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (g_trace) {
+        fprintf(stderr, "[east_hip] streamed preparation, %u chunks (ms since its start: staged / counted / queued):", C);
+        for (u32 c = 0; c < C; c++) fprintf(stderr, " [%u MiB %.2f %.2f %.2f]", (chunks[c].b1 - chunks[c].b0) >> 20, t_up[c], t_cnt[c], t_queued[c]);
+        fprintf(stderr, " done %.2f\n", since());
+    }
     h_off[D] = last.sym_base;
     return high == 0;
 }
