@@ -304,7 +304,7 @@ int east_hip_debug_set_speculation(int enabled);
  * east_hip_set_keyphrases / east_hip_score_table. */
 int east_hip_debug_set_score_scratch(int64_t bytes);
 /* Test knob: how east_hip_build_texts[_v] brings the raw text to the device.  -1 (default) = inputs of 8 MiB or more are
- * uploaded in about five chunks (cut where no token spans the cut) and every chunk is prepared while the next one is on its
+ * uploaded in four or five chunks (cut where no token spans the cut) and every chunk is prepared while the next one is on its
  * way; 0 = one upload, one preparation; > 0 = always in chunks of about that many bytes (a few dozen: every fixture goes
  * through the chunk-to-chunk carries). */
 int east_hip_debug_set_text_stream(int64_t chunk_bytes);
