@@ -474,7 +474,6 @@ __global__ __launch_bounds__(BLOCK) void ann_stream_kernel(const u32 *__restrict
 {
     __shared__ __attribute__((aligned(16))) u32 tile[ANN_TILE + 2 * ANN_HALO];
     __shared__ u32 work[ANN_TILE];
-    __shared__ u32 bmin[(ANN_TILE + 2 * ANN_HALO) / PYR_FAN];   // minima of the staged values, 16 at a time (phase 3)
     __shared__ u32 work_count, far_count;
     if (threadIdx.x == 0) { work_count = 0; far_count = 0; }
     // (the entries between n and the next multiple of 16 -- the pyramid searches of ann_wide_kernel read whole groups;
@@ -507,13 +506,6 @@ __global__ __launch_bounds__(BLOCK) void ann_stream_kernel(const u32 *__restrict
         }
     }
     __syncthreads();
-    if (threadIdx.x < (ANN_TILE + 2 * ANN_HALO) / PYR_FAN) {
-        const uint4 *g = reinterpret_cast<const uint4 *>(&tile[threadIdx.x * PYR_FAN]);
-        u32 m = NONE_U32;
-#pragma unroll
-        for (int q = 0; q < 4; q++) { const uint4 y = g[q]; m = min(min(m, min(y.x, y.y)), min(y.z, y.w)); }
-        bmin[threadIdx.x] = m;
-    }
     // level 1 of the min pyramid: entry e = min of the 16 ranks 16e .. 16e+15 (entries past the table: NONE)
     if (threadIdx.x < ANN_TILE / PYR_FAN) {
         const u32 e = tile_base / PYR_FAN + threadIdx.x;
@@ -585,26 +577,7 @@ __global__ __launch_bounds__(BLOCK) void ann_stream_kernel(const u32 *__restrict
         }
     }
     __syncthreads();
-    // phase 2: one rank per thread, a short walk over the staged values to either side.
-    // phase 3 (round 4): a walk that does not end within ANN_LOCAL ranks goes on over the WHOLE staged stretch, sixteen
-    // values at a time by their minima -- with many documents the nodes two or three symbols below a root (tens to a few
-    // hundred ranks wide, two per cent of all ranks at 256 x 1 MiB) are exactly the ones phase 2 gives up on, and all but
-    // the few that reach across the stretch's ends are settled here instead of by dependent fetches through the pyramid.
-    constexpr int STAGE = ANN_TILE + 2 * ANN_HALO;
-    auto find_left = [&](int s, u32 v) -> int {          // largest staged index <= s holding a value <= v, or -1
-        while (s >= 0 && (s & (PYR_FAN - 1)) != PYR_FAN - 1) { if (tile[s] <= v) return s; s--; }
-        while (s >= 0 && bmin[s >> PYR_SHIFT] > v) s -= PYR_FAN;
-        if (s < 0) return -1;
-        while (tile[s] > v) s--;
-        return s;
-    };
-    auto find_right = [&](int s, u32 v) -> int {         // smallest staged index >= s holding a value < v, or -1
-        while (s < STAGE && (s & (PYR_FAN - 1)) != 0) { if (tile[s] < v) return s; s++; }
-        while (s < STAGE && bmin[s >> PYR_SHIFT] >= v) s += PYR_FAN;
-        if (s >= STAGE) return -1;
-        while (tile[s] >= v) s++;
-        return s;
-    };
+    // phase 2: one rank per thread, a short walk over the staged values to either side
     const u32 count = work_count;
     for (u32 wi = threadIdx.x; wi < count; wi += BLOCK) {
         const u32 local = work[wi], at = ANN_HALO + local;
@@ -616,21 +589,13 @@ __global__ __launch_bounds__(BLOCK) void ann_stream_kernel(const u32 *__restrict
             x = tile[at - d];
             if (x <= v) break;
         }
-        if (d > ANN_LOCAL) {
-            const int s = find_left((int)at - (int)ANN_LOCAL - 1, v);
-            if (s < 0) far = true;
-            else { d = at - (u32)s; x = tile[s]; }
-        }
-        if (!far && x < v) {                                // first l-index: width = NSV - PSV
+        if (d > ANN_LOCAL) far = true;
+        else if (x < v) {                                   // first l-index: width = NSV - PSV
             u32 e;
             for (e = 1; e <= ANN_LOCAL; e++)
                 if (tile[at + e] < v) break;
-            if (e > ANN_LOCAL) {
-                const int s = find_right((int)at + (int)ANN_LOCAL + 1, v);
-                if (s < 0) far = true;
-                else e = (u32)s - at;
-            }
-            if (!far) a = d + e;
+            if (e > ANN_LOCAL) far = true;
+            else a = d + e;
         }
         // (the tile's own stretch of the list: a single counter for all workgroups would serialise them)
         if (far) wide_list[tile_base + atomicAdd(&far_count, 1u)] = tile_base + local;
