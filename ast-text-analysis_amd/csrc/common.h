@@ -80,6 +80,7 @@ struct Stats {
     i64 first_kept = 0, first_n = 0;    // all-suffix window sort: suffixes the placement pass left in large groups, of how many
     i64 fused_finish = 0;       // the last radix digit and the placement ran as one pass in LDS (lvl0_finish_kernel)
     i64 ht_keys = 0;            // the first-level keys held variable-length code words (ht_code.h)
+    i64 seg_sort = 0;           // the first-level sort was segmented by document (radix_sort.h: RsSeg)
 };
 
 // Optional per-kernel timing with HIP events on the handle's own stream (the
@@ -164,6 +165,8 @@ struct Ctx {
     int ht_max_len = 0;
     double ht_mean_len = 0.0;
     int plan_ht = -1, did_ht = 0;           // first-level keys of variable-length code words: plan (as plan_wide) / what was done
+    int did_seg = 0;                        // the first-level sort kept the documents apart by segments, not by key bits
+    std::vector<u32> seg_host;              // ... its tables on the host (the uploads are asynchronous)
     Stats *stats = nullptr;
     Profiler *prof = nullptr;
 };

@@ -765,7 +765,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     prepare_ht_code(h, ctx, n, sigma_t, m_total);
     if ((h->use_s8 || ctx.dry) && g_window_sort) {       // (the sizing run prices it with 64-bit keys)
         DocKey docs;
-        if (n_docs > 1) { docs.doc_off = h->doc_off; docs.n_docs = n_docs; docs.bits = doc_bits; }
+        if (n_docs > 1) { docs.doc_off = h->doc_off; docs.n_docs = n_docs; docs.bits = doc_bits; docs.h_doc_off = ctx.dry ? nullptr : off32.data(); }
         // the score walk's k-gram tables are marked off the sorted keys on the way (KgMark): as many levels
         // as a table of at most twice a document's size (and 1 GiB in all) has room for
         KgMark km;
@@ -2117,15 +2117,15 @@ void *east_hip_stream(east_hip_handle_t h) { return h ? (void *)h->stream : null
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap)
 {
     if (!h || !out) return EAST_HIP_ERR_INVALID;
-    const int64_t v[24] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
+    const int64_t v[25] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
                            (int64_t)h->arena.cap, (int64_t)h->arena.high, h->stats.radix_passes,
                            h->stats.radix_elems, h->stats.radix_elem_bytes, h->stats.radix_passes_u32,
                            h->stats.radix_elems_u32, h->stats.radix_passes_u64, h->stats.radix_elems_u64,
                            h->stats.levels_resolved, h->stats.merge_elems, h->stats.refine_rounds,
                            h->stats.window_sorted, h->stats.lds_sorted, h->stats.fused_finish, h->stats.first_kept,
-                           h->stats.first_n, h->stats.ht_keys};
-    for (int i = 0; i < 24 && i < cap; i++) out[i] = v[i];
-    return 24;
+                           h->stats.first_n, h->stats.ht_keys, h->stats.seg_sort};
+    for (int i = 0; i < 25 && i < cap; i++) out[i] = v[i];
+    return 25;
 }
 
 int east_hip_profile_enable(east_hip_handle_t h, int on)
@@ -2256,6 +2256,15 @@ int east_hip_debug_set_window_sort(int enabled)
     // 7: as 1, first-level keys of variable-length code words wherever a code can be made (ht_code.h); 9: the same
     // without the fused finish; 8: as 1 without such keys
     g_ht_mode = enabled == 7 || enabled == 9 ? 1 : enabled == 8 ? 0 : (getenv("EAST_HIP_HT") ? atoi(getenv("EAST_HIP_HT")) : -1);
+    g_plan_epoch++;
+    return EAST_HIP_OK;
+}
+
+int east_hip_debug_set_segmented_sort(int mode)
+{
+    // -1: the default (by size: a few large documents); 0: never (the document number is a key digit); 1: wherever it
+    // can be done (2 .. RS_SEG_MAX_DOCS documents of any size)
+    g_seg_mode = mode < 0 ? (getenv("EAST_HIP_SEG") ? atoi(getenv("EAST_HIP_SEG")) : -1) : (mode != 0);
     g_plan_epoch++;
     return EAST_HIP_OK;
 }

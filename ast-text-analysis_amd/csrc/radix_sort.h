@@ -33,6 +33,39 @@
 #define RS_TOTAL_SHARDS 8
 #endif
 
+// Segmented sort (RsSeg): the n pairs are the suffixes of several DOCUMENTS laid side by side -- document d owns the
+// positions [doc_off[d], doc_off[d + 1]) of the input AND of the output --, and every pass is a stable counting sort of
+// each document on its own: the document number never has to be a key digit (for 256 documents that is a whole pass
+// over HBM saved, or -- what window_sort.h does with it -- 8 more key bits of text in the same passes).  The tiles are
+// cut per document (the last one of a document is short) and so are the histogram groups (the last group of a document
+// may hold fewer than RS_GROUP tiles with pairs in them: "virtual" tiles, a workgroup that returns at once); a tile's
+// digit base is  doc_off[d] + (the document's pairs with smaller digits) + (the digit in the document's earlier tiles),
+// which is the spine's column scan run per document.  Meant for a handful to a few thousand large documents; a shard of
+// many small ones keeps the document number in the key.
+#define RS_SEG_MAX_DOCS 4096
+struct RsSeg {
+    const u32 *group_doc = nullptr;     // the document of (virtual) group g
+    const u32 *doc_group0 = nullptr;    // the first group of document d (n_docs + 1 entries)
+    const u32 *doc_off = nullptr;       // n_docs + 1 offsets
+    u32 n_docs = 0;                     // 0: one segment, tiles of RS_TILE pairs from position 0 on
+    u32 n_groups = 0;                   // all documents' groups
+    u32 shards = 1;                     // copies of a document's digit totals (see RS_TOTAL_SHARDS)
+};
+// the pairs of (virtual) tile `tile`: [base, base + count)
+__device__ __forceinline__ void rs_tile_range(const RsSeg &seg, u32 n, u32 tile, u32 &base, u32 &count)
+{
+    if (!seg.n_docs) {
+        base = tile * (u32)RS_TILE;
+        count = n - base < (u32)RS_TILE ? n - base : (u32)RS_TILE;
+        return;
+    }
+    const u32 d = seg.group_doc[tile / RS_GROUP];
+    const u32 t_in = tile - seg.doc_group0[d] * RS_GROUP;
+    const u32 end = seg.doc_off[d + 1];
+    base = seg.doc_off[d] + t_in * (u32)RS_TILE;        // (< n + RS_GROUP * RS_TILE < 2^32)
+    count = base < end ? (end - base < (u32)RS_TILE ? end - base : (u32)RS_TILE) : 0u;
+}
+
 // Where a pass reads its pairs from: the buffers of the previous pass, or -- first pass only -- a
 // generator (MODE 1: computes pair i on the fly, key(i) / val(i); MODE 2: fills a whole tile of keys in
 // LDS, see TextWindowGen in window_sort.h; the value of element i is i).  The keys then never make a
@@ -80,7 +113,7 @@ template <bool CHECK = true> __device__ __forceinline__ void radix_hist_add(u32 
 template <class K, class Src, bool CHECK = true>
 __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u32 n, int shift, u32 mask, u32 n_tiles,
                                                                      u32 *__restrict__ hist, u32 *__restrict__ group_sum,
-                                                                     u32 *__restrict__ digit_total)
+                                                                     u32 *__restrict__ digit_total, RsSeg seg)
 {
     constexpr int UW = RS_HIST_THREADS / WAVE;
     static_assert(RS_HIST_THREADS == RS_BINS, "thread d owns digit d");
@@ -95,18 +128,20 @@ __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u3
     const u32 t0 = g * RS_GROUP, t1 = t0 + RS_GROUP < n_tiles ? t0 + RS_GROUP : n_tiles;
     for (u32 tile = t0 + wave_id(); tile < t1; tile += UW) {
         u32 *mine = bins[tile - t0][lane & (RS_HIST_COPIES - 1)];
-        const u32 base = tile * RS_TILE;
-        const u32 count = n - base < (u32)RS_TILE ? n - base : (u32)RS_TILE;
+        u32 base, count;
+        rs_tile_range(seg, n, tile, base, count);
+        if (count == 0) continue;
         if constexpr (Src::MODE == 0) {
             constexpr u32 PER = 16 / sizeof(K);         // keys per 16-byte load
             constexpr int LOADS = RS_TILE / (WAVE * PER);
             static_assert(LOADS % RS_HIST_BATCH == 0, "batches of loads");
             if (count == (u32)RS_TILE) {
-                const uint4 *p = reinterpret_cast<const uint4 *>(src.keys + base) + lane;
+                // (a document's tiles start anywhere: 16-byte loads at 4-byte alignment)
+                const char *p = reinterpret_cast<const char *>(src.keys + base) + 16u * lane;
                 for (int j0 = 0; j0 < LOADS; j0 += RS_HIST_BATCH) {
                     uint4 q[RS_HIST_BATCH];
 #pragma unroll
-                    for (int j = 0; j < RS_HIST_BATCH; j++) q[j] = p[(j0 + j) * WAVE];
+                    for (int j = 0; j < RS_HIST_BATCH; j++) __builtin_memcpy(&q[j], p + (size_t)(j0 + j) * WAVE * 16u, 16);
 #pragma unroll
                     for (int j = 0; j < RS_HIST_BATCH; j++) {
                         if constexpr (sizeof(K) == 8) {
@@ -140,7 +175,9 @@ __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u3
     }
     group_sum[(size_t)g * RS_BINS + threadIdx.x] = run;     // one coalesced row per group
     // (RS_TOTAL_SHARDS copies of the totals: thousands of workgroups adding into one 1 KiB row queue up behind one another)
-    if (run) atomicAdd(&digit_total[(blockIdx.x % RS_TOTAL_SHARDS) * RS_BINS + threadIdx.x], run);
+    // (segmented: a row of totals per document)
+    const u32 row = seg.n_docs ? seg.group_doc[g] * seg.shards + g % seg.shards : g % RS_TOTAL_SHARDS;
+    if (run) atomicAdd(&digit_total[(size_t)row * RS_BINS + threadIdx.x], run);
 }
 
 // ---- spine: exclusive scan down the groups, per digit column, plus the digit bases --------------------
@@ -154,28 +191,32 @@ __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u3
 #define RS_SPINE_PARTS (BLOCK / RS_SPINE_COLS)
 __global__ __launch_bounds__(BLOCK) void radix_spine_kernel(const u32 *__restrict__ group_sum, u32 n_groups,
                                                             const u32 *__restrict__ digit_total,
-                                                            u32 *__restrict__ next_total, u32 *__restrict__ group_prefix)
+                                                            u32 *__restrict__ next_total, u32 *__restrict__ group_prefix,
+                                                            RsSeg seg)
 {
     static_assert(RS_BINS == BLOCK, "one digit per thread in the scan of the totals");
     __shared__ u32 base_of[RS_BINS];
     __shared__ u32 part_total[RS_SPINE_PARTS][RS_SPINE_COLS];
     __shared__ u32 lds4[WAVES_PER_BLOCK];
+    // (segmented: blockIdx.y = the document -- its groups, its row of totals, its first output position)
+    const u32 doc = blockIdx.y;
+    const u32 g_first = seg.n_docs ? seg.doc_group0[doc] : 0u;
+    const u32 g_count = seg.n_docs ? seg.doc_group0[doc + 1] - g_first : n_groups;
+    const u32 shards = seg.n_docs ? seg.shards : (u32)RS_TOTAL_SHARDS;
     {
+        const size_t row0 = (size_t)doc * shards * RS_BINS;
         u32 t = 0;
-#pragma unroll
-        for (int k = 0; k < RS_TOTAL_SHARDS; k++) t += digit_total[k * RS_BINS + threadIdx.x];
+        for (u32 k = 0; k < shards; k++) t += digit_total[row0 + k * RS_BINS + threadIdx.x];
         u32 total;
-        base_of[threadIdx.x] = block_exclusive_sum(t, lds4, total);
-        if (blockIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < RS_TOTAL_SHARDS; k++) next_total[k * RS_BINS + threadIdx.x] = 0;
-        }
+        base_of[threadIdx.x] = block_exclusive_sum(t, lds4, total) + (seg.n_docs ? seg.doc_off[doc] : 0u);
+        if (blockIdx.x == 0)
+            for (u32 k = 0; k < shards; k++) next_total[row0 + k * RS_BINS + threadIdx.x] = 0;
     }
     const u32 c = threadIdx.x & (RS_SPINE_COLS - 1u), part = threadIdx.x / RS_SPINE_COLS;
     const u32 col = blockIdx.x * RS_SPINE_COLS + c;
-    const u32 per = (n_groups + RS_SPINE_PARTS - 1u) / RS_SPINE_PARTS;
-    const u32 r0 = part * per < n_groups ? part * per : n_groups;
-    const u32 r1 = r0 + per < n_groups ? r0 + per : n_groups;
+    const u32 per = (g_count + RS_SPINE_PARTS - 1u) / RS_SPINE_PARTS;
+    const u32 r0 = g_first + (part * per < g_count ? part * per : g_count);
+    const u32 r1 = r0 + per < g_first + g_count ? r0 + per : g_first + g_count;
     u32 run = 0;
 #pragma unroll 8
     for (u32 r = r0; r < r1; r++) run += group_sum[(size_t)r * RS_BINS + col];
@@ -211,13 +252,12 @@ template <class K, class Src, bool FULL>
 __device__ __forceinline__ void radix_scatter_tile(ScatterLds<K> &lds, const Src &src, K *__restrict__ keys_out,
                                                    u32 *__restrict__ vals_out, int shift, u32 mask,
                                                    const u32 *__restrict__ hist, const u32 *__restrict__ group_prefix,
-                                                   u32 tile, u32 tile_count)
+                                                   u32 tile, u32 tile_base, u32 tile_count)
 {
     constexpr int WAVES = RS_THREADS / WAVE, IPT = RS_IPT, THREADS = RS_THREADS, BINS = RS_BINS, DB = RS_DB;
     constexpr int WAVE_ITEMS = WAVE * IPT;
     u32 *s_vals = reinterpret_cast<u32 *>(lds.s_keys);
     const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    const u32 tile_base = tile * (u32)RS_TILE;
 
     K key[IPT];
     u32 val[IPT];
@@ -361,7 +401,7 @@ __device__ __forceinline__ void radix_scatter_tile(ScatterLds<K> &lds, const Src
 template <class K, class Src>
 __global__ __launch_bounds__(RS_THREADS, (RS_IPT <= 4 ? 8 : 4)) void radix_scatter_kernel(
     Src src, K *__restrict__ keys_out, u32 *__restrict__ vals_out, u32 n, int shift, u32 mask,
-    const u32 *__restrict__ hist, const u32 *__restrict__ group_prefix, u32 n_tiles)
+    const u32 *__restrict__ hist, const u32 *__restrict__ group_prefix, u32 n_tiles, RsSeg seg)
 {
     // XCD-aware tile order: workgroups go round-robin over the 8 XCDs, each with its own L2.  The
     // per-digit runs of NEIGHBOURING tiles are neighbours in the output, so neighbouring tiles are
@@ -370,13 +410,15 @@ __global__ __launch_bounds__(RS_THREADS, (RS_IPT <= 4 ? 8 : 4)) void radix_scatt
     const u32 per_xcd = (n_tiles + 7u) / 8u;
     const u32 tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (tile >= n_tiles) return;
-    const u32 tile_count = (n - tile * RS_TILE) < (u32)RS_TILE ? (n - tile * RS_TILE) : (u32)RS_TILE;
-    // every tile but the last is full: no bounds tests in its code path
+    u32 tile_base, tile_count;
+    rs_tile_range(seg, n, tile, tile_base, tile_count);
+    if (tile_count == 0) return;                        // (segmented: the tiles that fill up a document's last group)
+    // every tile but the last (of a document) is full: no bounds tests in its code path
     __shared__ ScatterLds<K> lds;
     if (tile_count == (u32)RS_TILE)
-        radix_scatter_tile<K, Src, true>(lds, src, keys_out, vals_out, shift, mask, hist, group_prefix, tile, tile_count);
+        radix_scatter_tile<K, Src, true>(lds, src, keys_out, vals_out, shift, mask, hist, group_prefix, tile, tile_base, tile_count);
     else
-        radix_scatter_tile<K, Src, false>(lds, src, keys_out, vals_out, shift, mask, hist, group_prefix, tile, tile_count);
+        radix_scatter_tile<K, Src, false>(lds, src, keys_out, vals_out, shift, mask, hist, group_prefix, tile, tile_base, tile_count);
 }
 
 template <class K> struct SortBufs {
@@ -409,18 +451,20 @@ static inline void radix_account(Ctx &ctx, size_t key_bytes, u32 n, bool generat
 // check_from_bit: the histogram passes at or above that bit test every key for "the whole wavefront on one bin" (keys
 // that arrive sorted on their high bits: group numbers, document numbers); the passes below take the digits as spread out.
 template <class K, class Gen = NoGen>
-static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin_bit = 0, Gen gen = Gen(), int check_from_bit = 0)
+static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin_bit = 0, Gen gen = Gen(), int check_from_bit = 0,
+                            RsSeg seg = RsSeg())
 {
     constexpr bool HAS_GEN = !std::is_same<Gen, NoGen>::value;
     if (n == 0 || bits <= begin_bit) return 0;
-    const u32 n_tiles = ceil_div_u32(n, RS_TILE);
-    const u32 n_groups = ceil_div_u32(n_tiles, RS_GROUP);
+    const u32 n_groups = seg.n_docs ? seg.n_groups : ceil_div_u32(ceil_div_u32(n, RS_TILE), RS_GROUP);
+    const u32 n_tiles = seg.n_docs ? n_groups * RS_GROUP : ceil_div_u32(n, RS_TILE);
+    const size_t total_words = seg.n_docs ? (size_t)seg.n_docs * seg.shards * RS_BINS : (size_t)RS_TOTAL_SHARDS * RS_BINS;
     const size_t mark = ctx.arena->mark();
     u32 *hist = ctx.arena->alloc<u32>((size_t)RS_BINS * n_tiles);
     u32 *group_sum = ctx.arena->alloc<u32>((size_t)RS_BINS * n_groups);
     u32 *group_prefix = ctx.arena->alloc<u32>((size_t)RS_BINS * n_groups);
-    u32 *totals = ctx.arena->alloc<u32>(2 * RS_TOTAL_SHARDS * RS_BINS);
-    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(totals, 0, 2 * RS_TOTAL_SHARDS * RS_BINS * sizeof(u32), ctx.stream));
+    u32 *totals = ctx.arena->alloc<u32>(2 * total_words);
+    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(totals, 0, 2 * total_words * sizeof(u32), ctx.stream));
     const bool prof = ctx.prof && ctx.prof->enabled;
     int cur = 0, pass = 0;
     bool first = HAS_GEN;                       // the generator pass reads no buffers and writes [0]
@@ -428,7 +472,7 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin
         const u32 mask = (1u << std::min(RS_DB, bits - shift)) - 1u;
         const PairSrc<K> src{b.keys[cur], b.vals[cur]};
         const int out = first ? 0 : cur ^ 1;
-        u32 *tot = totals + (pass & 1) * RS_TOTAL_SHARDS * RS_BINS, *tot_next = totals + ((pass & 1) ^ 1) * RS_TOTAL_SHARDS * RS_BINS;
+        u32 *tot = totals + (pass & 1) * total_words, *tot_next = totals + ((pass & 1) ^ 1) * total_words;
         // (static strings: the profiler keeps the pointers)
         const char *name_hist = sizeof(K) == 8 ? (first ? "radix_hist_kernel<u64,gen>" : "radix_hist_kernel<u64>")
                                                : (first ? "radix_hist_kernel<u32,gen>" : "radix_hist_kernel<u32>");
@@ -440,33 +484,33 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin
             if constexpr (HAS_GEN) {
                 if (first && check)
                     hipLaunchKernelGGL((radix_hist_kernel<K, Gen, true>), dim3(n_groups), dim3(RS_HIST_THREADS), 0, ctx.stream, gen, n,
-                                       shift, mask, n_tiles, hist, group_sum, tot);
+                                       shift, mask, n_tiles, hist, group_sum, tot, seg);
                 else if (first)
                     hipLaunchKernelGGL((radix_hist_kernel<K, Gen, false>), dim3(n_groups), dim3(RS_HIST_THREADS), 0, ctx.stream, gen, n,
-                                       shift, mask, n_tiles, hist, group_sum, tot);
+                                       shift, mask, n_tiles, hist, group_sum, tot, seg);
             }
             if (!first && check)
                 hipLaunchKernelGGL((radix_hist_kernel<K, PairSrc<K>, true>), dim3(n_groups), dim3(RS_HIST_THREADS), 0, ctx.stream, src,
-                                   n, shift, mask, n_tiles, hist, group_sum, tot);
+                                   n, shift, mask, n_tiles, hist, group_sum, tot, seg);
             else if (!first)
                 hipLaunchKernelGGL((radix_hist_kernel<K, PairSrc<K>, false>), dim3(n_groups), dim3(RS_HIST_THREADS), 0, ctx.stream, src,
-                                   n, shift, mask, n_tiles, hist, group_sum, tot);
+                                   n, shift, mask, n_tiles, hist, group_sum, tot, seg);
             HIP_CHECK(hipGetLastError());
             if (prof) ctx.prof->end(ctx.stream);
         }
-        LAUNCH(ctx, radix_spine_kernel, RS_BINS / RS_SPINE_COLS, (const u32 *)group_sum, n_groups, (const u32 *)tot, tot_next,
-               group_prefix);
+        LAUNCH(ctx, radix_spine_kernel, dim3(RS_BINS / RS_SPINE_COLS, seg.n_docs ? seg.n_docs : 1u), (const u32 *)group_sum,
+                    n_groups, (const u32 *)tot, tot_next, group_prefix, seg);
         if (!ctx.dry) {
             if (prof) ctx.prof->begin(name_scatter, ctx.stream);
             const dim3 grid(8 * ((n_tiles + 7) / 8));
             if constexpr (HAS_GEN) {
                 if (first)
                     hipLaunchKernelGGL((radix_scatter_kernel<K, Gen>), grid, dim3(RS_THREADS), 0, ctx.stream, gen, b.keys[out],
-                                       b.vals[out], n, shift, mask, (const u32 *)hist, (const u32 *)group_prefix, n_tiles);
+                                       b.vals[out], n, shift, mask, (const u32 *)hist, (const u32 *)group_prefix, n_tiles, seg);
             }
             if (!first)
                 hipLaunchKernelGGL((radix_scatter_kernel<K, PairSrc<K>>), grid, dim3(RS_THREADS), 0, ctx.stream, src, b.keys[out],
-                                   b.vals[out], n, shift, mask, (const u32 *)hist, (const u32 *)group_prefix, n_tiles);
+                                   b.vals[out], n, shift, mask, (const u32 *)hist, (const u32 *)group_prefix, n_tiles, seg);
             HIP_CHECK(hipGetLastError());
             if (prof) ctx.prof->end(ctx.stream);
         }

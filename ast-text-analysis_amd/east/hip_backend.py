@@ -68,6 +68,7 @@ SIGNATURES = {
     "east_hip_debug_set_rank_bucket_bytes": (ctypes.c_int, [ctypes.c_int64]),
     "east_hip_debug_set_window_sort": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_debug_set_lds_rounds": (ctypes.c_int, [ctypes.c_int]),
+    "east_hip_debug_set_segmented_sort": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_debug_set_speculation": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_debug_set_score_scratch": (ctypes.c_int, [ctypes.c_int64]),
     "east_hip_debug_set_score_path": (ctypes.c_int, [ctypes.c_int]),
@@ -83,7 +84,7 @@ BUILD_INFO_FIELDS = ("n_total", "n_docs", "n_strings", "sigma_text", "bits_level
                      "arena_high_water", "radix_passes", "radix_elements", "radix_element_bytes",
                      "radix_passes_u32", "radix_elements_u32", "radix_passes_u64", "radix_elements_u64",
                      "dc3_levels_resolved", "merge_elements", "refine_rounds", "window_sorted", "lds_sorted",
-                     "fused_finish", "first_kept", "first_n", "ht_keys")
+                     "fused_finish", "first_kept", "first_n", "ht_keys", "seg_sort")
 
 _lib = None
 

@@ -392,7 +392,7 @@ def main():
             "build_algorithmic_GBps": 16.0 * n / (float(np.mean(build_ms)) * 1e-3) / 1e9,
             "dc3_levels": info["dc3_levels"], "dc3_levels_resolved": info["dc3_levels_resolved"],
             "dc3_refine_rounds": info["refine_rounds"], "window_sorted": info["window_sorted"],
-            "radix_passes": info["radix_passes"], "variable_length_keys": info.get("ht_keys", 0),
+            "radix_passes": info["radix_passes"], "variable_length_keys": info.get("ht_keys", 0), "segmented_sort": info.get("seg_sort", 0),
             "roofline": roofline, "roofline_by_kernel": by_kernel, "kernels_ms_per_step": per_step,
             "kernel_launches_per_step": {k: v[0] // profile_steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
             "profiling_pass": "%d untimed step(s) with every kernel bracketed: roofline_by_kernel, kernels_ms_per_step, "
@@ -524,7 +524,7 @@ def first_build_leg(hip_backend, torch, local_rank, d_symbols, n, doc_offsets, n
             "first_score_wall_ms": float(np.mean(s_wall)), "value_first_build": n_bytes / (step * 1e-3),
             "first_build_plan": {"fused_finish": info.get("fused_finish"), "u64_passes": info.get("radix_passes_u64"),
                                  "u32_passes": info.get("radix_passes_u32"), "refine_rounds": info.get("refine_rounds"),
-                                 "variable_length_keys": info.get("ht_keys", 0)},
+                                 "variable_length_keys": info.get("ht_keys", 0), "segmented_sort": info.get("seg_sort", 0)},
             "first_build_note": "fresh handle per repetition (%d), no hints from earlier builds; value_first_build = input "
                                 "bytes / (build wall + score wall)" % reps}
 
@@ -574,7 +574,7 @@ def from_text_leg(hip_backend, synthetic, local_rank):
         res[name] = {"bytes": n_bytes, "docs": len(texts), "symbols": info["n_total"],
                      "wall_ms": min(walls), "prep_ms": min(preps), "build_ms": min(builds),
                      "prep_kernels_ms": prep_kernels, "prep_kernels_total_ms": round(sum(prep_kernels.values()), 4),
-                     "variable_length_keys": info.get("ht_keys", 0), "refine_rounds": info["refine_rounds"],
+                     "variable_length_keys": info.get("ht_keys", 0), "segmented_sort": info.get("seg_sort", 0), "refine_rounds": info["refine_rounds"],
                      "first_call_wall_ms": min(firsts[1:]), "chars_per_s": n_bytes / (min(walls) * 1e-3),
                      "note": "wall = Python bytes -> finished index (H2D of the raw text from pageable memory included); "
                              "first_call = fresh handle, arena allocation included"}

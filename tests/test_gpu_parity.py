@@ -16,26 +16,34 @@ from conftest import load_golden, word_stream
 pytestmark = pytest.mark.gpu
 
 
-_PATH_KNOB = {"window_sort": 1, "window_sort_unfused": 4, "window_sort_ht": 7, "window_sort_ht_unfused": 9, "dc3_only": 0}
-_CURRENT = {"knob": 1}          # the knob of the running test (tests that check which path a build took)
+_PATH_KNOB = {"window_sort": 1, "window_sort_unfused": 4, "window_sort_ht": 7, "window_sort_ht_unfused": 9, "dc3_only": 0,
+              "window_sort_seg": 1, "window_sort_seg_unfused": 4, "window_sort_seg_ht": 7}
+_CURRENT = {"knob": 1, "seg": 0}          # the knobs of the running test (tests that check which path a build took)
 
 
-@pytest.fixture(autouse=True, params=["window_sort", "window_sort_unfused", "window_sort_ht", "window_sort_ht_unfused", "dc3_only"])
+@pytest.fixture(autouse=True, params=list(_PATH_KNOB))
 def suffix_sort_path(request, hip):
-    """Every parity test runs five times: through the all-suffix window sort as it ships (the last radix
+    """Every parity test runs eight times: through the all-suffix window sort as it ships (the last radix
     digit ordered in LDS by the fused finish), through the same sort with every pass global and the separate
     placement pass, through the window sort with first-level keys of variable-length code words wherever a code can
     be made (csrc/ht_code.h; by itself the build only takes them for text they pay on) with and without the fused
-    finish, and with the window sort
-    switched off, so that DC3 -- the fallback for repetitive inputs -- stays covered on every input as well.
+    finish, with the window sort switched off, so that DC3 -- the fallback for repetitive inputs -- stays covered on
+    every input as well, and (the `_seg` paths) through the segmented first-level sort -- every document sorted inside
+    its own range, no document number in the keys (csrc/radix_sort.h: RsSeg; by itself the build takes it for a few
+    large documents) -- wherever a shard holds 2 .. 4096 documents.
     (Tests that read `suffix_sort_path` get "window_sort" for the first two.)"""
     lib = hip.load()
+    seg = "_seg" in request.param
     assert lib.east_hip_debug_set_window_sort(_PATH_KNOB[request.param]) == 0
+    assert lib.east_hip_debug_set_segmented_sort(1 if seg else -1) == 0
     _CURRENT["knob"] = _PATH_KNOB[request.param]
-    # (the variant with variable-length keys gets its own name: the checks of WHICH passes ran do not apply to it)
+    _CURRENT["seg"] = int(seg)
+    # (the variants with variable-length keys / segments get their own names: the checks of WHICH passes ran do not apply)
     yield "window_sort" if request.param in ("window_sort", "window_sort_unfused") else request.param
     assert lib.east_hip_debug_set_window_sort(1) == 0
+    assert lib.east_hip_debug_set_segmented_sort(-1) == 0
     _CURRENT["knob"] = 1
+    _CURRENT["seg"] = 0
 
 
 TABLES = ("suftab", "lcptab", "anntab", "childtab_up", "childtab_down", "childtab_next_l_index")
@@ -630,6 +638,8 @@ def test_refinement_rounds_in_lds_and_by_the_global_sort(hip, oracle, suffix_sor
         if suffix_sort_path.startswith("window_sort_ht"):
             assert info["window_sorted"] == 1 and info["ht_keys"] >= 1, info      # variable-length keys really ran
             assert info["fused_finish"] == int(suffix_sort_path == "window_sort_ht"), info
+        if "_seg" in suffix_sort_path:
+            assert info["window_sorted"] == 1 and info["seg_sort"] == int(n_docs > 1), info   # the segmented sort really ran
         for d in range(n_docs):
             o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
             t = index.tables(d)
@@ -639,13 +649,16 @@ def test_refinement_rounds_in_lds_and_by_the_global_sort(hip, oracle, suffix_sor
         assert lib.east_hip_debug_set_lds_rounds(1) == 0
 
 
-def test_first_build_plans_the_window_from_its_own_text(hip, oracle, suffix_sort_path):
+@pytest.mark.parametrize("document_number_in_keys", [False, True])
+def test_first_build_plans_the_window_from_its_own_text(hip, oracle, suffix_sort_path, document_number_in_keys):
     """The first build on a fresh handle takes the window width and the fused finish from a sample of its own text
     (csrc/east_hip.hip: sample_prefix_kernel) -- no build has to go before: natural-language-like text over a large
     alphabet (most suffixes tied behind the three symbols that fit a 32-bit key) sorts 64-bit first-level keys at once,
     a random word stream 32-bit keys with the last digit ordered in LDS; a second build on the handle (queued without
     waiting, no sample) does as the first.  The tables are the oracle's either way."""
     from east import hip_backend, synthetic
+    if document_number_in_keys:                          # (the plan without the segmented sort; the autouse fixture restores the default)
+        assert hip.load().east_hip_debug_set_segmented_sort(0) == 0
     rng = np.random.default_rng(4711)
     vocab = synthetic.zipf_vocabulary(rng, size=40, exponent=1.0)
     docs = [synthetic.zipf_document(rng, 400000, vocab) for _ in range(2)]
@@ -663,7 +676,13 @@ def test_first_build_plans_the_window_from_its_own_text(hip, oracle, suffix_sort
     second = index.info()
     if suffix_sort_path == "window_sort":
         assert first["window_sorted"] == 1 and second["window_sorted"] == 1
-        assert first["radix_passes_u32"] == 0 and second["radix_passes_u32"] == 0, (first, second)   # 64-bit first-level keys at once
+        if first["seg_sort"]:
+            # two large documents sorted each inside its own range: all 32 key bits are text, and this text (a few symbols
+            # make up most of it) gets variable-length code words into them -- both builds
+            assert not document_number_in_keys and second["seg_sort"] == 1
+            assert first["ht_keys"] == 1 and second["ht_keys"] == 1, (first, second)
+        else:
+            assert first["radix_passes_u32"] == 0 and second["radix_passes_u32"] == 0, (first, second)   # 64-bit first-level keys at once
     for d in range(2):
         o = oracle.OracleEASA(symbols=sym[off[d]:off[d + 1]], n_strings=int(m[d]))
         t = index.tables(d)
