@@ -769,7 +769,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         // the score walk's k-gram tables are marked off the sorted keys on the way (KgMark): as many levels
         // as a table of at most twice a document's size (and 1 GiB in all) has room for
         KgMark km;
-        if (!ctx.dry && n_docs <= 65535) {
+        if (!ctx.dry && n_docs <= 65535 && !getenv("EAST_HIP_NO_KG_MARKS")) {     // (the variable: experiments -- the score side then builds its tables itself)
             km.A = sigma_t + 2;
             u64 bins = 1;
             while (km.k < KGRAM_KEYS_MAX_K && bins * km.A <= KGRAM_KEYS_MAX_BINS && bins * km.A <= 2 * ((u64)n / n_docs) + 4096 &&
@@ -2252,7 +2252,7 @@ int east_hip_debug_set_window_sort(int enabled)
     g_force_lean = enabled == 2;
     g_force_wide_keys = enabled == 3 || enabled == 5;
     g_fused_finish = enabled != 4 && enabled != 5 && enabled != 9 && getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;
-    g_force_fused = enabled == 6;                        // 6: as 1, the fused finish whatever the plan says (skewed text through it)
+    g_force_fused = enabled == 6 || getenv("EAST_HIP_FORCE_FUSED") != nullptr;                        // 6: as 1, the fused finish whatever the plan says (skewed text through it)
     // 7: as 1, first-level keys of variable-length code words wherever a code can be made (ht_code.h); 9: the same
     // without the fused finish; 8: as 1 without such keys
     g_ht_mode = enabled == 7 || enabled == 9 ? 1 : enabled == 8 ? 0 : (getenv("EAST_HIP_HT") ? atoi(getenv("EAST_HIP_HT")) : -1);

@@ -34,7 +34,7 @@ static bool g_force_wide_keys = getenv("EAST_HIP_WIDE_KEYS") != nullptr;        
 static bool g_force_lean = false;                           // east_hip_debug_set_window_sort(2) (tests)
 static bool g_window_sort = true;                            // east_hip_debug_set_window_sort (tests)
 static bool g_fused_finish = getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;    // east_hip_debug_set_window_sort(4 / 5) (tests, A/B timing)
-static bool g_force_fused = false;                           // east_hip_debug_set_window_sort(6): the fused finish whatever the plan says (tests: skewed text through it)
+static bool g_force_fused = getenv("EAST_HIP_FORCE_FUSED") != nullptr;                           // east_hip_debug_set_window_sort(6): the fused finish whatever the plan says (tests: skewed text through it)
 // variable-length first-level keys (ht_code.h): -1 = where the text's symbol statistics promise a symbol more per key,
 // 0 = never, 1 = whenever a code exists (east_hip_debug_set_window_sort(7) / EAST_HIP_HT: tests, A/B timing)
 static int g_ht_mode = getenv("EAST_HIP_HT") ? atoi(getenv("EAST_HIP_HT")) : -1;
@@ -2357,13 +2357,17 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
     // Segmented sort (radix_sort.h: RsSeg): a handful to a few thousand LARGE documents keep their ranges in every pass and
     // the key holds text only -- 256 documents of 1 MiB: 6 symbols + 2 bits of the 7th in a 32-bit key instead of 4 + 4
     // bits; the buckets of the fused finish shrink from 28 suffixes to one, next to nothing stays tied.  Worth it while the
-    // documents' own tiles and groups (the last group of a document is partly empty) stay close to the flat count: decided
-    // from n and the number of documents alone, so that the sizing run prices the same plan.
+    // documents' own tiles and groups (the last group of a document is partly empty) stay within twice the flat count:
+    // decided from n and the number of documents alone, so that the sizing run prices the same plan.
     const bool multi = docs.bits > 0;
     {
         const u32 flat_groups = ceil_div_u32(ceil_div_u32(n, RS_TILE), RS_GROUP);
         const bool can = multi && docs.n_docs <= RS_SEG_MAX_DOCS && (ctx.dry || docs.h_doc_off);
-        if (can && g_seg_mode != 0 && (g_seg_mode == 1 || docs.n_docs <= flat_groups / 4 + 1)) {
+        // (documents of a histogram group -- 32 768 suffixes -- or more on average: measured on 256 MiB of word text, build
+        // with / without: 256 x 1 MiB 7.3 / 7.8 ms, 1 024 x 256 KiB 6.9 / 7.3, 4 096 x 64 KiB 7.3 / 7.8, 8 192 x 32 KiB 7.9 / 8.4,
+        // 16 384 x 16 KiB 7.9 / 7.7 -- short tiles and mostly empty groups)
+        const u32 per_groups = getenv("EAST_HIP_SEG_DIV") ? (u32)std::max(1, atoi(getenv("EAST_HIP_SEG_DIV"))) : 1u;   // (experiments)
+        if (can && g_seg_mode != 0 && (g_seg_mode == 1 || docs.n_docs <= flat_groups / per_groups + 1)) {
             RsSeg &seg = docs.seg;
             seg.n_docs = docs.n_docs;
             seg.doc_off = docs.doc_off;

@@ -103,6 +103,7 @@ def main():
         knob = int(rng.choice([1, 1, 1, 0, 3, 2, 4, 5, 7, 7, 9, 9]))
         lib.east_hip_debug_set_window_sort(knob)
         lib.east_hip_debug_set_lds_rounds(int(rng.choice([1, 1, 2, 0])))
+        lib.east_hip_debug_set_segmented_sort(int(rng.choice([-1, 1, 1, 0])))     # (1: wherever a shard holds 2 .. 65535 documents)
         lib.east_hip_debug_set_score_path(int(rng.choice([1, 4, 4, 0, 2, 3])))
         parts = [to_symbols(sc) for sc in docs]
         sym = np.concatenate(parts)
@@ -161,6 +162,7 @@ def main():
         cases += 1
     lib.east_hip_debug_set_window_sort(1)
     lib.east_hip_debug_set_lds_rounds(1)
+    lib.east_hip_debug_set_segmented_sort(-1)
     lib.east_hip_debug_set_score_path(1)
     print("fuzz ok: %d collections, %d documents, %d symbols checked; paths (knob, window_sorted, dc3_levels, rounds, lifted, fused, "
           "variable-length keys):"
