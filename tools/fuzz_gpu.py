@@ -128,7 +128,7 @@ def main():
             index.build(dev_sym, off, np.array([len(sc) for sc in docs], dtype=np.int32))
             info = index.info()
             key = (knob, info["window_sorted"], min(info["dc3_levels"], 3), min(info["refine_rounds"], 3), int(lifted),
-                   info["fused_finish"], info["ht_keys"])
+                   info["fused_finish"], info["ht_keys"], info["seg_sort"])
             paths[key] = paths.get(key, 0) + 1
             queries = []
             for sc in docs[:2]:
@@ -165,7 +165,7 @@ def main():
     lib.east_hip_debug_set_segmented_sort(-1)
     lib.east_hip_debug_set_score_path(1)
     print("fuzz ok: %d collections, %d documents, %d symbols checked; paths (knob, window_sorted, dc3_levels, rounds, lifted, fused, "
-          "variable-length keys):"
+          "variable-length keys, segmented sort):"
           % (cases, docs_checked, symbols))
     for k in sorted(paths):
         print("   ", k, paths[k])
