@@ -688,6 +688,19 @@ __device__ __forceinline__ u32 lvl0_place_tied(u32 j, const Elem &elem, const St
     return 0;
 }
 
+// four consecutive keys with 16-byte loads (p: 16-byte aligned)
+template <class K> __device__ __forceinline__ void fin_load4(const K *p, K (&out)[5])
+{
+    if constexpr (sizeof(K) == 4) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(p);
+        out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
+    } else {
+        const uint4 q0 = reinterpret_cast<const uint4 *>(p)[0], q1 = reinterpret_cast<const uint4 *>(p)[1];
+        out[0] = ((u64)q0.y << 32) | q0.x; out[1] = ((u64)q0.w << 32) | q0.z;
+        out[2] = ((u64)q1.y << 32) | q1.x; out[3] = ((u64)q1.w << 32) | q1.z;
+    }
+}
+
 struct NoLcp {
     __device__ __forceinline__ u32 operator()(u32) const { return 0u; }
 };
@@ -756,18 +769,28 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     K k[PLACE_IPT + 2];
     u32 v[PLACE_IPT];
     if (j0 < m) {
-        // keys j0-1 .. j0+4 (the arrays carry 8 spare entries behind m), elements j0 .. j0+3
-        k[0] = j0 > 0 ? f.keys[j0 - 1] : (K)0;
+        // keys j0 .. j0+3 and their elements: 16-byte loads (the arrays carry 8 spare entries behind m: whole groups of 4);
+        // the keys to either side (j0-1, j0+4) come out of the staged tile behind the barrier -- variable-length keys read
+        // them before it (the walk over the five keys), from the array
+        {
+            K k4[5];
+            fin_load4<K>(f.keys + j0, k4);
 #pragma unroll
-        for (int e = 0; e < PLACE_IPT; e++) k[e + 1] = f.keys[j0 + e];
-        k[PLACE_IPT + 1] = f.keys[j0 + PLACE_IPT];
-#pragma unroll
-        for (int e = 0; e < PLACE_IPT; e++) v[e] = vals[j0 + e];
-#pragma unroll
-        for (int e = 0; e < PLACE_IPT; e++) {            // (the arrays carry 8 spare entries behind m: whole groups of 4)
-            key_tile[PLACE_HALO + threadIdx.x * PLACE_IPT + e] = k[e + 1];
-            val_tile[PLACE_HALO + threadIdx.x * PLACE_IPT + e] = v[e];
+            for (int e = 0; e < PLACE_IPT; e++) k[e + 1] = k4[e];
+            const uint4 q = *reinterpret_cast<const uint4 *>(vals + j0);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
         }
+        if constexpr (HT) {
+            k[0] = j0 > 0 ? f.keys[j0 - 1] : (K)0;
+            k[PLACE_IPT + 1] = f.keys[j0 + PLACE_IPT];
+        }
+        const u32 at0 = PLACE_HALO + threadIdx.x * PLACE_IPT;
+        if constexpr (sizeof(K) == 4) *reinterpret_cast<uint4 *>(&key_tile[at0]) = uint4{(u32)k[1], (u32)k[2], (u32)k[3], (u32)k[4]};
+        else {
+#pragma unroll
+            for (int e = 0; e < PLACE_IPT; e++) key_tile[at0 + e] = k[e + 1];
+        }
+        *reinterpret_cast<uint4 *>(&val_tile[at0]) = uint4{v[0], v[1], v[2], v[3]};
     }
     HtScan sc[PLACE_IPT + 1];                           // (HT) what the thread's keys hold; [PLACE_IPT]: the key behind them
     if constexpr (HT) {
@@ -810,6 +833,11 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     }
     __syncthreads();                                    // (the staged keys: the test for large groups reads them `limit` places away)
     if (j0 < m) {
+        if constexpr (!HT) {
+            // (the first stretch has no left halo: rank 0 has no key before it)
+            k[0] = j0 > 0 ? key_tile[PLACE_HALO + threadIdx.x * PLACE_IPT - 1] : (K)0;
+            k[PLACE_IPT + 1] = key_tile[PLACE_HALO + threadIdx.x * PLACE_IPT + PLACE_IPT];
+        }
         bool start[PLACE_IPT + 1];
 #pragma unroll
         for (int e = 0; e <= PLACE_IPT; e++) {
@@ -1028,18 +1056,6 @@ template <class GE> __device__ __forceinline__ int fin_next_bit(const u32 *fl, i
         if (found < 0 && wi + 1 < GE::WORDS) { wi++; word = fl[wi]; } else word = 0;
     }
     return found >= 0 && found <= hi ? found : -1;
-}
-
-template <class K> __device__ __forceinline__ void fin_load4(const K *p, K (&out)[5])
-{
-    if constexpr (sizeof(K) == 4) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(p);
-        out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
-    } else {
-        const uint4 q0 = reinterpret_cast<const uint4 *>(p)[0], q1 = reinterpret_cast<const uint4 *>(p)[1];
-        out[0] = ((u64)q0.y << 32) | q0.x; out[1] = ((u64)q0.w << 32) | q0.z;
-        out[2] = ((u64)q1.y << 32) | q1.x; out[3] = ((u64)q1.w << 32) | q1.z;
-    }
 }
 
 // lvl0_lcp_of_key_pair without the divisions by the symbol width
