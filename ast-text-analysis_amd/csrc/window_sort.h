@@ -768,6 +768,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     }
     K k[PLACE_IPT + 2];
     u32 v[PLACE_IPT];
+    u32 work_mask = 0;                                  // bit e: rank j0 + e goes to phase 2
     if (j0 < m) {
         // keys j0 .. j0+3 and their elements: 16-byte loads (the arrays carry 8 spare entries behind m: whole groups of 4);
         // the keys to either side (j0-1, j0+4) come out of the staged tile behind the barrier -- variable-length keys read
@@ -920,10 +921,20 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
                     order_g[j] = v[e];
                     if (names_g) names_g[j] = start[e];
                 } else {
-                    work[atomicAdd(&n_work, 1u)] = j;    // phase 2
+                    work_mask |= 1u << e;                // phase 2
                 }
             }
         }
+    }
+    {   // the work list: one LDS atomic per wavefront (natural-language text sends half of the ranks there)
+        const u32 wc = (u32)__popc(work_mask);
+        const u32 inc = wave_inclusive_sum(wc);
+        u32 wbase = 0;
+        if (lane_id() == 63u && inc) wbase = atomicAdd(&n_work, inc);
+        wbase = __shfl(wbase, 63, WAVE) + inc - wc;
+#pragma unroll
+        for (int e = 0; e < PLACE_IPT; e++)
+            if ((work_mask >> e) & 1u) work[wbase++] = j0 + e;
     }
     __syncthreads();
     // phase 2: the tied elements, one per thread, so that their text gathers run side by side
