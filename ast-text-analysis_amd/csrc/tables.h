@@ -441,13 +441,14 @@ __device__ __forceinline__ u32 pyr_leftmost_argmin(const Pyramid &P, u32 a, u32 
 
 // anntab (easa.py:306-331) in two launches.
 //
-// ann_stream_kernel: a workgroup stages 1024 consecutive LCP values plus 32 to either side in LDS.
+// ann_stream_kernel: a workgroup stages 1024 consecutive LCP values plus ANN_HALO to either side in LDS.
 //   phase 1  every thread decides its 4 ranks from the 8 neighbours to either side (five 16-byte LDS
 //            reads); most ranks end here and the thread writes one 16-byte store;
 //   phase 2  the rest -- first l-indices of intervals wider than that, a few per cent -- go to an LDS
-//            work list and are walked one per thread over the staged values, at most ANN_LOCAL ranks
-//            to either side (a wave per rank with 64 neighbours per ballot was measured: twice as slow,
-//            the ranks then queue up behind one another);
+//            work list and are looked at by eight lanes each over the staged values, at most ANN_LOCAL ranks
+//            to either side (one rank per thread: the tile's few dozen ranks queue up in one wavefront; a wave
+//            per rank with 64 neighbours per ballot was measured: twice as slow, the ranks then queue up
+//            behind one another);
 //   what is wider still (the top levels of the tree, about one rank in a hundred) is appended to a
 //   global list for ann_wide_kernel.
 //   The kernel also writes level 1 of the min pyramid (it has the values in LDS): the LCP table is read
@@ -458,11 +459,14 @@ __device__ __forceinline__ u32 pyr_leftmost_argmin(const Pyramid &P, u32 a, u32 
 #define ANN_NEAR 8
 #define ANN_IPT 4                       // consecutive ranks per thread: 16-byte loads and stores
 #define ANN_TILE (BLOCK * ANN_IPT)
+// (round 4, with eight lanes per rank in phase 2 -- halo / walk 32 / 24, 64 / 64, 96 / 96, 128 / 128: configs[2] ann_stream +
+// ann_wide 0.77 + 0.63, 0.84 + 0.13, 0.93 + 0.13, 1.03 + 0.13 ms -- its depth-3 intervals are 51 ranks wide --; configs[1]
+// 0.16 + 0.08, 0.17 + 0.08, 0.18 + 0.07, 0.20 + 0.04; the Zipf stand-in 0.32 + 0.14, 0.37 + 0.05, ...)
 #ifndef ANN_HALO
-#define ANN_HALO 32
+#define ANN_HALO 64
 #endif
 #ifndef ANN_LOCAL
-#define ANN_LOCAL 24                    // phase 2 walks at most this far; what is wider goes to ann_wide_kernel
+#define ANN_LOCAL 64                    // phase 2 looks at most this far; what is wider goes to ann_wide_kernel
 #endif
 
 __global__ __launch_bounds__(BLOCK) void ann_stream_kernel(const u32 *__restrict__ lcp, const u32 *__restrict__ doc_off,
@@ -577,29 +581,45 @@ __global__ __launch_bounds__(BLOCK) void ann_stream_kernel(const u32 *__restrict
         }
     }
     __syncthreads();
-    // phase 2: one rank per thread, a short walk over the staged values to either side
+    // phase 2: EIGHT lanes per rank -- lane q looks at the distances q + 1, q + 9, q + 17, ... to either side, the nearest hit
+    // of the eight comes from three shuffles.  (One rank per thread left a tile's two or three dozen ranks to the first
+    // lanes of ONE wavefront, each walking up to 2 x ANN_LOCAL dependent LDS reads while the other wavefronts waited at the
+    // barrier; a whole wavefront per rank was measured before and is slower still: the ranks queue up.)
     const u32 count = work_count;
-    for (u32 wi = threadIdx.x; wi < count; wi += BLOCK) {
+    const u32 sub = threadIdx.x & 7u;
+    for (u32 wi = threadIdx.x >> 3; wi < count; wi += BLOCK / 8) {
         const u32 local = work[wi], at = ANN_HALO + local;
         const u32 v = tile[at];
-        u32 d, x = 0;
-        bool far = false;
-        u32 a = 0;
-        for (d = 1; d <= ANN_LOCAL; d++) {
-            x = tile[at - d];
-            if (x <= v) break;
+        constexpr u32 NONE_D = ANN_LOCAL + 1;
+        u32 d = NONE_D;
+#pragma unroll
+        for (u32 t = 0; t < (ANN_LOCAL + 7) / 8; t++) {
+            const u32 dist = 1u + sub + 8u * t;
+            if (dist <= ANN_LOCAL && d == NONE_D && tile[at - dist] <= v) d = dist;
         }
-        if (d > ANN_LOCAL) far = true;
-        else if (x < v) {                                   // first l-index: width = NSV - PSV
-            u32 e;
-            for (e = 1; e <= ANN_LOCAL; e++)
-                if (tile[at + e] < v) break;
-            if (e > ANN_LOCAL) far = true;
+        d = min(d, (u32)__shfl_xor((int)d, 1, 8));
+        d = min(d, (u32)__shfl_xor((int)d, 2, 8));
+        d = min(d, (u32)__shfl_xor((int)d, 4, 8));
+        bool far = d == NONE_D;
+        u32 a = 0;
+        if (!far && tile[at - d] < v) {                     // first l-index: width = NSV - PSV
+            u32 e = NONE_D;
+#pragma unroll
+            for (u32 t = 0; t < (ANN_LOCAL + 7) / 8; t++) {
+                const u32 dist = 1u + sub + 8u * t;
+                if (dist <= ANN_LOCAL && e == NONE_D && tile[at + dist] < v) e = dist;
+            }
+            e = min(e, (u32)__shfl_xor((int)e, 1, 8));
+            e = min(e, (u32)__shfl_xor((int)e, 2, 8));
+            e = min(e, (u32)__shfl_xor((int)e, 4, 8));
+            if (e == NONE_D) far = true;
             else a = d + e;
         }
-        // (the tile's own stretch of the list: a single counter for all workgroups would serialise them)
-        if (far) wide_list[tile_base + atomicAdd(&far_count, 1u)] = tile_base + local;
-        else ann[tile_base + local] = a;
+        if (sub == 0) {
+            // (the tile's own stretch of the list: a single counter for all workgroups would serialise them)
+            if (far) wide_list[tile_base + atomicAdd(&far_count, 1u)] = tile_base + local;
+            else ann[tile_base + local] = a;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) wide_count[blockIdx.x] = far_count;
