@@ -107,8 +107,11 @@ template <bool CHECK = true> __device__ __forceinline__ void radix_hist_add(u32 
 // Copies of a tile's histogram, one per lane class (lane mod RS_HIST_COPIES): natural-language text puts several lanes
 // of a wavefront on the same few bins, and LDS atomics to one address are served one after the other -- the Zipf
 // stand-in counted at 2.0 TB/s where uniform text reaches 3.7.  Lanes of different classes never meet in a counter.
+// (4 copies when the document number sat in the keys; with text only in them -- the segmented sort -- 2 are as good on the
+// Zipf stand-in, 0.375 against 0.39 ms, and better on uniform text, where the copies cost occupancy: configs[2] 0.49 + 0.20
+// against 0.51 + 0.24 ms for the two histogram kernels, 1 copy 0.53 + 0.20 and 0.585 on the Zipf stand-in)
 #ifndef RS_HIST_COPIES
-#define RS_HIST_COPIES 4
+#define RS_HIST_COPIES 2
 #endif
 template <class K, class Src, bool CHECK = true>
 __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u32 n, int shift, u32 mask, u32 n_tiles,
