@@ -456,7 +456,9 @@ __device__ __forceinline__ u32 pyr_leftmost_argmin(const Pyramid &P, u32 a, u32 
 // ann_wide_kernel: the listed ranks, one per thread, through the pyramid (O(log16 n) groups each).
 // Document starts carry lcp == 0, which bounds every search inside the document; ranks outside
 // [0, n) read as 0.
+#ifndef ANN_NEAR
 #define ANN_NEAR 8
+#endif
 #define ANN_IPT 4                       // consecutive ranks per thread: 16-byte loads and stores
 #define ANN_TILE (BLOCK * ANN_IPT)
 // (round 4, with eight lanes per rank in phase 2 -- halo / walk 32 / 24, 64 / 64, 96 / 96, 128 / 128: configs[2] ann_stream +
