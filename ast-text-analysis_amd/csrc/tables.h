@@ -648,13 +648,21 @@ __global__ __launch_bounds__(BLOCK) void ann_wide_kernel(Pyramid P, u32 n, u32 n
 }
 
 // The three child tables, positions local to the document, 0 = none (easa.py:268-304), in two launches like the
-// annotation table.  child_stream_kernel stages 1024 LCP values + CH_HALO to either side in LDS; a thread walks from
-// each of its 4 ranks to the left until it meets a value <= its own (PSE) and to the right (NSE), at most CH_LOCAL
-// steps, keeping the leftmost minimum of what it passes -- that is up[] and down[] --; next[] is NSE where the
-// values are equal.  Ranks whose walk does not end inside CH_LOCAL steps (the top of the tree, about one in a
-// hundred) go to the tile's list for child_wide_kernel, which uses the pyramid.
-#define CH_HALO 32
-#define CH_LOCAL 24
+// annotation table.  child_stream_kernel stages 1024 LCP values + CH_HALO to either side in LDS.  For every rank: the
+// nearest value <= its own to the left (PSE) and to the right (NSE) and the leftmost minimum of what lies in between --
+// that is up[] and down[] --; next[] is NSE where the values are equal.  Phase 1 decides a thread's 4 ranks from the
+// CH_NEAR neighbours to either side out of registers; what lies further away goes to an LDS work list and is looked at
+// by eight lanes per rank, at most CH_LOCAL ranks to either side (round 4; before, every thread walked up to 24 ranks
+// from each of its 4 ranks, and with a few per cent of wide intervals nearly every wavefront waited for a full-length
+// walk at every one of the four: 0.59 ms for the 64 MiB document).  Ranks wider still (the top of the tree) go to the
+// tile's list for child_wide_kernel, which uses the pyramid.
+#define CH_NEAR 8
+#ifndef CH_HALO
+#define CH_HALO 64
+#endif
+#ifndef CH_LOCAL
+#define CH_LOCAL 64
+#endif
 #define CH_IPT 4
 #define CH_TILE (BLOCK * CH_IPT)
 
@@ -682,9 +690,10 @@ __global__ __launch_bounds__(BLOCK) void child_stream_kernel(Pyramid P, const u3
                                                              u32 *__restrict__ wide_count)
 {
     __shared__ __attribute__((aligned(16))) u32 tile[CH_TILE + 2 * CH_HALO];
-    __shared__ u32 far_count;
+    __shared__ u32 work[CH_TILE];
+    __shared__ u32 far_count, work_count;
     const u32 *lcp = P.ptr[0];
-    if (threadIdx.x == 0) far_count = 0;
+    if (threadIdx.x == 0) { far_count = 0; work_count = 0; }
     const u32 tile_base = blockIdx.x * CH_TILE;
     const u32 k0 = tile_base + threadIdx.x * CH_IPT;
     const u32 padded = (n + PYR_FAN - 1u) & ~(PYR_FAN - 1u);
@@ -710,64 +719,159 @@ __global__ __launch_bounds__(BLOCK) void child_stream_kernel(Pyramid P, const u3
         }
     }
     __syncthreads();
+    // phase 1: every thread decides its 4 ranks from the CH_NEAR neighbours to either side (registers); a rank whose PSE
+    // or NSE lies further away goes to the work list
     if (k0 < n) {
         // the document of the thread's first rank (the others step forward from it)
         u32 d = n_docs > 1 ? doc_of(doc_off, n_docs, k0) : 0u;
         u32 seg = n_docs > 1 ? doc_off[d] : 0u, seg_end = n_docs > 1 ? doc_off[d + 1] : n;
+        u32 c[CH_IPT + 2 * CH_NEAR];
+#pragma unroll
+        for (int q = 0; q < (CH_IPT + 2 * CH_NEAR) / 4; q++) {
+            const uint4 x = *reinterpret_cast<const uint4 *>(&tile[CH_HALO + threadIdx.x * CH_IPT - CH_NEAR + 4 * q]);
+            c[4 * q] = x.x; c[4 * q + 1] = x.y; c[4 * q + 2] = x.z; c[4 * q + 3] = x.w;
+        }
         u32 o_up[CH_IPT], o_dn[CH_IPT], o_nx[CH_IPT];
-        bool all_local = k0 + CH_IPT <= n;
+        u32 later = 0;                                      // bit e: rank k0 + e is left to phase 2
 #pragma unroll
         for (int e = 0; e < CH_IPT; e++) {
             const u32 k = k0 + e;
             o_up[e] = o_dn[e] = o_nx[e] = 0;
             if (k >= n) break;
             while (k >= seg_end) { d++; seg = seg_end; seg_end = doc_off[d + 1]; }
-            const u32 at = CH_HALO + threadIdx.x * CH_IPT + e;
-            const u32 v = tile[at];
+            const int i = CH_NEAR + e;                      // c[i] = lcp[k]
+            const u32 v = c[i];
             // to the left: nearest value <= v (PSE) and the leftmost minimum of the run before it
-            bool far = false;
-            u32 j, best = NONE_U32, best_at = 0;
             if (k > seg) {
-                for (j = 1; j <= CH_LOCAL; j++) {
-                    const u32 x = tile[at - j];
-                    if (x <= v) break;
-                    if (x <= best) { best = x; best_at = k - j; }        // (<=: the leftmost of equal minima)
+                u32 j = 0, best = NONE_U32, bj = 0;
+#pragma unroll
+                for (int t = 1; t <= CH_NEAR; t++) {
+                    const u32 x = c[i - t];
+                    if (j == 0) {
+                        if (x <= v) j = (u32)t;
+                        else if (x <= best) { best = x; bj = (u32)t; }   // (<=: the leftmost of equal minima)
+                    }
                 }
-                if (j > CH_LOCAL) far = true;
-                else if (j > 1) o_up[e] = best_at - seg;                // (pse = k - j >= seg: the document's first rank holds 0)
+                if (j == 0) { later |= 1u << e; continue; }
+                if (j > 1) o_up[e] = k - bj - seg;          // (pse = k - j >= seg: the document's first rank holds 0)
             }
             // to the right: nearest value <= v (NSE), inside the document, and the leftmost minimum before it
-            if (!far) {
-                best = NONE_U32;
-                for (j = 1; j <= CH_LOCAL; j++) {
-                    const u32 x = tile[at + j];
-                    if (x <= v) break;
-                    if (x < best) { best = x; best_at = k + j; }
+            {
+                u32 j = 0, best = NONE_U32, bj = 0;
+#pragma unroll
+                for (int t = 1; t <= CH_NEAR; t++) {
+                    const u32 x = c[i + t];
+                    if (j == 0) {
+                        if (x <= v) j = (u32)t;
+                        else if (x < best) { best = x; bj = (u32)t; }
+                    }
                 }
-                if (j > CH_LOCAL) far = true;
-                else if (k + j < seg_end) {                              // (a rank of the next document, or past the end: no NSE)
-                    if (tile[at + j] == v) o_nx[e] = k + j - seg;
-                    if (j > 1) o_dn[e] = best_at - seg;
+                if (j == 0) { later |= 1u << e; continue; }
+                if (k + j < seg_end) {                      // (a rank of the next document, or past the end: no NSE)
+                    if (c[i + j] == v) o_nx[e] = k + j - seg;
+                    if (j > 1) o_dn[e] = k + bj - seg;
                 }
-            }
-            if (far) {
-                all_local = false;
-                wide_list[tile_base + atomicAdd(&far_count, 1u)] = k;
-                o_up[e] = NONE_U32;                                      // (marks the rank for the scalar path below)
             }
         }
-        if (all_local) {
+        if (later == 0 && k0 + CH_IPT <= n) {
             *reinterpret_cast<uint4 *>(up + k0) = uint4{o_up[0], o_up[1], o_up[2], o_up[3]};
             *reinterpret_cast<uint4 *>(down + k0) = uint4{o_dn[0], o_dn[1], o_dn[2], o_dn[3]};
             *reinterpret_cast<uint4 *>(next + k0) = uint4{o_nx[0], o_nx[1], o_nx[2], o_nx[3]};
         } else {
 #pragma unroll
             for (int e = 0; e < CH_IPT; e++) {
-                if (k0 + e >= n || o_up[e] == NONE_U32) continue;
+                if (k0 + e >= n) break;
+                if ((later >> e) & 1u) { work[atomicAdd(&work_count, 1u)] = threadIdx.x * CH_IPT + e; continue; }
                 up[k0 + e] = o_up[e];
                 down[k0 + e] = o_dn[e];
                 next[k0 + e] = o_nx[e];
             }
+        }
+    }
+    __syncthreads();
+    // phase 2: eight lanes per rank (as in ann_stream_kernel) -- lane q looks at the distances q + 1, q + 9, ... up to CH_LOCAL;
+    // the nearest value <= v comes from three shuffles, the leftmost minimum in front of it from three more (value and
+    // distance in one 64-bit word: equal minima are told apart by the distance)
+    const u32 count = work_count;
+    const u32 sub = threadIdx.x & 7u;
+    for (u32 wi = threadIdx.x >> 3; wi < count; wi += BLOCK / 8) {
+        const u32 local = work[wi], at = CH_HALO + local, k = tile_base + local;
+        const u32 v = tile[at];
+        u32 seg = 0, seg_end = n;
+        if (n_docs > 1) {
+            const u32 d = doc_of(doc_off, n_docs, k);
+            seg = doc_off[d];
+            seg_end = doc_off[d + 1];
+        }
+        constexpr u32 NONE_D = CH_LOCAL + 1;
+        auto group_min = [](u32 x) -> u32 {
+            x = min(x, (u32)__shfl_xor((int)x, 1, 8));
+            x = min(x, (u32)__shfl_xor((int)x, 2, 8));
+            return min(x, (u32)__shfl_xor((int)x, 4, 8));
+        };
+        auto group_min64 = [](u64 x) -> u64 {
+#pragma unroll
+            for (int m = 1; m <= 4; m <<= 1) {
+                const u64 y = ((u64)(u32)__shfl_xor((int)(u32)(x >> 32), m, 8) << 32) | (u32)__shfl_xor((int)(u32)x, m, 8);
+                x = y < x ? y : x;
+            }
+            return x;
+        };
+        bool far = false;
+        u32 u = 0, dn = 0, nx = 0;
+        if (k > seg) {
+            u32 j = NONE_D;
+#pragma unroll
+            for (u32 t = 0; t < (CH_LOCAL + 7) / 8; t++) {
+                const u32 dist = 1u + sub + 8u * t;
+                if (dist <= CH_LOCAL && j == NONE_D && tile[at - dist] <= v) j = dist;
+            }
+            j = group_min(j);
+            if (j == NONE_D) far = true;
+            else if (j > 1) {
+                // the leftmost minimum of the ranks k - j + 1 .. k - 1: the smallest value, of equal ones the LARGEST distance
+                u64 best = ~0ull;
+#pragma unroll
+                for (u32 t = 0; t < (CH_LOCAL + 7) / 8; t++) {
+                    const u32 dist = 1u + sub + 8u * t;
+                    if (dist < j) {
+                        const u64 w = ((u64)tile[at - dist] << 32) | (u32)(~dist);
+                        best = w < best ? w : best;
+                    }
+                }
+                best = group_min64(best);
+                u = k - ~(u32)best - seg;
+            }
+        }
+        if (!far) {
+            u32 j = NONE_D;
+#pragma unroll
+            for (u32 t = 0; t < (CH_LOCAL + 7) / 8; t++) {
+                const u32 dist = 1u + sub + 8u * t;
+                if (dist <= CH_LOCAL && j == NONE_D && tile[at + dist] <= v) j = dist;
+            }
+            j = group_min(j);
+            if (j == NONE_D) far = true;
+            else if (k + j < seg_end) {                     // (a rank of the next document, or past the end: no NSE)
+                if (tile[at + j] == v) nx = k + j - seg;
+                if (j > 1) {
+                    u64 best = ~0ull;                       // ... of equal minima the SMALLEST distance
+#pragma unroll
+                    for (u32 t = 0; t < (CH_LOCAL + 7) / 8; t++) {
+                        const u32 dist = 1u + sub + 8u * t;
+                        if (dist < j) {
+                            const u64 w = ((u64)tile[at + dist] << 32) | dist;
+                            best = w < best ? w : best;
+                        }
+                    }
+                    best = group_min64(best);
+                    dn = k + (u32)best - seg;
+                }
+            }
+        }
+        if (sub == 0) {
+            if (far) wide_list[tile_base + atomicAdd(&far_count, 1u)] = k;
+            else { up[k] = u; down[k] = dn; next[k] = nx; }
         }
     }
     __syncthreads();
