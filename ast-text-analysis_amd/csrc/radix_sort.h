@@ -50,7 +50,12 @@ struct RsSeg {
     u32 n_docs = 0;                     // 0: one segment, tiles of RS_TILE pairs from position 0 on
     u32 n_groups = 0;                   // all documents' groups
     u32 shards = 1;                     // copies of a document's digit totals (see RS_TOTAL_SHARDS)
+    // the spine: documents of at most RS_SPINE_DOC_GROUPS groups take radix_spine_docs_kernel (one workgroup each), the
+    // n_big larger ones -- listed in big_docs -- the column-parallel kernel
+    const u32 *big_docs = nullptr;
+    u32 n_big = 0;
 };
+#define RS_SPINE_DOC_GROUPS 64          // (2 M pairs)
 // the pairs of (virtual) tile `tile`: [base, base + count)
 __device__ __forceinline__ void rs_tile_range(const RsSeg &seg, u32 n, u32 tile, u32 &base, u32 &count)
 {
@@ -201,8 +206,9 @@ __global__ __launch_bounds__(BLOCK) void radix_spine_kernel(const u32 *__restric
     __shared__ u32 base_of[RS_BINS];
     __shared__ u32 part_total[RS_SPINE_PARTS][RS_SPINE_COLS];
     __shared__ u32 lds4[WAVES_PER_BLOCK];
-    // (segmented: blockIdx.y = the document -- its groups, its row of totals, its first output position)
-    const u32 doc = blockIdx.y;
+    // (segmented: blockIdx.y = the document, or its place in the list of large documents -- its groups, its row of totals,
+    // its first output position)
+    const u32 doc = seg.big_docs ? seg.big_docs[blockIdx.y] : blockIdx.y;
     const u32 g_first = seg.n_docs ? seg.doc_group0[doc] : 0u;
     const u32 g_count = seg.n_docs ? seg.doc_group0[doc + 1] - g_first : n_groups;
     const u32 shards = seg.n_docs ? seg.shards : (u32)RS_TOTAL_SHARDS;
@@ -249,6 +255,7 @@ __global__ __launch_bounds__(BLOCK) void radix_spine_docs_kernel(const u32 *__re
     __shared__ u32 lds4[WAVES_PER_BLOCK];
     const u32 doc = blockIdx.x;
     const u32 g0 = seg.doc_group0[doc], g1 = seg.doc_group0[doc + 1];
+    if (g1 - g0 > (u32)RS_SPINE_DOC_GROUPS) return;     // (a large document: the column-parallel kernel)
     const size_t row0 = (size_t)doc * seg.shards * RS_BINS;
     u32 t = 0;
     for (u32 k = 0; k < seg.shards; k++) {
@@ -530,11 +537,16 @@ static int radix_sort_pairs(Ctx &ctx, SortBufs<K> &b, u32 n, int bits, int begin
             HIP_CHECK(hipGetLastError());
             if (prof) ctx.prof->end(ctx.stream);
         }
-        if (seg.n_docs && n_groups <= 64u * seg.n_docs)     // (documents of at most 2 M pairs on average)
-            LAUNCH(ctx, radix_spine_docs_kernel, seg.n_docs, (const u32 *)group_sum, (const u32 *)tot, tot_next, group_prefix, seg);
-        else
-            LAUNCH(ctx, radix_spine_kernel, dim3(RS_BINS / RS_SPINE_COLS, seg.n_docs ? seg.n_docs : 1u), (const u32 *)group_sum,
-                   n_groups, (const u32 *)tot, tot_next, group_prefix, seg);
+        if (seg.n_docs) {
+            if (seg.n_big < seg.n_docs)
+                LAUNCH(ctx, radix_spine_docs_kernel, seg.n_docs, (const u32 *)group_sum, (const u32 *)tot, tot_next, group_prefix, seg);
+            if (seg.n_big)
+                LAUNCH(ctx, radix_spine_kernel, dim3(RS_BINS / RS_SPINE_COLS, seg.n_big), (const u32 *)group_sum, n_groups,
+                       (const u32 *)tot, tot_next, group_prefix, seg);
+        } else {
+            LAUNCH(ctx, radix_spine_kernel, dim3(RS_BINS / RS_SPINE_COLS, 1u), (const u32 *)group_sum, n_groups, (const u32 *)tot,
+                   tot_next, group_prefix, seg);
+        }
         if (!ctx.dry) {
             if (prof) ctx.prof->begin(name_scatter, ctx.stream);
             const dim3 grid(8 * ((n_tiles + 7) / 8));

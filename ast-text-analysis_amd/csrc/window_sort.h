@@ -114,38 +114,56 @@ struct SegRanks {
     const u32 *doc_off = nullptr;
     u32 n_docs = 0;
 };
-__device__ __forceinline__ void seg_doc_bounds(const SegRanks &sr, u32 d0, u32 j, u32 &lo, u32 &hi)
+// (the document of the stretch's first rank and its range of ranks, staged in LDS by the workgroup: nearly every rank of
+// the stretch lies in it, and the question costs two LDS reads instead of two global loads)
+struct DocHint {
+    u32 d0, lo, hi;
+};
+__device__ __forceinline__ void seg_doc_bounds(const SegRanks &sr, const DocHint &h, u32 j, u32 &lo, u32 &hi)
 {
-    u32 d = d0;
+    if (j < h.hi) { lo = h.lo; hi = h.hi; return; }
+    u32 d = h.d0 + 1u;
     while (d + 1 < sr.n_docs && j >= sr.doc_off[d + 1]) d++;
     lo = sr.doc_off[d];
     hi = sr.doc_off[d + 1];
 }
+__device__ __forceinline__ DocHint doc_hint_of_rank(const u32 *__restrict__ doc_off, u32 n_docs, u32 j)
+{
+    const u32 d = doc_of_rank(doc_off, n_docs, j);
+    return DocHint{d, doc_off[d], doc_off[d + 1]};
+}
 
 // rank j (key k, the key before it kp, its suffix v) opens a k-gram bucket of its document?  Then write the mark(s).
-// (d0, by_rank only: the document of a rank at or in front of j -- the first rank of the workgroup's stretch)
+// (hint, by_rank only: the document of the first rank of the workgroup's stretch)
 // (SEG: 0 / 1 = km.by_rank known at compile time, 2 = read at run time)
 template <class K, int SEG = 2>
-__device__ __forceinline__ void kg_mark_key(const KgMark &km, int w, int b, int spare, u32 j, K k, K kp, u32 v, u32 d0 = 0)
+__device__ __forceinline__ void kg_mark_key(const KgMark &km, int w, int b, int spare, u32 j, K k, K kp, u32 v,
+                                            const DocHint &hint = DocHint{0u, 0u, 0u})
 {
     const int top = spare + (w - km.k) * b;
     const bool same = j != 0 && (K)(k >> top) == (K)(kp >> top);
-    u32 d = 0;
+    u32 d = 0, dlo;
     if (SEG == 1 || (SEG == 2 && km.by_rank)) {
         // equal class codes: the same bucket -- unless this is the first rank of a document; the key before it is then the
         // last of the document before, terminator first, and so is this one
         if (same && ((u32)(k >> (spare + (w - 1) * b)) & ((1u << b) - 1u)) != km.A - 1u) return;
-        d = d0;
-        while (d + 1 < km.n_docs && j >= km.doc_off[d + 1]) d++;
-        if (same && j != km.doc_off[d]) return;
+        d = hint.d0;
+        dlo = hint.lo;
+        if (j >= hint.hi) {                             // (a seam inside the stretch)
+            d++;
+            while (d + 1 < km.n_docs && j >= km.doc_off[d + 1]) d++;
+            dlo = km.doc_off[d];
+        }
+        if (same && j != dlo) return;
     } else {
         if (same) return;
         d = km.n_docs > 1 ? (u32)(k >> (w * b + spare)) : 0u;   // (one document: no bits above the window)
+        dlo = km.doc_off[d];
     }
     u32 code = 0;
     for (int q = 0; q < km.k; q++) code = code * km.A + ((u32)(k >> (spare + (w - 1 - q) * b)) & ((1u << b) - 1u));
     if (code >= km.bins) return;                        // (only in a speculative build that assumed the wrong alphabet)
-    const u32 jl = j - km.doc_off[d];
+    const u32 jl = j - dlo;
     if (!km.pairs) { km.kg[(size_t)d * (km.bins + 1) + code] = jl; return; }
     reinterpret_cast<uint2 *>(km.kg)[(size_t)d * (km.bins + 1) + code] = uint2{jl, v};
     const int top3 = top + b;                           // the level above: k - 1 symbols
@@ -737,11 +755,11 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     __shared__ uint16_t dec_lds[HT ? HT_DEC_SIZE : 1];  // the decode table
     __shared__ u32 term_bits[HT ? TB_WORDS : 1];        // by staged index: the key holds a terminator
     __shared__ uint8_t dep_tile[HT ? BLOCK * PLACE_IPT : 1];   // whole symbols of the stretch's keys
-    __shared__ u32 kg_d0;                               // (segmented sort) the document of the stretch's first rank
+    __shared__ DocHint kg_hint;                         // (segmented sort) the document of the stretch's first rank
     if (threadIdx.x < BLOCK * PLACE_IPT / 32) keep_bits[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         n_keep = 0; n_work = 0;
-        kg_d0 = sr.n_docs ? doc_of_rank(sr.doc_off, sr.n_docs, blockIdx.x * (BLOCK * PLACE_IPT)) : 0u;
+        kg_hint = sr.n_docs ? doc_hint_of_rank(sr.doc_off, sr.n_docs, blockIdx.x * (BLOCK * PLACE_IPT)) : DocHint{0u, 0u, 0u};
     }
     if constexpr (HT) {
         for (u32 i = threadIdx.x; i < HT_DEC_SIZE; i += BLOCK) dec_lds[i] = f.ht_dec[i];
@@ -833,6 +851,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
         }
     }
     __syncthreads();                                    // (the staged keys: the test for large groups reads them `limit` places away)
+    const DocHint hint = kg_hint;
     if (j0 < m) {
         if constexpr (!HT) {
             // (the first stretch has no left halo: rank 0 has no key before it)
@@ -853,7 +872,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
         if (OPTIMISTIC && km.kg) {                      // k-gram bucket starts, read off the keys (see KgMark)
 #pragma unroll
             for (int e = 0; e < PLACE_IPT; e++)
-                if (j0 + e < m) kg_mark_key<K>(km, w, b, spare, j0 + e, k[e + 1], k[e], v[e], kg_d0);
+                if (j0 + e < m) kg_mark_key<K>(km, w, b, spare, j0 + e, k[e + 1], k[e], v[e], hint);
         }
         // every rank: final (its key differs from both neighbours'), a member of a large group (sorted keys: an equal key
         // `limit` places away means more than `limit` equal keys around it -- natural-language text: half of the suffixes;
@@ -870,7 +889,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
             else if (k[e] == k[e + 1] && k[e + 2] == k[e + 1]) {                   // (tied on both sides: worth two more reads)
                 bool big;
                 u32 dlo = 0, dhi = m;                                              // (the sorted range the rank lies in)
-                if (sr.n_docs) seg_doc_bounds(sr, kg_d0, j, dlo, dhi);
+                if (sr.n_docs) seg_doc_bounds(sr, hint, j, dlo, dhi);
                 if constexpr (limit <= PLACE_HALO) {                               // (out of the staged keys)
                     const u32 at = PLACE_HALO + threadIdx.x * PLACE_IPT + e;
                     big = (j >= dlo + limit && key_tile[at - limit] == k[e + 1]) || (j + limit < dhi && key_tile[at + limit] == k[e + 1]);
@@ -1178,7 +1197,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     __shared__ u32 fl[FIN_WORDS];                       // bucket starts, by staged index
     __shared__ u32 keep_bits[FIN_WORDS], gs_bits[FIN_WORDS];
     __shared__ u32 n_keep, n_work;
-    __shared__ u32 kg_d0;                               // (segmented sort) the document of the stretch's first rank
+    __shared__ DocHint kg_hint;                         // (segmented sort) the document of the stretch's first rank
     __shared__ uint8_t dec8[HT ? HT_DEC_SIZE : 1];      // variable-length keys: the decode table (length, terminator bit)
     __shared__ uint8_t wdep[HT ? FIN_CHUNK + FIN_G : 1];   // ... the whole symbols of the tied members' keys, by work list index
     if constexpr (HT)
@@ -1193,7 +1212,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     if (tid < FIN_WORDS) { fl[tid] = 0; keep_bits[tid] = 0; gs_bits[tid] = 0; }
     if (tid == 0) {
         n_keep = 0; n_work = 0;
-        if constexpr (SEG) kg_d0 = doc_of_rank(a.km.doc_off, a.km.n_docs, c0);
+        if constexpr (SEG) kg_hint = doc_hint_of_rank(a.km.doc_off, a.km.n_docs, c0);
     }
     // ---- stage the pairs ---------------------------------------------------------------------------
     K key[HELD];
@@ -1343,11 +1362,12 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
         if ((own >> e) & 1u) { kt[dest[e]] = key[e]; vt[dest[e]] = val[e]; }
     __syncthreads();
     // ---- placement on the staged, sorted keys ----------------------------------------------------------
+    const DocHint hint = SEG ? kg_hint : DocHint{0u, 0u, 0u};
     const KeyNeqWindowIn<K> f{a.keys, a.rep_t, a.ones, a.highs};   // (keys / vals: never read -- everything the tie code touches is staged; a null pointer here crashes hipcc 7.2)
     const int w = a.w, b = a.b, spare = a.spare;
     u32 my_keep = 0;                                    // suffixes this thread left to the rounds (summed per wavefront at the end)
     auto kg_mark = [&](u32 j, K k, K kp, u32 v) {       // k-gram bucket starts, read off the keys (see KgMark)
-        kg_mark_key<K, SEG ? 1 : 0>(a.km, w, b, spare, j, k, kp, v, SEG ? kg_d0 : 0u);
+        kg_mark_key<K, SEG ? 1 : 0>(a.km, w, b, spare, j, k, kp, v, hint);
     };
     // rank `base + i` (one of this workgroup's): returns true when it is final here (suffix and LCP entry in sa_o / lcp_o,
     // to be stored by the caller); a rank handed to the rounds or a member of a small tie group is dealt with inside
@@ -1401,7 +1421,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
         {
             const int lo = i - (int)limit, hi = i + (int)limit;
             u32 dlo = 0, dhi = m;                       // (the sorted range the rank lies in)
-            if constexpr (SEG) seg_doc_bounds(SegRanks{a.km.doc_off, a.km.n_docs}, kg_d0, j, dlo, dhi);
+            if constexpr (SEG) seg_doc_bounds(SegRanks{a.km.doc_off, a.km.n_docs}, hint, j, dlo, dhi);
             if (lo >= 1 && j >= dlo + limit) big = kt[lo] == k;
             if (!big && hi <= (int)(FIN_LEFT + FIN_CHUNK + FIN_G) && j + limit < dhi) big = kt[hi] == k;   // (staged up to there)
         }
@@ -2394,7 +2414,9 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
         // with / without: 256 x 1 MiB 7.3 / 7.8 ms, 1 024 x 256 KiB 6.9 / 7.3, 4 096 x 64 KiB 7.3 / 7.8, 8 192 x 32 KiB 7.9 / 8.4,
         // 16 384 x 16 KiB 7.9 / 7.7 -- short tiles and mostly empty groups)
         const u32 per_groups = getenv("EAST_HIP_SEG_DIV") ? (u32)std::max(1, atoi(getenv("EAST_HIP_SEG_DIV"))) : 1u;   // (experiments)
-        if (can && g_seg_mode != 0 && (g_seg_mode == 1 || docs.n_docs <= flat_groups / per_groups + 1)) {
+        // (... and five or more of them: the document number of two to four documents costs the key a bit or two, less than
+        // the segments' short tiles cost the passes -- 2 x 32 MiB: 1.71 ms with, 1.68 without)
+        if (can && g_seg_mode != 0 && (g_seg_mode == 1 || (docs.n_docs >= 5 && docs.n_docs <= flat_groups / per_groups + 1))) {
             RsSeg &seg = docs.seg;
             seg.n_docs = docs.n_docs;
             seg.doc_off = docs.doc_off;
@@ -2404,6 +2426,7 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
             if (ctx.dry) {
                 seg.n_groups = flat_groups + docs.n_docs;
                 seg.group_doc = ar.alloc<u32>(seg.n_groups);
+                seg.big_docs = ar.alloc<u32>(docs.n_docs);
             } else {
                 std::vector<u32> &hs = ctx.seg_host;        // (lives as long as the build: the copies below are asynchronous)
                 hs.assign((size_t)docs.n_docs + 1, 0u);
@@ -2415,8 +2438,18 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
                 hs.resize((size_t)docs.n_docs + 1 + seg.n_groups);
                 for (u32 d = 0; d < docs.n_docs; d++)
                     for (u32 g = hs[d]; g < hs[d + 1]; g++) hs[(size_t)docs.n_docs + 1 + g] = d;
+                // (the documents of many groups, for the spine: see RsSeg)
+                const size_t big_at = hs.size();
+                for (u32 d = 0; d < docs.n_docs; d++)
+                    if (hs[d + 1] - hs[d] > (u32)RS_SPINE_DOC_GROUPS) hs.push_back(d);
+                seg.n_big = (u32)(hs.size() - big_at);
                 HIP_CHECK(hipMemcpyAsync(d_group0, hs.data(), ((size_t)docs.n_docs + 1) * 4, hipMemcpyHostToDevice, ctx.stream));
                 HIP_CHECK(hipMemcpyAsync(d_group_doc, hs.data() + docs.n_docs + 1, (size_t)seg.n_groups * 4, hipMemcpyHostToDevice, ctx.stream));
+                if (seg.n_big) {
+                    u32 *d_big = ar.alloc<u32>(seg.n_big);
+                    seg.big_docs = d_big;
+                    HIP_CHECK(hipMemcpyAsync(d_big, hs.data() + big_at, (size_t)seg.n_big * 4, hipMemcpyHostToDevice, ctx.stream));
+                }
             }
             docs.bits = 0;                              // (no document number in the keys)
         }

@@ -651,6 +651,32 @@ def test_refinement_rounds_in_lds_and_by_the_global_sort(hip, oracle, suffix_sor
         assert lib.east_hip_debug_set_lds_rounds(1) == 0
 
 
+def test_segmented_sort_of_unequal_documents(hip, oracle, suffix_sort_path):
+    """Documents of very different lengths in one shard -- two of more than 64 histogram groups (2 M suffixes: their
+    spine is the column-parallel kernel), one of a few groups, one of less than a tile, one of a few symbols -- through
+    the segmented first-level sort where the path or the sizes ask for it (csrc/radix_sort.h: RsSeg).  All six tables of
+    every document bit-exact against the oracle."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(8642)
+    vocab = synthetic.zipf_vocabulary(rng, size=2000, exponent=1.0)
+    docs = [synthetic.word_stream_document(rng, 2_600_000, want_text=False)[1:], synthetic.zipf_document(rng, 40_000, vocab),
+            synthetic.word_stream_document(rng, 300_000, want_text=False)[1:], synthetic.zipf_document(rng, 900, vocab),
+            synthetic.zipf_document(rng, 2_300_000, vocab), synthetic.word_stream_document(rng, 12, want_text=False)[1:]]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    index = hip_backend.HipIndex()
+    for _ in range(2):                                   # (the second build is the speculative one)
+        index.build(sym, off, np.array([d[1] for d in docs]))
+        info = index.info()
+        if suffix_sort_path in ("window_sort", "window_sort_seg", "window_sort_seg_unfused"):
+            assert info["window_sorted"] == 1 and info["seg_sort"] == 1, info     # (by size, too: 6 documents, 160 groups)
+        for d in range(len(docs)):
+            o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+            t = index.tables(d)
+            for name in TABLES:
+                assert np.array_equal(t[name], getattr(o, name)), (name, d, info)
+
+
 @pytest.mark.parametrize("document_number_in_keys", [False, True])
 def test_first_build_plans_the_window_from_its_own_text(hip, oracle, suffix_sort_path, document_number_in_keys):
     """The first build on a fresh handle takes the window width and the fused finish from a sample of its own text
