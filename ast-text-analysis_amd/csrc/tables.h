@@ -692,9 +692,17 @@ __global__ __launch_bounds__(BLOCK) void child_stream_kernel(Pyramid P, const u3
     __shared__ __attribute__((aligned(16))) u32 tile[CH_TILE + 2 * CH_HALO];
     __shared__ u32 work[CH_TILE];
     __shared__ u32 far_count, work_count;
+    __shared__ u32 tile_doc[3];                         // the document of the tile's first rank, its first rank, its end
     const u32 *lcp = P.ptr[0];
-    if (threadIdx.x == 0) { far_count = 0; work_count = 0; }
     const u32 tile_base = blockIdx.x * CH_TILE;
+    if (threadIdx.x == 0) {
+        far_count = 0; work_count = 0;
+        // (one binary search per workgroup instead of one per thread: nearly every rank of the tile lies in this document)
+        const u32 d = n_docs > 1 ? doc_of(doc_off, n_docs, tile_base < n ? tile_base : n - 1u) : 0u;
+        tile_doc[0] = d;
+        tile_doc[1] = n_docs > 1 ? doc_off[d] : 0u;
+        tile_doc[2] = n_docs > 1 ? doc_off[d + 1] : n;
+    }
     const u32 k0 = tile_base + threadIdx.x * CH_IPT;
     const u32 padded = (n + PYR_FAN - 1u) & ~(PYR_FAN - 1u);
     {   // ranks outside [0, n) read as 0, which ends every walk
@@ -723,8 +731,8 @@ __global__ __launch_bounds__(BLOCK) void child_stream_kernel(Pyramid P, const u3
     // or NSE lies further away goes to the work list
     if (k0 < n) {
         // the document of the thread's first rank (the others step forward from it)
-        u32 d = n_docs > 1 ? doc_of(doc_off, n_docs, k0) : 0u;
-        u32 seg = n_docs > 1 ? doc_off[d] : 0u, seg_end = n_docs > 1 ? doc_off[d + 1] : n;
+        u32 d = tile_doc[0], seg = tile_doc[1], seg_end = tile_doc[2];
+        while (k0 >= seg_end) { d++; seg = seg_end; seg_end = doc_off[d + 1]; }
         u32 c[CH_IPT + 2 * CH_NEAR];
 #pragma unroll
         for (int q = 0; q < (CH_IPT + 2 * CH_NEAR) / 4; q++) {
@@ -797,9 +805,10 @@ __global__ __launch_bounds__(BLOCK) void child_stream_kernel(Pyramid P, const u3
     for (u32 wi = threadIdx.x >> 3; wi < count; wi += BLOCK / 8) {
         const u32 local = work[wi], at = CH_HALO + local, k = tile_base + local;
         const u32 v = tile[at];
-        u32 seg = 0, seg_end = n;
-        if (n_docs > 1) {
-            const u32 d = doc_of(doc_off, n_docs, k);
+        u32 seg = tile_doc[1], seg_end = tile_doc[2];
+        if (k >= seg_end) {
+            u32 d = tile_doc[0] + 1u;
+            while (k >= doc_off[d + 1]) d++;
             seg = doc_off[d];
             seg_end = doc_off[d + 1];
         }
