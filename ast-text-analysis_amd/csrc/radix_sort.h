@@ -40,7 +40,7 @@
 // cut per document (the last one of a document is short) and so are the histogram groups (the last group of a document
 // may hold fewer than RS_GROUP tiles with pairs in them: "virtual" tiles, a workgroup that returns at once); a tile's
 // digit base is  doc_off[d] + (the document's pairs with smaller digits) + (the digit in the document's earlier tiles),
-// which is the spine's column scan run per document.  Meant for a handful to a few thousand large documents; a shard of
+// which is the spine's column scan run per document.  Meant for documents of a histogram group or more (window_sort.h decides); a shard of
 // many small ones keeps the document number in the key.
 #define RS_SEG_MAX_DOCS 65535              // (the spine's grid: one row of workgroups per document)
 struct RsSeg {

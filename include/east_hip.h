@@ -293,8 +293,8 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes);
  * set them while no build is in flight on any handle. */
 int east_hip_debug_set_window_sort(int enabled);
 /* Test knob: the first-level sort of a shard of several documents keeps every document in its own range pass by pass
- * (csrc/radix_sort.h: RsSeg -- no document number in the keys) -- -1 (default): where the documents are few and large,
- * 0: never, 1: wherever it can be done (2 .. 4096 documents of any size). */
+ * (csrc/radix_sort.h: RsSeg -- no document number in the keys) -- -1 (default): five documents or more of 32 768 symbols or more on average,
+ * 0: never, 1: wherever it can be done (2 .. 65 535 documents of any size). */
 int east_hip_debug_set_segmented_sort(int mode);
 /* Test knob: 0 = the tie-refinement rounds sort every group with the global radix sort; 1 (default) = groups
  * that fit a workgroup's LDS are sorted there (csrc/lds_group_sort.h), the global sort takes the rest. */

@@ -30,7 +30,7 @@ def suffix_sort_path(request, hip):
     finish, with the window sort switched off, so that DC3 -- the fallback for repetitive inputs -- stays covered on
     every input as well, and (the `_seg` paths) through the segmented first-level sort -- every document sorted inside
     its own range, no document number in the keys (csrc/radix_sort.h: RsSeg; by itself the build takes it for a few
-    large documents) -- wherever a shard holds 2 .. 4096 documents.
+    large documents) -- wherever a shard holds 2 .. 65 535 documents.
     (Tests that read `suffix_sort_path` get "window_sort" for the first two.)"""
     lib = hip.load()
     seg = "_seg" in request.param
