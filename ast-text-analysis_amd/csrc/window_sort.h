@@ -1046,7 +1046,7 @@ template <class K> struct FinishArgs {
     int w, b, spare, low_bits;
     u32 inv_b;                              // ceil(2^16 / b): (x * inv_b) >> 16 = x / b for the bit positions of a key
     K rep_t, ones, highs;                   // KeyNeqWindowIn's constants over all w symbol fields
-    K top_rep_t, top_ones, top_highs;       // ... over the fields that lie wholly inside the top part
+    K top_mask;                             // the bits of the fields that lie wholly inside the top part
     int kg_top;                             // 1: the k-gram class code reaches below the top part (marks inside a handed-over bucket would be missed)
     u32 *order_g, *lcp_g;
     u64 *keep, *gstart;                     // one bit per rank (zeroed; OR-ed into): left to the rounds / first of its group
@@ -1387,8 +1387,8 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
             bool constant;
             if constexpr (HT) constant = sc.term_top;
             else {
-                const K xt = k ^ a.top_rep_t;
-                constant = ((K)(xt - a.top_ones) & ~xt & a.top_highs) != 0;
+                const K xt = k ^ (a.rep_t & a.top_mask);
+                constant = ((K)(xt - (a.ones & a.top_mask)) & ~xt & (a.highs & a.top_mask)) != 0;
             }
             if (constant) return true;                  // a constant bucket: final as it stands
             note_depth(sc.top);
@@ -2032,13 +2032,9 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         fa.w = w; fa.b = bt; fa.spare = spare; fa.low_bits = low_bits;
         fa.inv_b = (65536u + (u32)bt - 1u) / (u32)bt;
         fa.rep_t = starts.rep_t; fa.ones = starts.ones; fa.highs = starts.highs;
-        fa.top_rep_t = fa.top_ones = fa.top_highs = 0;
+        fa.top_mask = 0;
         for (int j = 0; j < w; j++)
-            if (spare + j * bt >= low_bits) {
-                fa.top_rep_t |= (K)term_first << (spare + j * bt);
-                fa.top_ones |= (K)1 << (spare + j * bt);
-                fa.top_highs |= (K)1 << (spare + j * bt + bt - 1);
-            }
+            if (spare + j * bt >= low_bits) fa.top_mask |= (K)(((K)1 << bt) - 1) << (spare + j * bt);
         fa.kg_top = spare + (w - km.k) * bt < low_bits;
         fa.order_g = sa12; fa.lcp_g = lcp_out; fa.keep = keep; fa.gstart = gstart_bits;
         fa.block_keep = block_keep; fa.fail = fail; fa.kg_bad = ctx.kg_bad ? ctx.kg_bad : fail;
