@@ -280,7 +280,7 @@ __global__ __launch_bounds__(BLOCK) void radix_spine_docs_kernel(const u32 *__re
 // 4096*sizeof(K) + 2*WAVES*256 + 2 KiB of LDS: two 16-wave workgroups (32 waves, the hardware maximum)
 // fit a CU.  The per-wave digit counters are 16 bits wide, two to a word (a wave holds 256 pairs).
 template <class K> struct ScatterLds {
-    K s_keys[RS_TILE];
+    alignas(16) K s_keys[RS_TILE];                  // (the key generators store whole runs with 16-byte LDS writes)
     u32 wave_cnt[RS_THREADS / WAVE][RS_BINS / 2];   // per-wave digit counts (packed pairs), then wave bases
     u32 digit_start[RS_BINS];                       // first slot of the digit inside the tile
     u32 global_base[RS_BINS];                       // output index of slot 0 of the digit

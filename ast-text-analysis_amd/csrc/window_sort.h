@@ -273,20 +273,21 @@ template <class K> struct TextWindowGen {
 
     __device__ __forceinline__ void prepare() const {}
     // keys of the positions p0 .. p0 + 7 from x = the bytes s8[p0 .. p0 + 24)
-    __device__ __forceinline__ void keys_of_run(const u32 (&x)[6], K (&out)[TW_RUN]) const
+    template <int RUN = TW_RUN>
+    __device__ __forceinline__ void keys_of_run(const u32 (&x)[6], K (&out)[RUN]) const
     {
         const int top = spare + (w - 1) * b;
         const K fmask = ((K)1 << b) - 1;
         K key = 0;
 #pragma unroll
-        for (int q = TW_RUN + 12; q >= 0; q--) {
-            if (q > TW_RUN + w) continue;       // (uniform: the run starts w + 1 symbols to the right, from zero)
+        for (int q = RUN + 12; q >= 0; q--) {
+            if (q > RUN + w) continue;          // (uniform: the run starts w + 1 symbols to the right, from zero)
             const u32 c = (x[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
             const bool term = c == 0xFFu;
             const K body = key >> spare;        // the w full fields of key(q + 1)
             const K rest = (K)((body >> b) << spare) | (K)((body & fmask) >> (b - spare));
             key = ((K)(term ? term_first : c) << top) | (term ? (K)0 : rest);
-            if (q < TW_RUN) out[q] = key;
+            if (q < RUN) out[q] = key;
         }
     }
     __device__ __forceinline__ void load_run(u32 p0, u32 (&x)[6]) const
@@ -318,6 +319,25 @@ template <class K> struct TextWindowGen {
     }
     __device__ __forceinline__ void fill_tile(K *s_keys, u32 tile_base, u32 tile_count) const
     {
+        if (!docs.bits) {
+            // no document number to add: runs of RS_IPT = 4 positions, so that every thread of the scatter workgroup rolls
+            // one out (a run of 8 costs 8 + w + 1 steps of the recurrence and leaves half of the threads idle; one of 4
+            // costs 4 + w + 1 steps on all of them)
+            constexpr int HALF = TW_RUN / 2;
+            for (u32 r = threadIdx.x; r < (u32)RS_TILE / HALF; r += RS_THREADS) {
+                if (r * HALF >= tile_count) break;
+                u32 x[6];
+                K k[HALF];
+                load_run(tile_base + r * HALF, x);
+                keys_of_run<HALF>(x, k);
+                if constexpr (sizeof(K) == 4) *reinterpret_cast<uint4 *>(&s_keys[r * HALF]) = uint4{(u32)k[0], (u32)k[1], (u32)k[2], (u32)k[3]};
+                else {
+#pragma unroll
+                    for (int q = 0; q < HALF; q++) s_keys[r * HALF + q] = k[q];
+                }
+            }
+            return;
+        }
         for (u32 r = threadIdx.x; r < (u32)RS_TILE / TW_RUN; r += RS_THREADS) {
             if (r * TW_RUN >= tile_count) break;
             u32 x[6];
