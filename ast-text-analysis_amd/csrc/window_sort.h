@@ -164,7 +164,8 @@ __device__ __forceinline__ void kg_mark_key(const KgMark &km, int w, int b, int 
     u32 code = 0;
     for (int q = 0; q < km.k; q++) code = code * km.A + ((u32)(k >> (spare + (w - 1 - q) * b)) & ((1u << b) - 1u));
     if (code >= km.bins) return;                        // (only in a speculative build that assumed the wrong alphabet)
-    if (!by_rank) dlo = km.doc_off[d];                  // (read here, behind the code: measured -- 0.45 against 0.42 ms for the 64 MiB finish)
+    // (read here, behind the code: measured -- 0.45 against 0.42 ms for the 64 MiB finish; one document starts at rank 0)
+    if (!by_rank) dlo = km.n_docs > 1 ? km.doc_off[d] : 0u;
     const u32 jl = j - dlo;
     if (!km.pairs) { km.kg[(size_t)d * (km.bins + 1) + code] = jl; return; }
     reinterpret_cast<uint2 *>(km.kg)[(size_t)d * (km.bins + 1) + code] = uint2{jl, v};
