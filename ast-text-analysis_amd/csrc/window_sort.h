@@ -592,16 +592,19 @@ __device__ __forceinline__ u32 lvl0_lcp_of_key_pair(const KeyNeqWindowIn<K> &f, 
         whole = k == kp && !r.term;
         return r.common;
     }
+    // (the field of a bit position without a division per rank: x / b = (x * ceil(2^16 / b)) >> 16 for the positions of a
+    // key, x < 64; the reciprocal is the same for every rank -- uniform, computed once)
+    const u32 inv_b = (65536u + (u32)b - 1u) / (u32)b;
     const u64 d = (u64)(k ^ kp);
     u32 mism = (u32)w;                                   // leading symbol fields in common
     if (d) {
         const int hb = 63 - __builtin_clzll(d);
         if (hb >= spare + w * b) mism = 0;              // (different documents: the entry is reset by lcp_doc_starts)
-        else if (hb >= spare) mism = (u32)(w - 1 - (hb - spare) / b);
+        else if (hb >= spare) mism = (u32)w - 1u - (((u32)(hb - spare) * inv_b) >> 16);
     }
     const K x = k ^ f.rep_t;
     const u64 tz = (u64)((K)(x - f.ones) & ~x & f.highs);    // at most one field holds the terminator code
-    const u32 term = tz ? (u32)(w - 1 - (__builtin_ctzll(tz) - spare) / b) : (u32)w;
+    const u32 term = tz ? (u32)w - 1u - (((u32)(__builtin_ctzll(tz) - spare) * inv_b) >> 16) : (u32)w;
     const u32 h = mism < term ? mism : term;
     whole = h == (u32)w && d == 0;
     return h;
