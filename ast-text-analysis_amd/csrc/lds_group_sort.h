@@ -347,8 +347,9 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
             flag_out[r] = f;
             if (lcp_g && f && local > 0u && (k >> wbits) == (kp >> wbits)) {       // a seam inside a group (see dc3_refine_writeback_kernel)
                 const u64 d = (k ^ kp) & (((u64)1 << wbits) - 1ull);
-                const u32 mism = d ? (u32)(w2 - 1 - (63 - __builtin_clzll(d)) / b) : (u32)w2;
-                const u32 term = tz ? (u32)(w2 - 1 - __builtin_ctzll(tz) / b) : (u32)w2;
+                const u32 inv_b = (65536u + (u32)b - 1u) / (u32)b;   // (uniform: x / b = (x * inv_b) >> 16 for bit positions below 64)
+                const u32 mism = d ? (u32)w2 - 1u - (((u32)(63 - __builtin_clzll(d)) * inv_b) >> 16) : (u32)w2;
+                const u32 term = tz ? (u32)w2 - 1u - (((u32)__builtin_ctzll(tz) * inv_b) >> 16) : (u32)w2;
                 lcp_g[slot] = depth + (cls.xdep ? (u32)cls.xdep[r] : 0u) + (mism < term ? mism : term);
             }
         }
