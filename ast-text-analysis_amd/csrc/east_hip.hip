@@ -1742,6 +1742,7 @@ static void score_resident(east_hip_index *h, int normalized, unsigned long long
     KgTables kt;
     kt.kg = h->kg; kt.kg3 = h->kg3; kt.k = h->kg_k; kt.pairs = h->kg_k > 0 && h->kg_pairs; kt.A = h->kg_A; kt.bins = h->kg_bins;
     if (kt.pairs && h->kg_up_stride && h->kg_up) { kt.up = h->kg_up; kt.up_stride = h->kg_up_stride; }
+    if (kt.k > 0) kt.finish();
     // whole keyphrases per workgroup, summed in the walk (no per-suffix results unless the caller wants them: then the
     // documents go a stretch at a time, as far as the scratch reaches); otherwise per-suffix results + the reduction kernel
     const bool fused = h->n_blk > 0;

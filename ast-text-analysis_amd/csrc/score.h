@@ -281,7 +281,20 @@ struct KgTables {
     const u32 *kg = nullptr, *kg3 = nullptr, *up = nullptr;
     int k = 0, pairs = 0;
     u32 A = 0, bins = 0, up_stride = 0;
+    // (set by the host, so that no walk divides: the bins of the table the levels 1 .. k3 read -- bins / A with pairs -- and
+    // the stride of level i in it, A^(k3 - 1 - i))
+    u32 bins3 = 0;
+    u32 stride[KGRAM_KEYS_MAX_K] = {0, 0, 0, 0};
+    void finish()
+    {
+        const int k3 = pairs ? k - 1 : k;
+        bins3 = pairs ? bins / A : bins;
+        u32 acc = 1;
+        for (int i = KGRAM_KEYS_MAX_K - 1; i >= 0; i--)
+            if (i < k3) { stride[i] = acc; acc *= A; }
+    }
 };
+static_assert(KGRAM_KEYS_MAX_K == 4, "KgTables::stride");
 
 __device__ __forceinline__ uint2 load_pair_u32(const u32 *p)       // two adjacent 4-byte entries (4-byte aligned)
 {
@@ -317,7 +330,7 @@ __device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, c
         // before the first one is looked at: one memory round trip for the table levels instead of one per level (the
         // walk is bound by latency: a level's reads used to wait for the verdict of the level before).
         const int k3 = kt.pairs ? kt.k - 1 : kt.k;
-        const u32 bins3 = kt.pairs ? kt.bins / kt.A : kt.bins;
+        const u32 bins3 = kt.bins3;
         const u32 *row = (kt.pairs ? kt.kg3 : kt.kg) + (size_t)d * (bins3 + 1);
         const uint2 *row2 = reinterpret_cast<const uint2 *>(kt.kg) + (size_t)d * (kt.bins + 1);
         u32 cs[KGRAM_KEYS_MAX_K];
@@ -329,13 +342,13 @@ __device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, c
             if (c != Q_NOMATCH && L == i) L = i + 1;
         }
         u32 ta[KGRAM_KEYS_MAX_K], tb[KGRAM_KEYS_MAX_K];
-        u32 code = 0, stride = bins3, up_off = 0, up_len = kt.A;
+        u32 code = 0, up_off = 0, up_len = kt.A;
         const u32 *up = kt.up ? kt.up + (size_t)d * kt.up_stride : nullptr;
 #pragma unroll
         for (int i = 0; i < KGRAM_KEYS_MAX_K; i++) {
             ta[i] = tb[i] = 0;
             if (i < k3 && i < L) {
-                stride /= kt.A;
+                const u32 stride = kt.stride[i];
                 code = code * kt.A + cs[i];
                 if (stride == 1u || up) {                  // two adjacent entries: one load
                     const uint2 ab = load_pair_u32(stride == 1u ? row + code : up + up_off + code);
