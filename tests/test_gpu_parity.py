@@ -378,11 +378,17 @@ def test_256_documents_batched_equals_individual(hip):
         assert np.array_equal(single.score_table(qs, qo, True)[:, 0], table[:, d])
 
 
-def test_config2_256_documents_10000_keyphrases_vs_oracle(hip, oracle):
+def test_config2_256_documents_10000_keyphrases_vs_oracle(hip, oracle, suffix_sort_path):
     """BASELINE configs[2] at its full size: 256 word-stream documents of 1 MiB (text mode) and
     10 000 keyphrases in ONE batched build + ONE score call.  Every document: the properties that
     pin SA / LCP / annotation completely; 8 sampled documents: all six tables array_equal to the
     oracle and all 10 000 scores bit-equal, normalized and denormalized (applications.py:43-52)."""
+    # (by its size this shard takes the segmented sort on every window-sort path: the `_seg` paths would repeat the others --
+    # one of them runs with the document number in the keys instead, the other two are skipped at this size)
+    if suffix_sort_path in ("window_sort_seg_unfused", "window_sort_seg_ht"):
+        pytest.skip("the same builds as window_sort_unfused / window_sort_ht at this size")
+    if suffix_sort_path == "window_sort_seg":
+        assert hip.load().east_hip_debug_set_segmented_sort(0) == 0      # (the autouse fixture restores the default)
     from east import hip_backend, synthetic
     rng = np.random.default_rng(20240 + 3)
     docs = [synthetic.word_stream_document(rng, 1 << 20, want_text=False)[1:] for _ in range(256)]
@@ -1067,11 +1073,17 @@ def test_resident_build_fits_the_planned_arena(hip, corpus, wide_keys):
     assert int(t.sum()) == docs[0][0].size * (docs[0][0].size - 1) // 2       # a permutation of the document's positions
 
 
-def test_config5_zipf_100_documents_full_size(hip, oracle):
+def test_config5_zipf_100_documents_full_size(hip, oracle, suffix_sort_path):
     """BASELINE config 5 stand-in at its full size (enwik8 is not available offline): 100 natural-language-like
     documents of 1 MiB (Zipf vocabulary, 94 M symbols, tie-refinement rounds), one batched build.  Every document:
     the properties that pin SA / LCP / annotation; 6 sampled documents: tables and 400 scores, normalized and
     -d denormalized, bit-equal to the oracle (the oracle itself is pinned to ast_linear on the zipf_docs fixture)."""
+    # (by its size this shard takes the segmented sort on every window-sort path: the `_seg` paths would repeat the others --
+    # one of them runs with the document number in the keys instead, the other two are skipped at this size)
+    if suffix_sort_path in ("window_sort_seg_unfused", "window_sort_seg_ht"):
+        pytest.skip("the same builds as window_sort_unfused / window_sort_ht at this size")
+    if suffix_sort_path == "window_sort_seg":
+        assert hip.load().east_hip_debug_set_segmented_sort(0) == 0      # (the autouse fixture restores the default)
     from east import hip_backend, synthetic
     rng = np.random.default_rng(20240 + 5)
     vocab = synthetic.zipf_vocabulary(np.random.default_rng(20245))
