@@ -1189,7 +1189,11 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     // (ONE uploader: two threads with a copy stream each, the chunks' halves side by side, were measured and are slower --
     // 2.9 against 1.95 ms for 64 MiB: the staging copies of the runtime do not run side by side.  More, smaller chunks
     // towards the end -- a shorter tail behind the last upload -- lose to their launches and read-backs: 2.3 ms with six.)
-    std::atomic<int> uploaded{0}, upload_failed{0};
+    std::atomic<int> uploaded{0}, upload_failed{0}, upload_abort{0};
+    // The copy stream writes d_bytes (the bottom of the arena) and the chunks' counts: it must not start before what is
+    // still queued on the handle's stream -- a score call of the index before, say, reading its tables in the arena --
+    // has finished ("one HIP stream per handle": calls are ordered).  ev0 was recorded on h->stream when this call began.
+    HIP_CHECK(hipStreamWaitEvent(h->copy_stream, h->ev0, 0));
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     std::vector<double> t_up(C, 0.0), t_cnt(C, 0.0), t_queued(C, 0.0);     // (EAST_HIP_TRACE: when a chunk was staged / counted / queued)
@@ -1200,7 +1204,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         bool ok = hipSetDevice(device) == hipSuccess;
         if (ok && texts) ok = hipMemsetAsync(d_bytes, 0xFF, n_bytes, copy_stream) == hipSuccess;       // the separators
         if (ok) ok = hipMemsetAsync(d_bytes + n_bytes, 0, 32, copy_stream) == hipSuccess;
-        for (u32 c = 0; c < C && ok; c++) {
+        for (u32 c = 0; c < C && ok && !upload_abort.load(std::memory_order_acquire); c++) {
             const TpChunk &ch = chunks[c];
             if (texts) {
                 for (u32 i = 0; i < ch.n_docs && ok; i++) {
@@ -1228,7 +1232,20 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         }
         if (!ok) { (void)hipGetLastError(); upload_failed.store(1, std::memory_order_release); }
     });
-    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};
+    // (unwinding -- a HIP error or a thrown status on the compute side: the uploader stops queueing, and nothing it has
+    // queued may still be writing the arena or the host-side counts when they are released)
+    struct Joiner {
+        std::thread &t;
+        std::atomic<int> &abort;
+        hipStream_t copy;
+        ~Joiner()
+        {
+            if (!t.joinable()) return;                   // (the regular path has joined already)
+            abort.store(1, std::memory_order_release);
+            t.join();
+            (void)hipStreamSynchronize(copy);
+        }
+    } joiner{uploader, upload_abort, copy_stream};
 
     for (u32 c = 0; c < C; c++) {
         const TpChunk &ch = chunks[c];
@@ -1563,6 +1580,8 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
 #define SCORE_SCRATCH_BYTES ((size_t)1 << 30)
 static size_t g_score_scratch_bytes = SCORE_SCRATCH_BYTES;     // east_hip_debug_set_score_scratch (tests)
 static bool g_score_fused = getenv("EAST_HIP_SCORE_UNFUSED") == nullptr;   // east_hip_debug_set_score_path (tests, A/B timing)
+#define SCORE_GRID_BLOCKS ((u64)1 << 22)
+static u64 g_score_grid_blocks = SCORE_GRID_BLOCKS;            // east_hip_debug_set_score_grid (tests): workgroups per walk launch
 static u32 score_doc_chunk(u32 n_q, u32 n_docs)
 {
     const size_t per_doc = (size_t)n_q * 8;
@@ -1746,12 +1765,21 @@ static void score_resident(east_hip_index *h, int normalized, unsigned long long
     // whole keyphrases per workgroup, summed in the walk (no per-suffix results unless the caller wants them: then the
     // documents go a stretch at a time, as far as the scratch reaches); otherwise per-suffix results + the reduction kernel
     const bool fused = h->n_blk > 0;
-    const u32 chunk = fused && !suffix_host ? h->n_docs : h->score_chunk;
+    u32 chunk = h->score_chunk;
+    if (fused && !suffix_host) {
+        // (no scratch to bound the stretch -- the grid does: a launch of at most g_score_grid_blocks workgroups, far below
+        // HIP's limit of 2^32 threads per grid dimension; many short documents times thousands of keyphrases go a stretch
+        // of documents at a time, a multiple of 8 for the XCD-aware order)
+        const u64 fit = g_score_grid_blocks / h->n_blk;
+        chunk = (u32)std::min<u64>(h->n_docs, fit >= 8 ? fit & ~(u64)7 : std::max<u64>(fit, 1));
+    }
     for (u32 first = 0; first < h->n_docs; first += chunk) {
         const u32 count = std::min(chunk, h->n_docs - first);
         const int xcd_order = count >= 64;                // see score_walk_kernel
         const u32 per_doc = fused ? h->n_blk : ceil_div_u32(h->n_q, BLOCK);
-        const u32 walk_grid = (xcd_order ? 8u * ceil_div_u32(count, 8) : count) * per_doc;
+        const u64 walk_grid64 = (u64)(xcd_order ? 8u * ceil_div_u32(count, 8) : count) * per_doc;
+        if (walk_grid64 >= ((u64)1 << 24)) east_throw(EAST_HIP_ERR_INVALID, "keyphrase set too large for one score launch");
+        const u32 walk_grid = (u32)walk_grid64;
         double *suffix = fused && !suffix_host ? (double *)nullptr : h->suffix;
         const u32 *blk = fused ? (const u32 *)h->q_blk : (const u32 *)nullptr;
         if (h->use_s8)
@@ -2294,6 +2322,13 @@ int east_hip_debug_set_lds_rounds(int enabled)
 int east_hip_debug_set_score_scratch(int64_t bytes)
 {
     g_score_scratch_bytes = bytes > 0 ? (size_t)bytes : SCORE_SCRATCH_BYTES;
+    return EAST_HIP_OK;
+}
+
+int east_hip_debug_set_score_grid(int64_t workgroups)
+{
+    // workgroups a launch of the score walk may have when the sums run inside it (0 or less: the default, 2^22)
+    g_score_grid_blocks = workgroups > 0 ? (u64)std::min<int64_t>(workgroups, (int64_t)1 << 23) : SCORE_GRID_BLOCKS;
     return EAST_HIP_OK;
 }
 

@@ -39,7 +39,7 @@ static bool g_force_fused = getenv("EAST_HIP_FORCE_FUSED") != nullptr;          
 // 0 = never, 1 = whenever a code exists (east_hip_debug_set_window_sort(7) / EAST_HIP_HT: tests, A/B timing)
 static int g_ht_mode = getenv("EAST_HIP_HT") ? atoi(getenv("EAST_HIP_HT")) : -1;
 // segmented first-level sort of several documents (radix_sort.h: RsSeg): -1 by size, 0 never, 1 wherever it can be done
-// (east_hip_debug_set_window_sort 10 / 11; EAST_HIP_SEG)
+// (east_hip_debug_set_segmented_sort; EAST_HIP_SEG)
 static int g_seg_mode = getenv("EAST_HIP_SEG") ? atoi(getenv("EAST_HIP_SEG")) : -1;
 struct FusedAbort {};           // the fused finish met a repeat too long to order directly: the level is redone with the full sort
 
@@ -371,14 +371,15 @@ template <class K> struct TextWindowGen {
 
 // The same for keys of VARIABLE-LENGTH code words (ht_code.h): the key of position q is the first `sb` bits of the coded
 // suffix -- stream(q) = code(x[q]) on top of stream(q + 1) moved down by its length, nothing behind a terminator's code
-// word --, under the document number.  Code words have at least HT_MIN_LEN = 2 bits, so 16 symbols fill any key: the run
-// of 8 positions is rolled out of its 24 loaded bytes from the right.  enc[] (byte -> code << 8 | length) is staged in
+// word --, under the document number.  Code words have at least HT_MIN_LEN = 3 bits, so 16 symbols fill the HT_MAX_STREAM =
+// 48 stream bits a key may carry: the run of 8 positions is rolled out of its 24 loaded bytes from the right.  enc[] (byte -> code << 8 | length) is staged in
 // LDS by prepare(), which the two kernels of the first radix pass call once, workgroup-wide.
 __device__ __forceinline__ u32 *ht_enc_lds()
 {
     __shared__ u32 t[256];
     return t;
 }
+static_assert(HT_MAX_STREAM / HT_MIN_LEN <= 16, "HtWindowGen looks 16 symbols ahead: a key must not hold more");
 template <class K> struct HtWindowGen {
     static constexpr int MODE = 2;
     const uint8_t *s8;                          // byte stream; readable (any content) up to 24 bytes behind the last symbol

@@ -72,6 +72,7 @@ SIGNATURES = {
     "east_hip_debug_set_speculation": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_debug_set_score_scratch": (ctypes.c_int, [ctypes.c_int64]),
     "east_hip_debug_set_score_path": (ctypes.c_int, [ctypes.c_int]),
+    "east_hip_debug_set_score_grid": (ctypes.c_int, [ctypes.c_int64]),
     "east_hip_debug_set_text_stream": (ctypes.c_int, [ctypes.c_int64]),
     "east_hip_debug_alphabetic_code": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int32,
                                                       ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int32)]),

@@ -29,6 +29,10 @@ def _read(path):
         return f.read()
 
 
+_OPTIONS = "s:a:w:v:l:f:c:r:p:g:dy"
+_VALUE_OPTIONS = frozenset(c for c, nxt in zip(_OPTIONS, _OPTIONS[1:] + " ") if nxt == ":")
+
+
 def _world():
     """(world size, rank) a launcher gave this process (torch.distributed.run exports both)."""
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -36,24 +40,14 @@ def _world():
 
 def launch_ranks(n_ranks, argv):
     """The no-launcher spelling of a multi-GPU run (`-g N` / EAST_HIP_DEVICES=N): start N ranks of this module as
-    CHILD processes under torch.distributed.run, let their output through (only rank 0 prints) and return their exit
-    code.  Nothing in this process has touched a GPU at this point, and it never exec()s.  EAST_HIP_LAUNCHER replaces
-    the launcher command (tests)."""
-    import shlex
-    import socket
-    import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    launcher = shlex.split(os.environ.get("EAST_HIP_LAUNCHER", "")) or [sys.executable, "-m", "torch.distributed.run"]
-    cmd = launcher + ["--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
-                      "--master-port", str(port), "-m", "east.main"] + list(argv)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    env.pop("EAST_HIP_DEVICES", None)                       # (the ranks must not start ranks of their own)
-    env.pop("EAST_HIP_DEVICE", None)                        # every rank takes the device of its LOCAL_RANK
+    CHILD processes under torch.distributed.run (east/launch.py), let their output through (only rank 0 prints) and
+    return their exit code.  Nothing in this process has touched a GPU at this point, and it never exec()s.
+    EAST_HIP_LAUNCHER replaces the launcher command (tests)."""
+    from east import launch
     pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env["PYTHONPATH"] = pkg + os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else pkg
-    return subprocess.run(cmd, env=env).returncode
+    # (the ranks must not start ranks of their own, and every rank takes the device of its LOCAL_RANK)
+    return launch.run_ranks(n_ranks, ["-m", "east.main"] + list(argv), "EAST_HIP_LAUNCHER",
+                            env_drop=("EAST_HIP_DEVICES", "EAST_HIP_DEVICE"), pythonpath=pkg)
 
 
 def main(argv=None, measure_factory=None):
@@ -61,10 +55,11 @@ def main(argv=None, measure_factory=None):
     the collective logic then runs on gloo without a GPU)."""
     args = sys.argv[1:] if argv is None else list(argv)
     try:
-        opts, args = getopt.getopt(args, "s:a:w:v:l:f:c:r:p:g:dy")
+        opts, args = getopt.getopt(args, _OPTIONS)
     except getopt.GetoptError as e:
         print(e)
         return 1
+    opt_list = opts                                         # (as given: repeated options, empty values)
     opts = dict(opts)
     world, rank = _world()
     if world == 1:
@@ -76,9 +71,9 @@ def main(argv=None, measure_factory=None):
         if n_ranks > 1:
             # the same command line without -g: the ranks learn the world size from the launcher
             child_argv = []
-            for key, value in opts.items():
+            for key, value in opt_list:
                 if key != "-g":
-                    child_argv.extend([key, value] if value else [key])
+                    child_argv.extend([key, value] if key[1:] in _VALUE_OPTIONS else [key])
             child_argv.extend(args)
             return launch_ranks(n_ranks, child_argv)
     quiet = rank != 0                                       # under a launcher only rank 0 prints

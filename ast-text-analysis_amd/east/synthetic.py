@@ -165,3 +165,27 @@ def image_prose(max_bytes, keep_duplicates=False):
                 if total >= max_bytes:
                     return b"\n".join(parts)[:max_bytes], len(parts)
     return b"\n".join(parts), len(parts)
+
+
+# ---- the reference's own benchmark input ----------------------------------------------------------
+def worst_case_collection(rng, m, n):
+    """The input of the reference's runtime harness (analysis/runtime.py:19-31 on analysis/utils.py:5-9,
+    `worst_case_strings_collection(m, n)`): m strings that share one random prefix.  As shipped,
+    `utils.random_string(length)` returns length - 2 letters (east/utils.py:86-88), so the "2 differing symbols" are
+    empty and the collection is m IDENTICAL strings of n - 4 letters A-Z -- every suffix sits in a tie group of m
+    members that only the terminators tell apart, and the longest common prefix is the whole string.
+    Returns (symbols uint32 of one document: the m strings, each followed by its terminator; n_strings = m)."""
+    length = max(int(n) - 4, 1)
+    prefix = rng.integers(65, 91, size=length, dtype=np.uint32)
+    out = np.empty((int(m), length + 1), dtype=np.uint32)
+    out[:, :length] = prefix
+    out[:, length] = np.arange(int(m), dtype=np.uint32) + np.uint32(TERMINATOR_START)
+    return out.reshape(-1), int(m)
+
+
+def repeated_passage_document(rng, passage_symbols, copies):
+    """`get_ast([one string])` on a passage of random letters written `copies` times in a row: no terminator between the
+    copies, so common prefixes run to (copies - 1) x the passage.  Returns (symbols uint32, n_strings = 1)."""
+    passage = rng.integers(65, 91, size=int(passage_symbols), dtype=np.uint32)
+    out = np.concatenate([np.tile(passage, int(copies)), np.array([TERMINATOR_START], dtype=np.uint32)])
+    return out, 1

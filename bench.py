@@ -81,21 +81,13 @@ def parse():
 
 def launch_ranks(n_ranks, argv):
     """`python bench.py --gpus N` (N > 1) without a launcher around it: start the N ranks ourselves, as CHILD
-    processes under torch.distributed.run, relay what they print (rank 0's JSON line) and return their exit code.
-    Runs before torch is imported or anything else could touch a GPU -- this process never initialises one and never
-    exec()s (a process that has initialised the GPU must not be replaced on this pool).  EAST_BENCH_LAUNCHER replaces
-    the launcher command (tests: a stub that records its command line)."""
-    import shlex
-    import socket
-    import subprocess
-    with socket.socket() as sock:                            # a free rendezvous port on the loopback interface
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    launcher = shlex.split(os.environ.get("EAST_BENCH_LAUNCHER", "")) or [sys.executable, "-m", "torch.distributed.run"]
-    cmd = launcher + ["--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
-                      "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.run(cmd, env=env).returncode           # stdout / stderr inherited: the JSON line passes through
+    processes under torch.distributed.run (east/launch.py: rendezvous on a port the launcher binds itself), relay what
+    they print (rank 0's JSON line) and return their exit code.  Runs before torch is imported or anything else could
+    touch a GPU -- this process never initialises one and never exec()s (a process that has initialised the GPU must
+    not be replaced on this pool).  EAST_BENCH_LAUNCHER replaces the launcher command (tests: a stub that records its
+    command line)."""
+    from east import launch
+    return launch.run_ranks(n_ranks, [os.path.abspath(__file__)] + list(argv), "EAST_BENCH_LAUNCHER")
 
 
 def kernel_bytes(name, info, n, n_docs):

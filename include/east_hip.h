@@ -243,7 +243,8 @@ void *east_hip_stream(east_hip_handle_t h);
  * (no DC3 level ran; [5] is 0 then), [19] elements the refinement rounds ordered inside a workgroup's LDS,
  * [20] 1 when the last radix digit and the placement ran as one pass in LDS (the fused finish), [21] suffixes the
  * first placement left in large tie groups, [22] of how many, [23] 1 when the first-level keys held variable-length
- * (order-preserving) code words instead of fixed-width symbol fields (csrc/ht_code.h).
+ * (order-preserving) code words instead of fixed-width symbol fields (csrc/ht_code.h), [24] 1 when the first-level sort
+ * kept every document inside its own range of ranks (the segmented sort, csrc/radix_sort.h: RsSeg).
  */
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap);
 
@@ -307,6 +308,10 @@ int east_hip_debug_set_speculation(int enabled);
  * more documents than fit is scored a stretch of documents at a time.  Takes effect at the next
  * east_hip_set_keyphrases / east_hip_score_table. */
 int east_hip_debug_set_score_scratch(int64_t bytes);
+/* Test knob: workgroups one launch of the score walk may have when the per-keyphrase sums run inside it (default 2^22, far
+ * below HIP's limit of 2^32 threads per grid dimension; 0 restores it).  A table over more documents than fit one launch is
+ * scored a stretch of documents at a time. */
+int east_hip_debug_set_score_grid(int64_t workgroups);
 /* Test knob: how east_hip_build_texts[_v] brings the raw text to the device.  -1 (default) = inputs of 8 MiB or more are
  * uploaded in four or five chunks (cut where no token spans the cut) and every chunk is prepared while the next one is on its
  * way; 0 = one upload, one preparation; > 0 = always in chunks of about that many bytes (a few dozen: every fixture goes

@@ -50,6 +50,17 @@ TABLES = ("suftab", "lcptab", "anntab", "childtab_up", "childtab_down", "childta
 TOL = 1e-6
 
 
+def _raw_path(request):
+    """The parametrisation of the running test as the autouse fixture got it (suffix_sort_path folds two of them)."""
+    return request.node.callspec.params["suffix_sort_path"]
+
+
+def _only_paths(request, *paths):
+    """Full-size cases pay for a CPU oracle of tens of seconds: they run on the named paths and skip the others."""
+    if _raw_path(request) not in paths:
+        pytest.skip("full-size case: runs on %s only" % " / ".join(paths))
+
+
 def _check_case(base, case):
     ast = base.AST.get_ast(case["strings"])
     assert [ord(c) for c in ast.string] == case["string"]
@@ -302,6 +313,85 @@ def test_16mib_document_vs_oracle(hip, oracle):
         table = index.score_table(qs, qo, norm)
         for k in range(500):
             assert table[k, 0] == o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=True)
+
+
+def test_64mib_document_vs_oracle(hip, oracle, request):
+    """BASELINE configs[1] -- the headline configuration -- bit-exact at its real size: the 64 MiB word-stream document in
+    text mode (61.1 M symbols, 2.98 M strings), all six tables array_equal to the oracle (easa.py:16-24) and the bench's
+    1 000 keyphrases bit-equal in both modes (easa.py:26-36, 91-139).  The shipping path only: the oracle build alone
+    is 15 s of one core."""
+    _only_paths(request, "window_sort")
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(20240 + 2)                  # bench.py's document and keyphrases
+    _, sym, m = synthetic.word_stream_document(rng, 64 << 20, want_text=False)
+    qs, qo = synthetic.keyphrases(rng, sym, 1000)
+    index = hip_backend.HipIndex()
+    index.build(sym, np.array([0, sym.size]), np.array([m]))
+    info = index.info()
+    assert info["n_total"] == sym.size and info["window_sorted"] == 1 and info["fused_finish"] == 1
+    o = oracle.OracleEASA(symbols=sym, n_strings=m)
+    for name in TABLES:                                      # one at a time: 61 M int64 entries each
+        got = index.tables(0, names=(name,))[name]
+        assert np.array_equal(got, getattr(o, name)), name
+        del got
+    for norm in (True, False):
+        table = index.score_table(qs, qo, norm)
+        want = np.array([o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=True) for k in range(1000)])
+        assert np.array_equal(table[:, 0], want), norm
+        for k in range(0, 1000, 100):                        # ... and the reference's own walk over the sibling chains
+            assert table[k, 0] == o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=False), (k, norm)
+
+
+@pytest.mark.parametrize("n_docs", [1, 8])
+@pytest.mark.parametrize("n", [1000, 10000, 100000])
+def test_reference_worst_case_collection_vs_oracle(hip, oracle, request, n, n_docs):
+    """The input of the reference's own runtime harness (analysis/runtime.py:19-31 on analysis/utils.py:5-9): m = 100
+    identical strings of n - 4 letters -- every suffix in a tie group of 100 that only the terminators tell apart, common
+    prefixes as long as the string (far beyond the direct-comparison cap at n = 10^5: the blocked-Kasai finish) -- as one
+    document and as 8 documents of that shape.  All six tables array_equal to the oracle, scores bit-equal."""
+    if n == 100000:
+        _only_paths(request, "window_sort", "dc3_only", "window_sort_seg")
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(4100 + n + n_docs)
+    docs = [synthetic.worst_case_collection(rng, 100, n) for _ in range(n_docs)]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])]).astype(np.int64)
+    index = hip_backend.HipIndex()
+    index.build(sym, off, np.array([d[1] for d in docs], dtype=np.int32))
+    qs, qo = synthetic.keyphrases(rng, sym, 60)
+    tables = {norm: index.score_table(qs, qo, norm) for norm in (True, False)}
+    sampled = range(n_docs) if n < 100000 else sorted({0, n_docs - 1})       # (11 s of oracle per document at 10^5)
+    for d in sampled:
+        o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+        assert int(o.lcptab.max()) == n - 4
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d, n)
+        for norm in (True, False):
+            for k in range(60):
+                assert tables[norm][k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=True), (d, k, norm)
+        for k in range(0, 60, 6):
+            assert tables[True][k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=False), (d, k)
+
+
+def test_sixteen_copies_of_a_passage_in_one_string(hip, oracle, request):
+    """`get_ast([one string])` on a 1 MiB passage written 16 times in a row (16.8 M symbols, no terminator in between):
+    common prefixes of up to 15 MiB, tie groups nested 16 deep.  SA, LCP and annotation array_equal to the oracle."""
+    _only_paths(request, "window_sort", "dc3_only")
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(1616)
+    sym, m = synthetic.repeated_passage_document(rng, 1 << 20, 16)
+    index = hip_backend.HipIndex()
+    index.build(sym, np.array([0, sym.size]), np.array([m]))
+    o = oracle.OracleEASA(symbols=sym, n_strings=m)
+    assert int(o.lcptab.max()) == 15 << 20
+    t = index.tables(0)
+    for name in TABLES:
+        assert np.array_equal(t[name], getattr(o, name)), name
+    qs, qo = synthetic.keyphrases(rng, sym, 100)
+    table = index.score_table(qs, qo, True)
+    for k in range(100):
+        assert table[k, 0] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=True), k
 
 
 def _check_easa_properties(sym, m, t, spot=4000):
@@ -1580,6 +1670,37 @@ def test_score_in_stretches_of_documents(hip, oracle):
     o = oracle.OracleEASA(symbols=docs[77][0], n_strings=docs[77][1])
     for k in range(40):
         assert want[k, 77] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=True)
+
+
+def test_score_walk_grid_is_bounded(hip, oracle):
+    """Many short documents x many keyphrases with the per-keyphrase sums inside the walk kernel: a launch takes at most
+    a bounded number of workgroups (east_hip_debug_set_score_grid; by default 2^22, far below HIP's limit per grid
+    dimension), so the table comes out a stretch of documents at a time -- identical to the one-launch table, bit-equal
+    to the oracle.  Stretches of 8 or more documents are multiples of 8 (XCD-aware order), smaller ones are not."""
+    from east import hip_backend, synthetic
+    lib = hip.load()
+    rng = np.random.default_rng(424242)
+    docs = [synthetic.word_stream_document(rng, int(rng.integers(60, 400)), want_text=False)[1:] for _ in range(1500)]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])])
+    index = hip_backend.HipIndex()
+    index.build(sym, off, np.array([d[1] for d in docs]))
+    qs, qo = synthetic.keyphrases(rng, sym, 700)
+    want = {norm: index.score_table(qs, qo, norm) for norm in (True, False)}
+    n_blk = -(-int(qo[-1]) // 256)                            # at least this many workgroups per document
+    try:
+        for grid in (n_blk * 100, n_blk * 9, n_blk * 3, 1):    # 96-document stretches, 8, 3 (or fewer), one document at a time
+            assert lib.east_hip_debug_set_score_grid(grid) == 0
+            for norm in (True, False):
+                assert np.array_equal(index.score_table(qs, qo, norm), want[norm]), (grid, norm)
+            index.set_keyphrases(qs, qo)
+            index.score_resident(True)
+    finally:
+        assert lib.east_hip_debug_set_score_grid(0) == 0
+    for d in (0, 7, 8, 95, 96, 97, 1499):
+        o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+        for k in range(0, 700, 7):
+            assert want[True][k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=True), (d, k)
 
 
 @pytest.mark.parametrize("mode", [1, 0, 2, 3, 4])

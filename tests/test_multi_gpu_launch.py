@@ -56,7 +56,9 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     rec = json.load(open(record))
     argv = rec["argv"]
     assert argv[:3] == ["--nnodes=1", "--nproc-per-node", "2"]
-    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
+    # (no port picked in advance: the launcher's own c10d store binds one on the loopback interface)
+    assert "--rdzv-backend=c10d" in argv and "--rdzv-endpoint=127.0.0.1:0" in argv and "--master-port" not in argv
+    assert argv[argv.index("--local-addr") + 1] == "127.0.0.1"
     assert argv[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"]
     assert rec["world_env"] is None and rec["ipc"] == "0"
 
@@ -93,7 +95,7 @@ def test_cli_g_option_starts_ranks(tmp_path, spelling):
         for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
             os.environ.pop(k, None)
         os.environ.update(EAST_HIP_LAUNCHER=launcher, STUB_RECORD=record)
-        argv = ["-d", "-f", "csv", "keyphrases", "table", kp, tdir]
+        argv = ["-d", "-a", "easa", "-l", "", "-a", "easa", "-f", "csv", "keyphrases", "table", kp, tdir]
         if spelling == "option":
             argv = ["-g", "2"] + argv
         else:
@@ -108,6 +110,7 @@ def test_cli_g_option_starts_ranks(tmp_path, spelling):
     tail = argv[argv.index("-m"):]
     assert tail[:2] == ["-m", "east.main"] and "-g" not in tail and tail[-4:] == ["keyphrases", "table", kp, tdir]
     assert "-d" in tail and tail[tail.index("-f") + 1] == "csv"
+    assert tail[tail.index("-l") + 1] == "" and tail.count("-a") == 2      # as given: an empty value, a repeated option
     assert rec["devices_env"] is None and rec["ipc"] == "0"      # the ranks do not start ranks of their own
 
 
