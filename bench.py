@@ -153,13 +153,17 @@ def make_corpus(args, synthetic, rng, n_docs, doc_bytes):
     return symbols, doc_offsets, np.array(ms, dtype=np.int32), vocab is not None
 
 
-def load_traffic(name):
-    """HBM bytes per launch per kernel from the PMC passes (profiles/traffic*.json, tools/summarize_profiles.py)."""
+def load_traffic(name, meta=None):
+    """HBM bytes per launch per kernel from the PMC passes (profiles/traffic*.json, tools/summarize_profiles.py).
+    meta (a dict) receives the file's `_commit`: the commit of the tree the passes were taken on."""
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return {}
     with open(path) as f:
-        return {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        data = json.load(f)
+    if meta is not None:
+        meta["commit"] = data.get("_commit")
+    return {k: v for k, v in data.items() if not k.startswith("_")}
 
 
 def pmc_by_kernel(prof, steps, traffic, top=14):
@@ -320,9 +324,12 @@ def main():
     fence()
     local_s[0] = 0.0
     del gather_events[:]
+    step_wall_ms = []                                     # (a step ends synchronised: build read-back, score call)
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        t_s = time.perf_counter()
         step()
+        step_wall_ms.append((time.perf_counter() - t_s) * 1e3)
         build_ms.append(index.last_build_ms)
         score_ms.append(index.last_score_ms)
     fence()
@@ -349,7 +356,8 @@ def main():
         # (the counters were collected on these workloads: tools/profile_round.sh, profile_zipf.sh, profile_config2.sh)
         traffic_file = ("traffic.json" if default_shape else "traffic_zipf.json" if zipf_shape else
                         "traffic_config2.json" if config2_shape else None)
-        traffic = load_traffic(traffic_file) if traffic_file else {}
+        traffic_meta = {}
+        traffic = load_traffic(traffic_file, traffic_meta) if traffic_file else {}
         roofline, by_kernel, per_step = roofline_of(prof, info, n, D, profile_steps, traffic)
         live = prof_timed.get(dom_name)
         if live and live[0]:                             # the dominant kernel as measured inside the timed region
@@ -361,6 +369,7 @@ def main():
                 roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
             roofline["avg_launch_ms_profiling_pass"] = prof[dom_name][1] / prof[dom_name][0]
         roofline["rocprof_hbm_fraction"] = hbm_fraction(prof, traffic)
+        roofline["traffic_commit"] = traffic_meta.get("commit")
         roofline["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this "
                                       "workload (tools/profile_*.sh + summarize_profiles.py), committed with the code -- not "
                                       "measured by this run" % traffic_file) if traffic_file else None
@@ -377,6 +386,8 @@ def main():
                                       " [BASELINE configs[3] per-GPU shape]" if scaling_shape else ""),
                        "symbols_per_gpu": n, "strings_per_gpu": m, "parallelism": "doc-shard x%d" % world,
                        "all_gather_bytes_per_rank": K * D * 8 if use_dist else 0},
+            "step_ms_min": float(np.min(step_wall_ms)), "step_ms_median": float(np.median(step_wall_ms)),
+            "step_ms_max": float(np.max(step_wall_ms)),
             "build_ms": float(np.mean(build_ms)), "score_ms": float(np.mean(score_ms)),
             "build_symbols_per_s": n / (float(np.mean(build_ms)) * 1e-3),
             "build_chars_per_s": n_bytes / (float(np.mean(build_ms)) * 1e-3),
@@ -417,8 +428,21 @@ def main():
             if "child_tables_ms" in out:
                 # the reference's constructor also fills the child tables (easa.py:16-24); here they are built on first request
                 out["build_ms_constructor"] = out["build_ms"] + out["child_tables_ms"]
+        if "build_from_host_ms" in out:
+            # "from symbols resident on host ... H2D included" (the reference's constructor starts from a
+            # Python string, easa.py:16-24): east_hip_build from pageable host memory + the score call
+            host_step_ms = out["build_from_host_ms"]["wall_ms_min"] + out["score_ms"]
+            out["value_from_host"] = n_bytes / (host_step_ms * 1e-3)
+            out["value_from_host_note"] = ("input bytes / (east_hip_build wall, 4 B/symbol H2D from pageable memory included, "
+                                           "+ score call); value itself starts from symbols resident in HBM")
         if world == 1 and not args.no_config2 and default_shape:
             out["from_text"] = from_text_leg(hip_backend, synthetic, local_rank)
+            ft = out["from_text"].get("ascii_64MiB")
+            if ft:
+                # raw text (Python bytes) -> prepared + indexed on the device (main.py:67-89 -> utils.py:31-79 ->
+                # easa.py:16-24), + the score call: what `east keyphrases table` runs on this document
+                out["value_from_text"] = ft["bytes"] / ((ft["wall_ms"] + out["score_ms"]) * 1e-3)
+            out["worst_case"] = worst_case_leg(hip_backend, synthetic, torch, dev, local_rank, not args.no_cpu_baseline)
             out["config2"] = config2_leg(args, hip_backend, synthetic, torch, dev, local_rank)
             out["config5"] = config5_leg(args, hip_backend, synthetic, torch, dev, local_rank)
         if world == 1 and not args.no_cpu_baseline:
@@ -570,6 +594,62 @@ def from_text_leg(hip_backend, synthetic, local_rank):
                      "first_call_wall_ms": min(firsts[1:]), "chars_per_s": n_bytes / (min(walls) * 1e-3),
                      "note": "wall = Python bytes -> finished index (H2D of the raw text from pageable memory included); "
                              "first_call = fresh handle, arena allocation included"}
+    return res
+
+
+def worst_case_leg(hip_backend, synthetic, torch, dev, local_rank, with_oracle):
+    """The reference's own (and only) benchmark workload: analysis/runtime.py:19-31 times AST.get_ast on
+    analysis/utils.py:5-9 `worst_case_strings_collection(m = 100, n)` -- as shipped, 100 IDENTICAL strings of n - 4
+    letters.  Every suffix sits in a tie group of 100 that only the terminators tell apart and the common prefixes are as
+    long as the strings: the input that drives the tie-refinement rounds into prefix doubling, the capped LCP comparison
+    into the blocked-Kasai finish, or the build into the DC3 fallback.  Per n: the build (a fresh handle's first build
+    and the steady state), which path ran, the same number of symbols of random word-stream text beside it, and the
+    oracle's time on the same input."""
+    res = {"workload": "analysis/utils.py worst_case_strings_collection(m=100, n): 100 identical strings of n-4 letters, "
+                       "one document (AST.get_ast), symbols resident in HBM", "cases": []}
+    for n in (1000, 10000, 100000):
+        rng = np.random.default_rng(20240 + 6)
+        sym, m = synthetic.worst_case_collection(rng, 100, n)
+        off, ms = np.array([0, sym.size], dtype=np.int64), np.array([m], dtype=np.int32)
+        d_sym = torch.from_numpy(sym.view(np.int32)).to(dev)
+        index = hip_backend.HipIndex(local_rank, reserve_symbols=int(sym.size))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        index.build_device(d_sym.data_ptr(), sym.size, off, ms)
+        first_wall = (time.perf_counter() - t0) * 1e3
+        first_dev = index.last_build_ms
+        times = []
+        for _ in range(3):
+            index.build_device(d_sym.data_ptr(), sym.size, off, ms)
+            times.append(index.last_build_ms)
+        info = index.info()
+        index.close()
+        # random word-stream text with the same number of symbols (text mode: 3-word strings), same code
+        _, rsym, rm = synthetic.word_stream_document(np.random.default_rng(20240 + 7), int(sym.size * 1.07), want_text=False)
+        d_r = torch.from_numpy(rsym.view(np.int32)).to(dev)
+        rindex = hip_backend.HipIndex(local_rank, reserve_symbols=int(rsym.size))
+        rtimes = []
+        for _ in range(4):
+            rindex.build_device(d_r.data_ptr(), rsym.size, np.array([0, rsym.size]), np.array([rm]))
+            rtimes.append(rindex.last_build_ms)
+        rindex.close()
+        per_sym = min(times) / sym.size
+        per_sym_random = min(rtimes[1:]) / rsym.size
+        case = {"n": n, "m": 100, "symbols": int(sym.size), "build_ms": min(times), "first_build_ms": first_dev,
+                "first_build_wall_ms": first_wall, "chars_per_s": int(sym.size - m) / (min(times) * 1e-3),
+                "path": {"window_sorted": info["window_sorted"], "refine_rounds": info["refine_rounds"],
+                         "dc3_levels": info["dc3_levels"], "radix_passes": info["radix_passes"],
+                         "lds_sorted": info.get("lds_sorted", 0), "fused_finish": info.get("fused_finish", 0)},
+                "random_text_same_size_build_ms": min(rtimes[1:]), "random_text_symbols": int(rsym.size),
+                "ns_per_symbol": per_sym * 1e6, "ns_per_symbol_random_text": per_sym_random * 1e6,
+                "slowdown_vs_random_text_per_symbol": per_sym / per_sym_random}
+        if with_oracle:
+            from oracle import easa_oracle
+            t0 = time.perf_counter()
+            easa_oracle.OracleEASA(symbols=sym, n_strings=m)
+            case["oracle_build_s"] = time.perf_counter() - t0
+            case["speedup_vs_oracle_one_core"] = case["oracle_build_s"] * 1e3 / min(times)
+        res["cases"].append(case)
     return res
 
 

@@ -6,6 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/zipf
 rm -rf "$OUT"; mkdir -p "$OUT"
+echo "${EAST_COMMIT:-unknown}" > $OUT/commit.txt     # (the tree the passes are taken on: gpurun -- "EAST_COMMIT=$(git rev-parse --short HEAD) tools/...")
 ARGS="--corpus zipf --docs 100 --doc-mib 1 --keyphrases 1000 --no-cpu-baseline --no-config2 --no-extras"
 timeout 300 python3 bench.py $ARGS 2>/dev/null | tail -1 > $OUT/bench.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS --steps 5 --warmup 2 > $OUT/bench_profiled.json 2>/dev/null

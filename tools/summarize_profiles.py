@@ -109,7 +109,8 @@ out = {"_note": "HBM bytes per launch = (c*FETCH_SIZE + WRITE_SIZE)*1024 from se
        "_fetch_correction_1": "kernels priced with c = 1 (a LOWER bound where part of their reads is 16-byte streaming: "
                               "lvl0_finish_kernel / lvl0_place_kernel are short by about 4 B per suffix, the refinement "
                               "rounds' kernels by half of their streamed reads): " + ", ".join(sorted(k for k in traffic if k in GATHER)),
-       "_workload": bench["config"]["workload"]}
+       "_workload": bench["config"]["workload"],
+       "_commit": (open(os.path.join(SRC, "commit.txt")).read().strip() if os.path.exists(os.path.join(SRC, "commit.txt")) else None)}
 for k, v in traffic.items():
     out[names.get(k, k)] = v
 json.dump(out, open(os.path.join(DST, TRAFFIC), "w"), indent=1, sort_keys=True)
