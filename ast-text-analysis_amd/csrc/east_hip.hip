@@ -2412,3 +2412,7 @@ int east_hip_debug_suffix_array(int device, const uint32_t *symbols, int64_t n, 
 }
 
 }  // extern "C"
+
+// ---- several devices in one process ------------------------------------------------------------------
+#include "multi.h"
+#include "format.h"

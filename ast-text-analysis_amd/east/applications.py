@@ -1,10 +1,56 @@
 # -*- coding: utf-8 -*-
 """keyphrases_table / keyphrases_graph (reference east/applications.py:11-149)."""
 
+from collections.abc import Mapping
+
+import numpy as np
+
 from east import consts
 from east import logging
 from east import relevance
 from east import utils
+
+
+class _ScoreRow(Mapping):
+    """One keyphrase's row of a ScoreTable: {text name: score}, read off the K x D array."""
+
+    __slots__ = ("_table", "_k")
+
+    def __init__(self, table, k):
+        self._table, self._k = table, k
+
+    def __getitem__(self, title):
+        return float(self._table.scores[self._k, self._table._column[title]])
+
+    def __iter__(self):
+        return iter(self._table.text_titles)
+
+    def __len__(self):
+        return len(self._table.text_titles)
+
+
+class ScoreTable(Mapping):
+    """What keyphrases_table returns on the batched path: {raw keyphrase: {text name: score}} (applications.py:46-52) as a
+    read-only mapping over the K x D score array itself.  At BASELINE configs[2] the table holds 2.56 M scores: a dict of
+    dicts of Python floats costs seconds to make and a gigabyte to keep, the device fills the array in a millisecond.
+    Compares equal to the dict of dicts with the same content; `scores`, `keyphrases` (row order) and `text_titles`
+    (column order) are there for consumers that work on the array (east/formatting.py, keyphrases_graph)."""
+
+    def __init__(self, keyphrases, text_titles, scores):
+        self.keyphrases, self.text_titles, self.scores = list(keyphrases), list(text_titles), scores
+        self._row = {kp: k for k, kp in enumerate(self.keyphrases)}
+        self._column = {}
+        for d, title in enumerate(self.text_titles):         # (as dict(zip(titles, row)): a repeated title keeps its last column)
+            self._column[title] = d
+
+    def __getitem__(self, keyphrase):
+        return _ScoreRow(self, self._row[keyphrase])
+
+    def __iter__(self):
+        return iter(self.keyphrases)
+
+    def __len__(self):
+        return len(self.keyphrases)
 
 
 def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=None,
@@ -14,7 +60,8 @@ def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=Non
     :param keyphrases: raw keyphrase strings (empty ones are skipped, duplicates collapse)
     :param texts: {text name: text}
     :param similarity_measure: defaults to ASTRelevanceMeasure() (easa, normalized)
-    :returns: {raw keyphrase: {text name: score}}
+    :returns: {raw keyphrase: {text name: score}} (a ScoreTable -- a read-only mapping over the score array -- on the
+              batched path)
     """
     similarity_measure = similarity_measure or relevance.ASTRelevanceMeasure()
 
@@ -32,8 +79,7 @@ def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=Non
             prepared = [keyphrases_prepared[kp] for kp in wanted]
             scores = (similarity_measure.relevance_table(prepared, synonimizer) if synonimizer
                       else similarity_measure.relevance_table(prepared))
-            for keyphrase, row in zip(wanted, scores.tolist()):          # (one C-level conversion of the K x D table)
-                res[keyphrase] = dict(zip(text_titles, row))
+            return ScoreTable(wanted, text_titles, scores)                # (a mapping over the array: no K x D Python floats)
         return res
 
     i = 0
@@ -69,9 +115,15 @@ def keyphrases_graph(keyphrases, texts, referral_confidence=0.6, relevance_thres
     table = keyphrases_table(keyphrases, texts, measure, synonimizer, language)
 
     occurs_in = {}
-    for keyphrase in keyphrases:
-        row = table[keyphrase]
-        occurs_in[keyphrase] = set(name for name in texts if row[name] >= relevance_threshold)
+    if isinstance(table, ScoreTable):                        # (one comparison over the array instead of K x D look-ups)
+        hits = table.scores >= relevance_threshold
+        for keyphrase in keyphrases:
+            found = set(table.text_titles[d] for d in np.flatnonzero(hits[table._row[keyphrase]]).tolist())
+            occurs_in[keyphrase] = set(name for name in texts if name in found)
+    else:
+        for keyphrase in keyphrases:
+            row = table[keyphrase]
+            occurs_in[keyphrase] = set(name for name in texts if row[name] >= relevance_threshold)
 
     nodes = [{"id": position, "label": keyphrase, "support": len(occurs_in[keyphrase])}
              for position, keyphrase in enumerate(keyphrases)

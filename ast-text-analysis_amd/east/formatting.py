@@ -17,8 +17,42 @@ def format_table(table, format):
     return renderers[format](table)
 
 
+def _bulk(keyphrases_table, kind):
+    """A ScoreTable (applications.py) of many scores goes through the library's host-side formatter -- the same bytes,
+    written by a few threads straight from the score array -- instead of one Python '%.3f' per score.  None: not such a
+    table (a plain dict, a small table, names or scores the formatter does not take)."""
+    from east import applications
+    if not isinstance(keyphrases_table, applications.ScoreTable) or keyphrases_table.scores.size < _BULK_MIN_SCORES:
+        return None
+    import numpy as np
+    table = keyphrases_table
+    scores = np.asarray(table.scores, dtype=np.float64)
+    titles = table.text_titles
+    if len(table) == 0 or len(set(titles)) != len(titles) or not np.isfinite(scores).all() or np.abs(scores).max() >= 1e15:
+        return None
+    try:
+        from east import hip_backend
+        kp_order = sorted(range(len(table.keyphrases)), key=table.keyphrases.__getitem__)
+        text_order = sorted(range(len(titles)), key=titles.__getitem__)
+        if kind == "xml":
+            return hip_backend.format_table(scores, kp_order, text_order, table.keyphrases, titles, "xml")
+        return hip_backend.format_table(scores, kp_order, text_order, [_csv_quote(k) for k in table.keyphrases],
+                                        [_csv_quote(t) for t in titles], "csv")
+    except (ValueError, UnicodeError, Exception) as e:       # noqa: BLE001 (the library is missing, a NUL in a name ...)
+        from east import exceptions
+        if isinstance(e, (ValueError, UnicodeError, exceptions.HipBackendError)):
+            return None
+        raise
+
+
+_BULK_MIN_SCORES = 4096
+
+
 def table2xml(keyphrases_table):
     """<table> / <keyphrase value=..> / <text name=..>score</text>, keyphrases and texts sorted."""
+    text = _bulk(keyphrases_table, "xml")
+    if text is not None:
+        return text
     lines = ["<table>"]
     for keyphrase in sorted(keyphrases_table):
         row = keyphrases_table[keyphrase]
@@ -35,6 +69,9 @@ def _csv_quote(value):
 
 def table2csv(keyphrases_table):
     """Header row of quoted keyphrases, then one row per text: "name",score,score,..."""
+    text = _bulk(keyphrases_table, "csv")
+    if text is not None:
+        return text
     keyphrases = sorted(keyphrases_table)
     texts = sorted(keyphrases_table[keyphrases[0]])
     rows = ["," + ",".join(_csv_quote(k) for k in keyphrases)]

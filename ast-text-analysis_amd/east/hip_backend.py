@@ -76,6 +76,24 @@ SIGNATURES = {
     "east_hip_debug_set_text_stream": (ctypes.c_int, [ctypes.c_int64]),
     "east_hip_debug_alphabetic_code": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int32,
                                                       ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int32)]),
+    "east_hip_group_create": (ctypes.c_int, [_c_i32p, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
+    "east_hip_group_destroy": (None, [ctypes.c_void_p]),
+    "east_hip_group_build": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, ctypes.c_int64, _c_i64p, _c_i32p, ctypes.c_int32,
+                                            ctypes.c_int32]),
+    "east_hip_group_build_texts_v": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p), _c_i64p, ctypes.c_int32,
+                                                    ctypes.POINTER(ctypes.c_uint8), _c_u32p, _c_u32p, _c_u32p, _c_u32p,
+                                                    _c_u32p, ctypes.c_int32]),
+    "east_hip_group_shards": (ctypes.c_int, [ctypes.c_void_p, _c_i32p]),
+    "east_hip_group_handle": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int32]),
+    "east_hip_score_table_multi": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, _c_i64p, ctypes.c_int32, ctypes.c_int, _c_dblp]),
+    "east_hip_group_info": (ctypes.c_int, [ctypes.c_void_p, _c_dblp, ctypes.c_int32]),
+    "east_hip_debug_shard_documents": (ctypes.c_int, [_c_i64p, ctypes.c_int32, ctypes.c_int32, _c_i32p]),
+    "east_hip_format_table_xml": (ctypes.c_int64, [_c_dblp, ctypes.c_int32, ctypes.c_int32, _c_i32p, _c_i32p,
+                                                   ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
+                                                   ctypes.c_char_p, ctypes.c_int64]),
+    "east_hip_format_table_csv": (ctypes.c_int64, [_c_dblp, ctypes.c_int32, ctypes.c_int32, _c_i32p, _c_i32p,
+                                                   ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
+                                                   ctypes.c_char_p, ctypes.c_int64]),
     "east_hip_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "east_hip_profile_only": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
     "east_hip_profile_report": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
@@ -207,6 +225,19 @@ class HipIndex(object):
         self.doc_offsets = None
         self._host_symbols = None
 
+    @classmethod
+    def borrowed(cls, handle, device):
+        """A view of a handle somebody else owns (a shard of a HipGroup): close() leaves it alone."""
+        self = cls.__new__(cls)
+        self._lib = load()
+        self._h = ctypes.c_void_p(handle)
+        self._borrowed = True
+        self.device = int(device)
+        self.n_docs = 0
+        self.doc_offsets = None
+        self._host_symbols = None
+        return self
+
     def close(self):
         """Release the handle.  Handles of small indexes go back to a per-device pool instead of being
         destroyed: stream / event / memory set-up costs more than building a small collection."""
@@ -214,6 +245,8 @@ class HipIndex(object):
         if not h:
             return
         self._h = None
+        if getattr(self, "_borrowed", False):
+            return
         try:
             pool = _handle_pool.setdefault(self.device, [])
             buf = np.zeros(8, dtype=np.int64)
@@ -398,6 +431,127 @@ class HipIndex(object):
     @property
     def last_score_ms(self):
         return float(self._lib.east_hip_last_score_ms(self._h))
+
+
+class HipGroup(object):
+    """One collection over several devices in this process: a shard of documents -- one HipIndex -- per device, driven
+    by the library's own host threads, the K x D_local score blocks assembled by one all-gather (RCCL between distinct
+    devices; include/east_hip.h, "Several devices in one process").  `devices`: a count (devices 0 .. N-1) or a list of
+    ordinals; an ordinal may appear several times (logical shards on one device)."""
+
+    def __init__(self, devices):
+        self._lib = load()
+        self.devices = list(range(devices)) if isinstance(devices, int) else [int(d) for d in devices]
+        if not self.devices:
+            raise exceptions.HipBackendError(reason="a device group needs at least one device")
+        self._g = ctypes.c_void_p()
+        dev = np.array(self.devices, dtype=np.int32)
+        _check(self._lib.east_hip_group_create(_ptr(dev, _c_i32p), dev.size, ctypes.byref(self._g)))
+        self.n_docs = 0
+        self.first_doc = None
+        self.shards = []
+
+    def close(self):
+        g = getattr(self, "_g", None)
+        if g:
+            self._g = None
+            for shard in self.shards:
+                shard.close()
+            self._lib.east_hip_group_destroy(g)
+
+    __del__ = close
+
+    def _after_build(self, n_docs):
+        self.n_docs = int(n_docs)
+        first = np.zeros(len(self.devices) + 1, dtype=np.int32)
+        self._lib.east_hip_group_shards(self._g, _ptr(first, _c_i32p))
+        self.first_doc = first
+        self.shards = []
+        for s, device in enumerate(self.devices):
+            view = HipIndex.borrowed(self._lib.east_hip_group_handle(self._g, s), device)
+            view.n_docs = int(first[s + 1] - first[s])
+            if view.n_docs:
+                offsets = np.zeros(view.n_docs + 1, dtype=np.int64)
+                n_total = ctypes.c_int64(0)
+                if self._from_texts:
+                    _check(self._lib.east_hip_get_prepared(view._h, ctypes.byref(n_total), _ptr(offsets, _c_i64p), None, None))
+                else:
+                    b, e = int(first[s]), int(first[s + 1])
+                    offsets = (self._doc_offsets[b:e + 1] - self._doc_offsets[b]).astype(np.int64)
+                    view._host_symbols = self._symbols[int(self._doc_offsets[b]):int(self._doc_offsets[e])]
+                view.doc_offsets = offsets
+            self.shards.append(view)
+
+    def build(self, symbols, doc_offsets, n_strings):
+        symbols = np.ascontiguousarray(symbols, dtype=np.uint32)
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.int64)
+        n_strings = np.ascontiguousarray(n_strings, dtype=np.int32)
+        tagged = 1 if symbols.size and int(symbols[-1]) >> 31 else 0
+        _check(self._lib.east_hip_group_build(self._g, _ptr(symbols, _c_u32p), symbols.size, _ptr(doc_offsets, _c_i64p),
+                                              _ptr(n_strings, _c_i32p), n_strings.size, tagged))
+        self._from_texts, self._symbols, self._doc_offsets = False, symbols, doc_offsets
+        self._after_build(n_strings.size)
+
+    def build_texts(self, texts):
+        raw = [t if isinstance(t, bytes) else t.encode("utf-8", errors="surrogatepass") for t in texts]
+        cls, upper, word_hi, digit_hi, hi_from, hi_to = unicode_tables()
+        ptrs = (ctypes.c_char_p * len(raw))(*raw)
+        lengths = np.array([len(t) for t in raw], dtype=np.int64)
+        _check(self._lib.east_hip_group_build_texts_v(
+            self._g, ptrs, _ptr(lengths, _c_i64p), len(raw), _ptr(cls, ctypes.POINTER(ctypes.c_uint8)), _ptr(upper, _c_u32p),
+            _ptr(word_hi, _c_u32p), _ptr(digit_hi, _c_u32p), _ptr(hi_from, _c_u32p), _ptr(hi_to, _c_u32p), hi_from.size))
+        self._from_texts = True
+        self._after_build(len(raw))
+
+    def locate(self, doc):
+        """(shard view, document number inside the shard) of document `doc` of the collection."""
+        s = int(np.searchsorted(self.first_doc, doc, side="right")) - 1
+        return self.shards[s], int(doc - self.first_doc[s])
+
+    def score_table(self, q_symbols, q_offsets, normalized=True):
+        q_symbols = np.ascontiguousarray(q_symbols, dtype=np.uint32)
+        q_offsets = np.ascontiguousarray(q_offsets, dtype=np.int64)
+        K = q_offsets.size - 1
+        out = np.empty((K, self.n_docs), dtype=np.float64)
+        _check(self._lib.east_hip_score_table_multi(self._g, _ptr(q_symbols, _c_u32p), _ptr(q_offsets, _c_i64p), K,
+                                                    int(bool(normalized)), _ptr(out, _c_dblp)))
+        return out
+
+    def info(self):
+        buf = np.zeros(5, dtype=np.float64)
+        self._lib.east_hip_group_info(self._g, _ptr(buf, _c_dblp), buf.size)
+        return {"build_ms": float(buf[0]), "score_ms": float(buf[1]), "gather_ms": float(buf[2]),
+                "gather": {1: "rccl", 2: "copies"}.get(int(buf[3]), None), "shards": int(buf[4])}
+
+
+def shard_documents(sizes, n_shards):
+    """The library's sharding rule (host only): first_doc[n_shards + 1]."""
+    sizes = np.ascontiguousarray(sizes, dtype=np.int64)
+    first = np.zeros(n_shards + 1, dtype=np.int32)
+    _check(load().east_hip_debug_shard_documents(_ptr(sizes, _c_i64p), sizes.size, n_shards, _ptr(first, _c_i32p)))
+    return first
+
+
+def format_table(scores, kp_order, text_order, kp_names, text_names, kind):
+    """The keyphrase table as text through the library's host-side formatter (east_hip_format_table_xml / _csv): scores
+    K x D float64, the output order of rows / columns as index arrays, names as str (CSV: already quoted)."""
+    lib = load()
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    K, D = scores.shape
+    kp_order = np.ascontiguousarray(kp_order, dtype=np.int32)
+    text_order = np.ascontiguousarray(text_order, dtype=np.int32)
+    kp_b = [s.encode("utf-8", "surrogatepass") for s in kp_names]
+    text_b = [s.encode("utf-8", "surrogatepass") for s in text_names]
+    if any(b"\0" in b for b in kp_b) or any(b"\0" in b for b in text_b):
+        raise ValueError("NUL in a name")
+    fn = lib.east_hip_format_table_xml if kind == "xml" else lib.east_hip_format_table_csv
+    cap = 64 + sum(len(b) + 64 for b in kp_b) + (sum(len(b) + 64 for b in text_b) + 8) * max(K, 1) + 40 * K * D
+    buf = ctypes.create_string_buffer(cap)
+    n = fn(_ptr(scores, _c_dblp), K, D, _ptr(kp_order, _c_i32p), _ptr(text_order, _c_i32p),
+           (ctypes.c_char_p * max(K, 1))(*kp_b), (ctypes.c_char_p * max(D, 1))(*text_b), buf, cap)
+    if n < 0:
+        raise exceptions.HipBackendError(reason="table formatter: %d" % n)
+    return buf.raw[:n].decode("utf-8", "surrogatepass")
 
 
 def pack_queries(queries, keep_spaces=False):

@@ -68,7 +68,12 @@ def main(argv=None, measure_factory=None):
         except ValueError:
             print("Invalid number of GPUs: '%s'." % opts.get("-g", os.environ.get("EAST_HIP_DEVICES")))
             return 1
-        if n_ranks > 1:
+        if n_ranks > 1 and os.environ.get("EAST_HIP_MULTI", "threads") != "process":
+            # the default: N devices in THIS process (one AST shard and one host thread of the library per device, one
+            # RCCL all-gather of the score blocks -- east_hip_score_table_multi); no child processes, no torch
+            opts["-g"] = str(n_ranks)
+        elif n_ranks > 1:
+            # EAST_HIP_MULTI=process: one process per GPU under torch.distributed.run --
             # the same command line without -g: the ranks learn the world size from the launcher
             child_argv = []
             for key, value in opt_list:
@@ -118,11 +123,17 @@ def _main(opts, args, world, measure_factory):
                       for filename in sorted(os.listdir(text_collection_path)) if filename.endswith(".txt")]
     else:
         text_files = [text_collection_path]
+    distributed = world > 1 or os.environ.get("EAST_HIP_FORCE_DIST") == "1"
     texts = {}
     if len(text_files) == 1:      # a single file: one text per line
         lines = _read(text_files[0]).splitlines()
         for i in range(len(lines)):
             texts[str(i)] = lines[i]
+    elif distributed:
+        # one rank per GPU: the documents are sharded by their FILE SIZES (os.stat); a rank reads its own files only
+        from east import parallel
+        for filename in text_files:
+            texts[os.path.basename(filename)[:-4]] = parallel.LazyText(filename, _read)
     else:
         for filename in text_files:
             texts[os.path.basename(filename)[:-4]] = _read(filename)
@@ -137,7 +148,7 @@ def _main(opts, args, world, measure_factory):
 
     group_up = False
     try:
-        if world > 1 or os.environ.get("EAST_HIP_FORCE_DIST") == "1":     # (forced: the collective path with one rank)
+        if distributed:                                                   # (forced: the collective path with one rank)
             # one rank per GPU: this rank indexes its share of the documents on the device of its LOCAL_RANK and
             # the K x D table is assembled by one all-gather (east/parallel.py); every rank computes, rank 0 prints
             import torch.distributed as dist
@@ -155,7 +166,9 @@ def _main(opts, args, world, measure_factory):
                 group_up = True
             device = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else None
             similarity_measure = parallel.DistributedASTRelevanceMeasure(opts["-a"], "-d" not in opts, device=device,
-                                                                         measure_factory=measure_factory)
+                                                                         measure_factory=measure_factory, table_rank=0)
+        elif world == 1 and int(opts.get("-g", "1")) > 1:
+            similarity_measure = relevance.MultiDeviceASTRelevanceMeasure(opts["-a"], "-d" not in opts, int(opts["-g"]))
         else:
             similarity_measure = relevance.ASTRelevanceMeasure(opts["-a"], "-d" not in opts)      # main.py:95-98
         return _run(subcommand, keyphrases, texts, similarity_measure, opts)

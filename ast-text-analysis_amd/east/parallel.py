@@ -9,12 +9,34 @@ K x D score table: one all-gather of each rank's K x D_local block
 (`torch.distributed`, backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
 in the CPU tests).  A single document's suffix sort does not shard.
 """
+import os
+
 import numpy as np
 
 from east import consts
 from east import hip_backend
 from east import relevance
 from east import utils
+
+
+class LazyText(object):
+    """A text of the collection that is still a file: its size is known (os.stat), its bytes are read by the rank whose
+    shard holds it -- and by nobody else (`east keyphrases table` over a directory of a few thousand files would otherwise
+    read the whole corpus on every rank to index an eighth of it)."""
+
+    def __init__(self, path, reader=None):
+        self.path = path
+        self.size = os.stat(path).st_size
+        self._reader = reader
+
+    def __len__(self):
+        return self.size
+
+    def load(self):
+        if self._reader is not None:
+            return self._reader(self.path)
+        with open(self.path, "rb") as f:
+            return f.read()
 
 
 def shard_documents(sizes, world_size):
@@ -35,12 +57,13 @@ def shard_documents(sizes, world_size):
     return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
 
 
-def all_gather_table(local_block, counts, group=None):
+def all_gather_table(local_block, counts, group=None, assemble=True):
     """Assemble the K x D table from per-rank K x D_local blocks.
 
     local_block: torch tensor (K, D_local) float64 on the rank's device (cuda for
     RCCL, cpu for gloo); counts[r] = D_local of rank r.  Blocks are padded to the
-    largest D_local so that a single all_gather_into_tensor moves everything."""
+    largest D_local so that a single all_gather_into_tensor moves everything.
+    assemble=False: the rank takes part in the collective and returns None (it does not need the table)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -50,6 +73,8 @@ def all_gather_table(local_block, counts, group=None):
     padded[:, :local_block.shape[1]] = local_block
     gathered = torch.empty((world * K, width), dtype=local_block.dtype, device=local_block.device)
     dist.all_gather_into_tensor(gathered, padded.contiguous(), group=group)     # rank-major concatenation
+    if not assemble:
+        return None
     gathered = gathered.view(world, K, width)
     return torch.cat([gathered[r, :, :counts[r]] for r in range(world)], dim=1)
 
@@ -64,9 +89,12 @@ class DistributedASTRelevanceMeasure(relevance.ASTRelevanceMeasure):
     which goes straight into all_gather_into_tensor; the assembled table is copied to the host once."""
 
     def __init__(self, ast_algorithm=consts.ASTAlgorithm.EASA, normalized=True, device=None, group=None,
-                 measure_factory=None):
+                 measure_factory=None, table_rank=None):
+        """table_rank: None -- relevance_table returns the K x D table on every rank; r -- only rank r assembles it and
+        copies it to the host (the CLI: rank 0 prints), the others take part in the collective and get a K x 0 array."""
         super(DistributedASTRelevanceMeasure, self).__init__(ast_algorithm, normalized, device)
         self.group = group
+        self.table_rank = table_rank
         # ONE device for the index and for the collective: the explicit one, else EAST_HIP_DEVICE / LOCAL_RANK
         self.gpu = hip_backend.default_device() if device is None else int(device)
         # the local shard's measure; the factory hook exists so that the collective
@@ -91,7 +119,8 @@ class DistributedASTRelevanceMeasure(relevance.ASTRelevanceMeasure):
         self.local = self._factory()
         self.local.normalized = self.normalized
         if e > b:
-            self.local.set_text_collection(list(texts[b:e]), language)
+            # (texts that are still files are read here, by the rank that indexes them)
+            self.local.set_text_collection([t.load() if isinstance(t, LazyText) else t for t in texts[b:e]], language)
 
     def _check_queries(self, prepared_keyphrases, synonimizer):
         """What the reference raises on a query (easa.py:134 on an empty keyphrase or synonym variant, KeyError out of
@@ -149,8 +178,11 @@ class DistributedASTRelevanceMeasure(relevance.ASTRelevanceMeasure):
             raise error
         if int(flag.item()):
             raise RuntimeError("relevance_table failed on another rank of the process group")
-        table = all_gather_table(block, self.counts, self.group)
-        return table.cpu().numpy()
+        wanted = self.table_rank is None or dist.get_rank(self.group) == self.table_rank
+        table = all_gather_table(block, self.counts, self.group, assemble=wanted)
+        if not wanted:
+            return np.zeros((len(prepared_keyphrases), 0), dtype=np.float64)
+        return table.cpu().numpy()                       # the one copy of the assembled table to the host
 
     def relevance(self, keyphrase, text, synonimizer=None):
         return float(self.relevance_table([keyphrase], synonimizer)[0, text])

@@ -206,3 +206,73 @@ class ASTRelevanceMeasure(RelevanceMeasure):
             raise ZeroDivisionError("float division by zero")
         qs, qo = hip_backend.pack_queries(queries)
         return self.index.score_table(qs, qo, self.normalized)
+
+
+class MultiDeviceASTRelevanceMeasure(ASTRelevanceMeasure):
+    """ASTRelevanceMeasure over several GPUs of this process (`east -g N`): the documents are sharded over the devices --
+    contiguous blocks balanced by size, one AST shard per device, no collective on the build path --, every shard scores
+    its own documents and the K x D_local blocks are assembled by one all-gather (hip_backend.HipGroup ->
+    east_hip_score_table_multi: RCCL between distinct devices).  Same surface and same numbers as the single-device
+    measure (relevance.py:27-53); no torch, no child processes.  `devices`: a count or a list of device ordinals."""
+
+    def __init__(self, ast_algorithm=consts.ASTAlgorithm.EASA, normalized=True, devices=1):
+        super(MultiDeviceASTRelevanceMeasure, self).__init__(ast_algorithm, normalized, None)
+        # (EAST_HIP_GROUP_DEVICES=0,0,1: the shards' device ordinals spelled out -- logical shards on one device, the tests)
+        spelled = os.environ.get("EAST_HIP_GROUP_DEVICES", "")
+        self.devices = [int(d) for d in spelled.split(",")] if spelled and isinstance(devices, int) else devices
+        self.group = None
+        self._shards = []
+
+    def _after_build(self, n_docs):
+        self._shards = []
+        for view in self.group.shards:
+            shard = _Shard()
+            shard.index = view
+            self._shards.append(shard)
+        self.asts = []
+        for d in range(n_docs):
+            s = int(np.searchsorted(self.group.first_doc, d, side="right")) - 1
+            self.asts.append(_DocumentAST(self._shards[s], int(d - self.group.first_doc[s])))
+        self._row = (None, None)
+
+    def set_text_collection(self, texts, language=consts.Language.ENGLISH):
+        texts = list(texts)
+        self.texts = texts
+        self.language = language
+        if self.group is None:
+            self.group = hip_backend.HipGroup(self.devices)
+        if os.environ.get("EAST_HIP_TEXT_PREP", "device") == "device":
+            self.group.build_texts(texts)
+            self._after_build(len(texts))
+            return
+        self.set_strings_collections([utils.text_to_strings_collection(text) for text in texts])
+
+    def _build_from_parts(self, parts, collections):
+        doc_offsets = np.zeros(len(parts) + 1, dtype=np.int64)
+        np.cumsum([p.size for p in parts], out=doc_offsets[1:])
+        n_strings = np.array([len(sc) for sc in collections], dtype=np.int32)
+        if self.group is None:
+            self.group = hip_backend.HipGroup(self.devices)
+        self.group.build(np.concatenate(parts), doc_offsets, n_strings)
+        self._after_build(len(parts))                        # (the shard views keep their slices of the symbols)
+
+    def relevance(self, keyphrase, text, synonimizer=None):
+        key = (keyphrase, bool(self.normalized), None if not synonimizer else synonym_alternatives(keyphrase, synonimizer))
+        if self._row[0] != key:
+            self._row = (key, self.relevance_table([keyphrase], synonimizer or None)[0])
+        return float(self._row[1][text])
+
+    def relevance_table(self, prepared_keyphrases, synonimizer=None):
+        if synonimizer:
+            # (the segmented max over the variants runs per shard: the blocks side by side are the table)
+            groups = [synonym_variants(kp, synonimizer) for kp in prepared_keyphrases]
+            offsets = np.zeros(len(groups) + 1, dtype=np.int64)
+            np.cumsum([len(g) for g in groups], out=offsets[1:])
+            qs, qo = hip_backend.pack_queries([v for g in groups for v in g], keep_spaces=True)
+            blocks = [view.score_table_grouped(qs, qo, offsets, True) for view in self.group.shards if view.n_docs]
+            return np.concatenate(blocks, axis=1)
+        queries = [kp.replace(" ", "") for kp in prepared_keyphrases]
+        if not all(queries):
+            raise ZeroDivisionError("float division by zero")
+        qs, qo = hip_backend.pack_queries(queries)
+        return self.group.score_table(qs, qo, self.normalized)

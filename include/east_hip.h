@@ -225,6 +225,58 @@ int east_hip_get_lcp_intervals(east_hip_handle_t h, int32_t doc, int32_t *left);
  * one symbol each), the "probes" of SURVEY.md 8(d).  Not a timed path. */
 int east_hip_score_probes(east_hip_handle_t h, int normalized, int64_t *probes);
 
+/*
+ * Several devices in one process ("single-process/8-device fits the one-process CLI best").
+ * Every document is an independent AST (east/relevance.py:41-46) and every (keyphrase, document) score is independent
+ * (east/applications.py:43-52): a GROUP shards a collection at document granularity -- contiguous blocks of documents
+ * balanced by size, shard s on devices[s], one handle per shard -- and drives the shards with host threads of its own
+ * (ctypes drops the GIL around the call).  No collective on the build path.  east_hip_score_table_multi lets every shard
+ * score its documents and assembles the K x D_local blocks with ONE all-gather: RCCL (librccl.so loaded at run time,
+ * ncclCommInitAll + a grouped ncclAllGather over xGMI, blocks padded to the widest shard) where every shard has a device
+ * of its own, device-to-device copies to the first shard's device otherwise (logical shards sharing a device, no
+ * librccl.so; EAST_HIP_GROUP_GATHER=copy|rccl forces either); the K x D table then goes to the host once.  No torch, no
+ * process spawn.  `devices` may name a device several times (logical shards: the single-GPU tests).
+ *
+ *   east_hip_group_build           as east_hip_build (host symbols; `encoding` = EAST_HIP_SYMBOLS_*), sharded by symbols
+ *   east_hip_group_build_texts_v   as east_hip_build_texts_v (raw texts, device text preparation), sharded by bytes
+ *   east_hip_group_shards          first_doc[n_shards + 1]: shard s holds the documents [first_doc[s], first_doc[s+1]);
+ *                                  returns n_shards
+ *   east_hip_group_handle          shard s's handle (owned by the group) for east_hip_get_tables & co.; document d of the
+ *                                  collection is document d - first_doc[s] of its shard
+ *   east_hip_score_table_multi     out: K x D doubles, row-major, D = all documents in their original order
+ *   east_hip_group_info            [0] build, [1] score (slowest shard), [2] all-gather + copy to the host: wall ms of the
+ *                                  last calls; [3] 1 = RCCL all-gather, 2 = copies; [4] shards
+ * A group is not thread-safe; the east_hip_debug_* knobs must not be changed while a group call is in flight.
+ */
+typedef struct east_hip_group *east_hip_group_t;
+int east_hip_group_create(const int32_t *devices, int32_t n_shards, east_hip_group_t *out);
+void east_hip_group_destroy(east_hip_group_t g);
+int east_hip_group_build(east_hip_group_t g, const uint32_t *symbols, int64_t n_total, const int64_t *doc_offsets,
+                         const int32_t *n_strings, int32_t n_docs, int32_t encoding);
+int east_hip_group_build_texts_v(east_hip_group_t g, const uint8_t *const *texts, const int64_t *lengths, int32_t n_docs,
+                                 const uint8_t *cp_class, const uint32_t *cp_upper, const uint32_t *word_hi,
+                                 const uint32_t *digit_hi, const uint32_t *hi_upper_from, const uint32_t *hi_upper_to,
+                                 int32_t n_hi_upper);
+int east_hip_group_shards(east_hip_group_t g, int32_t *first_doc);
+east_hip_handle_t east_hip_group_handle(east_hip_group_t g, int32_t shard);
+int east_hip_score_table_multi(east_hip_group_t g, const uint32_t *q_symbols, const int64_t *q_offsets,
+                               int32_t n_keyphrases, int normalized, double *out);
+int east_hip_group_info(east_hip_group_t g, double *out, int32_t cap);
+/* Host only (needs no device): the group's sharding rule -- contiguous blocks balanced by size; first_doc[n_shards + 1]. */
+int east_hip_debug_shard_documents(const int64_t *sizes, int32_t n_docs, int32_t n_shards, int32_t *first_doc);
+
+/*
+ * Host only (needs no device): the keyphrase table as text -- east/formatting.py:14-39, table2xml / table2csv, byte for byte
+ * ('%s' names, '%.3f' scores) -- for tables of millions of scores, where a Python loop over the scores takes seconds
+ * (BASELINE configs[2]: 2.56 M).  table: K x D doubles, row-major; kp_order / text_order: the output order (the sorted
+ * names) as indices into the table's rows / columns; names NUL-terminated UTF-8 indexed like the table (CSV: already
+ * quoted).  Returns the length written, minus the bytes needed when cap is too small, or EAST_HIP_ERR_INVALID.
+ */
+int64_t east_hip_format_table_xml(const double *table, int32_t K, int32_t D, const int32_t *kp_order, const int32_t *text_order,
+                                  const char *const *kp_names, const char *const *text_names, char *out, int64_t cap);
+int64_t east_hip_format_table_csv(const double *table, int32_t K, int32_t D, const int32_t *kp_order, const int32_t *text_order,
+                                  const char *const *kp_quoted, const char *const *text_quoted, char *out, int64_t cap);
+
 /* Block until everything queued on the handle's stream has finished. */
 int east_hip_synchronize(east_hip_handle_t h);
 /* The handle's hipStream_t (as void*) so callers can record events on it. */

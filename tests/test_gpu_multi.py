@@ -1,0 +1,121 @@
+"""gpu tier: several devices in one process (include/east_hip.h: east_hip_group_*, east_hip_score_table_multi;
+csrc/multi.h).  The box has one GPU: the shards are LOGICAL shards on device 0 (tier 5) -- same code,
+same threads, the blocks assembled by device-to-device copies --, and the RCCL path runs as a communicator of one
+(ncclCommInitAll on one device).  Bar: everything identical to the single-handle build of the same collection."""
+import io
+import os
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from conftest import word_stream
+
+pytestmark = pytest.mark.gpu
+
+TABLES = ("suftab", "lcptab", "anntab", "childtab_up", "childtab_down", "childtab_next_l_index")
+
+
+def _collection(rng, sizes):
+    from east import synthetic
+    docs = [synthetic.word_stream_document(rng, int(n), want_text=False)[1:] for n in sizes]
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])]).astype(np.int64)
+    return docs, sym, off, np.array([d[1] for d in docs], dtype=np.int32)
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0]])
+def test_group_of_logical_shards_equals_one_handle(hip, oracle, devices):
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(900 + len(devices))
+    docs, sym, off, ms = _collection(rng, rng.integers(300, 60000, size=21))
+    qs, qo = synthetic.keyphrases(rng, sym, 150)
+    single = hip_backend.HipIndex()
+    single.build(sym, off, ms)
+    group = hip_backend.HipGroup(devices)
+    group.build(sym, off, ms)
+    assert group.first_doc.tolist() == hip_backend.shard_documents(np.diff(off), len(devices)).tolist()
+    for norm in (True, False):
+        assert np.array_equal(group.score_table(qs, qo, norm), single.score_table(qs, qo, norm)), norm
+    info = group.info()
+    assert info["shards"] == len(devices) and info["gather"] == ("rccl" if len(devices) == 1 else "copies")
+    for d in (0, 5, 20):
+        shard, local = group.locate(d)
+        ts, tg = single.tables(d), shard.tables(local)
+        for name in TABLES:
+            assert np.array_equal(ts[name], tg[name]), (name, d)
+    o = oracle.OracleEASA(symbols=docs[13][0], n_strings=docs[13][1])
+    table = group.score_table(qs, qo, True)
+    for k in range(150):
+        assert table[k, 13] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=True)
+    group.close()
+
+
+def test_group_with_more_shards_than_documents(hip):
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(77)
+    docs, sym, off, ms = _collection(rng, [4000, 900])
+    qs, qo = synthetic.keyphrases(rng, sym, 40)
+    single = hip_backend.HipIndex()
+    single.build(sym, off, ms)
+    group = hip_backend.HipGroup([0, 0, 0, 0, 0])
+    group.build(sym, off, ms)
+    assert sum(1 for s in group.shards if s.n_docs == 0) == 3
+    assert np.array_equal(group.score_table(qs, qo, True), single.score_table(qs, qo, True))
+    group.build(sym, off, ms)                                # again on the same group
+    assert np.array_equal(group.score_table(qs, qo, False), single.score_table(qs, qo, False))
+
+
+def test_group_from_raw_texts_and_the_measure_surface(hip):
+    """east_hip_group_build_texts_v (device text preparation per shard) and MultiDeviceASTRelevanceMeasure: the same table,
+    per-pair relevance, per-document views (score with per-suffix results, traversal) as the single-device measure."""
+    from east import relevance, utils
+    rng = np.random.default_rng(31)
+    texts = [word_stream(rng, int(n)) for n in (5000, 200, 90000, 1200, 40000, 7, 3000)] + ["Ёж и ЁЛКА, снова ёж".encode("utf-8")]
+    keyphrases = [word_stream(rng, int(rng.integers(5, 30))).decode() for _ in range(25)]
+    prepared = [utils.prepare_text(k) for k in keyphrases]
+    for normalized in (True, False):
+        one = relevance.ASTRelevanceMeasure("easa", normalized, device=0)
+        one.set_text_collection(texts)
+        many = relevance.MultiDeviceASTRelevanceMeasure("easa", normalized, devices=[0, 0, 0])
+        many.set_text_collection(texts)
+        assert np.array_equal(many.relevance_table(prepared), one.relevance_table(prepared))
+        assert many.relevance(prepared[3], 4) == one.relevance(prepared[3], 4)
+        for d in (0, 2, 7):
+            assert many.asts[d].score(prepared[1], normalized, return_suffix_scores=True) == \
+                one.asts[d].score(prepared[1], normalized, return_suffix_scores=True)
+    seen_one, seen_many = [], []
+    one.asts[4].traverse(seen_one.append)
+    many.asts[4].traverse(seen_many.append)
+    assert seen_one == seen_many and len(seen_one) > 10
+
+
+def test_cli_g_option_in_process(hip, tmp_path, monkeypatch):
+    """`east -g 3 keyphrases table ...` with the three shards on device 0 (EAST_HIP_GROUP_DEVICES): the output of the
+    single-device CLI, byte for byte; a device that does not exist is an error message and exit code 1."""
+    from east import main
+    rng = np.random.default_rng(8)
+    tdir = tmp_path / "texts"
+    tdir.mkdir()
+    for i, size in enumerate([3000, 600, 5000, 1200, 2500, 40, 9000]):
+        (tdir / ("doc%02d.txt" % i)).write_bytes(word_stream(rng, size))
+    kp = tmp_path / "keyphrases.txt"
+    kp.write_text("\n".join(word_stream(rng, int(rng.integers(6, 24))).decode() for _ in range(12)) + "\n")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EAST_HIP_MULTI", "EAST_HIP_DEVICES", "EAST_HIP_GROUP_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+
+    def run(argv):
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            code = main.main(argv)
+        return code, buf.getvalue()
+
+    for flags in (["-f", "csv"], ["-d"]):
+        tail = flags + ["keyphrases", "table", str(kp), str(tdir)]
+        want = run(tail)
+        monkeypatch.setenv("EAST_HIP_GROUP_DEVICES", "0,0,0")
+        assert run(["-g", "3"] + tail) == want and want[0] == 0
+        monkeypatch.delenv("EAST_HIP_GROUP_DEVICES")
+    n = hip.device_count()
+    code, out = run(["-g", str(n + 1), "keyphrases", "table", str(kp), str(tdir)])
+    assert code == 1 and "device" in out

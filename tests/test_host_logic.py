@@ -278,3 +278,17 @@ def test_order_preserving_variable_length_code():
             flat = int(np.max(w)) <= 1000 and length.min() > 3
             assert got >= want and (got == want or not flat), (len(w), got, want)
     assert code_of(np.array([1, 2, 3]))[0] != 0                                           # too few symbols: no code
+
+
+def test_group_sharding_rule_matches_the_process_per_gpu_path():
+    """The in-process device group (east_hip_group_*: csrc/multi.h) and the one-process-per-GPU path (east/parallel.py)
+    cut a collection into the same contiguous blocks: balanced by size, possibly empty with fewer documents than shards."""
+    from east import hip_backend, parallel
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        n, g = int(rng.integers(0, 50)), int(rng.integers(1, 10))
+        sizes = rng.integers(1, 5000, size=n)
+        first = hip_backend.shard_documents(sizes, g).tolist()
+        blocks = parallel.shard_documents(sizes, g)
+        assert first == [b for b, _ in blocks] + [blocks[-1][1]]
+        assert first[0] == 0 and first[-1] == n and all(a <= b for a, b in zip(first, first[1:]))

@@ -94,7 +94,7 @@ def test_cli_g_option_starts_ranks(tmp_path, spelling):
     try:
         for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
             os.environ.pop(k, None)
-        os.environ.update(EAST_HIP_LAUNCHER=launcher, STUB_RECORD=record)
+        os.environ.update(EAST_HIP_LAUNCHER=launcher, STUB_RECORD=record, EAST_HIP_MULTI="process")    # (the launcher spelling)
         argv = ["-d", "-a", "easa", "-l", "", "-a", "easa", "-f", "csv", "keyphrases", "table", kp, tdir]
         if spelling == "option":
             argv = ["-g", "2"] + argv
@@ -122,6 +122,9 @@ def _cli_rank(rank, world, port, kp, tdir, out_dir):
                       LOCAL_RANK=str(rank), EAST_HIP_DIST_BACKEND="gloo")
     from east import main
     from test_distributed_gloo import OracleMeasure
+    opened = []
+    real_read = main._read
+    main._read = lambda path: (opened.append(path), real_read(path))[1]
     for fmt, flags in (("csv", []), ("xml", ["-d"])):
         buf = io.StringIO()
         normalized = "-d" not in flags
@@ -134,6 +137,8 @@ def _cli_rank(rank, world, port, kp, tdir, out_dir):
             sys.stdout = real_stdout
         with open(os.path.join(out_dir, "out_%s_%d.txt" % (fmt, rank)), "w") as f:
             f.write("%d\n%s" % (code, buf.getvalue()))
+    with open(os.path.join(out_dir, "opened_%d.json" % rank), "w") as f:
+        json.dump(opened, f)
 
 
 def test_cli_table_under_a_launcher_world_2_gloo(tmp_path):
@@ -150,3 +155,43 @@ def test_cli_table_under_a_launcher_world_2_gloo(tmp_path):
         got1 = open(os.path.join(str(tmp_path), "out_%s_1.txt" % fmt)).read()
         assert got0 == "0\n" + want + "\n"                 # rank 0 prints the single-process table
         assert got1 == "0\n"                               # rank 1 computed, returned 0 and printed nothing
+    # the documents are sharded by file size BEFORE anything is read: a rank opens the keyphrase file and its own texts
+    from east import parallel
+    names = sorted(os.listdir(tdir))
+    shards = parallel.shard_documents([os.path.getsize(os.path.join(tdir, n)) for n in names], 2)
+    for rank, (b, e) in enumerate(shards):
+        opened = json.load(open(os.path.join(str(tmp_path), "opened_%d.json" % rank)))
+        mine = [os.path.join(tdir, n) for n in names[b:e]]
+        assert sorted(set(opened)) == sorted([kp] + mine), rank
+        assert 0 < e - b < len(names)
+
+
+def test_cli_g_option_runs_the_devices_in_this_process_by_default(tmp_path, monkeypatch):
+    """`east -g N` without EAST_HIP_MULTI=process: no launcher, no child process -- the CLI builds the in-process
+    multi-device measure (east_hip_score_table_multi) with N devices.  (The measure itself needs a GPU: gpu tier.)"""
+    from east import main, relevance
+    launcher, record = _stub(tmp_path)
+    kp, tdir = _write_inputs(tmp_path)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EAST_HIP_MULTI", "EAST_HIP_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("EAST_HIP_LAUNCHER", launcher)
+    monkeypatch.setenv("STUB_RECORD", record)
+    seen = {}
+
+    class Recorder(object):
+        def __init__(self, algorithm, normalized, devices):
+            seen.update(algorithm=algorithm, normalized=normalized, devices=devices)
+
+        def set_text_collection(self, texts, language=None):
+            seen["n_texts"] = len(texts)
+
+        def relevance_table(self, prepared):
+            return np.zeros((len(prepared), seen["n_texts"]))
+
+    monkeypatch.setattr(relevance, "MultiDeviceASTRelevanceMeasure", Recorder)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        assert main.main(["-g", "3", "-d", "-f", "csv", "keyphrases", "table", kp, tdir]) == 0
+    assert seen == {"algorithm": "easa", "normalized": False, "devices": 3, "n_texts": 5}
+    assert not os.path.exists(record)                       # the launcher was never started
+    assert buf.getvalue().count("\n") == 7                  # header + five texts, print adds one
