@@ -20,10 +20,21 @@ typedef int64_t i64;
 #include "../../include/east_hip.h"
 
 // Direct LCP comparison is capped: ranks whose common prefix reaches LCP_DIRECT_CAP symbols are
-// marked with LCP_CAP_MARK and finished by the Kasai-style pass in tables.h, so that a highly
+// marked (LCP_PARTIAL_BIT) and finished by the Kasai-style pass in tables.h, so that a highly
 // repetitive input costs O(n + work of the marked ranks) instead of the sum of all LCPs.
 #define LCP_DIRECT_CAP (1u << 14)
-#define LCP_CAP_MARK 0xFFFFFFFEu
+// ... and a build only lets a BOUNDED number of comparisons go that far: one that reaches LCP_SOFT_CAP symbols asks the
+// build's budget (LcpBudget: n / 256 deep comparisons, counted in 64 slots) and stops there once it is spent -- an input
+// in which every suffix has a long common prefix with its neighbour (the reference's own benchmark input, analysis/
+// utils.py:5-9: 100 identical strings) would otherwise cost n x 16 384 symbol comparisons before the Kasai pass gets its
+// turn (measured: 109 of 127 ms for 10 M symbols).  An unfinished entry is LCP_PARTIAL_BIT | the length known to agree.
+#define LCP_SOFT_CAP 256u
+#define LCP_PARTIAL_BIT 0x80000000u
+#define LCP_BUDGET_SLOTS 64u
+struct LcpBudget {              // (how it is counted: lcp_deep_allowed below)
+    u32 *slots = nullptr;
+    u32 per_slot = 0;
+};
 
 #define WAVE 64
 #define BLOCK 256              // threads per workgroup everywhere
@@ -167,6 +178,7 @@ struct Ctx {
     int plan_ht = -1, did_ht = 0;           // first-level keys of variable-length code words: plan (as plan_wide) / what was done
     int did_seg = 0;                        // the first-level sort kept the documents apart by segments, not by key bits
     std::vector<u32> seg_host;              // ... its tables on the host (the uploads are asynchronous)
+    LcpBudget lcp_budget;                   // the build's budget of deep LCP comparisons (LCP_SOFT_CAP)
     Stats *stats = nullptr;
     Profiler *prof = nullptr;
 };
@@ -240,6 +252,42 @@ __device__ __forceinline__ void syncthreads_after_lds_atomics()
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
+}
+
+// The budget of deep LCP comparisons of one build (see LCP_SOFT_CAP): LCP_BUDGET_SLOTS counters, zeroed with the build's
+// flag words; a workgroup counts in slot blockIdx mod 64.  slots == nullptr: no budget (every comparison may go deep).
+__device__ __forceinline__ bool lcp_deep_allowed(const LcpBudget &b)
+{
+    if (!b.slots) return true;
+    u32 *c = b.slots + (blockIdx.x & (LCP_BUDGET_SLOTS - 1u));
+    // (a plain look first: once the budget is spent nobody adds any more -- millions of atomics on 64 words would cost
+    // what they are meant to save; a stale value only lets a few more comparisons through)
+    if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= b.per_slot) return false;
+    return atomicAdd(c, 1u) < b.per_slot;
+}
+
+// Common prefix of the suffixes at i and j of the byte stream, the first h symbols known to agree (0xFF bytes --
+// terminators, each a symbol of its own -- end it; the stream is padded so that 8-byte reads stay in bounds).  Returns the
+// exact length, or LCP_PARTIAL_BIT | (a length known to agree) where the comparison was cut: at LCP_SOFT_CAP once the
+// build's budget of deep comparisons is spent, at LCP_DIRECT_CAP in any case -- lcp_finish_kernel (tables.h) takes over.
+__device__ __forceinline__ u32 lcp_bytes_capped(const uint8_t *__restrict__ s8, u32 i, u32 j, u32 h, const LcpBudget &b)
+{
+    bool deep = false;
+    while (true) {
+        if (h >= LCP_SOFT_CAP && !deep) {
+            if (!lcp_deep_allowed(b)) return LCP_PARTIAL_BIT | h;
+            deep = true;
+        }
+        if (h >= LCP_DIRECT_CAP) return LCP_PARTIAL_BIT | h;
+        const u64 x = load_u64_unaligned(s8 + i + h), y = load_u64_unaligned(s8 + j + h);
+        const u64 d = x ^ y, z = ~x;                                 // zero byte of z <=> 0xFF in x
+        const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+        const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+        const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
+        const u32 step = mism < term ? mism : term;
+        h += step;
+        if (step < 8u) return h;
+    }
 }
 
 // Inclusive prefix sum across the 64 lanes of a wavefront.

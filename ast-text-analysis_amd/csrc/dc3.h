@@ -484,21 +484,16 @@ __global__ __launch_bounds__(BLOCK) void dc3_merge_partition_rec_kernel(const ui
 
 // common prefix of two suffixes whose first 8 symbols are the windows wa, wb; beyond the
 // windows the byte stream is read directly (rare)
-__device__ __forceinline__ u32 dc3_window_lcp(u64 wa, u64 wb, const uint8_t *__restrict__ s8, u32 pa, u32 pb)
+__device__ __forceinline__ u32 dc3_window_lcp(u64 wa, u64 wb, const uint8_t *__restrict__ s8, u32 pa, u32 pb,
+                                              const LcpBudget &budget)
 {
-    u32 h = 0;
-    while (true) {
-        const u64 d = wa ^ wb, z = ~wa;
-        const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
-        const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
-        const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
-        const u32 step = mism < term ? mism : term;
-        h += step;
-        if (step < 8u) return h;
-        if (h >= LCP_DIRECT_CAP) return LCP_CAP_MARK;          // finished by lcp_finish_kernel
-        __builtin_memcpy(&wa, s8 + pa + h, 8);
-        __builtin_memcpy(&wb, s8 + pb + h, 8);
-    }
+    const u64 d = wa ^ wb, z = ~wa;
+    const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+    const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+    const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
+    const u32 step = mism < term ? mism : term;
+    if (step < 8u) return step;
+    return lcp_bytes_capped(s8, pa, pb, 8u, budget);           // (LCP_PARTIAL_BIT set: finished by lcp_finish_kernel)
 }
 
 __global__ __launch_bounds__(BLOCK) void dc3_merge_lcp_tile_kernel(const uint4 *__restrict__ rec,
@@ -508,7 +503,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_merge_lcp_tile_kernel(const uint4 *
                                                                    const u32 *__restrict__ splits,
                                                                    u32 *__restrict__ sa_out,
                                                                    u32 *__restrict__ lcp_out,
-                                                                   u32 *__restrict__ capped)
+                                                                   u32 *__restrict__ capped, LcpBudget budget)
 {
     __shared__ u32 l_lo[MERGE_TILE], l_hi[MERGE_TILE], l_r1[MERGE_TILE], l_r2[MERGE_TILE];
     __shared__ u32 l_pos[MERGE_TILE];       // text position; bit 31 = "sample with p mod 3 == 1"
@@ -580,8 +575,8 @@ __global__ __launch_bounds__(BLOCK) void dc3_merge_lcp_tile_kernel(const uint4 *
                 const u32 sa_ = l_src[o - 1];
                 const u32 pa = l_pos[sa_] & 0x7FFFFFFFu;
                 const u32 h = dc3_window_lcp(((u64)l_hi[sa_] << 32) | l_lo[sa_], ((u64)l_hi[sb] << 32) | l_lo[sb],
-                                             s8, pa, pb);
-                if (h == LCP_CAP_MARK) atomicOr(capped, 1u);
+                                             s8, pa, pb, budget);
+                if (h & LCP_PARTIAL_BIT) atomicOr(capped, 1u);
                 lcp_out[k0 + o] = h;
             }
         }
@@ -591,7 +586,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_merge_lcp_tile_kernel(const uint4 *
 // LCP of the first rank of every merge tile (its left neighbour lives in the previous tile)
 __global__ __launch_bounds__(BLOCK) void dc3_lcp_heads_kernel(const uint8_t *__restrict__ s8,
                                                               const u32 *__restrict__ sa, u32 n,
-                                                              u32 *__restrict__ lcp, u32 *__restrict__ capped)
+                                                              u32 *__restrict__ lcp, u32 *__restrict__ capped, LcpBudget budget)
 {
     const u64 r64 = ((u64)blockIdx.x * BLOCK + threadIdx.x) * MERGE_TILE;
     if (r64 >= n) return;
@@ -601,8 +596,8 @@ __global__ __launch_bounds__(BLOCK) void dc3_lcp_heads_kernel(const uint8_t *__r
     u64 wa, wb;
     __builtin_memcpy(&wa, s8 + pa, 8);
     __builtin_memcpy(&wb, s8 + pb, 8);
-    const u32 h = dc3_window_lcp(wa, wb, s8, pa, pb);
-    if (h == LCP_CAP_MARK) atomicOr(capped, 1u);
+    const u32 h = dc3_window_lcp(wa, wb, s8, pa, pb, budget);
+    if (h & LCP_PARTIAL_BIT) atomicOr(capped, 1u);
     lcp[r] = h;
 }
 
@@ -787,10 +782,10 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
             LAUNCH(ctx, dc3_merge_partition_rec_kernel, ceil_div_u32((u64)n_tiles + 1, BLOCK), (const uint4 *)rec,
                    (const u32 *)sa12 + skip, nA, (const u32 *)s0.vals[r0], n0, n0, n_tiles, splits);
             LAUNCH(ctx, dc3_merge_lcp_tile_kernel, n_tiles, (const uint4 *)rec, s8, (const u32 *)sa12 + skip, nA,
-                   (const u32 *)s0.vals[r0], n0, n0, (const u32 *)splits, sa_out, lcp_out, lcp_capped);
+                   (const u32 *)s0.vals[r0], n0, n0, (const u32 *)splits, sa_out, lcp_out, lcp_capped, ctx.lcp_budget);
             if (lcp_out)
                 LAUNCH(ctx, dc3_lcp_heads_kernel, ceil_div_u32(n_tiles, BLOCK), s8, (const u32 *)sa_out, n, lcp_out,
-                       lcp_capped);
+                       lcp_capped, ctx.lcp_budget);
         } else {
             LAUNCH(ctx, dc3_merge_partition_kernel, ceil_div_u32((u64)n_tiles + 1, BLOCK), (const uint2 *)sr,
                    (const u32 *)sa12 + skip, nA, (const u32 *)s0.vals[r0], n0, n0, n_tiles, splits);

@@ -627,7 +627,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     h->next = ar.alloc<u32>(n);
     h->doc_off = ar.alloc<u32>((size_t)n_docs + 1);
     h->n_strings = ar.alloc<u32>(n_docs);
-    h->code_map = ar.alloc<u32>(TEXT_SYMBOLS + FLAG_WORDS + PRESENT_WORDS + 1);   // + the flag words (FLAG_*) + the presence bitmap and its status word
+    h->code_map = ar.alloc<u32>(TEXT_SYMBOLS + FLAG_WORDS + PRESENT_WORDS + 1 + LCP_BUDGET_SLOTS);   // + the flag words (FLAG_*) + the presence bitmap and its status word + the budget of deep LCP comparisons
     h->hi_bits = tagged ? ar.alloc<u32>(HI_WORDS) : nullptr;
     h->hi_rank = tagged ? ar.alloc<u32>(HI_WORDS) : nullptr;
     Pyramid pyr;
@@ -661,7 +661,10 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     u32 *flags = h->code_map + TEXT_SYMBOLS;              // flag words behind the code map
     u32 *capped = flags + FLAG_CAPPED, *status = flags + FLAG_STATUS;
     u32 *present = flags + FLAG_WORDS;                    // PRESENT_WORDS + 1 (status word): zeroed in the same fill
-    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(flags, 0, (FLAG_WORDS + PRESENT_WORDS + 1) * sizeof(u32), ctx.stream));
+    if (!ctx.dry) HIP_CHECK(hipMemsetAsync(flags, 0, (FLAG_WORDS + PRESENT_WORDS + 1 + LCP_BUDGET_SLOTS) * sizeof(u32), ctx.stream));
+    // (deep LCP comparisons -- beyond LCP_SOFT_CAP symbols -- this build may make: n / 256, see common.h)
+    ctx.lcp_budget.slots = ctx.dry ? nullptr : present + PRESENT_WORDS + 1;
+    ctx.lcp_budget.per_slot = std::max<u32>(n / 256u / LCP_BUDGET_SLOTS, 4u);
     ctx.spec_out = flags + FLAG_KEEP;
     ctx.zeroed_word = ctx.dry ? nullptr : flags + FLAG_PLACE_FAIL;
     ctx.kg_bad = ctx.dry ? nullptr : flags + FLAG_KG_BAD;
@@ -855,10 +858,10 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
             // (the table's padding up to a multiple of 16 is written by ann_stream_kernel)
         } else if (h->use_s8) {
             LAUNCH(ctx, lcp8_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const uint8_t *)h->s8, (const u32 *)h->sa,
-                   n, h->lcp, capped);
+                   n, h->lcp, capped, ctx.lcp_budget);
         } else {
             LAUNCH(ctx, lcp_kernel, ceil_div_u32(pyr_padded(n), BLOCK), (const u32 *)h->s, (const u32 *)h->sa,
-                   n, h->lcp, capped);
+                   n, h->lcp, capped, ctx.lcp_budget);
         }
         if (n_docs > 1)
             LAUNCH(ctx, lcp_doc_starts_kernel, ceil_div_u32(n_docs, BLOCK), (const u32 *)h->doc_off, n_docs, h->lcp);
@@ -881,11 +884,14 @@ static void finish_capped_lcp(east_hip_index *h, Ctx &ctx)
     const size_t mark = ar.mark();
     u32 *rank = ar.alloc<u32>(n);
     LAUNCH(ctx, inverse_sa_kernel, ceil_div_u32(n, BLOCK), (const u32 *)h->sa, n, rank);
-    const u32 kb = ceil_div_u32(ceil_div_u32(n, KASAI_BLOCK), BLOCK);
+    // (a thread walks kasai_block consecutive text positions: about four threads per lane of the chip)
+    u32 kasai_block = KASAI_BLOCK_MAX;
+    while (kasai_block > KASAI_BLOCK_MIN && (u64)n / kasai_block < 4u * 256u * 256u) kasai_block >>= 1;
+    const u32 kb = ceil_div_u32(ceil_div_u32(n, kasai_block), BLOCK);
     if (h->use_s8)
-        LAUNCH(ctx, (lcp_finish_kernel<true>), kb, (const void *)h->s8, (const u32 *)h->sa, (const u32 *)rank, n, h->lcp);
+        LAUNCH(ctx, (lcp_finish_kernel<true>), kb, (const void *)h->s8, (const u32 *)h->sa, (const u32 *)rank, n, kasai_block, h->lcp);
     else
-        LAUNCH(ctx, (lcp_finish_kernel<false>), kb, (const void *)h->s, (const u32 *)h->sa, (const u32 *)rank, n, h->lcp);
+        LAUNCH(ctx, (lcp_finish_kernel<false>), kb, (const void *)h->s, (const u32 *)h->sa, (const u32 *)rank, n, kasai_block, h->lcp);
     ar.release(mark);
     annotate(h, ctx);
 }

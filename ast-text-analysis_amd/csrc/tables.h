@@ -114,7 +114,7 @@ __global__ __launch_bounds__(BLOCK) void lcp_doc_starts_kernel(const u32 *__rest
 
 __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
                                                     const u32 *__restrict__ sa,
-                                                    u32 n, u32 *__restrict__ lcp, u32 *__restrict__ capped)
+                                                    u32 n, u32 *__restrict__ lcp, u32 *__restrict__ capped, LcpBudget budget)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) {
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
     // suffixes end in distinct terminators => the comparison always stops in
     // bounds.  Four symbols per step (8 independent loads in flight); the three
     // pad words behind the stream make the look-ahead safe.
+    bool deep = false, cut = false;
     while (true) {
         const u32 a0 = s[i + h], a1 = s[i + h + 1], a2 = s[i + h + 2], a3 = s[i + h + 3];
         const u32 b0 = s[j + h], b1 = s[j + h + 1], b2 = s[j + h + 2], b3 = s[j + h + 3];
@@ -136,10 +137,14 @@ __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
         if (a2 != b2) { h += 2; break; }
         if (a3 != b3) { h += 3; break; }
         h += 4;
-        if (h >= LCP_DIRECT_CAP) break;
+        if (h >= LCP_SOFT_CAP && !deep) {                    // (see LCP_SOFT_CAP, common.h)
+            if (!lcp_deep_allowed(budget)) { cut = true; break; }
+            deep = true;
+        }
+        if (h >= LCP_DIRECT_CAP) { cut = true; break; }
     }
     // (the first rank of every document is reset to 0 by lcp_doc_starts_kernel)
-    if (h >= LCP_DIRECT_CAP) { h = LCP_CAP_MARK; atomicOr(capped, 1u); }
+    if (cut) { h |= LCP_PARTIAL_BIT; atomicOr(capped, 1u); }
     lcp[r] = h;
 }
 
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
 // common prefix.  The stream is padded with 16 zero bytes.
 __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__ s8,
                                                      const u32 *__restrict__ sa, u32 n,
-                                                     u32 *__restrict__ lcp, u32 *__restrict__ capped)
+                                                     u32 *__restrict__ lcp, u32 *__restrict__ capped, LcpBudget budget)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = r < n;
@@ -171,22 +176,17 @@ __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__
         return;
     }
     if (r == 0) { lcp[0] = 0; return; }
-    u32 h = 0;
-    u64 x = a, y = b;
-    while (true) {
-        const u64 d = x ^ y;
-        const u64 z = ~x;                                            // zero byte <=> 0xFF in x
+    u32 h;
+    {
+        const u64 d = a ^ b, z = ~a;                                 // zero byte of z <=> 0xFF in a
         const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
         const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
         const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
-        const u32 step = mism < term ? mism : term;
-        h += step;
-        if (step < 8u || h >= LCP_DIRECT_CAP) break;
-        x = load_u64_unaligned(s8 + i + h);
-        y = load_u64_unaligned(s8 + j + h);
+        h = mism < term ? mism : term;
     }
+    if (h == 8u) h = lcp_bytes_capped(s8, i, j, 8u, budget);         // (most ranks end inside the first windows)
     // (the first rank of every document is reset to 0 by lcp_doc_starts_kernel)
-    if (h >= LCP_DIRECT_CAP) { h = LCP_CAP_MARK; atomicOr(capped, 1u); }
+    if (h & LCP_PARTIAL_BIT) atomicOr(capped, 1u);
     lcp[r] = h;
 }
 
@@ -195,7 +195,10 @@ __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__
 // positions: h(p+1) >= h(p) - 1 inside a document, so after the first marked position of a
 // run the comparisons resume where the previous one ended.  Unmarked ranks only feed the
 // carry.  BYTES: byte stream with the 0xFF rule, else exact u32 symbols.
-#define KASAI_BLOCK 1024u
+// (positions per thread: chosen by the host so that the launch has a few threads per SIMD lane -- a block's first marked
+// position starts from what its entry knows, so shorter blocks cost restarts, longer ones leave the chip idle)
+#define KASAI_BLOCK_MAX 1024u
+#define KASAI_BLOCK_MIN 32u
 
 __global__ __launch_bounds__(BLOCK) void inverse_sa_kernel(const u32 *__restrict__ sa, u32 n, u32 *__restrict__ rank)
 {
@@ -206,19 +209,20 @@ __global__ __launch_bounds__(BLOCK) void inverse_sa_kernel(const u32 *__restrict
 template <bool BYTES>
 __global__ __launch_bounds__(BLOCK) void lcp_finish_kernel(const void *__restrict__ sym,
                                                            const u32 *__restrict__ sa,
-                                                           const u32 *__restrict__ rank, u32 n,
+                                                           const u32 *__restrict__ rank, u32 n, u32 kasai_block,
                                                            u32 *__restrict__ lcp)
 {
-    const u64 p0 = ((u64)blockIdx.x * BLOCK + threadIdx.x) * KASAI_BLOCK;
+    const u64 p0 = ((u64)blockIdx.x * BLOCK + threadIdx.x) * kasai_block;
     if (p0 >= n) return;
-    const u32 p1 = p0 + KASAI_BLOCK < n ? (u32)p0 + KASAI_BLOCK : n;
+    const u32 p1 = p0 + kasai_block < n ? (u32)p0 + kasai_block : n;
     u32 carry = 0;                                 // lcp of the previous position
     for (u32 p = (u32)p0; p < p1; p++) {
         const u32 r = rank[p];
         u32 h = lcp[r];
-        if (h == LCP_CAP_MARK) {                   // never a document's first rank (those hold 0)
+        if (h & LCP_PARTIAL_BIT) {                 // never a document's first rank (those hold 0)
             const u32 q = sa[r - 1];
-            h = carry > LCP_DIRECT_CAP + 1u ? carry - 1u : LCP_DIRECT_CAP;
+            const u32 known = h & ~LCP_PARTIAL_BIT;       // (what the direct comparison had seen to agree when it was cut)
+            h = carry > known + 1u ? carry - 1u : known;
             if (BYTES) {
                 const uint8_t *s8 = (const uint8_t *)sym;
                 while (true) {

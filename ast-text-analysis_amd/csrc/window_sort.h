@@ -1594,55 +1594,20 @@ struct BitStarts {
     __device__ __forceinline__ u32 operator()(u32 i) const { return (u32)(bits[i >> 6] >> (i & 63u)) & 1u; }
 };
 
-// LCP entries of the marked ranks by comparing the two suffixes from their first symbol (prefix-doubling rounds
-// behind the fused finish: no sorted key array to start from).  Same cap rule as lcp8_kernel.
-__global__ __launch_bounds__(BLOCK) void lvl0_lcp_text_kernel(const uint8_t *__restrict__ s8, const u32 *__restrict__ sa, u32 n,
-                                                              const u64 *__restrict__ only, u32 *__restrict__ lcp,
-                                                              u32 *__restrict__ capped)
-{
-    const u32 r = blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= n) return;
-    if (only && !((only[r >> 6] >> (r & 63u)) & 1ull)) return;
-    if (r == 0) { lcp[0] = 0; return; }
-    const u32 i = sa[r - 1], j = sa[r];
-    u32 h = 0;
-    while (true) {
-        const u64 xa = load_u64_unaligned(s8 + i + h), xb = load_u64_unaligned(s8 + j + h);
-        const u64 dd = xa ^ xb, z = ~xa;
-        const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
-        const u32 mm = dd ? (u32)__builtin_ctzll(dd) >> 3 : 8u;
-        const u32 tt = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
-        const u32 step = mm < tt ? mm : tt;
-        h += step;
-        if (step < 8u || h >= LCP_DIRECT_CAP) break;
-    }
-    if (h >= LCP_DIRECT_CAP) { h = LCP_CAP_MARK; atomicOr(capped, 1u); }
-    lcp[r] = h;
-}
-
+// LCP entries by comparing the two suffixes from their first symbol (same cap rule as lcp8_kernel)
 // ... of a LIST of ranks: the members of the groups that were still open when the rounds went over to prefix doubling
 // (their slots, kept when that round compacted its domain) -- a few per cent of all ranks, no pass over the others
 __global__ __launch_bounds__(BLOCK) void lvl0_lcp_text_list_kernel(const uint8_t *__restrict__ s8, const u32 *__restrict__ sa,
                                                                    const u32 *__restrict__ ranks, u32 count,
-                                                                   u32 *__restrict__ lcp, u32 *__restrict__ capped)
+                                                                   u32 *__restrict__ lcp, u32 *__restrict__ capped,
+                                                                   LcpBudget budget)
 {
     const u32 t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= count) return;
     const u32 r = ranks[t];
     if (r == 0) { lcp[0] = 0; return; }
-    const u32 i = sa[r - 1], j = sa[r];
-    u32 h = 0;
-    while (true) {
-        const u64 xa = load_u64_unaligned(s8 + i + h), xb = load_u64_unaligned(s8 + j + h);
-        const u64 dd = xa ^ xb, z = ~xa;
-        const u64 tz = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
-        const u32 mm = dd ? (u32)__builtin_ctzll(dd) >> 3 : 8u;
-        const u32 tt = tz ? (u32)__builtin_ctzll(tz) >> 3 : 8u;
-        const u32 step = mm < tt ? mm : tt;
-        h += step;
-        if (step < 8u || h >= LCP_DIRECT_CAP) break;
-    }
-    if (h >= LCP_DIRECT_CAP) { h = LCP_CAP_MARK; atomicOr(capped, 1u); }
+    const u32 h = lcp_bytes_capped(s8, sa[r - 1], sa[r], 0u, budget);
+    if (h & LCP_PARTIAL_BIT) atomicOr(capped, 1u);
     lcp[r] = h;
 }
 
@@ -1856,44 +1821,6 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_writeback_kernel(const u64 *
         const u32 term = tz ? (u32)w2 - 1u - (((u32)__builtin_ctzll(tz) * inv_b) >> 16) : (u32)w2;
         lcp_g[slot] = depth + (xdep ? (u32)xdep[at] : 0u) + (mism < term ? mism : term);
     }
-}
-
-// LCP table straight from the sorted window keys (all-suffix mode, one document): neighbours with
-// different keys share exactly the leading symbol fields the two keys have in common, cut at the
-// first terminator field (equal terminator codes are two DIFFERENT terminators) -- no text is
-// touched.  Only neighbours whose whole window agrees (the tied ones, reordered in place since)
-// read their suffixes, from offset w on.  Same cap rule as lcp8_kernel.
-// only != nullptr: one bit per rank, set for the members of the groups the placement pass left to the rounds --
-// every other entry was written by that pass and stands (a rank outside those groups has a neighbour with another
-// key: its entry never depended on which member of the neighbouring group ended up next to it).
-template <class K>
-__global__ __launch_bounds__(BLOCK) void lvl0_lcp_keys_kernel(KeyNeqWindowIn<K> f, int w, int b, int spare,
-                                                              const uint8_t *__restrict__ s8,
-                                                              const u32 *__restrict__ sa, u32 n,
-                                                              const u64 *__restrict__ only,
-                                                              u32 *__restrict__ lcp, u32 *__restrict__ capped)
-{
-    const u32 r = blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= n) return;
-    if (only && !((only[r >> 6] >> (r & 63u)) & 1ull)) return;
-    if (r == 0) { lcp[0] = 0; return; }
-    bool whole;
-    u32 h = lvl0_lcp_of_keys(f, w, b, spare, r, whole);
-    if (whole) {                                         // the whole window agrees: continue on the text
-        const u32 i = sa[r - 1], j = sa[r];
-        while (true) {
-            const u64 xa = load_u64_unaligned(s8 + i + h), xb = load_u64_unaligned(s8 + j + h);
-            const u64 dd = xa ^ xb, z = ~xa;
-            const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
-            const u32 mm = dd ? (u32)__builtin_ctzll(dd) >> 3 : 8u;
-            const u32 tt = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
-            const u32 step = mm < tt ? mm : tt;
-            h += step;
-            if (step < 8u || h >= LCP_DIRECT_CAP) break;
-        }
-        if (h >= LCP_DIRECT_CAP) { h = LCP_CAP_MARK; atomicOr(capped, 1u); }
-    }
-    lcp[r] = h;
 }
 
 // one bit per rank: the slots of the kept members of a domain
@@ -2152,7 +2079,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
 
     // ---- refinement rounds on the members of large groups ---------------------------------
     // (ctx.lean: the device is short of memory for the rounds' buffers -- straight on to the recursion / DC3)
-    // the placement pass's verdict is kept: the LCP entries of everything it placed are final (lvl0_lcp_keys_kernel)
+    // the placement pass's verdict is kept: the LCP entries of everything it placed are final
     // (the ranks whose entries the rounds do NOT write -- those that go through prefix-doubling rounds, whose keys are
     // names -- are marked when the rounds switch over, and only they are computed at the end)
     // (the ranks whose entries have to be computed at the end: the slots of the domain of the round that switched over)
@@ -2372,7 +2299,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         if (ctx.stats) ctx.stats->levels_resolved++;
         if (lcp_out && !lcp_from_rounds && redo_n)      // (prefix doubling: the entries of everything those rounds placed)
             LAUNCH(ctx, lvl0_lcp_text_list_kernel, ceil_div_u32(redo_n, BLOCK), s8, (const u32 *)sa12, (const u32 *)lcp_redo, redo_n,
-                   lcp_out, lcp_capped);
+                   lcp_out, lcp_capped, ctx.lcp_budget);
         return true;
     }
     if (!s12) return false;                            // all-suffix mode: the caller falls back to DC3

@@ -19,6 +19,8 @@ docs = [synthetic.worst_case_collection(rng, m, n) for _ in range(n_docs)]
 sym = np.concatenate([d[0] for d in docs])
 off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])]).astype(np.int64)
 ms = np.array([d[1] for d in docs], dtype=np.int32)
+if os.environ.get("EAST_WC_KNOB"):                       # e.g. 0 = DC3 only (east_hip_debug_set_window_sort)
+    hip_backend.load().east_hip_debug_set_window_sort(int(os.environ["EAST_WC_KNOB"]))
 index = hip_backend.HipIndex(0, reserve_symbols=int(sym.size))
 index.build(sym, off, ms)
 t0 = time.perf_counter()
