@@ -272,6 +272,21 @@ __device__ __forceinline__ bool lcp_deep_allowed(const LcpBudget &b)
 // build's budget of deep comparisons is spent, at LCP_DIRECT_CAP in any case -- lcp_finish_kernel (tables.h) takes over.
 __device__ __forceinline__ u32 lcp_bytes_capped(const uint8_t *__restrict__ s8, u32 i, u32 j, u32 h, const LcpBudget &b)
 {
+    auto step_of = [](u64 x, u64 y) -> u32 {
+        const u64 d = x ^ y, z = ~x;                                 // zero byte of z <=> 0xFF in x
+        const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+        const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+        const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
+        return mism < term ? mism : term;
+    };
+    // (most comparisons end within a few symbols: two steps of 8; what goes on takes 32 symbols per step, eight loads in
+    // flight -- a step costs a memory round trip whatever its width.  The byte stream is readable 32 bytes past any
+    // position a comparison can reach: it stops at the document's last terminator at the latest, and the arena goes on)
+    for (int k = 0; k < 2 && h < LCP_SOFT_CAP; k++) {
+        const u32 step = step_of(load_u64_unaligned(s8 + i + h), load_u64_unaligned(s8 + j + h));
+        h += step;
+        if (step < 8u) return h;
+    }
     bool deep = false;
     while (true) {
         if (h >= LCP_SOFT_CAP && !deep) {
@@ -279,14 +294,15 @@ __device__ __forceinline__ u32 lcp_bytes_capped(const uint8_t *__restrict__ s8, 
             deep = true;
         }
         if (h >= LCP_DIRECT_CAP) return LCP_PARTIAL_BIT | h;
-        const u64 x = load_u64_unaligned(s8 + i + h), y = load_u64_unaligned(s8 + j + h);
-        const u64 d = x ^ y, z = ~x;                                 // zero byte of z <=> 0xFF in x
-        const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
-        const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
-        const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
-        const u32 step = mism < term ? mism : term;
-        h += step;
-        if (step < 8u) return h;
+        u64 x[4], y[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { x[k] = load_u64_unaligned(s8 + i + h + 8 * k); y[k] = load_u64_unaligned(s8 + j + h + 8 * k); }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 step = step_of(x[k], y[k]);
+            h += step;
+            if (step < 8u) return h;
+        }
     }
 }
 

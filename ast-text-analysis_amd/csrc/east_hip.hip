@@ -618,7 +618,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     ar.release(0);
     // ---- persistent arrays --------------------------------------------------
     h->s = ar.alloc<u32>((size_t)n + 3);
-    h->s8 = ar.alloc<uint8_t>((size_t)n + 16);
+    h->s8 = ar.alloc<uint8_t>((size_t)n + 64)            // (16 zero bytes behind the stream; comparisons look up to 32 bytes ahead);
     h->sa = ar.alloc<u32>(n);
     h->lcp = ar.alloc<u32>(pyr_padded(n));
     h->ann = ar.alloc<u32>(n);
@@ -884,14 +884,11 @@ static void finish_capped_lcp(east_hip_index *h, Ctx &ctx)
     const size_t mark = ar.mark();
     u32 *rank = ar.alloc<u32>(n);
     LAUNCH(ctx, inverse_sa_kernel, ceil_div_u32(n, BLOCK), (const u32 *)h->sa, n, rank);
-    // (a thread walks kasai_block consecutive text positions: about four threads per lane of the chip)
-    u32 kasai_block = KASAI_BLOCK_MAX;
-    while (kasai_block > KASAI_BLOCK_MIN && (u64)n / kasai_block < 4u * 256u * 256u) kasai_block >>= 1;
-    const u32 kb = ceil_div_u32(ceil_div_u32(n, kasai_block), BLOCK);
+    const u32 kb = ceil_div_u32(ceil_div_u32(n, KASAI_BLOCK), BLOCK);
     if (h->use_s8)
-        LAUNCH(ctx, (lcp_finish_kernel<true>), kb, (const void *)h->s8, (const u32 *)h->sa, (const u32 *)rank, n, kasai_block, h->lcp);
+        LAUNCH(ctx, (lcp_finish_kernel<true>), kb, (const void *)h->s8, (const u32 *)h->sa, (const u32 *)rank, n, h->lcp);
     else
-        LAUNCH(ctx, (lcp_finish_kernel<false>), kb, (const void *)h->s, (const u32 *)h->sa, (const u32 *)rank, n, kasai_block, h->lcp);
+        LAUNCH(ctx, (lcp_finish_kernel<false>), kb, (const void *)h->s, (const u32 *)h->sa, (const u32 *)rank, n, h->lcp);
     ar.release(mark);
     annotate(h, ctx);
 }

@@ -191,14 +191,15 @@ __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__
 }
 
 // ---- finishing pass for capped ranks (Kasai et al. 2001, blocked over the text) ----------
-// rank[p] = rank of the suffix at p.  One thread walks KASAI_BLOCK consecutive text
-// positions: h(p+1) >= h(p) - 1 inside a document, so after the first marked position of a
-// run the comparisons resume where the previous one ended.  Unmarked ranks only feed the
-// carry.  BYTES: byte stream with the 0xFF rule, else exact u32 symbols.
-// (positions per thread: chosen by the host so that the launch has a few threads per SIMD lane -- a block's first marked
-// position starts from what its entry knows, so shorter blocks cost restarts, longer ones leave the chip idle)
-#define KASAI_BLOCK_MAX 1024u
-#define KASAI_BLOCK_MIN 32u
+// rank[p] = rank of the suffix at p.  lcp(p + 1) >= lcp(p) - 1 inside a document, so a walk over consecutive text
+// positions resumes every comparison where the one before ended.  One thread walks KASAI_BLOCK positions; what does not
+// depend on the carry is fetched for the whole block up front -- the ranks (128 contiguous bytes), then the entries and
+// the left neighbours of all 32 positions with 32 gathers in flight each -- so that the walk itself waits for ONE memory
+// round trip per position, the text behind the carry (first version: five dependent gathers per position, 8.2 ms for the
+// 10 M positions of the reference's worst-case input; now the comparison looks at 32 symbols per step, eight 8-byte loads
+// in flight).  Unmarked ranks only feed the carry.  A block's first marked position starts from what its entry knows
+// (LCP_PARTIAL_BIT | length).  BYTES: byte stream with the 0xFF rule, else exact u32 symbols.
+#define KASAI_BLOCK 32u
 
 __global__ __launch_bounds__(BLOCK) void inverse_sa_kernel(const u32 *__restrict__ sa, u32 n, u32 *__restrict__ rank)
 {
@@ -206,40 +207,65 @@ __global__ __launch_bounds__(BLOCK) void inverse_sa_kernel(const u32 *__restrict
     if (r < n) rank[sa[r]] = r;
 }
 
+// common prefix of the suffixes at p and q from h symbols on (known to agree), no cap
+template <bool BYTES> __device__ __forceinline__ u32 kasai_extend(const void *__restrict__ sym, u32 p, u32 q, u32 h)
+{
+    if (BYTES) {
+        const uint8_t *s8 = (const uint8_t *)sym;
+        while (true) {
+            u64 x[4], y[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { x[k] = load_u64_unaligned(s8 + p + h + 8 * k); y[k] = load_u64_unaligned(s8 + q + h + 8 * k); }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u64 d = x[k] ^ y[k], z = ~x[k];
+                const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+                const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+                const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
+                const u32 step = mism < term ? mism : term;
+                h += step;
+                if (step < 8u) return h;
+            }
+        }
+    } else {
+        const u32 *s = (const u32 *)sym;
+        while (s[p + h] == s[q + h]) h++;
+        return h;
+    }
+}
+
 template <bool BYTES>
 __global__ __launch_bounds__(BLOCK) void lcp_finish_kernel(const void *__restrict__ sym,
                                                            const u32 *__restrict__ sa,
-                                                           const u32 *__restrict__ rank, u32 n, u32 kasai_block,
+                                                           const u32 *__restrict__ rank, u32 n,
                                                            u32 *__restrict__ lcp)
 {
-    const u64 p0 = ((u64)blockIdx.x * BLOCK + threadIdx.x) * kasai_block;
+    const u64 p0 = ((u64)blockIdx.x * BLOCK + threadIdx.x) * KASAI_BLOCK;
     if (p0 >= n) return;
-    const u32 p1 = p0 + kasai_block < n ? (u32)p0 + kasai_block : n;
+    const u32 cnt = p0 + KASAI_BLOCK <= n ? KASAI_BLOCK : n - (u32)p0;
+    u32 r[KASAI_BLOCK], hv[KASAI_BLOCK], q[KASAI_BLOCK];
+    if (cnt == KASAI_BLOCK) {                      // (rank[] comes from the arena: 256-byte aligned, p0 a multiple of 32)
+#pragma unroll
+        for (int k = 0; k < (int)KASAI_BLOCK / 4; k++) {
+            const uint4 v = reinterpret_cast<const uint4 *>(rank + p0)[k];
+            r[4 * k] = v.x; r[4 * k + 1] = v.y; r[4 * k + 2] = v.z; r[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < (int)KASAI_BLOCK; k++) r[k] = (u32)k < cnt ? rank[p0 + k] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < (int)KASAI_BLOCK; k++) hv[k] = (u32)k < cnt ? lcp[r[k]] : 0u;
+#pragma unroll
+    for (int k = 0; k < (int)KASAI_BLOCK; k++) q[k] = (hv[k] & LCP_PARTIAL_BIT) ? sa[r[k] - 1u] : 0u;   // (never a document's first rank: those hold 0)
     u32 carry = 0;                                 // lcp of the previous position
-    for (u32 p = (u32)p0; p < p1; p++) {
-        const u32 r = rank[p];
-        u32 h = lcp[r];
-        if (h & LCP_PARTIAL_BIT) {                 // never a document's first rank (those hold 0)
-            const u32 q = sa[r - 1];
+#pragma unroll
+    for (int k = 0; k < (int)KASAI_BLOCK; k++) {
+        u32 h = hv[k];
+        if (h & LCP_PARTIAL_BIT) {
             const u32 known = h & ~LCP_PARTIAL_BIT;       // (what the direct comparison had seen to agree when it was cut)
-            h = carry > known + 1u ? carry - 1u : known;
-            if (BYTES) {
-                const uint8_t *s8 = (const uint8_t *)sym;
-                while (true) {
-                    const u64 x = load_u64_unaligned(s8 + p + h), y = load_u64_unaligned(s8 + q + h);
-                    const u64 d = x ^ y, z = ~x;
-                    const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
-                    const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
-                    const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
-                    const u32 step = mism < term ? mism : term;
-                    h += step;
-                    if (step < 8u) break;
-                }
-            } else {
-                const u32 *s = (const u32 *)sym;
-                while (s[p + h] == s[q + h]) h++;
-            }
-            lcp[r] = h;
+            h = kasai_extend<BYTES>(sym, (u32)p0 + (u32)k, q[k], carry > known + 1u ? carry - 1u : known);
+            lcp[r[k]] = h;
         }
         carry = h;
     }

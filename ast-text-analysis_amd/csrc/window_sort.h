@@ -2182,7 +2182,9 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // the global radix sort by (group, key).
             // (the classification of the next domain rides along with the in-LDS round, see LgClassify: symbol windows, the
             // usual limits, no groups with long repeats known)
-            const bool endgame = m <= REFINE_ENDGAME_DOMAIN;
+            // (once groups with long repeats are known to exist the direct ordering of large groups only burns time: every
+            // member of such a group compares REFINE_ENDGAME_LEN symbols with every other before it gives up)
+            const bool endgame = m <= REFINE_ENDGAME_DOMAIN && !long_repeats;
             const bool fuse_cls = g_lds_rounds && g_fused_classify && !doubling && !endgame && !long_repeats;
             u32 round_left = m;                         // what the in-LDS round left to the global sort
             auto sort_round = [&](bool names, int w2, const KeyNeqWindowIn<u64> &f) {
