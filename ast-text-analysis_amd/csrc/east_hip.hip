@@ -618,7 +618,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     ar.release(0);
     // ---- persistent arrays --------------------------------------------------
     h->s = ar.alloc<u32>((size_t)n + 3);
-    h->s8 = ar.alloc<uint8_t>((size_t)n + 64)            // (16 zero bytes behind the stream; comparisons look up to 32 bytes ahead);
+    h->s8 = ar.alloc<uint8_t>((size_t)n + 64);           // (16 zero bytes behind the stream; comparisons look up to 32 bytes ahead)
     h->sa = ar.alloc<u32>(n);
     h->lcp = ar.alloc<u32>(pyr_padded(n));
     h->ann = ar.alloc<u32>(n);
