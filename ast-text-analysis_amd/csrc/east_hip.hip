@@ -480,6 +480,10 @@ struct east_hip_index {
     // the streamed text preparation: a copy stream of its own and one event per chunk
     hipStream_t copy_stream = nullptr;     // (created with the handle: creating a stream costs milliseconds)
     std::vector<hipEvent_t> copy_events;
+    // ... and a ring of pinned host memory through which MANY separate texts go up (tp_upload_through_ring): allocated on
+    // first use, kept with the handle
+    char *ring = nullptr;
+    std::vector<hipEvent_t> ring_events;
     // symbols prepared on the device by east_hip_build_texts (own allocation)
     u32 *prep_sym = nullptr;
     size_t prep_cap = 0;
@@ -1128,6 +1132,35 @@ static std::vector<TpChunk> tp_plan_chunks(const uint8_t *bytes, const uint8_t *
     return chunks;
 }
 
+// ---- many separate texts: through a ring of pinned memory -------------------------------------------------------------
+// A copy out of pageable memory is pinned in place by the runtime, copied, unpinned: ~45 us of set-up per call, which a
+// 64 MiB text hides and 64 texts of 1 MiB do not (2.75 ms against 1.5 ms; 256 x 1 MiB: 11 ms).  Separate texts of less
+// than TP_RING_MAX_TEXT bytes on average therefore go through TP_RING_SLOTS slots of pinned memory: a few host threads
+// copy the stream -- text bytes and the 0xFF separators -- into a slot, each its share, while the slots before it are on
+// their way to the device (one DMA per slot and chunk, no set-up); the uploader thread alone talks to the runtime.
+#define TP_RING_SLOT ((size_t)4 << 20)
+#define TP_RING_SLOTS 4
+#define TP_RING_MAX_TEXT ((u64)8 << 20)
+static int g_tp_ring = getenv("EAST_HIP_TEXT_RING") ? atoi(getenv("EAST_HIP_TEXT_RING")) : -1;   // -1: by shape, 0: never, 1: whenever the texts lie apart
+static size_t g_tp_ring_slot = TP_RING_SLOT;                 // east_hip_debug_set_text_ring (tests: slots of a few hundred bytes)
+
+// bytes [a, b) of the concatenated stream (texts d with their 0xFF separators, text_offsets as in build_from_texts) -> dst
+static void tp_fill_stream(char *dst, u64 a, u64 b, const uint8_t *const *texts, const i64 *text_offsets, u32 D)
+{
+    u32 d = (u32)(std::upper_bound(text_offsets, text_offsets + D + 1, (i64)a) - text_offsets) - 1u;
+    while (a < b) {
+        const u64 t0 = (u64)text_offsets[d], sep = (u64)text_offsets[d + 1] - 1u;      // text d = [t0, sep), then its separator
+        if (a < sep) {
+            const u64 e = std::min(b, sep);
+            memcpy(dst, texts[d] + (a - t0), (size_t)(e - a));
+            dst += e - a;
+            a = e;
+        }
+        if (a == sep && a < b) { *dst++ = (char)0xFF; a++; }
+        if (a > sep) d++;
+    }
+}
+
 // Prepares the collection chunk by chunk; the symbols end up in h->prep_sym, the per-document offsets and string counts in
 // h_off / h_m.  Returns false when the monolithic preparation has to take over: kept text at or above U+0A00 (the tagged
 // encoding rewrites terminators the chunks no longer remember).  d_bytes: n_bytes + 32 bytes of the arena, nothing uploaded yet.
@@ -1203,13 +1236,71 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     const int device = h->device;
     hipStream_t copy_stream = h->copy_stream;
     const std::vector<hipEvent_t> &events = h->copy_events;
+    // (the ring: see tp_fill_stream above)
+    const bool use_ring = texts && g_tp_ring != 0 && (g_tp_ring > 0 || (D >= 4 && (u64)n_bytes / D < TP_RING_MAX_TEXT));
+    const size_t ring_slot = g_tp_ring_slot;
+    const u32 n_slots = use_ring ? ceil_div_u32(n_bytes, ring_slot) : 0u;
+    const int n_fill = use_ring ? (int)std::min<u32>(8u, std::max<u32>(2u, std::thread::hardware_concurrency() / 2u)) : 0;
+    if (use_ring && !h->ring) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, TP_RING_SLOT * TP_RING_SLOTS, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); east_throw(EAST_HIP_ERR_OOM, "hipHostMalloc of the upload ring failed"); }
+        h->ring = (char *)p;
+        for (int i = 0; i < TP_RING_SLOTS; i++) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->ring_events.push_back(e);
+        }
+    }
+    std::vector<std::atomic<int>> slot_parts(n_slots);         // fill threads done with their share of a slot
+    for (auto &a : slot_parts) a.store(0, std::memory_order_relaxed);
+    std::atomic<u32> slots_free{TP_RING_SLOTS};                 // stream slots [0, slots_free) may be filled (their ring slot's last DMA is done)
+    char *ring = h->ring;
+    std::vector<std::thread> fillers;
+    for (int j = 0; j < n_fill; j++)
+        fillers.emplace_back([&, j]() {
+            for (u32 sl = 0; sl < n_slots; sl++) {
+                while (slots_free.load(std::memory_order_acquire) <= sl) {
+                    if (upload_abort.load(std::memory_order_acquire)) return;
+                    std::this_thread::yield();
+                }
+                const u64 a = (u64)sl * ring_slot, len = std::min<u64>(ring_slot, (u64)n_bytes - a);
+                const u64 lo = a + len * (u64)j / (u64)n_fill, hi = a + len * (u64)(j + 1) / (u64)n_fill;
+                if (hi > lo) tp_fill_stream(ring + (size_t)(sl % TP_RING_SLOTS) * ring_slot + (lo - a), lo, hi, texts, text_offsets, D);
+                slot_parts[sl].fetch_add(1, std::memory_order_release);
+            }
+        });
+    const std::vector<hipEvent_t> &ring_events = h->ring_events;
     std::thread uploader([&, device, copy_stream]() {
         bool ok = hipSetDevice(device) == hipSuccess;
-        if (ok && texts) ok = hipMemsetAsync(d_bytes, 0xFF, n_bytes, copy_stream) == hipSuccess;       // the separators
+        if (ok && texts && !use_ring) ok = hipMemsetAsync(d_bytes, 0xFF, n_bytes, copy_stream) == hipSuccess;       // the separators
         if (ok) ok = hipMemsetAsync(d_bytes + n_bytes, 0, 32, copy_stream) == hipSuccess;
+        u32 sl_next = 0;                                          // (ring) the next stream slot to send, and how far it has been sent
+        u64 sent = 0;
         for (u32 c = 0; c < C && ok && !upload_abort.load(std::memory_order_acquire); c++) {
             const TpChunk &ch = chunks[c];
-            if (texts) {
+            if (use_ring) {
+                // the chunk's bytes: the pieces of the slots it overlaps, one DMA each; a slot is handed back to the fill
+                // threads when the DMA of its last piece is done (waited for one slot behind, so that the next is queued)
+                while (ok && sent < ch.b1) {
+                    while (slot_parts[sl_next].load(std::memory_order_acquire) < n_fill) {
+                        if (upload_abort.load(std::memory_order_acquire)) { ok = false; break; }
+                        std::this_thread::yield();
+                    }
+                    if (!ok) break;
+                    const u64 s_end = std::min<u64>((u64)(sl_next + 1) * ring_slot, n_bytes), e = std::min<u64>(s_end, ch.b1);
+                    ok = hipMemcpyAsync(d_bytes + sent, ring + (size_t)(sl_next % TP_RING_SLOTS) * ring_slot + (sent - (u64)sl_next * ring_slot),
+                                        (size_t)(e - sent), hipMemcpyHostToDevice, copy_stream) == hipSuccess;
+                    sent = e;
+                    if (ok && sent == s_end) {
+                        ok = hipEventRecord(ring_events[sl_next % TP_RING_SLOTS], copy_stream) == hipSuccess;
+                        if (ok && sl_next >= 1) {
+                            ok = hipEventSynchronize(ring_events[(sl_next - 1) % TP_RING_SLOTS]) == hipSuccess;
+                            slots_free.store(sl_next - 1 + 1 + TP_RING_SLOTS, std::memory_order_release);
+                        }
+                        sl_next++;
+                    }
+                }
+            } else if (texts) {
                 for (u32 i = 0; i < ch.n_docs && ok; i++) {
                     const u32 d = ch.doc_first + i;
                     const u32 lo = std::max(ch.b0, (u32)text_offsets[d]), hi = std::min(ch.b1, (u32)text_offsets[d + 1] - 1u);    // (without the separator)
@@ -1239,16 +1330,20 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     // queued may still be writing the arena or the host-side counts when they are released)
     struct Joiner {
         std::thread &t;
+        std::vector<std::thread> &fill;
         std::atomic<int> &abort;
         hipStream_t copy;
         ~Joiner()
         {
-            if (!t.joinable()) return;                   // (the regular path has joined already)
-            abort.store(1, std::memory_order_release);
-            t.join();
-            (void)hipStreamSynchronize(copy);
+            if (t.joinable()) {                          // (the regular path has joined already)
+                abort.store(1, std::memory_order_release);
+                t.join();
+                (void)hipStreamSynchronize(copy);
+            }
+            for (auto &f : fill)
+                if (f.joinable()) f.join();
         }
-    } joiner{uploader, upload_abort, copy_stream};
+    } joiner{uploader, fillers, upload_abort, copy_stream};
 
     for (u32 c = 0; c < C; c++) {
         const TpChunk &ch = chunks[c];
@@ -1279,7 +1374,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
             device_scan<ArrIn, false>(ctx, ArrIn{byte_prefix}, n_bblk + 1, byte_prefix);
             LAUNCH(ctx, tp_decode_kernel, ceil_div_u32(nb, BLOCK), b, nb, (const u32 *)byte_prefix, tables, cpu, cw);
         }
-        LAUNCH(ctx, tp_doc_cp_offsets_kernel, ceil_div_u32(Dl + 1, BLOCK), b, nb, bytewise ? (const u32 *)nullptr : (const u32 *)byte_prefix,
+        LAUNCH(ctx, tp_doc_cp_offsets_kernel, ceil_div_u32(Dl + 1, WAVES_PER_BLOCK), b, nb, bytewise ? (const u32 *)nullptr : (const u32 *)byte_prefix,
                (const u32 *)d_text_off, Dl, doc_cp_off);
         // code points -> tokens (their number stays on the device: the last entry of the blocks' prefix sums)
         const u32 n_tblk = ceil_div_u32(n_cp, TP_RANK_BLOCK);
@@ -1297,7 +1392,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         // tokens -> the documents' strings and symbols, with what earlier chunks emitted of the first document
         const TpCarry *cin = carry + (c & 1u);
         TpCarry *cout = carry + ((c + 1u) & 1u);
-        LAUNCH(ctx, tp_stream_docs_kernel, ceil_div_u32(Dl + 1, BLOCK), (const u32 *)doc_cp_off, (const uint8_t *)cw, n_cp, (const u32 *)tok_prefix, (const u32 *)keep_ex,
+        LAUNCH(ctx, tp_stream_docs_kernel, ceil_div_u32(Dl + 1, WAVES_PER_BLOCK), (const u32 *)doc_cp_off, (const uint8_t *)cw, n_cp, (const u32 *)tok_prefix, (const u32 *)keep_ex,
                (const u32 *)klen_ex, Dl, (u32)ch.cont_in, (u32)ch.cont_out, cin, first_tok, n_loc, kept_tot, chars_tot);
         device_scan<ArrIn, false>(ctx, ArrIn{n_loc}, Dl + 1, off_loc);
         LAUNCH(ctx, tp_stream_token_out_kernel, ceil_div_u32(ub, BLOCK), (const u32 *)tstart, (const u32 *)tend, (const u32 *)keep_ex,
@@ -1311,6 +1406,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         t_queued[c] = since();
     }
     uploader.join();
+    for (auto &f : fillers) f.join();
     // the total, the per-document offsets and string counts, "kept text at or above U+0A00"
     h_off.resize((size_t)D + 1);
     h_m.resize(D);
@@ -1495,7 +1591,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
         LAUNCH(ctx, tp_decode_kernel, ceil_div_u32(n_bytes, BLOCK), (const uint8_t *)d_bytes, n_bytes, (const u32 *)byte_prefix,
                tables, cpu, cw);
     }
-    LAUNCH(ctx, tp_doc_cp_offsets_kernel, ceil_div_u32(D + 1, BLOCK), (const uint8_t *)d_bytes, n_bytes,
+    LAUNCH(ctx, tp_doc_cp_offsets_kernel, ceil_div_u32(D + 1, WAVES_PER_BLOCK), (const uint8_t *)d_bytes, n_bytes,
            bytewise ? (const u32 *)nullptr : (const u32 *)byte_prefix, (const u32 *)d_text_off, D, doc_cp_off);
 
     // code points -> tokens (token starts in front of every block of 256 code points; the last entry: their number)
@@ -1527,7 +1623,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     u32 *first_tok = ar.alloc<u32>((size_t)D + 1), *m_d = ar.alloc<u32>(D), *n_d = ar.alloc<u32>((size_t)D + 1);
     u32 *doc_sym_off = ar.alloc<u32>((size_t)D + 1);
     HIP_CHECK(hipMemsetAsync(n_d + D, 0, 4, h->stream));
-    LAUNCH(ctx, tp_doc_counts_kernel, ceil_div_u32(D + 1, BLOCK), (const u32 *)doc_cp_off, (const uint8_t *)cw, n_cp, (const u32 *)tok_prefix,
+    LAUNCH(ctx, tp_doc_counts_kernel, ceil_div_u32(D + 1, WAVES_PER_BLOCK), (const u32 *)doc_cp_off, (const uint8_t *)cw, n_cp, (const u32 *)tok_prefix,
            (const u32 *)keep_ex, (const u32 *)klen_ex, D, first_tok, m_d, n_d);
     device_scan<ArrIn, false>(ctx, ArrIn{n_d}, D + 1, doc_sym_off);
     std::vector<u32> h_off((size_t)D + 1), h_m(D);
@@ -1883,6 +1979,8 @@ void east_hip_destroy(east_hip_handle_t h)
     if (h->tp_tables) (void)hipFree(h->tp_tables);
     if (h->ht_tab) (void)hipFree(h->ht_tab);
     for (auto e : h->copy_events) (void)hipEventDestroy(e);
+    for (auto e : h->ring_events) (void)hipEventDestroy(e);
+    if (h->ring) (void)hipHostFree(h->ring);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->guess) (void)hipFree(h->guess);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -2332,6 +2430,16 @@ int east_hip_debug_set_score_grid(int64_t workgroups)
 {
     // workgroups a launch of the score walk may have when the sums run inside it (0 or less: the default, 2^22)
     g_score_grid_blocks = workgroups > 0 ? (u64)std::min<int64_t>(workgroups, (int64_t)1 << 23) : SCORE_GRID_BLOCKS;
+    return EAST_HIP_OK;
+}
+
+int east_hip_debug_set_text_ring(int mode, int64_t slot_bytes)
+{
+    // mode -1: separate texts go up through the pinned ring when there are four or more of less than 8 MiB on average
+    // (and the preparation is streamed); 0: never; 1: whenever the texts lie apart.  slot_bytes: size of a ring slot
+    // (0 or less: the default, 4 MiB; at most that)
+    g_tp_ring = mode;
+    g_tp_ring_slot = slot_bytes > 0 ? (size_t)std::min<int64_t>(slot_bytes, (int64_t)TP_RING_SLOT) : TP_RING_SLOT;
     return EAST_HIP_OK;
 }
 

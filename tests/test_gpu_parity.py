@@ -1411,6 +1411,47 @@ def test_device_text_preparation_large(hip, chunk):
         assert lib.east_hip_debug_set_text_stream(-1) == 0
 
 
+@pytest.mark.parametrize("slot", [64, 1000, 100000, 0])
+def test_device_text_preparation_through_the_pinned_ring(hip, monkeypatch, request, slot):
+    """Separate texts (east_hip_build_texts_v) of a streamed preparation go up through a ring of pinned host memory, filled
+    by a few host threads and sent slot by slot (east_hip.hip: tp_fill_stream): forced on, with slots of 64 bytes to 4 MiB
+    -- slots that end inside texts, at separators, inside chunks and at their ends, many times round the ring -- the
+    prepared symbols equal the host chain's.  Fixtures, a fuzz, 40 documents of 300 KB, and the default path's choice."""
+    import random
+    from east import synthetic
+    _only_paths(request, "window_sort", "dc3_only")           # (the upload does not depend on the sort path)
+    lib = hip.load()
+    monkeypatch.setattr(hip, "JOIN_FREE_MIN_BYTES", 0)        # (small collections through the separate-texts entry point too)
+    assert lib.east_hip_debug_set_text_ring(1, slot) == 0
+    try:
+        g = load_golden("utils_vectors.json")
+        texts = [v["text_utf8"].encode("utf-8") for v in g["text_to_strings_collection"]]
+        h = load_golden("hse_config1.json")
+        hse = [t.encode("utf-8") for t in h["texts"].values()]
+        rng = random.Random(77)
+        words = ["alpha", "be", "Gamma9", "12", "дом", "éclair", "x_y'z", "0042", "Ωmega", "it's"]
+        fuzz = [[(" ".join(rng.choice(words) for _ in range(rng.randint(0, 60)))).encode("utf-8") for _ in range(rng.randint(1, 9))]
+                for _ in range(25)]
+        for chunk in (23, 600, 5000):
+            assert lib.east_hip_debug_set_text_stream(chunk) == 0
+            _check_device_prep(hip, texts)
+            _check_device_prep(hip, hse)
+            _check_device_prep(hip, [b"", b"a b", b"", b"only one tokenhere"])
+            for collection in fuzz:
+                _check_device_prep(hip, collection)
+        assert lib.east_hip_debug_set_text_stream(-1) == 0
+        if slot >= 100000 or slot == 0:                        # 12 MiB: the default chunks, the ring by its own choice as well
+            nrng = np.random.default_rng(5)
+            docs = [synthetic.word_stream_document(nrng, 300000)[0] for _ in range(40)]
+            docs[7] = docs[7][:100] + "é λ — ".encode("utf-8") + docs[7][100:]
+            _check_device_prep(hip, docs)
+            assert lib.east_hip_debug_set_text_ring(-1, slot) == 0
+            _check_device_prep(hip, docs)
+    finally:
+        assert lib.east_hip_debug_set_text_stream(-1) == 0
+        assert lib.east_hip_debug_set_text_ring(-1, 0) == 0
+
+
 def test_host_and_device_text_preparation_give_the_same_table(hip, monkeypatch):
     from east import applications, relevance
     g = load_golden("zipf_docs.json")
