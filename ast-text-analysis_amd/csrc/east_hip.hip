@@ -1382,13 +1382,14 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         device_scan<ArrIn, false>(ctx, ArrIn{tok_prefix}, n_tblk + 1, tok_prefix);
         const u32 *n_tok_dev = tok_prefix + n_tblk;
         const u32 ub = n_cp / 2 + 2;
-        HIP_CHECK(hipMemsetAsync(tok_nd, 0, (size_t)(klen + ub + 1 - tok_nd) * 4, h->stream));
+        // (everything over the tokens is bounded by their number on the device -- a third to a quarter of the upper bound ub:
+        // the zeroing, and ONE scan for kept tokens and kept symbols together, scan.h: device_scan_pair_bounded)
+        LAUNCH(ctx, tp_zero_tokens_kernel, ceil_div_u32((u64)ub + 1, BLOCK * 4), tok_nd, keep, klen, ub, n_tok_dev);
         LAUNCH(ctx, tp_token_bounds_kernel, ceil_div_u32(n_cp, BLOCK * TP_VEC), (const uint8_t *)cw, (const u32 *)tok_prefix, n_cp, tstart,
                tend, tok_nd);
         LAUNCH(ctx, tp_token_keep_kernel, ceil_div_u32(ub, BLOCK), (const u32 *)tstart, (const u32 *)tend, (const u32 *)tok_nd, ub, keep,
                klen, n_tok_dev);
-        device_scan<ArrIn, false>(ctx, ArrIn{keep}, ub + 1, keep_ex);
-        device_scan<ArrIn, false>(ctx, ArrIn{klen}, ub + 1, klen_ex);
+        device_scan_pair_bounded(ctx, keep, klen, ub + 1, n_tok_dev, 1u, keep_ex, klen_ex);
         // tokens -> the documents' strings and symbols, with what earlier chunks emitted of the first document
         const TpCarry *cin = carry + (c & 1u);
         TpCarry *cout = carry + ((c + 1u) & 1u);

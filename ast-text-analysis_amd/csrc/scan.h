@@ -119,3 +119,111 @@ static void device_scan(Ctx &ctx, In in, u32 n, u32 *out)
     LAUNCH(ctx, (scan_apply_kernel<In, INCLUSIVE>), nb, in, n, (const u32 *)sums, out);
     ctx.arena->release(mark);
 }
+
+// ---- two sums at once, over a length the DEVICE knows ------------------------------------------------------------------
+// out_a / out_b = exclusive prefix sums of a[] / b[] over the elements [0, min(n, *n_dev + extra)); tiles wholly behind
+// that bound return at once and their outputs stay unwritten (nobody reads them).  The streamed text preparation scans
+// per-token quantities this way: its kernels run on an upper bound of the token count (half the code points), the real
+// count -- a third to a quarter of that -- is on the device, and the two quantities (kept tokens, kept symbols) used to be
+// two scans of three launches each over the whole upper bound.
+__global__ __launch_bounds__(BLOCK) void scan_reduce2_kernel(const u32 *__restrict__ a, const u32 *__restrict__ b, u32 n,
+                                                             const u32 *__restrict__ n_dev, u32 extra, uint2 *__restrict__ block_sums)
+{
+    __shared__ u32 lds[2 * WAVES_PER_BLOCK];
+    const u32 bound = min(n, *n_dev + extra);
+    const u32 base = blockIdx.x * SCAN_TILE;
+    if (base >= bound) { if (threadIdx.x == 0) block_sums[blockIdx.x] = uint2{0u, 0u}; return; }
+    u32 sa = 0, sb = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT / 4; j++) {
+        const u32 i = base + (j * BLOCK + threadIdx.x) * 4u;
+        u32 x[4], y[4];
+        scan_load4(ArrIn{a}, i, bound, x);
+        scan_load4(ArrIn{b}, i, bound, y);
+        sa += x[0] + x[1] + x[2] + x[3];
+        sb += y[0] + y[1] + y[2] + y[3];
+    }
+    sa = wave_sum(sa);
+    sb = wave_sum(sb);
+    if (lane_id() == 0) { lds[wave_id()] = sa; lds[WAVES_PER_BLOCK + wave_id()] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = uint2{lds[0] + lds[1] + lds[2] + lds[3], lds[4] + lds[5] + lds[6] + lds[7]};
+}
+
+// exclusive scan of the tile sums, in place; one workgroup
+__global__ __launch_bounds__(BLOCK) void scan_sums2_kernel(uint2 *__restrict__ sums, u32 nb)
+{
+    __shared__ u32 lds4[WAVES_PER_BLOCK];
+    u32 run_a = 0, run_b = 0;
+    for (u32 t0 = 0; t0 < nb; t0 += BLOCK) {
+        const u32 t = t0 + threadIdx.x;
+        const uint2 v = t < nb ? sums[t] : uint2{0u, 0u};
+        u32 tot_a, tot_b;
+        const u32 ea = block_exclusive_sum(v.x, lds4, tot_a);
+        const u32 eb = block_exclusive_sum(v.y, lds4, tot_b);
+        if (t < nb) sums[t] = uint2{run_a + ea, run_b + eb};
+        run_a += tot_a;
+        run_b += tot_b;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void scan_apply2_kernel(const u32 *__restrict__ a, const u32 *__restrict__ b, u32 n,
+                                                            const u32 *__restrict__ n_dev, u32 extra,
+                                                            const uint2 *__restrict__ block_offsets, u32 *__restrict__ out_a,
+                                                            u32 *__restrict__ out_b)
+{
+    __shared__ u32 lds[2 * WAVES_PER_BLOCK];
+    const u32 bound = min(n, *n_dev + extra);
+    if (blockIdx.x * SCAN_TILE >= bound) return;
+    const u32 lane = lane_id(), w = wave_id();
+    const u32 wave_base = blockIdx.x * SCAN_TILE + w * (SCAN_TILE / WAVES_PER_BLOCK);
+    u32 va[4][4], vb[4][4];
+    u32 carry_a = 0, carry_b = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u32 i = wave_base + r * 256 + lane * 4;
+        u32 x[4], y[4];
+        scan_load4(ArrIn{a}, i, bound, x);
+        scan_load4(ArrIn{b}, i, bound, y);
+        const u32 ta = x[0] + x[1] + x[2] + x[3], tb = y[0] + y[1] + y[2] + y[3];
+        const u32 ia = wave_inclusive_sum(ta), ib = wave_inclusive_sum(tb);
+        u32 ra = carry_a + ia - ta, rb = carry_b + ib - tb;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { va[r][k] = ra; ra += x[k]; vb[r][k] = rb; rb += y[k]; }
+        carry_a += __shfl(ia, 63, WAVE);
+        carry_b += __shfl(ib, 63, WAVE);
+    }
+    if (lane == 0) { lds[w] = carry_a; lds[WAVES_PER_BLOCK + w] = carry_b; }
+    __syncthreads();
+    const uint2 off = block_offsets ? block_offsets[blockIdx.x] : uint2{0u, 0u};
+    u32 base_a = off.x, base_b = off.y;
+    for (u32 q = 0; q < w; q++) { base_a += lds[q]; base_b += lds[WAVES_PER_BLOCK + q]; }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u32 i = wave_base + r * 256 + lane * 4;
+        if (i + 3 < bound) {
+            *reinterpret_cast<uint4 *>(out_a + i) = make_uint4(va[r][0] + base_a, va[r][1] + base_a, va[r][2] + base_a, va[r][3] + base_a);
+            *reinterpret_cast<uint4 *>(out_b + i) = make_uint4(vb[r][0] + base_b, vb[r][1] + base_b, vb[r][2] + base_b, vb[r][3] + base_b);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (i + k < bound) { out_a[i + k] = va[r][k] + base_a; out_b[i + k] = vb[r][k] + base_b; }
+        }
+    }
+}
+
+// a, b, out_a, out_b: arrays of n words from the arena (16-byte aligned); n_dev: one word on the device
+static void device_scan_pair_bounded(Ctx &ctx, const u32 *a, const u32 *b, u32 n, const u32 *n_dev, u32 extra, u32 *out_a, u32 *out_b)
+{
+    if (n == 0) return;
+    const u32 nb = ceil_div_u32(n, SCAN_TILE);
+    const size_t mark = ctx.arena->mark();
+    uint2 *sums = nullptr;
+    if (nb > 1) {
+        sums = ctx.arena->alloc<uint2>(nb);
+        LAUNCH(ctx, scan_reduce2_kernel, nb, a, b, n, n_dev, extra, sums);
+        LAUNCH(ctx, scan_sums2_kernel, 1, sums, nb);
+    }
+    LAUNCH(ctx, scan_apply2_kernel, nb, a, b, n, n_dev, extra, (const uint2 *)sums, out_a, out_b);
+    ctx.arena->release(mark);
+}

@@ -287,6 +287,20 @@ __global__ __launch_bounds__(BLOCK) void tp_token_keep_kernel(const u32 *__restr
     klen[k] = kp ? len : 0u;
 }
 
+// what the kernels over a chunk's tokens want zeroed: tok_nd[0 .. n_tok] (raised by the token-bounds pass) and the entry
+// behind the last token of keep / klen (the scans read one element more than there are tokens) -- n_tok from the device
+__global__ __launch_bounds__(BLOCK) void tp_zero_tokens_kernel(u32 *__restrict__ tok_nd, u32 *__restrict__ keep, u32 *__restrict__ klen,
+                                                               u32 ub, const u32 *__restrict__ n_tok_dev)
+{
+    const u32 n_tok = min(*n_tok_dev, ub);
+    const u32 i = (blockIdx.x * BLOCK + threadIdx.x) * 4u;
+    if (i > n_tok) return;
+    if (i + 3u <= ub) *reinterpret_cast<uint4 *>(tok_nd + i) = uint4{0u, 0u, 0u, 0u};     // (the arrays hold ub + 1 words)
+    else
+        for (u32 k = i; k <= ub; k++) tok_nd[k] = 0u;
+    if (i == 0) { keep[n_tok] = 0u; klen[n_tok] = 0u; }
+}
+
 // per document: first token, kept tokens, strings m_d, symbols n_d
 __global__ __launch_bounds__(BLOCK) void tp_doc_counts_kernel(const u32 *__restrict__ doc_cp_off,
                                                               const uint8_t *__restrict__ cw, u32 n_cp,
