@@ -1138,11 +1138,12 @@ static std::vector<TpChunk> tp_plan_chunks(const uint8_t *bytes, const uint8_t *
 // than TP_RING_MAX_TEXT bytes on average therefore go through TP_RING_SLOTS slots of pinned memory: a few host threads
 // copy the stream -- text bytes and the 0xFF separators -- into a slot, each its share, while the slots before it are on
 // their way to the device (one DMA per slot and chunk, no set-up); the uploader thread alone talks to the runtime.
-#define TP_RING_SLOT ((size_t)4 << 20)
-#define TP_RING_SLOTS 4
+#define TP_RING_SLOT ((size_t)8 << 20)
+#define TP_RING_SLOTS 3
 #define TP_RING_MAX_TEXT ((u64)8 << 20)
 static int g_tp_ring = getenv("EAST_HIP_TEXT_RING") ? atoi(getenv("EAST_HIP_TEXT_RING")) : -1;   // -1: by shape, 0: never, 1: whenever the texts lie apart
-static size_t g_tp_ring_slot = TP_RING_SLOT;                 // east_hip_debug_set_text_ring (tests: slots of a few hundred bytes)
+static size_t g_tp_ring_slot = getenv("EAST_HIP_RING_SLOT") ? std::min<size_t>(TP_RING_SLOT, (size_t)std::max(64, atoi(getenv("EAST_HIP_RING_SLOT"))))
+                                                            : TP_RING_SLOT;   // east_hip_debug_set_text_ring (tests: slots of a few hundred bytes)
 
 // bytes [a, b) of the concatenated stream (texts d with their 0xFF separators, text_offsets as in build_from_texts) -> dst
 static void tp_fill_stream(char *dst, u64 a, u64 b, const uint8_t *const *texts, const i64 *text_offsets, u32 D)
@@ -1240,7 +1241,12 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     const bool use_ring = texts && g_tp_ring != 0 && (g_tp_ring > 0 || (D >= 4 && (u64)n_bytes / D < TP_RING_MAX_TEXT));
     const size_t ring_slot = g_tp_ring_slot;
     const u32 n_slots = use_ring ? ceil_div_u32(n_bytes, ring_slot) : 0u;
-    const int n_fill = use_ring ? (int)std::min<u32>(8u, std::max<u32>(2u, std::thread::hardware_concurrency() / 2u)) : 0;
+    // (fill threads: three -- measured on the 256-thread host of the MI355X box, 64 texts of 1 MiB: 4 threads 2.25 ms of
+    // preparation, 8: 2.3-2.6, 16: 2.6, 32: 2.95 -- starting the threads costs more than their copies save; a 16 MiB
+    // chunk is staged in 0.45 ms either way, 37 GB/s)
+    static const int ring_threads_env = getenv("EAST_HIP_RING_THREADS") ? atoi(getenv("EAST_HIP_RING_THREADS")) : 0;     // (experiments)
+    const int n_fill = !use_ring ? 0 : ring_threads_env > 0 ? std::min(ring_threads_env, 64)
+                                     : (int)std::min<u32>(3u, std::max<u32>(2u, std::thread::hardware_concurrency() / 2u));
     if (use_ring && !h->ring) {
         void *p = nullptr;
         if (hipHostMalloc(&p, TP_RING_SLOT * TP_RING_SLOTS, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); east_throw(EAST_HIP_ERR_OOM, "hipHostMalloc of the upload ring failed"); }
@@ -2438,7 +2444,7 @@ int east_hip_debug_set_text_ring(int mode, int64_t slot_bytes)
 {
     // mode -1: separate texts go up through the pinned ring when there are four or more of less than 8 MiB on average
     // (and the preparation is streamed); 0: never; 1: whenever the texts lie apart.  slot_bytes: size of a ring slot
-    // (0 or less: the default, 4 MiB; at most that)
+    // (0 or less: the default, 8 MiB; at most that)
     g_tp_ring = mode;
     g_tp_ring_slot = slot_bytes > 0 ? (size_t)std::min<int64_t>(slot_bytes, (int64_t)TP_RING_SLOT) : TP_RING_SLOT;
     return EAST_HIP_OK;

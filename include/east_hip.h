@@ -372,7 +372,7 @@ int east_hip_debug_set_text_stream(int64_t chunk_bytes);
 /* Test knob: how separate texts (east_hip_build_texts_v) reach the device when the preparation is streamed.  A copy out of
  * pageable memory costs ~45 us of set-up, which one large text hides and hundreds of small ones do not: they are copied by
  * a few host threads into a ring of pinned memory and go up slot by slot.  mode -1 (default): four or more texts of less
- * than 8 MiB on average; 0: never; 1: always.  slot_bytes: size of a ring slot (0: the default, 4 MiB). */
+ * than 8 MiB on average; 0: never; 1: always.  slot_bytes: size of a ring slot (0: the default, 8 MiB). */
 int east_hip_debug_set_text_ring(int mode, int64_t slot_bytes);
 /* Host only (needs no device): the order-preserving variable-length code csrc/ht_code.h makes for n symbols (in their
  * order) with the given weights -- code[i] = the len[i] bits of symbol i's code word, right-aligned.  EAST_HIP_ERR_DOMAIN

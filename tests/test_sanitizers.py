@@ -1,0 +1,138 @@
+"""CPU tier: the host code under AddressSanitizer + UndefinedBehaviorSanitizer (sanitizers).
+
+  * oracle/easa_oracle.c (`make -C oracle asan`, gcc): the golden fixtures and a fuzz through the sanitized build;
+  * the HOST side of libeast_hip.so (`make -C ast-text-analysis_amd/csrc asan`, hipcc -fsanitize=address,undefined
+    -fno-gpu-sanitize: the device code is compiled as ever, GPU sanitizers are not available on this pool): the entry
+    points that need no device -- the arena planner's dry runs of the whole host orchestration (window sort with its
+    rounds, DC3 recursion, tagged streams), the code construction of csrc/ht_code.h, the sharding rule of the device
+    groups, the table formatter.
+
+The sanitizer runtime has to be the first library of the process: each check runs in a child started with LD_PRELOAD."""
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT, PKG
+
+CHILD_ORACLE = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(pkg)r)
+import numpy as np
+from oracle import easa_oracle
+assert "asan" in easa_oracle._LIB_PATH
+golden = os.path.join(%(root)r, "tests", "golden")
+g = json.load(open(os.path.join(golden, "readme_example.json")))
+cases = [g] if "strings" in g else list(g.get("cases", []))
+cases += json.load(open(os.path.join(golden, "fuzz_small.json")))["cases"]
+n = 0
+for case in cases:
+    o = easa_oracle.OracleEASA(case["strings"])
+    for name in ("suftab", "lcptab", "anntab", "childtab_up", "childtab_down", "childtab_next_l_index"):
+        assert getattr(o, name).tolist() == case[name], (name, case["strings"])
+    for q in case["queries"]:
+        for fast in (False, True):
+            assert o.score(q["query"], True, fast=fast) == q["normalized"]
+            assert o.score(q["query"], False, fast=fast) == q["denormalized"]
+    n += 1
+rng = np.random.default_rng(3)
+for _ in range(200):                                          # random collections: every table, both walks agree
+    strings = ["".join(rng.choice(list("AB C"), size=int(rng.integers(1, 12)))) for _ in range(int(rng.integers(1, 6)))]
+    o = easa_oracle.OracleEASA(strings)
+    q = "".join(rng.choice(list("ABCD"), size=int(rng.integers(1, 9))))
+    if q.replace(" ", ""):
+        assert o.score(q, True, fast=False) == o.score(q, True, fast=True)
+try:
+    easa_oracle.OracleEASA(symbols=np.array([1, 0x0A00], dtype=np.uint32), n_strings=1)      # outside the domain: refused, no overrun
+    raise SystemExit("U+0001 accepted")
+except ValueError:
+    pass
+print("oracle under sanitizers: %%d fixture cases" %% n)
+"""
+
+CHILD_LIBRARY = r"""
+import ctypes, sys
+sys.path.insert(0, %(pkg)r)
+import numpy as np
+from east import applications, formatting, hip_backend
+lib = hip_backend.load()
+assert "asan" in hip_backend.LIB_PATH
+# the arena planner: dry runs of the whole host orchestration (no device)
+for n, d in ((1, 1), (17, 1), (4096, 3), (70000, 2), (1 << 20, 1), (3 << 20, 64), (1 << 24, 300), (1 << 27, 70000)):
+    full, lean = lib.east_hip_plan_arena_bytes(n, d), lib.east_hip_plan_arena_bytes_lean(n, d)
+    assert 0 < lean <= full, (n, d, full, lean)
+for knob in (0, 2, 3, 4, 5, 7, 9, 1):
+    assert lib.east_hip_debug_set_window_sort(knob) == 0
+    assert lib.east_hip_plan_arena_bytes(5 << 20, 9) > 0
+for seg in (0, 1, -1):
+    assert lib.east_hip_debug_set_segmented_sort(seg) == 0
+    assert lib.east_hip_plan_arena_bytes(5 << 20, 9) > 0
+assert lib.east_hip_plan_arena_bytes(0, 1) < 0 and lib.east_hip_plan_arena_bytes(1 << 20, 0) < 0
+# the order-preserving variable-length code (csrc/ht_code.h)
+rng = np.random.default_rng(11)
+for n in (8, 9, 27, 64, 113, 200, 256):
+    for shape in ("uniform", "zipf", "one_heavy"):
+        w = {"uniform": np.full(n, 10), "zipf": (1e6 / np.arange(1, n + 1) ** 1.2).astype(np.int64) + 1,
+             "one_heavy": np.concatenate([[10 ** 9], rng.integers(1, 5, size=n - 1)])}[shape].astype(np.uint64)
+        rng.shuffle(w)
+        code, ln = np.zeros(n, np.uint32), np.zeros(n, np.int32)
+        rc = lib.east_hip_debug_alphabetic_code(w.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n,
+                                                code.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                                ln.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        assert rc == 0, (n, shape, rc)
+        words = [format(int(c), "0%%db" %% l) for c, l in zip(code, ln)]
+        assert words == sorted(words) and all(3 <= l <= 12 for l in ln)                     # alphabetic, lengths in range
+        assert all(not b.startswith(a) for a, b in zip(words, words[1:]))                   # prefix-free (neighbours suffice in sorted order)
+for n in (0, 1, 7, 257):
+    w = np.ones(max(n, 1), np.uint64); code = np.zeros(max(n, 1), np.uint32); ln = np.zeros(max(n, 1), np.int32)
+    assert lib.east_hip_debug_alphabetic_code(w.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n,
+                                              code.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                              ln.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))) != 0
+# the sharding rule of the device groups
+for _ in range(100):
+    n, g = int(rng.integers(0, 60)), int(rng.integers(1, 12))
+    first = hip_backend.shard_documents(rng.integers(1, 10 ** 6, size=n), g)
+    assert first[0] == 0 and first[-1] == n and (np.diff(first) >= 0).all()
+# the table formatter against the Python rendering
+for K, D in ((1, 1), (3, 200), (150, 40), (700, 9)):
+    scores = rng.random((K, D)) * rng.choice([1.0, 1.0, 7.0, 1e6], size=(K, D))
+    scores[0, 0] = 0.0625
+    names_k = ["kp %%d \"q\" é" %% i for i in rng.permutation(K)]
+    names_t = ["%%s.txt" %% ("x" * int(rng.integers(1, 40))) + str(i) for i in rng.permutation(D)]
+    table = applications.ScoreTable(names_k, names_t, scores)
+    plain = {k: dict(table[k].items()) for k in table}
+    formatting._BULK_MIN_SCORES = 1
+    xml, csv = formatting.table2xml(table), formatting.table2csv(table)
+    formatting._BULK_MIN_SCORES = 10 ** 12
+    assert xml == formatting.table2xml(plain) and csv == formatting.table2csv(plain), (K, D)
+print("library host code under sanitizers: ok")
+"""
+
+
+def _run_child(code, preload, env_extra):
+    env = dict(os.environ, LD_PRELOAD=preload, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
+               **env_extra)
+    done = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    out, err = done.stdout.decode(), done.stderr.decode()
+    assert done.returncode == 0, (out[-2000:], err[-4000:])
+    assert "ERROR: AddressSanitizer" not in err and "runtime error:" not in err, err[-4000:]
+    return out
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"])
+    gcc_asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    out = _run_child(CHILD_ORACLE % {"root": ROOT, "pkg": PKG}, gcc_asan,
+                     {"EASA_ORACLE_LIBRARY": os.path.join(ROOT, "oracle", "libeasa_oracle_asan.so")})
+    assert "fixture cases" in out
+
+
+def test_library_host_code_under_address_and_ub_sanitizers():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "csrc"), "asan"])          # (about a minute of hipcc)
+    runtimes = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    assert runtimes, "no clang AddressSanitizer runtime under /opt/rocm"
+    out = _run_child(CHILD_LIBRARY % {"pkg": PKG}, runtimes[-1],
+                     {"EAST_HIP_LIBRARY": os.path.join(PKG, "east", "_lib", "libeast_hip_asan.so")})
+    assert "under sanitizers: ok" in out
