@@ -189,3 +189,73 @@ def repeated_passage_document(rng, passage_symbols, copies):
     passage = rng.integers(65, 91, size=int(passage_symbols), dtype=np.uint32)
     out = np.concatenate([np.tile(passage, int(copies)), np.array([TERMINATOR_START], dtype=np.uint32)])
     return out, 1
+
+
+# ---- prose-like text from a character model ---------------------------------------------------------
+# BASELINE config 5 names enwik8, which is not available offline.  The Zipf stand-in above has the word statistics of
+# natural language but uniform letters; this one has the letters too: an order-3 character model (the 8 likeliest
+# successors of every 3-character context) trained on the prose that ships with the container image
+# (tools/train_prose_model.py -> east/data/prose_order3.npz, committed, so that the generator gives the same bytes on
+# any machine).  Text comes out of many short chains run side by side (numpy), each started at a word start.
+PROSE_ALPHABET = "abcdefghijklmnopqrstuvwxyz \n0123456789.,;:'\"-()!?"
+PROSE_ALPHABET_SIZE = len(PROSE_ALPHABET)
+_prose_model = None
+
+
+def prose_model():
+    """The committed order-3 model as sampling tables over the contexts that occur (numbered 0 .. C-1): pick[c, u] = which
+    of the context's 8 likeliest successors a random byte u selects (probabilities in 1/256), succ[c, k] that character,
+    next_ctx[c, k] the context that follows (-1: never seen with a successor), the word-start contexts with their distribution."""
+    global _prose_model
+    if _prose_model is None:
+        import os
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "prose_order3.npz"))
+        A = PROSE_ALPHABET_SIZE
+        contexts = z["contexts"].astype(np.int64)               # sorted ids (c1 * A + c2) * A + c3
+        thr = np.minimum(np.floor(z["cum"].astype(np.float64) * 256.0), 255).astype(np.int64)
+        pick = (thr[:, None, :] < np.arange(256)[None, :, None]).sum(axis=2).astype(np.uint8)    # [C, 256] inverse CDF: which of the 8
+        succ = z["succ"].astype(np.uint8)                                                        # [C, 8]
+        follow = (contexts[:, None] % (A * A)) * A + succ.astype(np.int64)                       # [C, 8] ids of the following contexts
+        pos = np.searchsorted(contexts, follow).clip(0, contexts.size - 1)
+        next_ctx = np.where(contexts[pos] == follow, pos, -1).astype(np.int32)
+        starts = np.searchsorted(contexts, z["starts"].astype(np.int64))
+        _prose_model = {"pick": pick.reshape(-1), "succ": succ.reshape(-1), "next_ctx": next_ctx.reshape(-1), "contexts": contexts,
+                        "starts": starts, "start_cdf": z["start_cdf"],
+                        "chars": np.frombuffer(PROSE_ALPHABET.encode("ascii"), dtype=np.uint8)}
+    return _prose_model
+
+
+def prose_like_texts(rng, n_docs, doc_bytes, chain=256):
+    """n_docs raw texts (bytes, ASCII: lower-case prose with punctuation and line breaks; 8 % of the words capitalised) of
+    doc_bytes each, from the character model.  All documents are generated together: chains of `chain` characters side
+    by side, two table look-ups per chain and character."""
+    m = prose_model()
+    A = PROSE_ALPHABET_SIZE
+    per_doc = -(-doc_bytes // chain)
+    n_chains = n_docs * per_doc
+
+    def fresh(k):
+        return m["starts"][np.searchsorted(m["start_cdf"], rng.random(k), side="left").clip(0, m["starts"].size - 1)]
+
+    ctx = fresh(n_chains).astype(np.int64)
+    out = np.empty((chain, n_chains), dtype=np.uint8)          # (a row per step: contiguous writes; transposed at the end)
+    ids = m["contexts"][ctx]                                   # a start context is (blank, c1, c2): the chain opens with c1 c2
+    out[0] = (ids // A) % A
+    out[1] = ids % A
+    for t in range(2, chain):
+        k = ctx * 8 + m["pick"][ctx * 256 + rng.integers(0, 256, size=n_chains)]
+        out[t] = m["succ"][k]
+        ctx = m["next_ctx"][k].astype(np.int64)
+        dead = ctx < 0
+        if dead.any():                                         # (a context seen only at the very end of the training text)
+            ctx[dead] = fresh(int(dead.sum()))
+    text = np.ascontiguousarray(m["chars"][out].T)             # [n_chains, chain] bytes
+    text[:, -1] = 32                                           # chains are joined by a blank
+    # capitals: the first letter of 8 % of the words
+    flat = text.reshape(-1)
+    word_start = np.ones(flat.size, dtype=bool)
+    word_start[1:] = (flat[:-1] == 32) | (flat[:-1] == 10)
+    cap = np.flatnonzero(word_start & (flat >= 97) & (flat <= 122))
+    flat[cap[rng.random(cap.size) < 0.08]] -= 32
+    docs = text.reshape(n_docs, per_doc * chain)[:, :doc_bytes]
+    return [bytes(row) for row in docs]

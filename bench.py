@@ -445,6 +445,7 @@ def main():
             out["worst_case"] = worst_case_leg(hip_backend, synthetic, torch, dev, local_rank, not args.no_cpu_baseline)
             out["config2"] = config2_leg(args, hip_backend, synthetic, torch, dev, local_rank)
             out["config5"] = config5_leg(args, hip_backend, synthetic, torch, dev, local_rank)
+            out["config5_prose"] = config5_prose_leg(hip_backend, synthetic, torch, dev, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, synthetic)
     if use_dist:
@@ -702,6 +703,63 @@ def config5_leg(args, hip_backend, synthetic, torch, dev, local_rank):
             "symbols": n, "build_ms": float(np.mean(build_ms)), "score_ms": float(np.mean(score_ms)),
             "refine_rounds": info["refine_rounds"], "lds_sorted": info.get("lds_sorted", 0),
             "window_sorted": info["window_sorted"], "kernels_ms_per_step": dict(list(per_step.items())[:12])}
+
+
+def config5_prose_leg(hip_backend, synthetic, torch, dev, local_rank):
+    """BASELINE config 5, second stand-in: 100 x 1 MiB of prose-like text from the order-3 character model of
+    east/synthetic.py (trained on the image's prose: English letter statistics, frequent words and word pairs; the Zipf
+    stand-in of `config5` has uniform letters), 1 000 keyphrases.  Two figures: raw text (Python bytes) -> finished index
+    through the device text preparation, wall clock; and the steady-state step on the prepared symbols resident in HBM."""
+    D, K, steps = 100, 1000, 3
+    texts = synthetic.prose_like_texts(np.random.default_rng(20240 + 5), D, 1 << 20)
+    index = hip_backend.HipIndex(local_rank)
+    walls = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        index.build_texts(texts)
+        walls.append((time.perf_counter() - t0) * 1e3)
+    prep_ms, text_build_ms = index.last_prep_ms, index.last_build_ms
+    symbols, doc_offsets, n_strings = index.prepared()
+    index.close()
+    n = int(symbols.size)
+    rng = np.random.default_rng(20240 + 5)
+    qs, qo = synthetic.keyphrases(rng, symbols, K)
+    d_symbols = torch.from_numpy(symbols.view(np.int32)).to(dev)
+    block = torch.empty((K, D), dtype=torch.float64, device=dev)
+    index = hip_backend.HipIndex(local_rank, reserve_symbols=n)
+    index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)
+    first_build_ms = index.last_build_ms
+    index.set_keyphrases(qs, qo)
+    index.score_resident(True, block.data_ptr())
+    build_ms, score_ms = [], []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)
+        index.score_resident(True, block.data_ptr())
+        build_ms.append(index.last_build_ms)
+        score_ms.append(index.last_score_ms)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    index.profile_enable(True)
+    for _ in range(steps):
+        index.build_device(d_symbols.data_ptr(), n, doc_offsets, n_strings)
+        index.score_resident(True, block.data_ptr())
+    torch.cuda.synchronize()
+    prof = index.profile_report()
+    index.profile_enable(False)
+    info = index.info()
+    index.close()
+    per_step = {k: round(v[1] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+    return {"workload": "100 x 1 MiB prose-like text (order-3 character model trained on the image's prose), text mode, 1000 "
+                        "keyphrases, normalized",
+            "steps": steps, "ms_per_step": elapsed * 1e3 / steps, "value": D * (1 << 20) / (elapsed / steps), "unit": "chars/s",
+            "symbols": n, "strings": int(np.sum(n_strings)), "build_ms": float(np.mean(build_ms)), "score_ms": float(np.mean(score_ms)),
+            "first_build_ms": first_build_ms,
+            "from_text": {"wall_ms": min(walls[1:]), "prep_ms": prep_ms, "build_ms": text_build_ms,
+                          "chars_per_s": D * (1 << 20) / (min(walls[1:]) * 1e-3)},
+            "refine_rounds": info["refine_rounds"], "variable_length_keys": info.get("ht_keys", 0), "segmented_sort": info.get("seg_sort", 0),
+            "lds_sorted": info.get("lds_sorted", 0), "first_kept": info.get("first_kept"), "kernels_ms_per_step": dict(list(per_step.items())[:12])}
 
 
 def config2_leg(args, hip_backend, synthetic, torch, dev, local_rank):

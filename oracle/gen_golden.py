@@ -16,6 +16,7 @@ Files written (tests/golden/):
   hse_graph.json        keyphrases_graph + gml/edges output on the HSE corpus (17 keyphrases)
   fuzz_small.json       random small collections: every table + scores (easa == ast_linear)
   zipf_docs.json        natural-language-like docs scored by ast_linear and easa (config 5 sub-sample)
+  prose_like_docs.json  4 prose-like docs (order-3 character model) x 200 keyphrases scored by ast_linear and easa
   high_text.json        text at or above U+0A00 (Thai, Georgian, CJK, Hangul, precomposed Vietnamese, a supplementary-
                         plane letter): tables + scores of strings collections, and a keyphrase table over raw texts
   traversal_synonyms.json  pre-/post-order lcp-interval traversals (easa.py:38-85) and synonym-expanded
@@ -249,6 +250,43 @@ def gen_zipf():
     write("zipf_docs.json", d)
 
 
+def gen_prose_like():
+    """BASELINE config 5 sub-sample, second stand-in: 4 documents of prose-like text from the order-3 character model of
+    the build's synthetic.py (trained on the image's prose; tables committed with it) x 200 keyphrases, scored by the
+    reference's ast_linear (ast_linear.py:12-208, ast.py:19-73) and by its easa -- identical, as its own test demands."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location(
+        "amd_synthetic", os.path.join(os.path.dirname(HERE), "ast-text-analysis_amd", "east", "synthetic.py"))
+    synthetic = importlib.util.module_from_spec(spec)       # (by path: the package `east` here is the reference's)
+    spec.loader.exec_module(synthetic)
+    nrng = np.random.default_rng(20246)
+    raw = synthetic.prose_like_texts(nrng, 5, 6000)
+    docs = {("doc%d" % i): raw[i].decode("ascii") for i in range(4)}
+    other = raw[4].decode("ascii").split()
+    rng = random.Random(20246)
+    names = sorted(docs)
+    kps = set()
+    while len(kps) < 200:
+        if len(kps) % 2 == 0:                               # words as they stand in a document
+            toks = docs[rng.choice(names)].split()
+            st = rng.randrange(len(toks) - 3)
+            kp = " ".join(toks[st:st + rng.randint(1, 3)])
+        else:                                               # prose-like words that need not occur anywhere
+            st = rng.randrange(len(other) - 3)
+            kp = " ".join(other[st:st + rng.randint(1, 3)])
+        if utils.prepare_text(kp).replace(" ", ""):
+            kps.add(kp)
+    kps = sorted(kps)
+    texts = {k: v.encode("utf-8") for k, v in docs.items()}
+    lin = table_dump(kps, texts, "ast_linear")
+    easa = table_dump(kps, texts, "easa")
+    assert lin == easa
+    d = {"keyphrases": kps, "texts": docs, "scored_by": ["ast_linear", "easa"]}
+    d.update(lin)
+    write("prose_like_docs.json", d)
+
+
 class StubSynonimizer(object):
     """What score() needs of a SynonymExtractor (synonyms/synonyms.py): get_synonyms() -> {word: [synonyms]}."""
 
@@ -389,5 +427,6 @@ if __name__ == "__main__":
     gen_hse()
     gen_fuzz()
     gen_zipf()
+    gen_prose_like()
     gen_traversal_synonyms()
     gen_high_text()

@@ -129,7 +129,7 @@ def _table_equal(got, want):
             assert got[kp][t] == want[kp][t], (kp, t, got[kp][t], want[kp][t])
 
 
-@pytest.mark.parametrize("fixture", ["sample_table.json", "hse_config1.json", "zipf_docs.json"])
+@pytest.mark.parametrize("fixture", ["sample_table.json", "hse_config1.json", "zipf_docs.json", "prose_like_docs.json"])
 def test_keyphrases_table_fixtures(hip, fixture):
     """BASELINE config 1 (30 HSE docs x 10 keyphrases), the XABXAC sample and the
     natural-language-like docs scored by ast_linear: the batched build + batched score."""
@@ -1199,6 +1199,39 @@ def test_config5_zipf_100_documents_full_size(hip, oracle, suffix_sort_path):
             for norm in (True, False):
                 for k in range(0, 400, 2):
                     assert tables[norm][k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=False), (d, k, norm)
+
+
+def test_config5_prose_like_100_documents_full_size(hip, oracle, request):
+    """BASELINE config 5, the second stand-in at full size: 100 documents of 1 MiB of prose-like text (the order-3
+    character model of east/synthetic.py: English letter statistics, frequent words and word pairs -- the text class
+    whose build goes through variable-length keys and prefix-doubling rounds) from raw bytes through the device text
+    preparation; four sampled documents: the prepared symbols equal the host chain's, all six tables array_equal to the
+    oracle, 300 keyphrases bit-equal in both modes (the oracle is pinned to ast_linear on prose_like_docs.json)."""
+    _only_paths(request, "window_sort", "window_sort_ht_unfused", "dc3_only", "window_sort_seg")
+    from east import hip_backend, synthetic, utils
+    from east.asts import utils as ast_utils
+    texts = synthetic.prose_like_texts(np.random.default_rng(20240 + 5), 100, 1 << 20)
+    index = hip_backend.HipIndex()
+    index.build_texts(texts)
+    sym, off, ms = index.prepared()
+    assert index.info()["n_docs"] == 100 and off[-1] == sym.size
+    rng = np.random.default_rng(9)
+    qs, qo = synthetic.keyphrases(rng, sym, 300)
+    tables = {norm: index.score_table(qs, qo, norm) for norm in (True, False)}
+    assert (tables[True].max(axis=1)[0::2] > 0).all()
+    for d in (0, 41, 77, 99):
+        want = ast_utils.strings_to_symbols(utils.text_to_strings_collection(texts[d]))
+        assert np.array_equal(sym[off[d]:off[d + 1]], want), d
+        o = oracle.OracleEASA(symbols=want, n_strings=int(ms[d]))
+        t = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+        for norm in (True, False):
+            got = tables[norm][:, d]
+            ref = np.array([o.score_symbols(qs[qo[k]:qo[k + 1]], norm, fast=True) for k in range(300)])
+            assert np.array_equal(got, ref), (d, norm)
+        for k in range(0, 300, 15):
+            assert tables[True][k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=False), (d, k)
 
 
 def test_speculative_builds_on_one_handle(hip, oracle):

@@ -292,3 +292,20 @@ def test_group_sharding_rule_matches_the_process_per_gpu_path():
         blocks = parallel.shard_documents(sizes, g)
         assert first == [b for b, _ in blocks] + [blocks[-1][1]]
         assert first[0] == 0 and first[-1] == n and all(a <= b for a, b in zip(first, first[1:]))
+
+
+def test_prose_like_generator_is_deterministic_and_looks_like_prose():
+    """synthetic.prose_like_texts (the order-3 character model committed under east/data/): the same bytes for the same
+    seed -- the fixture tests/golden/prose_like_docs.json holds the documents of seed 20246 --, letter statistics of
+    English text rather than uniform letters, and text the preparation chain turns into strings of three words."""
+    import collections
+    from east import synthetic, utils
+    g = load_golden("prose_like_docs.json")
+    docs = synthetic.prose_like_texts(np.random.default_rng(20246), 5, 6000)
+    assert [d.decode("ascii") for d in docs[:4]] == [g["texts"]["doc%d" % i] for i in range(4)]
+    big = b" ".join(synthetic.prose_like_texts(np.random.default_rng(1), 3, 100000))
+    counts = collections.Counter(big.lower())
+    letters = sorted((c for c in counts if 97 <= c <= 122), key=lambda c: -counts[c])
+    assert set(bytes(letters[:6]).decode()) <= set("etaoinsrh") and counts[ord("e")] > 8 * counts[ord("z")]
+    strings = utils.text_to_strings_collection(big)
+    assert len(strings) > 8000 and all(s == s.upper() for s in strings[:100])

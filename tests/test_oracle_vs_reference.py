@@ -84,10 +84,15 @@ def test_golden_fixtures_are_reproducible(tmp_path):
     gen = tmp_path / "oracle"
     shutil.copytree(os.path.join(ROOT, "oracle"), gen, ignore=shutil.ignore_patterns("*.so", "__pycache__"))
     (tmp_path / "tests" / "golden").mkdir(parents=True)
+    # (the prose-like documents come out of the build's own generator: its module and its committed model, by path)
+    east_dir = tmp_path / "ast-text-analysis_amd" / "east"
+    (east_dir / "data").mkdir(parents=True)
+    shutil.copy(os.path.join(ROOT, "ast-text-analysis_amd", "east", "synthetic.py"), str(east_dir / "synthetic.py"))
+    shutil.copy(os.path.join(ROOT, "ast-text-analysis_amd", "east", "data", "prose_order3.npz"), str(east_dir / "data" / "prose_order3.npz"))
     r = subprocess.run([sys.executable, str(gen / "gen_golden.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     committed = sorted(f for f in os.listdir(os.path.join(ROOT, "tests", "golden")) if f.endswith(".json"))
-    assert len(committed) == 10 and "high_text.json" in committed and "traversal_synonyms.json" in committed
+    assert len(committed) == 11 and "high_text.json" in committed and "prose_like_docs.json" in committed and "traversal_synonyms.json" in committed
     assert sorted(os.listdir(str(tmp_path / "tests" / "golden"))) == committed      # every fixture, and nothing else
     for name in committed:
         assert filecmp.cmp(str(tmp_path / "tests" / "golden" / name), os.path.join(ROOT, "tests", "golden", name),
