@@ -79,7 +79,9 @@ def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=Non
             prepared = [keyphrases_prepared[kp] for kp in wanted]
             scores = (similarity_measure.relevance_table(prepared, synonimizer) if synonimizer
                       else similarity_measure.relevance_table(prepared))
-            return ScoreTable(wanted, text_titles, scores)                # (a mapping over the array: no K x D Python floats)
+            # (a mapping over the array: no K x D Python floats.  A rank of a multi-process run that is not the one to
+            # print gets a K x 0 array -- east/parallel.py, table_rank --: rows without entries, as zip() made them)
+            return ScoreTable(wanted, text_titles[:scores.shape[1]], scores)
         return res
 
     i = 0
