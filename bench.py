@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config2", action="store_true", help="skip the configs[2] and config 5 legs of the N=1 line")
     ap.add_argument("--no-extras", action="store_true", help="skip build_from_host / child tables / probe count")
+    ap.add_argument("--base-value", type=float, default=float(os.environ.get("EAST_BENCH_BASE_VALUE", "0") or 0),
+                    help="N > 1: the same-shape single-GPU value (config2.value of the N = 1 line, chars/s) -- the line "
+                         "then carries multi_gpu.scaling_efficiency = value / (N x base)")
     ap.add_argument("--cpu-sample-mib", type=float, default=64.0,
                     help="size of the CPU-baseline document (64 = the bench document itself, about 15 s of one core)")
     args = ap.parse_args()
@@ -410,6 +413,8 @@ def main():
             out["multi_gpu"] = {"step_local_ms": step_local_ms, "allgather_ms": allgather_ms,
                                 "local_fraction_of_step": step_local_ms / ms_per_step if ms_per_step else None,
                                 "rccl_world_size": rccl_world, "backend": dist.get_backend(),
+                                "scaling_efficiency": value / (world * args.base_value) if args.base_value > 0 else None,
+                                "scaling_base_value": args.base_value if args.base_value > 0 else None,
                                 "same_shape_single_gpu_base": "config2.value of the N=1 line (256 x 1 MiB docs, 10000 keyphrases)",
                                 "note": "max over ranks; local_fraction_of_step = local / whole step (1 = the collective is free) -- NOT a "
                                         "scaling efficiency: that is value(N) / (N x the same-shape N=1 value), which the "

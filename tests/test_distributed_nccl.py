@@ -55,7 +55,7 @@ def test_bench_distributed_line_on_one_gpu(tmp_path):
                MASTER_PORT=str(29700 + os.getpid() % 200), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     env.pop("EAST_HIP_DEVICE", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--docs", "8",
-           "--doc-mib", "0.25", "--keyphrases", "200", "--no-cpu-baseline", "--no-extras", "--no-config2"]
+           "--doc-mib", "0.25", "--keyphrases", "200", "--no-cpu-baseline", "--no-extras", "--no-config2", "--base-value", "1e9"]
     done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert done.returncode == 0, done.stderr.decode(errors="replace")[-4000:]
     line = [ln for ln in done.stdout.decode().splitlines() if ln.startswith("{")][-1]
@@ -65,6 +65,7 @@ def test_bench_distributed_line_on_one_gpu(tmp_path):
     assert mg["rccl_world_size"] == 1 and mg["backend"] == "nccl"
     assert 0 < mg["step_local_ms"] <= out["ms_per_step"] * 1.05 and mg["allgather_ms"] >= 0
     assert 0 < mg["local_fraction_of_step"] <= 1.05
+    assert abs(mg["scaling_efficiency"] - out["value"] / 1e9) < 1e-9 * mg["scaling_efficiency"] and mg["scaling_base_value"] == 1e9
     assert out["config"]["all_gather_bytes_per_rank"] == 200 * 8 * 8
     assert out["roofline"]["kernel"] and out["roofline"]["peak"] == 8000.0
 
@@ -98,9 +99,12 @@ def test_cli_table_multi_gpu_equals_single_process(tmp_path, world):
         env["EAST_HIP_FORCE_DIST"] = "1"
     else:
         cmd = [sys.executable, "-m", "east.main", "-g", str(world)] + tail
-    multi = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    assert multi.returncode == 0, multi.stderr.decode(errors="replace")[-3000:]
     table = [ln for ln in single.stdout.decode().splitlines() if ln.strip()]
     assert len(table) == 8 and table[0].count(',') == 40       # header row of 40 keyphrases + one row per text
-    got = [ln for ln in multi.stdout.decode().splitlines() if ln.strip()]
-    assert got[-len(table):] == table          # (RCCL may print a banner in front)
+    # -g N: the devices inside one process (the default: east_hip_score_table_multi, RCCL through ncclCommInitAll), and
+    # one process per GPU under torch.distributed.run (EAST_HIP_MULTI=process)
+    for mode in (("threads", "process") if world > 1 else ("process",)):
+        multi = subprocess.run(cmd, env=dict(env, EAST_HIP_MULTI=mode), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert multi.returncode == 0, (mode, multi.stderr.decode(errors="replace")[-3000:])
+        got = [ln for ln in multi.stdout.decode().splitlines() if ln.strip()]
+        assert got[-len(table):] == table, mode     # (RCCL may print a banner in front)
