@@ -1132,6 +1132,8 @@ static std::vector<TpChunk> tp_plan_chunks(const uint8_t *bytes, const uint8_t *
     return chunks;
 }
 
+static thread_local std::chrono::steady_clock::time_point g_tp_call_start;     // (EAST_HIP_TRACE: when build_from_texts was entered)
+
 // ---- many separate texts: through a ring of pinned memory -------------------------------------------------------------
 // A copy out of pageable memory is pinned in place by the runtime, copied, unpinned: ~45 us of set-up per call, which a
 // 64 MiB text hides and 64 texts of 1 MiB do not (2.75 ms against 1.5 ms; 256 x 1 MiB: 11 ms).  Separate texts of less
@@ -1233,6 +1235,8 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     HIP_CHECK(hipStreamWaitEvent(h->copy_stream, h->ev0, 0));
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    const double t_before = std::chrono::duration<double, std::milli>(t_begin - g_tp_call_start).count();
+    std::atomic<double> t_first_fill{0.0}, t_first_dma{0.0};
     std::vector<double> t_up(C, 0.0), t_cnt(C, 0.0), t_queued(C, 0.0);     // (EAST_HIP_TRACE: when a chunk was staged / counted / queued)
     const int device = h->device;
     hipStream_t copy_stream = h->copy_stream;
@@ -1272,7 +1276,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
                 const u64 a = (u64)sl * ring_slot, len = std::min<u64>(ring_slot, (u64)n_bytes - a);
                 const u64 lo = a + len * (u64)j / (u64)n_fill, hi = a + len * (u64)(j + 1) / (u64)n_fill;
                 if (hi > lo) tp_fill_stream(ring + (size_t)(sl % TP_RING_SLOTS) * ring_slot + (lo - a), lo, hi, texts, text_offsets, D);
-                slot_parts[sl].fetch_add(1, std::memory_order_release);
+                if (slot_parts[sl].fetch_add(1, std::memory_order_release) + 1 == n_fill && sl == 0) t_first_fill.store(since());
             }
         });
     const std::vector<hipEvent_t> &ring_events = h->ring_events;
@@ -1296,6 +1300,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
                     const u64 s_end = std::min<u64>((u64)(sl_next + 1) * ring_slot, n_bytes), e = std::min<u64>(s_end, ch.b1);
                     ok = hipMemcpyAsync(d_bytes + sent, ring + (size_t)(sl_next % TP_RING_SLOTS) * ring_slot + (sent - (u64)sl_next * ring_slot),
                                         (size_t)(e - sent), hipMemcpyHostToDevice, copy_stream) == hipSuccess;
+                    if (sent == 0) t_first_dma.store(since());
                     sent = e;
                     if (ok && sent == s_end) {
                         ok = hipEventRecord(ring_events[sl_next % TP_RING_SLOTS], copy_stream) == hipSuccess;
@@ -1428,7 +1433,10 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     if (g_trace) {
         fprintf(stderr, "[east_hip] streamed preparation, %u chunks (ms since its start: staged / counted / queued):", C);
         for (u32 c = 0; c < C; c++) fprintf(stderr, " [%u MiB %.2f %.2f %.2f]", (chunks[c].b1 - chunks[c].b0) >> 20, t_up[c], t_cnt[c], t_queued[c]);
-        fprintf(stderr, " done %.2f\n", since());
+        fprintf(stderr, " done %.2f", since());
+        if (use_ring) fprintf(stderr, "; %.2f ms of the call in front of it, first ring slot filled at %.2f, its DMA queued at %.2f", t_before,
+                              t_first_fill.load(), t_first_dma.load());
+        fprintf(stderr, "\n");
     }
     h_off[D] = last.sym_base;
     return high == 0;
@@ -1442,6 +1450,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
                              const u32 *digit_hi, const u32 *hi_upper_from, const u32 *hi_upper_to, int32_t n_hi_upper,
                              const uint8_t *const *texts = nullptr)
 {
+    g_tp_call_start = std::chrono::steady_clock::now();
     if (!h) east_throw(EAST_HIP_ERR_INVALID, "null handle");
     if ((!bytes && !texts) || !text_offsets || !cp_class || !cp_upper || !word_hi || !digit_hi || n_docs < 1 || n_hi_upper < 0 ||
         (n_hi_upper > 0 && (!hi_upper_from || !hi_upper_to)))
@@ -1866,7 +1875,12 @@ static void score_resident(east_hip_index *h, int normalized, unsigned long long
            h->sigma_hi ? h->sigma_t - h->sigma_hi + 1u : 0u, h->q_code);
     KgTables kt;
     kt.kg = h->kg; kt.kg3 = h->kg3; kt.k = h->kg_k; kt.pairs = h->kg_k > 0 && h->kg_pairs; kt.A = h->kg_A; kt.bins = h->kg_bins;
-    if (kt.pairs && h->kg_up_stride && h->kg_up) { kt.up = h->kg_up; kt.up_stride = h->kg_up_stride; }
+    if (kt.pairs && h->kg_up_stride && h->kg_up) {
+        kt.up = h->kg_up;
+        kt.up_stride = h->kg_up_stride;
+        static const bool up_lds_off = getenv("EAST_HIP_SCORE_UP_LDS") && atoi(getenv("EAST_HIP_SCORE_UP_LDS")) == 0;   // (A/B timing)
+        kt.up_lds = !up_lds_off && h->kg_up_stride <= KG_UP_LDS_WORDS;
+    }
     if (kt.k > 0) kt.finish();
     // whole keyphrases per workgroup, summed in the walk (no per-suffix results unless the caller wants them: then the
     // documents go a stretch at a time, as far as the scratch reaches); otherwise per-suffix results + the reduction kernel

@@ -14,7 +14,9 @@
 #pragma once
 #include "common.h"
 
+#ifndef LG_THREADS
 #define LG_THREADS 1024
+#endif
 #ifndef LG_IPT
 #define LG_IPT 5
 #endif

@@ -277,9 +277,11 @@ __global__ __launch_bounds__(BLOCK) void query_map_kernel(const u32 *__restrict_
 // A^2 + 1, ... entries one after the other, copied out of kg3 once it is filled), so that EVERY level's interval is two
 // adjacent entries -- one 8-byte load per level.  (The walk is bound by the number of address-divergent loads a
 // wavefront issues -- every lane another sector --, not by bytes and not by the length of its dependency chain.)
+#define KG_UP_LDS_WORDS 1024u              // the small upper tables of one document staged in LDS (A + 1 + A^2 + 1 <= 1024: A <= 30)
 struct KgTables {
     const u32 *kg = nullptr, *kg3 = nullptr, *up = nullptr;
     int k = 0, pairs = 0;
+    int up_lds = 0;                         // the walk kernel stages the document's `up` tables in LDS (they fit KG_UP_LDS_WORDS)
     u32 A = 0, bins = 0, up_stride = 0;
     // (set by the host, so that no walk divides: the bins of the table the levels 1 .. k3 read -- bins / A with pairs -- and
     // the stride of level i in it, A^(k3 - 1 - i))
@@ -309,7 +311,7 @@ __device__ __forceinline__ uint2 load_pair_u32(const u32 *p)       // two adjace
 template <class SYM>
 __device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, const u32 *__restrict__ sad, u32 nd, u32 root_ann,
                                                     const u32 *__restrict__ q_code, u32 t0, u32 end, int normalized,
-                                                    const KgTables &kt, u32 d, u32 &probes)
+                                                    const KgTables &kt, u32 d, u32 &probes, const u32 *up_lds = nullptr)
 {
     u32 lo = 0, hi = nd - 1, depth = 0, nodes = 0;
     double acc = 0.0;
@@ -350,7 +352,10 @@ __device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, c
             if (i < k3 && i < L) {
                 const u32 stride = kt.stride[i];
                 code = code * kt.A + cs[i];
-                if (stride == 1u || up) {                  // two adjacent entries: one load
+                if (stride != 1u && up_lds) {              // the document's small upper tables, staged by the workgroup
+                    ta[i] = up_lds[up_off + code];
+                    tb[i] = up_lds[up_off + code + 1u];
+                } else if (stride == 1u || up) {           // two adjacent entries: one load
                     const uint2 ab = load_pair_u32(stride == 1u ? row + code : up + up_off + code);
                     ta[i] = ab.x; tb[i] = ab.y;
                 } else {
@@ -449,6 +454,7 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
     // its documents one after the other), so the top of that document's binary searches stays in that L2.
     // (Only with many documents -- xcd_order, host side: with a handful an XCD would sit idle.)
     __shared__ double res[BLOCK];
+    __shared__ u32 up_stage[KG_UP_LDS_WORDS];
     const u32 blocks_per_doc = blk ? n_blk : (n_q + BLOCK - 1u) / BLOCK;
     const u32 local = xcd_order ? blockIdx.x >> 3 : blockIdx.x;
     // (the documents [doc_first, doc_first + doc_count) of this launch: the per-suffix scratch is bounded, see score_resident)
@@ -459,12 +465,22 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
     if (blk) { kp0 = blk[bi]; kp1 = blk[bi + 1]; s0 = q_off[kp0]; s1 = q_off[kp1]; }
     const u32 si = s0 + threadIdx.x;
     const u32 d = doc_first + dl;
+    // The document's small upper tables (levels 1 .. k - 2 of a pair layout: A + 1, A^2 + 1 entries) come into LDS once per
+    // workgroup, coalesced: every walk reads them, and the walk is bound by the number of requests its lanes send to the L2
+    // (one per lane and level: each lane another line) -- two levels fewer of them.
+    const u32 *up_lds = nullptr;
+    if (kt.up_lds) {
+        const u32 *src = kt.up + (size_t)d * kt.up_stride;
+        for (u32 i = threadIdx.x; i < kt.up_stride; i += BLOCK) up_stage[i] = src[i];
+        __syncthreads();
+        up_lds = up_stage;
+    }
     double r = 0.0;
     if (si < s1) {
         u32 probes = 0;                 // table reads and binary-search probes of this walk (roofline accounting)
         const u32 seg = doc_off[d];
         const u32 nd = doc_off[d + 1] - seg;
-        r = score_walk_suffix<SYM>(s, sa + seg, nd, nd - n_strings[d], q_code, si, q_end[si], normalized, kt, d, probes);
+        r = score_walk_suffix<SYM>(s, sa + seg, nd, nd - n_strings[d], q_code, si, q_end[si], normalized, kt, d, probes, up_lds);
         if (suffix_out) suffix_out[(u64)dl * n_q + si] = r;
         if (probe_count) atomicAdd(probe_count, (unsigned long long)probes);   // (counting runs only: east_hip_score_probes)
     }
