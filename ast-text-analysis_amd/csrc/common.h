@@ -9,6 +9,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -148,7 +150,53 @@ struct Profiler {
     }
 };
 
+// The test knobs (east_hip_debug_*; include/east_hip.h says what each value means).  g_knobs holds the process-wide
+// DEFAULTS the setters change; every entry point copies them ONCE when it starts (knobs_snapshot -> Ctx::knobs or a local),
+// so a call runs from its first launch to its last on one consistent set of values whatever another thread sets meanwhile
+// -- distinct handles stay independent of each other in that respect too (the in-process device groups drive several).
+#define SCORE_SCRATCH_BYTES ((size_t)1 << 30)
+#define SCORE_GRID_BLOCKS ((u64)1 << 22)
+#define TP_RING_SLOT ((size_t)8 << 20)
+static int env_int(const char *name, int absent) { const char *v = getenv(name); return v ? atoi(v) : absent; }
+struct Knobs {
+    bool window_sort = true;                                            // east_hip_debug_set_window_sort
+    bool force_lean = false;                                            // ... (2)
+    bool force_wide_keys = getenv("EAST_HIP_WIDE_KEYS") != nullptr;     // ... (3 / 5)
+    bool fused_finish = getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;  // ... (4 / 5 / 9 switch it off)
+    bool force_fused = getenv("EAST_HIP_FORCE_FUSED") != nullptr;       // ... (6): the fused finish whatever the plan says
+    // variable-length first-level keys (ht_code.h): -1 = where the text's symbol statistics promise a symbol more per
+    // key, 0 = never, 1 = whenever a code exists (... (7 / 9 / 8); EAST_HIP_HT: A/B timing)
+    int ht_mode = env_int("EAST_HIP_HT", -1);
+    int seg_mode = env_int("EAST_HIP_SEG", -1);                         // east_hip_debug_set_segmented_sort: -1 by size, 0 never, 1 wherever it can be done
+    bool lds_rounds = getenv("EAST_HIP_NO_LDS_ROUNDS") == nullptr;      // east_hip_debug_set_lds_rounds
+    bool fused_classify = getenv("EAST_HIP_NO_FUSED_CLASSIFY") == nullptr;      // ... (2): the stand-alone classification pass
+    size_t rank_bucket_bytes = (size_t)192 << 20;                       // east_hip_debug_set_rank_bucket_bytes
+    bool speculate = getenv("EAST_HIP_NO_SPECULATION") == nullptr;      // east_hip_debug_set_speculation
+    bool kg_pairs = getenv("EAST_HIP_NO_KG_PAIRS") == nullptr;          // east_hip_debug_set_score_path
+    bool kg_pairs_forced = false;                                       // ... (4)
+    bool score_fused = getenv("EAST_HIP_SCORE_UNFUSED") == nullptr;     // ... (1 / 3 / 4)
+    size_t score_scratch_bytes = SCORE_SCRATCH_BYTES;                   // east_hip_debug_set_score_scratch
+    u64 score_grid_blocks = SCORE_GRID_BLOCKS;                          // east_hip_debug_set_score_grid
+    i64 tp_stream = getenv("EAST_HIP_TEXT_STREAM") ? atoll(getenv("EAST_HIP_TEXT_STREAM")) : -1;   // east_hip_debug_set_text_stream
+    int tp_ring = env_int("EAST_HIP_TEXT_RING", -1);                    // east_hip_debug_set_text_ring
+    size_t tp_ring_slot = getenv("EAST_HIP_RING_SLOT") ? std::min<size_t>(TP_RING_SLOT, (size_t)std::max(64, atoi(getenv("EAST_HIP_RING_SLOT")))) : TP_RING_SLOT;
+    u32 plan_epoch = 1;                                                 // bumped by the knobs that change what a build allocates
+};
+static Knobs g_knobs;
+static std::mutex g_knobs_mutex;
+static inline Knobs knobs_snapshot()
+{
+    std::lock_guard<std::mutex> lock(g_knobs_mutex);
+    return g_knobs;
+}
+template <class F> static inline void knobs_update(F f)
+{
+    std::lock_guard<std::mutex> lock(g_knobs_mutex);
+    f(g_knobs);
+}
+
 struct Ctx {
+    Knobs knobs = knobs_snapshot();         // the test knobs as they stood when the call began
     hipStream_t stream = nullptr;
     Arena *arena = nullptr;
     bool dry = false;

@@ -195,7 +195,6 @@ __global__ __launch_bounds__(BLOCK) void dc3_rank_kernel(const u32 *__restrict__
     if (i < n02) r12[dc3_r12_index(sa12[i], n0)] = i + 1;
 }
 
-static size_t g_rank_bucket_bytes = (size_t)192 << 20;      // east_hip_debug_set_rank_bucket_bytes (tests)
 
 // Beyond the Infinity Cache (R12 > ~192 MB) the random 4-byte stores above each cost a
 // read-modify-write of a 64-byte sector in HBM.  Then the (slot, rank) pairs are first
@@ -643,7 +642,7 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         const size_t mark = ar.mark();
         const int bt = bit_width_u32(term_first);          // bits of the compressed level-0 alphabet
         const int w = lvl0_window(n, bt, term_first);
-        const bool final_order = w * bt <= 32 && !g_force_wide_keys
+        const bool final_order = w * bt <= 32 && !ctx.knobs.force_wide_keys
             ? dc3_level0_bytes<u32>(ctx, s8, n0, n02, w, bt, term_first, sa12, s12, n_names)
             : dc3_level0_bytes<u64>(ctx, s8, n0, n02, w, bt, term_first, sa12, s12, n_names);
         if (final_order) n_names = n02;
@@ -734,7 +733,7 @@ static int dc3_suffix_array(Ctx &ctx, const u32 *s, u32 n, u32 sigma, u32 *sa_ou
         // (unique names: sa12 is the sorted order itself, so rank = index + 1 either way)
         u32 *r12 = ar.alloc<u32>((size_t)2 * n0 + 4);
         if (!ctx.dry) HIP_CHECK(hipMemsetAsync(r12, 0, ((size_t)2 * n0 + 4) * sizeof(u32), ctx.stream));
-        if (((size_t)2 * n0 + 4) * sizeof(u32) > g_rank_bucket_bytes || ctx.dry) {
+        if (((size_t)2 * n0 + 4) * sizeof(u32) > ctx.knobs.rank_bucket_bytes || ctx.dry) {
             const size_t mark = ar.mark();
             SortBufs<u32> rp;
             for (int k = 0; k < 2; k++) { rp.keys[k] = ar.alloc<u32>(n02); rp.vals[k] = ar.alloc<u32>(n02); }

@@ -37,10 +37,6 @@
 #define HI_WORDS (HI_SYMBOLS / 32u)                 // 34736
 
 static thread_local std::string g_last_error;
-static bool g_speculate = getenv("EAST_HIP_NO_SPECULATION") == nullptr;     // east_hip_debug_set_speculation (tests)
-static bool g_kg_pairs = getenv("EAST_HIP_NO_KG_PAIRS") == nullptr;         // east_hip_debug_set_score_path (tests, A/B timing)
-static bool g_kg_pairs_forced = false;                                      // ... (4): the pair layout whatever the number of documents
-static u32 g_plan_epoch = 1;        // bumped by the test knobs that change what a build allocates
 
 // ------------------------------------------------------------ prep kernels --
 // (vec: the caller's symbol array is 16-byte aligned, as every allocation is; a misaligned view of a
@@ -563,17 +559,17 @@ __global__ __launch_bounds__(BLOCK) void byte_hist_kernel(const uint8_t *__restr
 static void prepare_ht_code(east_hip_index *h, Ctx &ctx, u32 n, u32 sigma_t, u32 m_total)
 {
     ctx.ht_max_len = 0;
-    if (ctx.dry || !h->use_s8 || !g_window_sort || g_ht_mode == 0) return;
+    if (ctx.dry || !h->use_s8 || !ctx.knobs.window_sort || ctx.knobs.ht_mode == 0) return;
     if (ctx.spec) {
         if (!h->ht_valid || h->ht_sigma != sigma_t) {
             // (no code from the build before.  Forced -- the tests -- the build starts over with its read-backs in place and makes one)
-            if (g_ht_mode == 1 && sigma_t + 1 >= 8 && n >= 64) throw SpecAbort();
+            if (ctx.knobs.ht_mode == 1 && sigma_t + 1 >= 8 && n >= 64) throw SpecAbort();
             return;
         }
     } else {
         h->ht_valid = false;
         // (an alphabet of at most 5 bits -- letters only -- has nothing to gain: at best a fraction of a symbol per key)
-        if (sigma_t + 1 < 8 || (g_ht_mode != 1 && (bit_width_u32(sigma_t + 1) < 6 || n < 65536)) || n < 64) return;
+        if (sigma_t + 1 < 8 || (ctx.knobs.ht_mode != 1 && (bit_width_u32(sigma_t + 1) < 6 || n < 65536)) || n < 64) return;
         Arena &ar = *ctx.arena;
         const size_t mark = ar.mark();
         u32 *d_counts = ar.alloc<u32>(256);
@@ -770,7 +766,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
     const int doc_bits = n_docs > 1 ? bit_width_u32(n_docs - 1) : 0;
     h->kg_marked = false;
     prepare_ht_code(h, ctx, n, sigma_t, m_total);
-    if ((h->use_s8 || ctx.dry) && g_window_sort) {       // (the sizing run prices it with 64-bit keys)
+    if ((h->use_s8 || ctx.dry) && ctx.knobs.window_sort) {       // (the sizing run prices it with 64-bit keys)
         DocKey docs;
         if (n_docs > 1) { docs.doc_off = h->doc_off; docs.n_docs = n_docs; docs.bits = doc_bits; docs.h_doc_off = ctx.dry ? nullptr : off32.data(); }
         // the score walk's k-gram tables are marked off the sorted keys on the way (KgMark): as many levels
@@ -791,7 +787,7 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
                 // (the pair layout: the level above the last in a table of its own, behind the 8-byte entries)
                 // (... where the score table has many columns: with a handful of long documents the 8-byte marks cost the
                 // build more than the few thousand walks of a score call get back; forced by the test knob)
-                if (g_kg_pairs && (n_docs >= 16 || g_kg_pairs_forced)) km.kg3 = h->kg + 2 * (size_t)(bins + 1) * n_docs;
+                if (ctx.knobs.kg_pairs && (n_docs >= 16 || ctx.knobs.kg_pairs_forced)) km.kg3 = h->kg + 2 * (size_t)(bins + 1) * n_docs;
                 h->kg3 = km.kg3;
                 h->kg_up = km.kg3 ? km.kg3 + (size_t)(bins / km.A + 1) * n_docs : nullptr;
             } else {
@@ -897,7 +893,7 @@ static void finish_capped_lcp(east_hip_index *h, Ctx &ctx)
     annotate(h, ctx);
 }
 
-static size_t plan_arena_bytes(u32 n, u32 n_docs, bool lean = false, bool tagged = false)
+static size_t plan_arena_bytes(u32 n, u32 n_docs, bool lean = false, bool tagged = false, const Knobs *knobs = nullptr)
 {
     // (a tagged stream is priced both ways: as the byte stream it becomes when its alphabet is small -- the window
     // sort with its rounds, which the sizing run of the widest alphabet never enters -- and as dense u32 codes)
@@ -908,6 +904,7 @@ static size_t plan_arena_bytes(u32 n, u32 n_docs, bool lean = false, bool tagged
         dry.dry = true;
         Stats st;
         Ctx ctx;
+        if (knobs) ctx.knobs = *knobs;
         ctx.arena = &dry;
         ctx.dry = true;
         ctx.lean = lean;
@@ -959,17 +956,18 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     check_build_args(n_total, doc_offsets, n_strings, n_docs);
     use_device(h);
     h->built = false;
+    const Knobs kn = knobs_snapshot();                   // (the test knobs of this call, from its sizing run to its last launch)
     const u32 n = (u32)n_total;
     const size_t staging_bytes = sym_on_host ? ((size_t)n * 4 + 255) & ~(size_t)255 : 0;
-    if (h->plan_n != n || h->plan_docs != (u32)n_docs || h->plan_epoch != g_plan_epoch || h->plan_tagged != tagged) {     // (the sizing run costs host time: remembered per shape)
-        h->plan_bytes = plan_arena_bytes(n, (u32)n_docs, false, tagged);
+    if (h->plan_n != n || h->plan_docs != (u32)n_docs || h->plan_epoch != kn.plan_epoch || h->plan_tagged != tagged) {     // (the sizing run costs host time: remembered per shape)
+        h->plan_bytes = plan_arena_bytes(n, (u32)n_docs, false, tagged, &kn);
         h->plan_tagged = tagged;
         h->plan_n = n;
         h->plan_docs = (u32)n_docs;
-        h->plan_epoch = g_plan_epoch;
+        h->plan_epoch = kn.plan_epoch;
     }
     size_t need = h->plan_bytes + staging_bytes;
-    bool lean = g_force_lean;
+    bool lean = kn.force_lean;
     if (!lean && need > h->arena.cap) {
         // the tie-refinement rounds are the largest consumer: when they do not fit next to what else
         // lives on the device, build without them (heavy ties then take the DC3 recursion)
@@ -977,7 +975,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         lean = need > (size_t)(0.92 * (double)(free_b + h->arena.cap));
     }
-    if (lean) need = plan_arena_bytes(n, (u32)n_docs, true, tagged) + staging_bytes;
+    if (lean) need = plan_arena_bytes(n, (u32)n_docs, true, tagged, &kn) + staging_bytes;
     u32 *staging = nullptr;
     ensure_arena(h, need);
     if (sym_on_host) {   // raw symbols are staged at the top of the arena
@@ -988,6 +986,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     h->stats = Stats();
     h->arena.high = 0;
     Ctx ctx;
+    ctx.knobs = kn;
     ctx.stream = h->stream;
     ctx.arena = &h->arena;
     ctx.stats = &h->stats;
@@ -1020,7 +1019,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     };
     HIP_CHECK(hipEventRecord(h->ev0, h->stream));
     // (the alphabet is guessed whenever the last build took the window sort; that no tie group is large only if it found none)
-    const bool speculate = g_speculate && g_window_sort && h->hint_valid && h->hint_window && h->hint_sigma <= 254 && !tagged;
+    const bool speculate = kn.speculate && kn.window_sort && h->hint_valid && h->hint_window && h->hint_sigma <= 254 && !tagged;
     const bool spec_rounds = speculate && h->hint_no_rounds;
     const bool went_through = run(speculate, spec_rounds);
     if (speculate && (!went_through || (flags[FLAG_STATUS] & STATUS_SIGMA_GUESS) ||
@@ -1072,7 +1071,6 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
 // ---- the streamed preparation (textprep.h, "the streamed preparation") --------------------------------------------
 // -1: streamed for inputs of TP_STREAM_MIN bytes or more, in about TP_STREAM_CHUNKS chunks; 0: never; > 0: always, in chunks
 // of about that many bytes (east_hip_debug_set_text_stream: the tests push the fixtures through chunks of a few dozen bytes)
-static i64 g_tp_stream = getenv("EAST_HIP_TEXT_STREAM") ? atoll(getenv("EAST_HIP_TEXT_STREAM")) : -1;
 #define TP_STREAM_MIN ((u32)8 << 20)
 #define TP_STREAM_CHUNKS 4
 
@@ -1140,12 +1138,8 @@ static thread_local std::chrono::steady_clock::time_point g_tp_call_start;     /
 // than TP_RING_MAX_TEXT bytes on average therefore go through TP_RING_SLOTS slots of pinned memory: a few host threads
 // copy the stream -- text bytes and the 0xFF separators -- into a slot, each its share, while the slots before it are on
 // their way to the device (one DMA per slot and chunk, no set-up); the uploader thread alone talks to the runtime.
-#define TP_RING_SLOT ((size_t)8 << 20)
 #define TP_RING_SLOTS 3
 #define TP_RING_MAX_TEXT ((u64)8 << 20)
-static int g_tp_ring = getenv("EAST_HIP_TEXT_RING") ? atoi(getenv("EAST_HIP_TEXT_RING")) : -1;   // -1: by shape, 0: never, 1: whenever the texts lie apart
-static size_t g_tp_ring_slot = getenv("EAST_HIP_RING_SLOT") ? std::min<size_t>(TP_RING_SLOT, (size_t)std::max(64, atoi(getenv("EAST_HIP_RING_SLOT"))))
-                                                            : TP_RING_SLOT;   // east_hip_debug_set_text_ring (tests: slots of a few hundred bytes)
 
 // bytes [a, b) of the concatenated stream (texts d with their 0xFF separators, text_offsets as in build_from_texts) -> dst
 static void tp_fill_stream(char *dst, u64 a, u64 b, const uint8_t *const *texts, const i64 *text_offsets, u32 D)
@@ -1242,8 +1236,8 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     hipStream_t copy_stream = h->copy_stream;
     const std::vector<hipEvent_t> &events = h->copy_events;
     // (the ring: see tp_fill_stream above)
-    const bool use_ring = texts && g_tp_ring != 0 && (g_tp_ring > 0 || (D >= 4 && (u64)n_bytes / D < TP_RING_MAX_TEXT));
-    const size_t ring_slot = g_tp_ring_slot;
+    const bool use_ring = texts && ctx.knobs.tp_ring != 0 && (ctx.knobs.tp_ring > 0 || (D >= 4 && (u64)n_bytes / D < TP_RING_MAX_TEXT));
+    const size_t ring_slot = ctx.knobs.tp_ring_slot;
     const u32 n_slots = use_ring ? ceil_div_u32(n_bytes, ring_slot) : 0u;
     // (fill threads: three -- measured on the 256-thread host of the MI355X box, 64 texts of 1 MiB: 4 threads 2.25 ms of
     // preparation, 8: 2.3-2.6, 16: 2.6, 32: 2.95 -- starting the threads costs more than their copies save; a 16 MiB
@@ -1483,8 +1477,8 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     std::vector<u32> off32((size_t)D + 1);
     for (u32 d = 0; d <= D; d++) off32[d] = (u32)text_offsets[d];
     // (large inputs: the text goes up chunk by chunk and is prepared as it arrives, see prepare_texts_streamed)
-    const u32 stream_chunk = g_tp_stream > 0 ? (u32)std::min<i64>(g_tp_stream, 0x40000000)
-                             : g_tp_stream < 0 && n_bytes >= TP_STREAM_MIN ? std::max<u32>(n_bytes / TP_STREAM_CHUNKS + 1, 1u << 20) : 0u;
+    const u32 stream_chunk = ctx.knobs.tp_stream > 0 ? (u32)std::min<i64>(ctx.knobs.tp_stream, 0x40000000)
+                             : ctx.knobs.tp_stream < 0 && n_bytes >= TP_STREAM_MIN ? std::max<u32>(n_bytes / TP_STREAM_CHUNKS + 1, 1u << 20) : 0u;
     auto upload_all = [&]() {
         if (texts) {
             HIP_CHECK(hipMemsetAsync(d_bytes, 0xFF, n_bytes, h->stream));              // the separators
@@ -1692,15 +1686,10 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
 // ------------------------------------------------------------------ score --
 // The walk writes one fp64 per (keyphrase suffix, document); that scratch is bounded -- a table over a million
 // one-line documents would need hundreds of GB -- and the documents are scored a stretch at a time.
-#define SCORE_SCRATCH_BYTES ((size_t)1 << 30)
-static size_t g_score_scratch_bytes = SCORE_SCRATCH_BYTES;     // east_hip_debug_set_score_scratch (tests)
-static bool g_score_fused = getenv("EAST_HIP_SCORE_UNFUSED") == nullptr;   // east_hip_debug_set_score_path (tests, A/B timing)
-#define SCORE_GRID_BLOCKS ((u64)1 << 22)
-static u64 g_score_grid_blocks = SCORE_GRID_BLOCKS;            // east_hip_debug_set_score_grid (tests): workgroups per walk launch
-static u32 score_doc_chunk(u32 n_q, u32 n_docs)
+static u32 score_doc_chunk(u32 n_q, u32 n_docs, size_t scratch_bytes)
 {
     const size_t per_doc = (size_t)n_q * 8;
-    const size_t fit = per_doc ? g_score_scratch_bytes / per_doc : n_docs;
+    const size_t fit = per_doc ? scratch_bytes / per_doc : n_docs;
     return (u32)std::min<size_t>(n_docs, std::max<size_t>(fit, 1));
 }
 
@@ -1719,7 +1708,8 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
     use_device(h);
     const u32 n_q = (u32)S;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const u32 chunk = score_doc_chunk(n_q, h->n_docs);
+    const Knobs kn = knobs_snapshot();
+    const u32 chunk = score_doc_chunk(n_q, h->n_docs, kn.score_scratch_bytes);
     const size_t bytes = 256 + al((size_t)n_q * 4) * 3 + al(((size_t)n_kp + 1) * 4) * 3 +
                          al((size_t)n_q * chunk * 8) + al((size_t)n_kp * h->n_docs * 8) * 2;
     if (bytes > h->q_cap) {
@@ -1752,7 +1742,7 @@ static void set_keyphrases(east_hip_index *h, const u32 *q_symbols, const i64 *q
     // into stretches of at most BLOCK suffixes
     std::vector<u32> blk;
     blk.push_back(0);
-    bool fits = g_score_fused;
+    bool fits = kn.score_fused;
     for (int32_t k = 0, used = 0; k < n_kp && fits; k++) {
         const i64 len = q_offsets[k + 1] - q_offsets[k];
         if (len > BLOCK) { fits = false; break; }
@@ -1887,10 +1877,10 @@ static void score_resident(east_hip_index *h, int normalized, unsigned long long
     const bool fused = h->n_blk > 0;
     u32 chunk = h->score_chunk;
     if (fused && !suffix_host) {
-        // (no scratch to bound the stretch -- the grid does: a launch of at most g_score_grid_blocks workgroups, far below
+        // (no scratch to bound the stretch -- the grid does: a launch of at most Knobs::score_grid_blocks workgroups, far below
         // HIP's limit of 2^32 threads per grid dimension; many short documents times thousands of keyphrases go a stretch
         // of documents at a time, a multiple of 8 for the XCD-aware order)
-        const u64 fit = g_score_grid_blocks / h->n_blk;
+        const u64 fit = ctx.knobs.score_grid_blocks / h->n_blk;
         chunk = (u32)std::min<u64>(h->n_docs, fit >= 8 ? fit & ~(u64)7 : std::max<u64>(fit, 1));
     }
     for (u32 first = 0; first < h->n_docs; first += chunk) {
@@ -2390,8 +2380,7 @@ extern "C" {
 int east_hip_debug_set_rank_bucket_bytes(int64_t bytes)
 {
     if (bytes < 0) return EAST_HIP_ERR_INVALID;
-    g_rank_bucket_bytes = (size_t)bytes;
-    g_plan_epoch++;
+    knobs_update([&](Knobs &k) { k.rank_bucket_bytes = (size_t)bytes; k.plan_epoch++; });
     return EAST_HIP_OK;
 }
 
@@ -2399,15 +2388,17 @@ int east_hip_debug_set_window_sort(int enabled)
 {
     // 0: DC3 only; 1: the default; 2: lean (no refinement rounds); 3: 64-bit window keys; 4 / 5: as 1 / 3 without the
     // fused finish (every radix pass global, then lvl0_place_kernel)
-    g_window_sort = enabled != 0;
-    g_force_lean = enabled == 2;
-    g_force_wide_keys = enabled == 3 || enabled == 5;
-    g_fused_finish = enabled != 4 && enabled != 5 && enabled != 9 && getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;
-    g_force_fused = enabled == 6 || getenv("EAST_HIP_FORCE_FUSED") != nullptr;                        // 6: as 1, the fused finish whatever the plan says (skewed text through it)
+    knobs_update([&](Knobs &k) {
+    k.window_sort = enabled != 0;
+    k.force_lean = enabled == 2;
+    k.force_wide_keys = enabled == 3 || enabled == 5;
+    k.fused_finish = enabled != 4 && enabled != 5 && enabled != 9 && getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;
+    k.force_fused = enabled == 6 || getenv("EAST_HIP_FORCE_FUSED") != nullptr;                        // 6: as 1, the fused finish whatever the plan says (skewed text through it)
     // 7: as 1, first-level keys of variable-length code words wherever a code can be made (ht_code.h); 9: the same
     // without the fused finish; 8: as 1 without such keys
-    g_ht_mode = enabled == 7 || enabled == 9 ? 1 : enabled == 8 ? 0 : (getenv("EAST_HIP_HT") ? atoi(getenv("EAST_HIP_HT")) : -1);
-    g_plan_epoch++;
+    k.ht_mode = enabled == 7 || enabled == 9 ? 1 : enabled == 8 ? 0 : env_int("EAST_HIP_HT", -1);
+    k.plan_epoch++;
+    });
     return EAST_HIP_OK;
 }
 
@@ -2415,8 +2406,7 @@ int east_hip_debug_set_segmented_sort(int mode)
 {
     // -1: the default (by size: a few large documents); 0: never (the document number is a key digit); 1: wherever it
     // can be done (2 .. RS_SEG_MAX_DOCS documents of any size)
-    g_seg_mode = mode < 0 ? (getenv("EAST_HIP_SEG") ? atoi(getenv("EAST_HIP_SEG")) : -1) : (mode != 0);
-    g_plan_epoch++;
+    knobs_update([&](Knobs &k) { k.seg_mode = mode < 0 ? env_int("EAST_HIP_SEG", -1) : (mode != 0); k.plan_epoch++; });
     return EAST_HIP_OK;
 }
 
@@ -2436,21 +2426,23 @@ int east_hip_debug_set_lds_rounds(int enabled)
 {
     // 0: every round through the global sort; 1: the default (in-LDS rounds that also classify the next domain);
     // 2: in-LDS rounds with the stand-alone classification pass
-    g_lds_rounds = enabled != 0;
-    g_fused_classify = enabled != 2 && getenv("EAST_HIP_NO_FUSED_CLASSIFY") == nullptr;
+    knobs_update([&](Knobs &k) {
+        k.lds_rounds = enabled != 0;
+        k.fused_classify = enabled != 2 && getenv("EAST_HIP_NO_FUSED_CLASSIFY") == nullptr;
+    });
     return EAST_HIP_OK;
 }
 
 int east_hip_debug_set_score_scratch(int64_t bytes)
 {
-    g_score_scratch_bytes = bytes > 0 ? (size_t)bytes : SCORE_SCRATCH_BYTES;
+    knobs_update([&](Knobs &k) { k.score_scratch_bytes = bytes > 0 ? (size_t)bytes : SCORE_SCRATCH_BYTES; });
     return EAST_HIP_OK;
 }
 
 int east_hip_debug_set_score_grid(int64_t workgroups)
 {
     // workgroups a launch of the score walk may have when the sums run inside it (0 or less: the default, 2^22)
-    g_score_grid_blocks = workgroups > 0 ? (u64)std::min<int64_t>(workgroups, (int64_t)1 << 23) : SCORE_GRID_BLOCKS;
+    knobs_update([&](Knobs &k) { k.score_grid_blocks = workgroups > 0 ? (u64)std::min<int64_t>(workgroups, (int64_t)1 << 23) : SCORE_GRID_BLOCKS; });
     return EAST_HIP_OK;
 }
 
@@ -2459,8 +2451,10 @@ int east_hip_debug_set_text_ring(int mode, int64_t slot_bytes)
     // mode -1: separate texts go up through the pinned ring when there are four or more of less than 8 MiB on average
     // (and the preparation is streamed); 0: never; 1: whenever the texts lie apart.  slot_bytes: size of a ring slot
     // (0 or less: the default, 8 MiB; at most that)
-    g_tp_ring = mode;
-    g_tp_ring_slot = slot_bytes > 0 ? (size_t)std::min<int64_t>(slot_bytes, (int64_t)TP_RING_SLOT) : TP_RING_SLOT;
+    knobs_update([&](Knobs &k) {
+        k.tp_ring = mode;
+        k.tp_ring_slot = slot_bytes > 0 ? (size_t)std::min<int64_t>(slot_bytes, (int64_t)TP_RING_SLOT) : TP_RING_SLOT;
+    });
     return EAST_HIP_OK;
 }
 
@@ -2468,7 +2462,7 @@ int east_hip_debug_set_text_stream(int64_t chunk_bytes)
 {
     // -1: the default (inputs of 8 MiB or more go up and are prepared in about five chunks); 0: the raw text goes up and
     // is prepared in one piece; > 0: always in chunks of about that many bytes
-    g_tp_stream = chunk_bytes;
+    knobs_update([&](Knobs &k) { k.tp_stream = chunk_bytes; });
     return EAST_HIP_OK;
 }
 
@@ -2477,15 +2471,17 @@ int east_hip_debug_set_score_path(int mode)
     // 1: the default; 0: the walk as rounds 1-3 ran it -- one filled k-gram table of 4-byte entries, per-suffix results in
     // HBM and a reduction kernel; 2: pair tables, separate reduction; 3: filled table, the sums inside the walk.
     // (takes effect with the next build / the next set of keyphrases)
-    g_kg_pairs = mode == 1 || mode == 2 || mode == 4;
-    g_kg_pairs_forced = mode == 4;                      // 4: as 1, the pair tables also for collections of fewer than 16 documents
-    g_score_fused = mode == 1 || mode == 3 || mode == 4;
+    knobs_update([&](Knobs &k) {
+        k.kg_pairs = mode == 1 || mode == 2 || mode == 4;
+        k.kg_pairs_forced = mode == 4;                  // 4: as 1, the pair tables also for collections of fewer than 16 documents
+        k.score_fused = mode == 1 || mode == 3 || mode == 4;
+    });
     return EAST_HIP_OK;
 }
 
 int east_hip_debug_set_speculation(int enabled)
 {
-    g_speculate = enabled != 0;
+    knobs_update([&](Knobs &k) { k.speculate = enabled != 0; });
     return EAST_HIP_OK;
 }
 

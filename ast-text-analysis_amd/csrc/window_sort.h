@@ -26,21 +26,8 @@ __device__ __forceinline__ u32 dc3_sample_pos(u32 t, u32 n0)
 // or over ALL suffixes (n0 == 0: element t = text position), see window_suffix_sort.
 __device__ __forceinline__ u32 lvl0_pos(u32 t, u32 n0) { return n0 ? dc3_sample_pos(t, n0) : t; }
 #include "lds_group_sort.h"
-static bool g_lds_rounds = getenv("EAST_HIP_NO_LDS_ROUNDS") == nullptr;     // east_hip_debug_set_lds_rounds (tests, A/B timing)
-static bool g_fused_classify = getenv("EAST_HIP_NO_FUSED_CLASSIFY") == nullptr;   // ... (2): the in-LDS rounds with the stand-alone classification pass
-
+// (the test knobs of this file live in Ctx::knobs -- common.h: Knobs)
 static const bool g_trace = getenv("EAST_HIP_TRACE") != nullptr;   // per-round progress on stderr
-static bool g_force_wide_keys = getenv("EAST_HIP_WIDE_KEYS") != nullptr;                      // east_hip_debug_set_window_sort(3) (tests)
-static bool g_force_lean = false;                           // east_hip_debug_set_window_sort(2) (tests)
-static bool g_window_sort = true;                            // east_hip_debug_set_window_sort (tests)
-static bool g_fused_finish = getenv("EAST_HIP_NO_FUSED_FINISH") == nullptr;    // east_hip_debug_set_window_sort(4 / 5) (tests, A/B timing)
-static bool g_force_fused = getenv("EAST_HIP_FORCE_FUSED") != nullptr;                           // east_hip_debug_set_window_sort(6): the fused finish whatever the plan says (tests: skewed text through it)
-// variable-length first-level keys (ht_code.h): -1 = where the text's symbol statistics promise a symbol more per key,
-// 0 = never, 1 = whenever a code exists (east_hip_debug_set_window_sort(7) / EAST_HIP_HT: tests, A/B timing)
-static int g_ht_mode = getenv("EAST_HIP_HT") ? atoi(getenv("EAST_HIP_HT")) : -1;
-// segmented first-level sort of several documents (radix_sort.h: RsSeg): -1 by size, 0 never, 1 wherever it can be done
-// (east_hip_debug_set_segmented_sort; EAST_HIP_SEG)
-static int g_seg_mode = getenv("EAST_HIP_SEG") ? atoi(getenv("EAST_HIP_SEG")) : -1;
 struct FusedAbort {};           // the fused finish met a repeat too long to order directly: the level is redone with the full sort
 
 #define RESOLVE_MAX_LEN 2048            // longest direct comparison of two suffixes (symbols)
@@ -1892,10 +1879,10 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     for (int j = 0; j < w; j++)
         if (spare + j * bt >= FIN_LOW_BITS) depth0++;
     if (ht) depth0 = (ht_sb - FIN_LOW_BITS) / ht->max_len;          // the whole symbols any top part holds at least
-    bool fused = allow_fused && g_fused_finish && n0 == 0 && total_bits >= 2 * FIN_LOW_BITS && depth0 >= 1;
+    bool fused = allow_fused && ctx.knobs.fused_finish && n0 == 0 && total_bits >= 2 * FIN_LOW_BITS && depth0 >= 1;
     bool fin_small_halo = false;                        // buckets of at most ten suffixes expected: the kernel with the halo of 32
     if (fused && !ctx.dry) {
-        if (g_force_fused) {
+        if (ctx.knobs.force_fused) {
             // (test knob: buckets of any size -- the large ones go to the rounds)
         } else if (ctx.plan_fused >= 0) {
             fused = ctx.plan_fused != 0;                 // (speculative build: as the build before)
@@ -2185,13 +2172,13 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // (once groups with long repeats are known to exist the direct ordering of large groups only burns time: every
             // member of such a group compares REFINE_ENDGAME_LEN symbols with every other before it gives up)
             const bool endgame = m <= REFINE_ENDGAME_DOMAIN && !long_repeats;
-            const bool fuse_cls = g_lds_rounds && g_fused_classify && !doubling && !endgame && !long_repeats;
+            const bool fuse_cls = ctx.knobs.lds_rounds && ctx.knobs.fused_classify && !doubling && !endgame && !long_repeats;
             u32 round_left = m;                         // what the in-LDS round left to the global sort
             auto sort_round = [&](bool names, int w2, const KeyNeqWindowIn<u64> &f) {
                 const int kbits = names ? 32 : w2 * bt;
                 u32 *lcp_r = names ? (u32 *)nullptr : lcp_out;
                 u32 m_left = m;
-                if (g_lds_rounds) {
+                if (ctx.knobs.lds_rounds) {
                     if (fuse_cls) HIP_CHECK(hipMemsetAsync(keep, 0, (((size_t)m >> 6) + 2) * sizeof(u64), ctx.stream));
                     LAUNCH_BLOCK(ctx, refine_lds_sort_kernel, ceil_div_u32(m, LG_CHUNK), LG_THREADS, s8, (const u32 *)ebuf[e_c],
                                  (const u32 *)gstart, (const u32 *)slot_c, m, n0, depth, w2, bt, term_first, (u64)f.rep_t,
@@ -2369,7 +2356,7 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
         const u32 per_groups = getenv("EAST_HIP_SEG_DIV") ? (u32)std::max(1, atoi(getenv("EAST_HIP_SEG_DIV"))) : 1u;   // (experiments)
         // (... and five or more of them: the document number of two to four documents costs the key a bit or two, less than
         // the segments' short tiles cost the passes -- 2 x 32 MiB: 1.71 ms with, 1.68 without)
-        if (can && g_seg_mode != 0 && (g_seg_mode == 1 || (docs.n_docs >= 5 && docs.n_docs <= flat_groups / per_groups + 1))) {
+        if (can && ctx.knobs.seg_mode != 0 && (ctx.knobs.seg_mode == 1 || (docs.n_docs >= 5 && docs.n_docs <= flat_groups / per_groups + 1))) {
             RsSeg &seg = docs.seg;
             seg.n_docs = docs.n_docs;
             seg.doc_off = docs.doc_off;
@@ -2434,8 +2421,8 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
     // 6.1 ms on 64 x 1 MiB of prose -- twice the suffixes in the rounds.  Forced -- mode 1 -- they take the key width the
     // fixed-width plan would have taken: the tests go through both.)
     bool use_ht = false, ht_wide = false;
-    if (ctx.ht_max_len > 0 && !ctx.dry && g_ht_mode != 0) {
-        if (g_ht_mode == 1) { use_ht = true; ht_wide = wide || g_force_wide_keys || w * bt + docs.bits > 32; }
+    if (ctx.ht_max_len > 0 && !ctx.dry && ctx.knobs.ht_mode != 0) {
+        if (ctx.knobs.ht_mode == 1) { use_ht = true; ht_wide = wide || ctx.knobs.force_wide_keys || w * bt + docs.bits > 32; }
         else if (ctx.plan_ht >= 0) { use_ht = ctx.plan_ht != 0; ht_wide = ctx.plan_ht == 2; }
         else if (docs.seg.n_docs) {
             // (segmented sort: all 32 bits of a narrow key are text -- six and a half symbols of prose, sorted in four passes
@@ -2445,7 +2432,7 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
             ht_wide = false;
             if (use_ht) wide = false;
         } else { use_ht = ht_wide = wide && ctx.ht_mean_len <= (double)bt - 1.5; }
-        if (use_ht && !ht_wide && (32 - docs.bits < 20 || g_force_wide_keys)) ht_wide = true;
+        if (use_ht && !ht_wide && (32 - docs.bits < 20 || ctx.knobs.force_wide_keys)) ht_wide = true;
         if (use_ht && ht_wide && 64 - docs.bits < 20) use_ht = false;
     }
     int ht_sb = !use_ht ? 0 : ht_wide ? std::min(HT_MAX_STREAM, 64 - docs.bits) : std::min(HT_MAX_STREAM, 32 - docs.bits);
@@ -2469,7 +2456,7 @@ static bool window_suffix_sort(Ctx &ctx, const uint8_t *s8, u32 n, u32 term_firs
         if (use_ht)
             return dc3_level0_bytes<u32>(ctx, s8, 0, n, 0, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
                                          kg_mark, allow_fused, multi ? longest : n, &hk);
-        return w * bt + docs.bits <= 32 && !g_force_wide_keys
+        return w * bt + docs.bits <= 32 && !ctx.knobs.force_wide_keys
                    ? dc3_level0_bytes<u32>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,
                                            kg_mark, allow_fused, multi ? longest : n)
                    : dc3_level0_bytes<u64>(ctx, s8, 0, n, w, bt, term_first, sa_out, nullptr, n_names, lcp_out, lcp_capped, docs,

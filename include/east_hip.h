@@ -15,8 +15,9 @@
  *   - plain pointers and sizes only; the caller owns every host buffer
  *     (C-contiguous), the library owns device memory behind the opaque handle
  *   - calls are blocking unless the name ends in _async; a handle is not
- *     thread-safe, distinct handles are -- EXCEPT with respect to the east_hip_debug_* setters, which change
- *     process-wide test knobs and must only be called while no build or score call is in flight on any handle;
+ *     thread-safe, distinct handles are.  The east_hip_debug_* setters change process-wide DEFAULTS of the test
+ *     knobs; every build / score / text call copies them once when it starts and runs on that copy to its end, so a
+ *     setter never reaches into a call that is already in flight -- on this handle or another;
  *     one HIP stream per handle; every call runs on
  *     the handle's device and restores the calling thread's current HIP device before it returns
  *   - indices are int32 on the device (n_total < 2^31 - 8); the Python side
@@ -246,7 +247,7 @@ int east_hip_score_probes(east_hip_handle_t h, int normalized, int64_t *probes);
  *   east_hip_score_table_multi     out: K x D doubles, row-major, D = all documents in their original order
  *   east_hip_group_info            [0] build, [1] score (slowest shard), [2] all-gather + copy to the host: wall ms of the
  *                                  last calls; [3] 1 = RCCL all-gather, 2 = copies; [4] shards
- * A group is not thread-safe; the east_hip_debug_* knobs must not be changed while a group call is in flight.
+ * A group is not thread-safe (its shards run on threads of its own).
  */
 typedef struct east_hip_group *east_hip_group_t;
 int east_hip_group_create(const int32_t *devices, int32_t n_shards, east_hip_group_t *out);
@@ -342,8 +343,8 @@ int east_hip_debug_set_rank_bucket_bytes(int64_t bytes);
  * plan says (skewed text, whose large buckets it hands to the refinement rounds); 7 = as 1 with first-level keys of
  * variable-length code words wherever a code can be made (csrc/ht_code.h), 9 = the same without the fused finish,
  * 8 = as 1 without such keys.
- * The test knobs of this section are PROCESS-WIDE (they exist to steer a test run through every code path):
- * set them while no build is in flight on any handle. */
+ * The test knobs of this section are process-wide defaults (they exist to steer a test run through every code path); a
+ * call takes the values that hold when it starts (csrc/common.h: Knobs). */
 int east_hip_debug_set_window_sort(int enabled);
 /* Test knob: the first-level sort of a shard of several documents keeps every document in its own range pass by pass
  * (csrc/radix_sort.h: RsSeg -- no document number in the keys) -- -1 (default): five documents or more of 32 768 symbols or more on average,
