@@ -116,6 +116,9 @@ def keyphrases_graph(keyphrases, texts, referral_confidence=0.6, relevance_thres
     measure = similarity_measure or relevance.ASTRelevanceMeasure()
     table = keyphrases_table(keyphrases, texts, measure, synonimizer, language)
 
+    if isinstance(table, ScoreTable) and len(set(table.text_titles)) == len(table.text_titles):
+        return _graph_from_array(keyphrases, table, referral_confidence, relevance_threshold, support_threshold)
+
     occurs_in = {}
     if isinstance(table, ScoreTable):                        # (one comparison over the array instead of K x D look-ups)
         hits = table.scores >= relevance_threshold
@@ -142,5 +145,29 @@ def keyphrases_graph(keyphrases, texts, referral_confidence=0.6, relevance_thres
             if confidence >= referral_confidence:
                 edges.append({"source": source["id"], "target": target["id"], "confidence": confidence})
 
+    return {"nodes": nodes, "edges": edges, "referral_confidence": referral_confidence,
+            "relevance_threshold": relevance_threshold, "support_threshold": support_threshold}
+
+
+def _graph_from_array(keyphrases, table, referral_confidence, relevance_threshold, support_threshold):
+    """keyphrases_graph on the K x D score array: the same nodes and edges in the same order as the loops above (sources in
+    the order of the keyphrase list, a source's targets in that order too), the pair counts by matrix products over
+    blocks of sources instead of K^2 set intersections in Python (10 000 keyphrases: 10^8 of them)."""
+    rows = np.array([table._row[kp] for kp in keyphrases], dtype=np.int64)            # (a repeated keyphrase: the same row twice)
+    hits = table.scores[rows] >= relevance_threshold                                   # [n, D]
+    support = hits.sum(axis=1)
+    kept = np.flatnonzero(support >= support_threshold)
+    nodes = [{"id": int(position), "label": keyphrases[position], "support": int(support[position])} for position in kept]
+    edges = []
+    h = hits[kept].astype(np.float32)                                                  # (counts up to D are exact in float32 below 2^24)
+    sup = support[kept].astype(np.float64)
+    block = max(1, (1 << 24) // max(len(kept), 1))
+    for b in range(0, len(kept), block):
+        shared = (h[b:b + block] @ h.T).astype(np.float64)                             # texts that hold source AND target
+        confidence = shared / np.maximum(sup[b:b + block, None], 1.0)                  # float(shared) / max(len(source_texts), 1)
+        src, dst = np.nonzero(confidence >= referral_confidence)
+        off = src + b != dst                                                           # (no edge from a node to itself)
+        for i, j, c in zip((src[off] + b).tolist(), dst[off].tolist(), confidence[src[off], dst[off]].tolist()):
+            edges.append({"source": int(kept[i]), "target": int(kept[j]), "confidence": c})
     return {"nodes": nodes, "edges": edges, "referral_confidence": referral_confidence,
             "relevance_threshold": relevance_threshold, "support_threshold": support_threshold}

@@ -309,3 +309,43 @@ def test_prose_like_generator_is_deterministic_and_looks_like_prose():
     assert set(bytes(letters[:6]).decode()) <= set("etaoinsrh") and counts[ord("e")] > 8 * counts[ord("z")]
     strings = utils.text_to_strings_collection(big)
     assert len(strings) > 8000 and all(s == s.upper() for s in strings[:100])
+
+
+class _ArrayMeasure(object):
+    """A batched measure that returns a given K x D array (keyphrases_table's fast path without a device)."""
+
+    def __init__(self, scores):
+        self.scores = scores
+
+    def set_text_collection(self, texts, language=None):
+        pass
+
+    def relevance_table(self, prepared):
+        return self.scores
+
+
+def test_score_table_is_the_dict_of_dicts_and_the_graph_from_the_array_is_the_graph_of_the_loops(monkeypatch):
+    """applications.ScoreTable (what keyphrases_table returns on the batched path: a mapping over the K x D array) equals
+    the reference's dict of dicts (applications.py:46-52), and keyphrases_graph worked out on the array (matrix products)
+    gives the nodes and edges of the reference's loops (applications.py:59-149), in their order -- repeated keyphrases,
+    filtered nodes, self-pairs and zero-support sources included."""
+    from east import applications
+    rng = np.random.default_rng(5)
+    for K, D in ((7, 5), (60, 17), (200, 33)):
+        kps = ["kp%d" % i for i in range(K)]
+        kps[3] = kps[1]                                       # a repeated keyphrase
+        uniq = list(dict.fromkeys(kps))
+        scores = rng.random((len(uniq), D)) * 0.5
+        scores[0] = 0.0                                       # a keyphrase that occurs nowhere
+        texts = {"t%d" % i: b"x" for i in range(D)}
+        table = applications.keyphrases_table(kps, texts, _ArrayMeasure(scores))
+        assert isinstance(table, applications.ScoreTable)
+        plain = {k: {t: float(scores[i, j]) for j, t in enumerate(texts)} for i, k in enumerate(uniq)}
+        assert table == plain and dict(table) == plain and sorted(table) == sorted(plain)
+        assert list(table[uniq[2]].items()) == list(plain[uniq[2]].items())
+        for support in (0, 1, 3):
+            fast = applications.keyphrases_graph(kps, texts, 0.4, 0.25, support, _ArrayMeasure(scores))
+            monkeypatch.setattr(applications, "keyphrases_table", lambda *a, **k: plain)
+            slow = applications.keyphrases_graph(kps, texts, 0.4, 0.25, support, _ArrayMeasure(scores))
+            monkeypatch.undo()
+            assert fast == slow and len(fast["edges"]) > 0, (K, D, support)
