@@ -977,7 +977,14 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     }
     if (lean) need = plan_arena_bytes(n, (u32)n_docs, true, tagged, &kn) + staging_bytes;
     u32 *staging = nullptr;
-    ensure_arena(h, need);
+    {
+        const size_t cap_before = h->arena.cap;
+        const auto t_a = std::chrono::steady_clock::now();
+        ensure_arena(h, need);
+        if (g_trace && h->arena.cap != cap_before)
+            fprintf(stderr, "[east_hip] build: arena grown to %.2f GiB in %.2f ms\n", h->arena.cap / 1073741824.0,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count());
+    }
     if (sym_on_host) {   // raw symbols are staged at the top of the arena
         staging = (u32 *)(h->arena.base + (h->arena.cap - (((size_t)n * 4 + 255) & ~(size_t)255)));
         HIP_CHECK(hipMemcpyAsync(staging, sym, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
@@ -1249,6 +1256,9 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
         void *p = nullptr;
         if (hipHostMalloc(&p, TP_RING_SLOT * TP_RING_SLOTS, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); east_throw(EAST_HIP_ERR_OOM, "hipHostMalloc of the upload ring failed"); }
         h->ring = (char *)p;
+        if (g_trace)
+            fprintf(stderr, "[east_hip] text preparation: pinned ring of %zu MiB allocated, %.2f ms into the call\n", (TP_RING_SLOT * TP_RING_SLOTS) >> 20,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_tp_call_start).count());
         for (int i = 0; i < TP_RING_SLOTS; i++) {
             hipEvent_t e;
             HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1460,7 +1470,11 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     use_device(h);
     h->built = false;
     const u32 n_bytes = (u32)n_bytes64, D = (u32)n_docs;
+    const size_t arena_before = h->arena.cap;
     ensure_arena(h, (size_t)n_bytes * 46 + (size_t)D * 96 + (8u << 20));
+    if (g_trace && h->arena.cap != arena_before)
+        fprintf(stderr, "[east_hip] text preparation: arena of %.2f GiB allocated, %.2f ms into the call\n", h->arena.cap / 1073741824.0,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_tp_call_start).count());
     Arena &ar = h->arena;
     ar.release(0);
     ar.high = 0;

@@ -57,11 +57,26 @@ __device__ __forceinline__ void scan_load4(const ArrIn &in, u32 i, u32 n, u32 x[
 // sum of all earlier tiles.  block_offsets == nullptr means a single tile.
 // Wave w owns 1024 contiguous inputs as 4 rows of 64 lanes x 4 inputs: every
 // load and store is a coalesced 1 KiB (16 B per lane) wavefront access.
+// raw != 0: block_offsets holds the tiles' SUMS as scan_reduce_kernel wrote them, not their prefix sums -- the workgroup
+// adds up the sums of the tiles in front of its own (at most SCAN_RAW_TILES of them: a few coalesced loads per thread),
+// which saves the launch that scans the sums: most scans of a build run over a few hundred tiles, where a launch costs
+// more than the kernel in it.
+#define SCAN_RAW_TILES 2048u
 template <class In, bool INCLUSIVE>
 __global__ __launch_bounds__(BLOCK) void scan_apply_kernel(In in, u32 n, const u32 *block_offsets,
-                                                           u32 *out)
+                                                           u32 *out, int raw = 0)
 {
     __shared__ u32 lds[WAVES_PER_BLOCK];
+    __shared__ u32 lds_raw[WAVES_PER_BLOCK];
+    u32 raw_base = 0;
+    if (raw) {
+        u32 part = 0;
+        for (u32 t = threadIdx.x; t < blockIdx.x; t += BLOCK) part += block_offsets[t];
+        part = wave_sum(part);
+        if (lane_id() == 0) lds_raw[wave_id()] = part;
+        __syncthreads();
+        raw_base = lds_raw[0] + lds_raw[1] + lds_raw[2] + lds_raw[3];
+    }
     const u32 lane = lane_id(), w = wave_id();
     const u32 wave_base = blockIdx.x * SCAN_TILE + w * (SCAN_TILE / WAVES_PER_BLOCK);
     u32 v[4][4];
@@ -84,7 +99,7 @@ __global__ __launch_bounds__(BLOCK) void scan_apply_kernel(In in, u32 n, const u
     }
     if (lane == 0) lds[w] = carry;
     __syncthreads();
-    u32 base = block_offsets ? block_offsets[blockIdx.x] : 0u;
+    u32 base = raw ? raw_base : block_offsets ? block_offsets[blockIdx.x] : 0u;
     if (w > 0) base += lds[0];
     if (w > 1) base += lds[1];
     if (w > 2) base += lds[2];
@@ -111,12 +126,13 @@ static void device_scan(Ctx &ctx, In in, u32 n, u32 *out)
     const u32 nb = ceil_div_u32(n, SCAN_TILE);
     const size_t mark = ctx.arena->mark();
     u32 *sums = nullptr;
+    const int raw = nb > 1 && nb <= SCAN_RAW_TILES;
     if (nb > 1) {
         sums = ctx.arena->alloc<u32>(nb);
         LAUNCH(ctx, (scan_reduce_kernel<In>), nb, in, n, sums);
-        device_scan<ArrIn, false>(ctx, ArrIn{sums}, nb, sums);
+        if (!raw) device_scan<ArrIn, false>(ctx, ArrIn{sums}, nb, sums);
     }
-    LAUNCH(ctx, (scan_apply_kernel<In, INCLUSIVE>), nb, in, n, (const u32 *)sums, out);
+    LAUNCH(ctx, (scan_apply_kernel<In, INCLUSIVE>), nb, in, n, (const u32 *)sums, out, raw);
     ctx.arena->release(mark);
 }
 

@@ -5,7 +5,10 @@ summed over its launches and dimensions, plus the ratios one reads them for:
   wait_any_frac      SQ_WAIT_ANY / SQ_WAVE_CYCLES        waves parked at s_waitcnt or a barrier
   wait_inst_frac     SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES   waves stalled at issue (of it wait_inst_lds_frac: the LDS queue)
   active_frac        SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES waves issuing
-  waves_resident     SQ_LEVEL_WAVES / SQ_BUSY_CYCLES     mean waves resident per SQ-busy cycle (of the launches' shader engines)
+  waves_per_simd     SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / 7.5   waves resident per SIMD while the kernel runs (SQ_LEVEL_WAVES reads 0 on this
+                     pool; the ratio of the two cycle counters is calibrated on kernels whose residency the launch fixes:
+                     score_walk_kernel and radix_scatter_kernel, 8 per SIMD by their registers / LDS, give 59.6-60.9 -> the
+                     factor 7.5; lvl0_finish_kernel, 6 per SIMD at 78 VGPRs, gives 45.1 -> 6.0)
   lds_conflict_frac  SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE   extra LDS-array cycles through bank conflicts
   vmem_rd_per_wave   SQ_INSTS_VMEM_RD / SQ_WAVES         vector loads a wave issues
   l2_hit_frac        TCC_HIT / (TCC_HIT + TCC_MISS)
@@ -52,12 +55,13 @@ for pass_dir in sorted(glob.glob(os.path.join(SRC, "*/"))):
 
 
 def ratio(row, a, b):
-    return row[a] / row[b] if a in row and b in row and row[b] else None
+    r = row[a] / row[b] if a in row and b in row and row[b] else None
+    return r / 7.5 if r is not None and (a, b) == ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES") else r
 
 
 derived = [("wait_any_frac", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES"), ("wait_inst_frac", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"),
            ("wait_inst_lds_frac", "SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES"), ("active_frac", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES"),
-           ("waves_resident", "SQ_LEVEL_WAVES", "SQ_BUSY_CYCLES"), ("lds_conflict_frac", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"),
+           ("waves_per_simd", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"), ("lds_conflict_frac", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"),
            ("vmem_rd_per_wave", "SQ_INSTS_VMEM_RD", "SQ_WAVES"), ("vmem_wr_per_wave", "SQ_INSTS_VMEM_WR", "SQ_WAVES"),
            ("lds_inst_per_wave", "SQ_INSTS_LDS", "SQ_WAVES"), ("valu_inst_per_wave", "SQ_INSTS_VALU", "SQ_WAVES"),
            ("ta_busy_per_wave_cycle", "TA_TA_BUSY_sum", "SQ_WAVE_CYCLES")]
@@ -73,7 +77,7 @@ with open(dst, "w") as f:
         vals = [ratio(row, a, b) for _, a, b in derived]
         hit = row.get("TCC_HIT_sum"), row.get("TCC_MISS_sum")
         vals.append(hit[0] / (hit[0] + hit[1]) if hit[0] is not None and hit[1] is not None and hit[0] + hit[1] else None)
-        f.write(",".join([k, str(launches.get(k, 0))] + ["" if v is None else "%.4g" % v for v in vals] +
+        f.write(",".join(['"%s"' % k, str(launches.get(k, 0))] + ["" if v is None else "%.4g" % v for v in vals] +
                          ["%.6g" % row[c] if c in row else "" for c in counters]) + "\n")
 print("wrote", dst)
 for k in order[:14]:
