@@ -25,6 +25,8 @@
 #include "textprep.h"
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include <algorithm>
@@ -480,6 +482,10 @@ struct east_hip_index {
     // first use, kept with the handle
     char *ring = nullptr;
     std::vector<hipEvent_t> ring_events;
+    std::thread ring_alloc;                 // pins the ring in the background after a first call that went without it
+    std::atomic<char *> ring_pending{nullptr};
+    bool ring_wanted = false;               // (the call under way would have taken the ring: pin it once the call is over --
+                                            // while it runs, the pinning and the call's own copies fight over the runtime's locks)
     // symbols prepared on the device by east_hip_build_texts (own allocation)
     u32 *prep_sym = nullptr;
     size_t prep_cap = 0;
@@ -1147,6 +1153,7 @@ static thread_local std::chrono::steady_clock::time_point g_tp_call_start;     /
 // their way to the device (one DMA per slot and chunk, no set-up); the uploader thread alone talks to the runtime.
 #define TP_RING_SLOTS 3
 #define TP_RING_MAX_TEXT ((u64)8 << 20)
+#define TP_RING_FIRST_TEXTS 128u              // a handle's first call pins the ring in line only for this many texts or more
 
 // bytes [a, b) of the concatenated stream (texts d with their 0xFF separators, text_offsets as in build_from_texts) -> dst
 static void tp_fill_stream(char *dst, u64 a, u64 b, const uint8_t *const *texts, const i64 *text_offsets, u32 D)
@@ -1163,6 +1170,20 @@ static void tp_fill_stream(char *dst, u64 a, u64 b, const uint8_t *const *texts,
         if (a == sep && a < b) { *dst++ = (char)0xFF; a++; }
         if (a > sep) d++;
     }
+}
+
+// a first call went without the ring (see prepare_texts_streamed): pin it now that the call is over, in the background
+static void ring_pin_later(east_hip_index *h)
+{
+    if (!h->ring_wanted || h->ring || h->ring_alloc.joinable() || h->ring_pending.load()) return;
+    h->ring_wanted = false;
+    const int dev = h->device;
+    std::atomic<char *> *slot = &h->ring_pending;
+    h->ring_alloc = std::thread([dev, slot]() {
+        void *p = nullptr;
+        if (hipSetDevice(dev) == hipSuccess && hipHostMalloc(&p, TP_RING_SLOT * TP_RING_SLOTS, hipHostMallocDefault) == hipSuccess) slot->store((char *)p);
+        else (void)hipGetLastError();
+    });
 }
 
 // Prepares the collection chunk by chunk; the symbols end up in h->prep_sym, the per-document offsets and string counts in
@@ -1243,7 +1264,15 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     hipStream_t copy_stream = h->copy_stream;
     const std::vector<hipEvent_t> &events = h->copy_events;
     // (the ring: see tp_fill_stream above)
-    const bool use_ring = texts && ctx.knobs.tp_ring != 0 && (ctx.knobs.tp_ring > 0 || (D >= 4 && (u64)n_bytes / D < TP_RING_MAX_TEXT));
+    // Pinning the ring costs 3-5 ms (hipHostMalloc of 24 MiB), a copy out of pageable memory ~45 us: a handle's FIRST call
+    // takes the ring only where that pays at once (TP_RING_FIRST_TEXTS texts or more) -- otherwise it goes the old way and
+    // leaves the pinning to a background thread, for the calls after it (`east keyphrases table` over a few dozen files
+    // is one call: 64 texts of 1 MiB, first call 11.4-13 ms with the ring pinned in line, second call 5.9).
+    if (h->ring_alloc.joinable() && (h->ring_pending.load() || ctx.knobs.tp_ring > 0)) h->ring_alloc.join();
+    if (!h->ring && !h->ring_alloc.joinable() && h->ring_pending.load()) h->ring = h->ring_pending.load();
+    const bool ring_shape = texts && ctx.knobs.tp_ring != 0 && (ctx.knobs.tp_ring > 0 || (D >= 4 && (u64)n_bytes / D < TP_RING_MAX_TEXT));
+    const bool use_ring = ring_shape && (h->ring || ctx.knobs.tp_ring > 0 || D >= TP_RING_FIRST_TEXTS);
+    if (ring_shape && !use_ring && !h->ring_alloc.joinable() && !h->ring_pending.load()) h->ring_wanted = true;   // (pinned when this call is over: ring_pin_later)
     const size_t ring_slot = ctx.knobs.tp_ring_slot;
     const u32 n_slots = use_ring ? ceil_div_u32(n_bytes, ring_slot) : 0u;
     // (fill threads: three -- measured on the 256-thread host of the MI355X box, 64 texts of 1 MiB: 4 threads 2.25 ms of
@@ -1252,6 +1281,12 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     static const int ring_threads_env = getenv("EAST_HIP_RING_THREADS") ? atoi(getenv("EAST_HIP_RING_THREADS")) : 0;     // (experiments)
     const int n_fill = !use_ring ? 0 : ring_threads_env > 0 ? std::min(ring_threads_env, 64)
                                      : (int)std::min<u32>(3u, std::max<u32>(2u, std::thread::hardware_concurrency() / 2u));
+    if (use_ring && h->ring && h->ring_events.empty())
+        for (int i = 0; i < TP_RING_SLOTS; i++) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->ring_events.push_back(e);
+        }
     if (use_ring && !h->ring) {
         void *p = nullptr;
         if (hipHostMalloc(&p, TP_RING_SLOT * TP_RING_SLOTS, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); east_throw(EAST_HIP_ERR_OOM, "hipHostMalloc of the upload ring failed"); }
@@ -1471,7 +1506,17 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
     h->built = false;
     const u32 n_bytes = (u32)n_bytes64, D = (u32)n_docs;
     const size_t arena_before = h->arena.cap;
-    ensure_arena(h, (size_t)n_bytes * 46 + (size_t)D * 96 + (8u << 20));
+    size_t arena_need = (size_t)n_bytes * 46 + (size_t)D * 96 + (8u << 20);
+    if (arena_before < arena_need) {
+        // (the arena has to grow anyway -- a handle's first call: sized for the build behind the preparation at once, on the
+        // most symbols these bytes can turn into, instead of a second hipMalloc + hipFree of gigabytes in the same call)
+        const u64 n_upper = std::min<u64>((u64)n_bytes + (u64)n_bytes / 9 + 2 * (u64)D + 64, 0x7FFFFFE0ull);
+        size_t free_b = 0, total_b = 0;
+        const size_t both = plan_arena_bytes((u32)n_upper, D);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && both < (size_t)(0.5 * (double)(free_b + arena_before))) arena_need = std::max(arena_need, both);
+        else (void)hipGetLastError();
+    }
+    ensure_arena(h, arena_need);
     if (g_trace && h->arena.cap != arena_before)
         fprintf(stderr, "[east_hip] text preparation: arena of %.2f GiB allocated, %.2f ms into the call\n", h->arena.cap / 1073741824.0,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_tp_call_start).count());
@@ -1584,6 +1629,7 @@ static void build_from_texts(east_hip_index *h, const uint8_t *bytes, i64 n_byte
             for (u32 d = 0; d <= D; d++) h->prep_doc_off[d] = s_off[d];
             for (u32 d = 0; d < D; d++) h->prep_n_strings[d] = (int32_t)s_m[d];
             build_common(h, h->prep_sym, false, s_off[D], h->prep_doc_off.data(), h->prep_n_strings.data(), n_docs, false);
+            ring_pin_later(h);
             return;
         }
         upload_all();                                   // (kept text at or above U+0A00: the preparation in one piece, tagged encoding)
@@ -2004,6 +2050,8 @@ void east_hip_destroy(east_hip_handle_t h)
     if (h->tp_tables) (void)hipFree(h->tp_tables);
     if (h->ht_tab) (void)hipFree(h->ht_tab);
     for (auto e : h->copy_events) (void)hipEventDestroy(e);
+    if (h->ring_alloc.joinable()) h->ring_alloc.join();
+    if (!h->ring && h->ring_pending.load()) h->ring = h->ring_pending.load();
     for (auto e : h->ring_events) (void)hipEventDestroy(e);
     if (h->ring) (void)hipHostFree(h->ring);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
