@@ -119,3 +119,77 @@ def test_cli_g_option_in_process(hip, tmp_path, monkeypatch):
     n = hip.device_count()
     code, out = run(["-g", str(n + 1), "keyphrases", "table", str(kp), str(tdir)])
     assert code == 1 and "device" in out
+
+
+def test_group_errors_name_the_shard(hip):
+    """An error inside one shard's build or score call comes back through the group call with the shard and its device in
+    the message (csrc/multi.h: on_every_shard), and the group stays usable."""
+    from east import exceptions, hip_backend, synthetic
+    rng = np.random.default_rng(11)
+    docs, sym, off, ms = _collection(rng, [3000, 2000, 2500, 1800])
+    bad = sym.copy()
+    bad[off[3] - 1] = ord("A")                               # the third document no longer ends in a terminator
+    group = hip_backend.HipGroup([0, 0, 0])
+    with pytest.raises(exceptions.HipBackendError, match=r"shard [12] \(device 0\).*terminator"):
+        group.build(bad, off, ms)
+    with pytest.raises(exceptions.HipBackendError, match="no collection has been built"):
+        group.score_table(np.array([65, 66], dtype=np.uint32), np.array([0, 2]))
+    group.build(sym, off, ms)
+    with pytest.raises(exceptions.HipBackendError, match="empty keyphrase"):
+        group.score_table(np.array([65, 66], dtype=np.uint32), np.array([0, 2, 2]))
+    qs, qo = synthetic.keyphrases(rng, sym, 20)
+    single = hip_backend.HipIndex()
+    single.build(sym, off, ms)
+    assert np.array_equal(group.score_table(qs, qo, True), single.score_table(qs, qo, True))
+    with pytest.raises(exceptions.HipBackendError, match="device"):
+        hip_backend.HipGroup([0, hip.device_count()])
+
+
+def test_distinct_handles_on_concurrent_threads(hip, oracle):
+    """"A handle is not thread-safe, distinct handles are" (include/east_hip.h): six Python threads (ctypes drops the GIL),
+    each with a handle of its own, build and score different collections at the same time -- raw texts through the
+    streamed preparation and its uploader threads among them -- while the main thread flips a test knob back and forth
+    (a call copies the knobs when it starts); every result equals the one obtained alone."""
+    import threading
+    from east import hip_backend, synthetic
+    lib = hip.load()
+    rng = np.random.default_rng(99)
+    jobs = []
+    for i in range(6):
+        if i % 3 == 2:
+            texts = [word_stream(rng, int(n)) for n in rng.integers(200000, 4000000, size=5)]
+            jobs.append(("texts", texts))
+        else:
+            docs, sym, off, ms = _collection(rng, rng.integers(20000, 900000, size=int(rng.integers(1, 6))))
+            jobs.append(("symbols", (sym, off, ms)))
+    queries = synthetic.keyphrases(rng, np.concatenate([j[1][0] for j in jobs if j[0] == "symbols"]), 60)
+
+    def run(job, out, k):
+        index = hip_backend.HipIndex()
+        for _ in range(3):
+            if job[0] == "texts":
+                index.build_texts(job[1])
+            else:
+                index.build(*job[1])
+            table = index.score_table(queries[0], queries[1], True)
+        out[k] = (table, index.tables(0, names=("suftab", "lcptab", "anntab")))
+
+    alone, together = {}, {}
+    for k, job in enumerate(jobs):
+        run(job, alone, k)
+    threads = [threading.Thread(target=run, args=(job, together, k)) for k, job in enumerate(jobs)]
+    for t in threads:
+        t.start()
+    flips = 0
+    while any(t.is_alive() for t in threads):
+        assert lib.east_hip_debug_set_lds_rounds(flips % 2) == 0
+        assert lib.east_hip_debug_set_text_stream(-1 if flips % 2 else 1 << 20) == 0
+        flips += 1
+    for t in threads:
+        t.join()
+    assert lib.east_hip_debug_set_lds_rounds(1) == 0 and lib.east_hip_debug_set_text_stream(-1) == 0
+    assert len(together) == len(jobs) and flips > 0
+    for k in range(len(jobs)):
+        assert np.array_equal(alone[k][0], together[k][0]), k
+        for name in ("suftab", "lcptab", "anntab"):
+            assert np.array_equal(alone[k][1][name], together[k][1][name]), (k, name)
