@@ -888,13 +888,30 @@ static void finish_capped_lcp(east_hip_index *h, Ctx &ctx)
     Arena &ar = *ctx.arena;
     const u32 n = h->pyr.len[0];
     const size_t mark = ar.mark();
-    u32 *rank = ar.alloc<u32>(n);
-    LAUNCH(ctx, inverse_sa_kernel, ceil_div_u32(n, BLOCK), (const u32 *)h->sa, n, rank);
-    const u32 kb = ceil_div_u32(ceil_div_u32(n, KASAI_BLOCK), BLOCK);
-    if (h->use_s8)
-        LAUNCH(ctx, (lcp_finish_kernel<true>), kb, (const void *)h->s8, (const u32 *)h->sa, (const u32 *)rank, n, h->lcp);
-    else
-        LAUNCH(ctx, (lcp_finish_kernel<false>), kb, (const void *)h->s, (const u32 *)h->sa, (const u32 *)rank, n, h->lcp);
+    const u32 gn = ceil_div_u32(n, BLOCK);
+    u32 *rank = ar.alloc<u32>(n), *count = ar.alloc<u32>(n), *apos = ar.alloc<u32>(n);
+    u32 *list = ar.alloc<u32>(n), *long_list = ar.alloc<u32>(n), *counters = ar.alloc<u32>(2);
+    uint8_t *anchor = ar.alloc<uint8_t>((size_t)n + 16);
+    const void *sym = h->use_s8 ? (const void *)h->s8 : (const void *)h->s;
+    HIP_CHECK(hipMemsetAsync(counters, 0, 2 * sizeof(u32), ctx.stream));
+    LAUNCH(ctx, inverse_sa_kernel, gn, (const u32 *)h->sa, n, rank);
+    // (tables.h, "finishing pass for unfinished LCP entries": classify, compare the irreducible positions, fill the rest)
+    if (h->use_s8) {
+        LAUNCH(ctx, (lcp_phi_classify_kernel<true>), gn, sym, (const u32 *)h->sa, (const u32 *)rank, (const u32 *)h->lcp, n, anchor, list, counters);
+        LAUNCH(ctx, (lcp_phi_compare_kernel<true>), std::min<u32>(ceil_div_u32(n, WAVES_PER_BLOCK), 8192u), sym, (const u32 *)h->sa, (const u32 *)rank, (const u32 *)list,
+               (const u32 *)counters, n, h->lcp, long_list, counters + 1);
+        LAUNCH_BLOCK(ctx, (lcp_phi_long_kernel<true>), 512, PHI_LONG_THREADS, sym, (const u32 *)h->sa, (const u32 *)rank, (const u32 *)long_list,
+                     (const u32 *)(counters + 1), n, h->lcp);
+    } else {
+        LAUNCH(ctx, (lcp_phi_classify_kernel<false>), gn, sym, (const u32 *)h->sa, (const u32 *)rank, (const u32 *)h->lcp, n, anchor, list, counters);
+        LAUNCH(ctx, (lcp_phi_compare_kernel<false>), std::min<u32>(ceil_div_u32(n, WAVES_PER_BLOCK), 8192u), sym, (const u32 *)h->sa, (const u32 *)rank, (const u32 *)list,
+               (const u32 *)counters, n, h->lcp, long_list, counters + 1);
+        LAUNCH_BLOCK(ctx, (lcp_phi_long_kernel<false>), 512, PHI_LONG_THREADS, sym, (const u32 *)h->sa, (const u32 *)rank, (const u32 *)long_list,
+                     (const u32 *)(counters + 1), n, h->lcp);
+    }
+    device_scan<U8In, true>(ctx, U8In{anchor}, n, count);
+    LAUNCH(ctx, lcp_phi_anchors_kernel, gn, (const uint8_t *)anchor, (const u32 *)count, n, apos);
+    LAUNCH(ctx, lcp_phi_fill_kernel, gn, (const uint8_t *)anchor, (const u32 *)count, (const u32 *)apos, (const u32 *)rank, n, h->lcp);
     ar.release(mark);
     annotate(h, ctx);
 }

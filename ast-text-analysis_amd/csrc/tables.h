@@ -190,85 +190,182 @@ __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__
     lcp[r] = h;
 }
 
-// ---- finishing pass for capped ranks (Kasai et al. 2001, blocked over the text) ----------
-// rank[p] = rank of the suffix at p.  lcp(p + 1) >= lcp(p) - 1 inside a document, so a walk over consecutive text
-// positions resumes every comparison where the one before ended.  One thread walks KASAI_BLOCK positions; what does not
-// depend on the carry is fetched for the whole block up front -- the ranks (128 contiguous bytes), then the entries and
-// the left neighbours of all 32 positions with 32 gathers in flight each -- so that the walk itself waits for ONE memory
-// round trip per position, the text behind the carry (first version: five dependent gathers per position, 8.2 ms for the
-// 10 M positions of the reference's worst-case input; now the comparison looks at 32 symbols per step, eight 8-byte loads
-// in flight).  Unmarked ranks only feed the carry.  A block's first marked position starts from what its entry knows
-// (LCP_PARTIAL_BIT | length).  BYTES: byte stream with the 0xFF rule, else exact u32 symbols.
-#define KASAI_BLOCK 32u
-
+// ---- finishing pass for unfinished LCP entries (LCP_PARTIAL_BIT) ----------------------------------------------------
+// rank[p] = rank of the suffix at p; PLCP(p) = lcp[rank[p]]; phi(p) = sa[rank[p] - 1], the suffix in front of p's.
+// Kasai's bound PLCP(p) >= PLCP(p - 1) - 1 lets a walk over the text resume every comparison where the one before ended,
+// but a walk has to START somewhere, and a start inside a long repeat compares its whole length: a blocked walk costs
+// (n / block) x the mean LCP -- quadratic on a run of one symbol, a short period, a passage written twice (measured, 32
+// positions per thread: 144 of 162 ms for 4 M symbols of one letter, 0.8 s for 16 M).  What is used instead is the
+// irreducible-LCP lemma (Karkkainen, Manzini, Puglisi: Permuted Longest-Common-Prefix Array, CPM 2009): if the symbols
+// IN FRONT of p and of phi(p) agree (p is "reducible"), PLCP(p) = PLCP(p - 1) - 1 exactly -- no comparison at all --, and
+// the PLCP values of the irreducible positions sum to at most 2 n log n.  So:
+//   classify  one thread per position: finished entries and irreducible positions are ANCHORS (the latter are listed);
+//   compare   the listed positions get their entry by comparing text, a wavefront each, 512 symbols per step (entries
+//             longer than 8 K symbols: a workgroup of 1024 each, 32 K symbols per step);
+//   fill      every other position p: PLCP(p) = PLCP(j) - (p - j), j the nearest anchor in front of p (found from an
+//             inclusive count of the anchors and their compacted positions).
+// All four passes are data-parallel; no text is read for a reducible position.  (A document's first position is
+// irreducible -- the symbol in front of it is the terminator of the document before, which equals nothing --, so no run
+// crosses a document.)  BYTES: byte stream with the 0xFF rule (equal 0xFF bytes are different terminators), else exact
+// u32 symbols, whose terminators are numbered apart.
 __global__ __launch_bounds__(BLOCK) void inverse_sa_kernel(const u32 *__restrict__ sa, u32 n, u32 *__restrict__ rank)
 {
     const u32 r = blockIdx.x * BLOCK + threadIdx.x;
     if (r < n) rank[sa[r]] = r;
 }
 
-// common prefix of the suffixes at p and q from h symbols on (known to agree), no cap
-template <bool BYTES> __device__ __forceinline__ u32 kasai_extend(const void *__restrict__ sym, u32 p, u32 q, u32 h)
+struct U8In {                                     // one flag per element, a byte each
+    const uint8_t *p;
+    __device__ __forceinline__ u32 operator()(u32 i) const { return p[i]; }
+};
+
+template <bool BYTES>
+__global__ __launch_bounds__(BLOCK) void lcp_phi_classify_kernel(const void *__restrict__ sym, const u32 *__restrict__ sa,
+                                                                 const u32 *__restrict__ rank, const u32 *__restrict__ lcp, u32 n,
+                                                                 uint8_t *__restrict__ anchor, u32 *__restrict__ list,
+                                                                 u32 *__restrict__ list_n)
 {
-    if (BYTES) {
-        const uint8_t *s8 = (const uint8_t *)sym;
-        while (true) {
-            u64 x[4], y[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) { x[k] = load_u64_unaligned(s8 + p + h + 8 * k); y[k] = load_u64_unaligned(s8 + q + h + 8 * k); }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const u64 d = x[k] ^ y[k], z = ~x[k];
-                const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
-                const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
-                const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
-                const u32 step = mism < term ? mism : term;
-                h += step;
-                if (step < 8u) return h;
+    const u32 p = blockIdx.x * BLOCK + threadIdx.x;
+    bool irreducible = false;
+    if (p < n) {
+        const u32 r = rank[p];
+        const u32 h = lcp[r];
+        bool is_anchor = true;
+        if (h & LCP_PARTIAL_BIT) {                 // (never a document's first rank: those hold 0)
+            const u32 q = sa[r - 1];
+            bool reducible = false;
+            if (p > 0 && q > 0) {
+                if (BYTES) {
+                    const uint8_t a = ((const uint8_t *)sym)[p - 1], b = ((const uint8_t *)sym)[q - 1];
+                    reducible = a == b && a != 0xFFu;
+                } else {
+                    reducible = ((const u32 *)sym)[p - 1] == ((const u32 *)sym)[q - 1];
+                }
             }
+            is_anchor = irreducible = !reducible;
         }
-    } else {
-        const u32 *s = (const u32 *)sym;
-        while (s[p + h] == s[q + h]) h++;
-        return h;
+        anchor[p] = is_anchor ? 1 : 0;
+    }
+    const u64 bal = __ballot(irreducible);         // one list append per wavefront
+    if (bal) {
+        u32 at = 0;
+        if (lane_id() == (u32)__builtin_ctzll(bal)) at = atomicAdd(list_n, (u32)__popcll(bal));
+        at = __shfl(at, __builtin_ctzll(bal), WAVE) + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+        if (irreducible) list[at] = p;
     }
 }
 
+// one step of a cooperative comparison: every lane looks at 8 symbols (BYTES) or 1 symbol at its own offset; returns
+// the number of symbols of the step's stretch that agree before the first difference (or terminator), stretch if all do
 template <bool BYTES>
-__global__ __launch_bounds__(BLOCK) void lcp_finish_kernel(const void *__restrict__ sym,
-                                                           const u32 *__restrict__ sa,
-                                                           const u32 *__restrict__ rank, u32 n,
-                                                           u32 *__restrict__ lcp)
+__device__ __forceinline__ u32 lcp_phi_step(const void *__restrict__ sym, u32 p, u32 q, u32 at, u32 lanes_rank, u32 &stretch)
 {
-    const u64 p0 = ((u64)blockIdx.x * BLOCK + threadIdx.x) * KASAI_BLOCK;
-    if (p0 >= n) return;
-    const u32 cnt = p0 + KASAI_BLOCK <= n ? KASAI_BLOCK : n - (u32)p0;
-    u32 r[KASAI_BLOCK], hv[KASAI_BLOCK], q[KASAI_BLOCK];
-    if (cnt == KASAI_BLOCK) {                      // (rank[] comes from the arena: 256-byte aligned, p0 a multiple of 32)
-#pragma unroll
-        for (int k = 0; k < (int)KASAI_BLOCK / 4; k++) {
-            const uint4 v = reinterpret_cast<const uint4 *>(rank + p0)[k];
-            r[4 * k] = v.x; r[4 * k + 1] = v.y; r[4 * k + 2] = v.z; r[4 * k + 3] = v.w;
-        }
+    if (BYTES) {
+        const uint8_t *s8 = (const uint8_t *)sym;
+        const u64 x = load_u64_unaligned(s8 + p + at + 8u * lanes_rank), y = load_u64_unaligned(s8 + q + at + 8u * lanes_rank);
+        const u64 d = x ^ y, z = ~x;
+        const u64 t = (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+        const u32 mism = d ? (u32)__builtin_ctzll(d) >> 3 : 8u;
+        const u32 term = t ? (u32)__builtin_ctzll(t) >> 3 : 8u;
+        stretch = 8u;
+        return mism < term ? mism : term;
     } else {
-#pragma unroll
-        for (int k = 0; k < (int)KASAI_BLOCK; k++) r[k] = (u32)k < cnt ? rank[p0 + k] : 0u;
+        const u32 *s = (const u32 *)sym;
+        stretch = 1u;
+        return s[p + at + lanes_rank] == s[q + at + lanes_rank] ? 1u : 0u;
     }
-#pragma unroll
-    for (int k = 0; k < (int)KASAI_BLOCK; k++) hv[k] = (u32)k < cnt ? lcp[r[k]] : 0u;
-#pragma unroll
-    for (int k = 0; k < (int)KASAI_BLOCK; k++) q[k] = (hv[k] & LCP_PARTIAL_BIT) ? sa[r[k] - 1u] : 0u;   // (never a document's first rank: those hold 0)
-    u32 carry = 0;                                 // lcp of the previous position
-#pragma unroll
-    for (int k = 0; k < (int)KASAI_BLOCK; k++) {
-        u32 h = hv[k];
-        if (h & LCP_PARTIAL_BIT) {
-            const u32 known = h & ~LCP_PARTIAL_BIT;       // (what the direct comparison had seen to agree when it was cut)
-            h = kasai_extend<BYTES>(sym, (u32)p0 + (u32)k, q[k], carry > known + 1u ? carry - 1u : known);
-            lcp[r[k]] = h;
+}
+
+// the listed positions, a wavefront each; what is not decided within PHI_WAVE_STEPS steps goes to the long list
+#define PHI_WAVE_STEPS 16u
+template <bool BYTES>
+__global__ __launch_bounds__(BLOCK) void lcp_phi_compare_kernel(const void *__restrict__ sym, const u32 *__restrict__ sa,
+                                                                const u32 *__restrict__ rank, const u32 *__restrict__ list,
+                                                                const u32 *__restrict__ list_n, u32 n, u32 *__restrict__ lcp,
+                                                                u32 *__restrict__ long_list, u32 *__restrict__ long_n)
+{
+    const u32 count = *list_n;
+    for (u32 i = blockIdx.x * WAVES_PER_BLOCK + wave_id(); i < count; i += gridDim.x * WAVES_PER_BLOCK) {
+        const u32 p = list[i], r = rank[p], q = sa[r - 1];
+        u32 h = lcp[r] & ~LCP_PARTIAL_BIT;         // what the direct comparison had seen to agree when it was cut
+        // (the stream is readable far enough behind every position a comparison can reach: it ends at the document's last
+        // terminator at the latest, a step looks at most 512 bytes / 64 words past that -- inside the arena, see build_impl)
+        const u32 limit = n - (p > q ? p : q);      // symbols left behind the later of the two positions
+        bool done = false;
+        for (u32 step = 0; step < PHI_WAVE_STEPS && !done; step++) {
+            u32 stretch;
+            const u32 agree = lcp_phi_step<BYTES>(sym, p, q, h, lane_id(), stretch);
+            const u64 bal = __ballot(agree < stretch);
+            if (bal) {
+                const u32 first = (u32)__builtin_ctzll(bal);
+                h += first * stretch + __shfl(agree, first, WAVE);
+                done = true;
+            } else {
+                h += WAVE * stretch;
+                if (h >= limit) done = true;        // (cannot happen: the last symbol is a terminator of its own)
+            }
         }
-        carry = h;
+        if (lane_id() == 0) {
+            if (done) lcp[r] = h < limit ? h : limit;
+            else {
+                lcp[r] = LCP_PARTIAL_BIT | h;
+                long_list[atomicAdd(long_n, 1u)] = p;
+            }
+        }
     }
+}
+
+// the long list: a workgroup of PHI_LONG_THREADS per position
+#define PHI_LONG_THREADS 1024
+template <bool BYTES>
+__global__ __launch_bounds__(PHI_LONG_THREADS) void lcp_phi_long_kernel(const void *__restrict__ sym, const u32 *__restrict__ sa,
+                                                                        const u32 *__restrict__ rank, const u32 *__restrict__ list,
+                                                                        const u32 *__restrict__ list_n, u32 n, u32 *__restrict__ lcp)
+{
+    __shared__ u32 first_wave[PHI_LONG_THREADS / WAVE];
+    for (u32 i = blockIdx.x; i < *list_n; i += gridDim.x) {
+        const u32 p = list[i], r = rank[p], q = sa[r - 1];
+        u32 h = lcp[r] & ~LCP_PARTIAL_BIT;
+        const u32 limit = n - (p > q ? p : q);
+        while (true) {
+            u32 stretch;
+            const u32 agree = lcp_phi_step<BYTES>(sym, p, q, h, threadIdx.x, stretch);
+            const u64 bal = __ballot(agree < stretch);
+            u32 mine = 0xFFFFFFFFu;                 // symbols of the step's stretch in front of this wave's first difference
+            if (bal) {
+                const u32 first = (u32)__builtin_ctzll(bal);
+                mine = (wave_id() * WAVE + first) * stretch + __shfl(agree, first, WAVE);
+            }
+            if (lane_id() == 0) first_wave[wave_id()] = mine;
+            __syncthreads();
+            u32 best = 0xFFFFFFFFu;
+            for (u32 w = 0; w < PHI_LONG_THREADS / WAVE; w++) best = first_wave[w] < best ? first_wave[w] : best;
+            __syncthreads();
+            if (best != 0xFFFFFFFFu) { h += best; break; }
+            h += PHI_LONG_THREADS * stretch;
+            if (h >= limit) break;
+        }
+        if (threadIdx.x == 0) lcp[r] = h < limit ? h : limit;
+    }
+}
+
+// the anchors' positions, compacted: apos[c - 1] = p for anchor p with inclusive count c
+__global__ __launch_bounds__(BLOCK) void lcp_phi_anchors_kernel(const uint8_t *__restrict__ anchor, const u32 *__restrict__ count, u32 n,
+                                                                u32 *__restrict__ apos)
+{
+    const u32 p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p < n && anchor[p]) apos[count[p] - 1u] = p;
+}
+
+// every position that is no anchor: its entry from the nearest anchor in front of it
+__global__ __launch_bounds__(BLOCK) void lcp_phi_fill_kernel(const uint8_t *__restrict__ anchor, const u32 *__restrict__ count,
+                                                             const u32 *__restrict__ apos, const u32 *__restrict__ rank, u32 n,
+                                                             u32 *__restrict__ lcp)
+{
+    const u32 p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= n || anchor[p]) return;
+    const u32 j = apos[count[p] - 1u];             // (position 0 is an anchor: the count is at least 1)
+    lcp[rank[p]] = lcp[rank[j]] - (p - j);
 }
 
 // out[i] = min of in[16i .. 16i+15]; the padding of out becomes NONE_U32
