@@ -538,6 +538,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_scatter_names_kernel(const u32 *__r
 #define REFINE_ENDGAME_DOMAIN 262144     // domains this small: groups up to REFINE_ENDGAME_GROUP are ordered directly,
 #define REFINE_ENDGAME_GROUP 128         // with comparisons of at most REFINE_ENDGAME_LEN symbols (longer: give up)
 #define REFINE_ENDGAME_LEN 256
+#define REFINE_DOUBLING_LEN 64           // direct comparisons of small groups in prefix-doubling rounds once long repeats are known
 #define REFINE_SMALL_INPUT 65536          // inputs this small use the endgame limits from the placement pass on
 
 struct BitIn {                                  // one flag per element, 64 to a word (written by wave ballots)
@@ -2252,7 +2253,11 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 if (!rest_only || round_left > 0)       // (rest_only: the in-LDS round has classified its own tiles)
                     LAUNCH(ctx, dc3_refine_classify_kernel, gt, elem, FlagArrIn{flag}, slot, m, s8, n0, depth, sa12, names_g, keep,
                            fail, endgame ? (u32)REFINE_ENDGAME_GROUP : (u32)REFINE_SMALL_GROUP,
-                           endgame ? (u32)REFINE_ENDGAME_LEN : (u32)RESOLVE_MAX_LEN, doubling ? name_of : (u32 *)nullptr,
+                           // (doubling rounds with long repeats known -- mark + commit, an undecided group simply stays for the
+                           // next round, which doubles the depth by one name look-up per member: comparing 2 048 symbols of text
+                           // for it first was 60 of the 96 ms of a 16 M-symbol Fibonacci string)
+                           endgame ? (u32)REFINE_ENDGAME_LEN : doubling && mode != 0 ? (u32)REFINE_DOUBLING_LEN : (u32)RESOLVE_MAX_LEN,
+                           doubling ? name_of : (u32 *)nullptr,
                            LongRepeats{bad, mode}, lcp_out, rest_only ? (const uint2 *)cover : (const uint2 *)nullptr,
                            doubling ? (const uint8_t *)nullptr : xdep);
                 if (mode == 1) return;

@@ -1323,6 +1323,54 @@ def test_repetitive_inputs_lcp_beyond_the_direct_cap(hip, oracle, case):
     assert index.score_table(qs, qo, True)[0, 0] == oracle.OracleEASA(docs[0]).score(q)
 
 
+@pytest.mark.parametrize("case", ["one_symbol", "period3", "fibonacci", "sixteen_copies"])
+def test_long_repeats_at_four_million_symbols(hip, oracle, request, case):
+    """Repetitive inputs at a size where a quadratic step shows (a blocked Kasai walk took 0.16 s here and 0.8 s at 16 M;
+    the finishing pass now goes by the irreducible-LCP lemma, csrc/tables.h): 4 Mi symbols of one letter, of a period of
+    three, a Fibonacci string, 16 copies of a passage -- suffix array and LCP table array_equal to the oracle's DC3 + Kasai
+    (the reference's annotation pass, and with it the full oracle, is quadratic on such trees: minutes at 1 M), annotation
+    table by its closed form on sampled ranks; and the build stays within a bound."""
+    _only_paths(request, "window_sort", "dc3_only")
+    import time
+    from east import hip_backend
+    n = 1 << 22
+    rng = np.random.default_rng(7)
+    if case == "one_symbol":
+        body = np.full(n, 65, np.uint32)
+    elif case == "period3":
+        body = np.resize(np.array([65, 66, 67], np.uint32), n)
+    elif case == "fibonacci":
+        a, b = np.array([65], np.uint32), np.array([65, 66], np.uint32)
+        while b.size < n:
+            a, b = b, np.concatenate([b, a])
+        body = b[:n]
+    else:
+        body = np.tile(rng.integers(65, 91, size=n // 16, dtype=np.uint32), 16)
+    sym = np.concatenate([body, [0x0A00]]).astype(np.uint32)
+    index = hip_backend.HipIndex()
+    index.build(sym, np.array([0, sym.size]), np.array([1]))
+    t0 = time.perf_counter()
+    index.build(sym, np.array([0, sym.size]), np.array([1]))
+    assert time.perf_counter() - t0 < 0.5                     # (60 ms or less on an MI355X; 0.16-0.2 s with the quadratic step)
+    o = oracle.OracleEASA(symbols=sym, n_strings=1, tables=False)
+    t = index.tables(0, names=("suftab", "lcptab", "anntab"))
+    assert np.array_equal(t["suftab"], o.suftab) and np.array_equal(t["lcptab"], o.lcptab)
+    lcp, ann = t["lcptab"], t["anntab"]
+    assert int(ann[0]) == sym.size - 1
+    checked = 0
+    for i in rng.integers(1, sym.size, size=400).tolist():     # anntab[k] = NSV(k) - PSV(k) at first l-indices, 0 elsewhere
+        v, p, j = lcp[i], i - 1, i + 1
+        while p > 0 and lcp[p] > v and i - p < 20000:
+            p -= 1
+        while j < sym.size and lcp[j] >= v and j - i < 20000:
+            j += 1
+        if i - p >= 20000 or j - i >= 20000:
+            continue                                           # (an interval too wide for a plain scan)
+        checked += 1
+        assert ann[i] == (0 if v == 0 or lcp[p] == v else j - p), (case, i)
+    assert checked > 0 or case in ("one_symbol", "period3")
+
+
 def test_c_abi_rejects_inconsistent_input(hip):
     """n_strings that does not match the terminators, or a document without a final terminator,
     is an EAST_HIP_ERR_DOMAIN error (not silent garbage, not an out-of-bounds comparison)."""
