@@ -656,6 +656,34 @@ def worst_case_leg(hip_backend, synthetic, torch, dev, local_rank, with_oracle):
             case["oracle_build_s"] = time.perf_counter() - t0
             case["speedup_vs_oracle_one_core"] = case["oracle_build_s"] * 1e3 / min(times)
         res["cases"].append(case)
+    # long repeats of other shapes, 16 Mi symbols in one string (get_ast([one string])): a run of one letter, a period of
+    # three, a passage written 16 times, a Fibonacci string -- the inputs on which a step that restarts comparisons inside
+    # repeats goes quadratic (the finishing pass of the LCP table did: 0.8 s)
+    n = 16 << 20
+    rng = np.random.default_rng(20240 + 8)
+    fa, fb = np.array([65], np.uint32), np.array([65, 66], np.uint32)
+    while fb.size < n:
+        fa, fb = fb, np.concatenate([fb, fa])
+    shapes = {"random A-Z": rng.integers(65, 91, size=n, dtype=np.uint32), "one letter": np.full(n, 65, np.uint32),
+              "period of three": np.resize(np.array([65, 66, 67], np.uint32), n),
+              "16 copies of a 1 MiB passage": np.tile(rng.integers(65, 91, size=n // 16, dtype=np.uint32), 16),
+              "Fibonacci string": fb[:n]}
+    index = hip_backend.HipIndex(local_rank, reserve_symbols=n + 1)
+    res["long_repeats"] = []
+    base_ms = None
+    for name, body in shapes.items():
+        sym = np.concatenate([body, [synthetic.TERMINATOR_START]]).astype(np.uint32)
+        d_sym = torch.from_numpy(sym.view(np.int32)).to(dev)
+        times = []
+        for _ in range(3):
+            index.build_device(d_sym.data_ptr(), sym.size, np.array([0, sym.size]), np.array([1]))
+            times.append(index.last_build_ms)
+        info = index.info()
+        base_ms = base_ms or min(times)
+        res["long_repeats"].append({"input": name, "symbols": int(sym.size), "build_ms": min(times), "ns_per_symbol": min(times) * 1e6 / sym.size,
+                                    "slowdown_vs_random_text": min(times) / base_ms, "refine_rounds": info["refine_rounds"],
+                                    "window_sorted": info["window_sorted"], "dc3_levels": info["dc3_levels"]})
+    index.close()
     return res
 
 
