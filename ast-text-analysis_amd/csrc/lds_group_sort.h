@@ -285,7 +285,7 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
     // groups of the tile: the starts in [begin_q, begin_q + n_act)
     const u32 last = begin_q + n_act - 1u;
     const u32 n_groups = lds.word_prefix[last >> 6] + (u32)__popcll(lds.start_bits[last >> 6] & (((u64)2 << (last & 63u)) - 1ull));
-    const int wbits = name_of ? 32 : w2 * b;
+    const int wbits = name_of ? w2 : w2 * b;            // (prefix doubling: w2 = the bits of a name -- a rank, bit_width(n))
     const int bits = wbits + (n_groups > 1u ? 32 - (int)__builtin_clz(n_groups - 1u) : 0);
     const bool active = w * (LG_IPT * WAVE) < n_act;
     // ---- keys from the text ----
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
                 const u32 gid = lds.word_prefix[q >> 6] + (u32)__popcll(lds.start_bits[q >> 6] & (((u64)2 << (q & 63u)) - 1ull)) - 1u;
                 u64 k = gid;
                 if (name_of) {
-                    k = (k << 32) | (u64)name_of[e + depth];
+                    k = (k << wbits) | (u64)name_of[e + depth];
                 } else {
                     const u32 p = lvl0_pos(e, n0) + depth + (cls.xdep ? (u32)cls.xdep[base + q] : 0u);
                     u64 lo8, hi8;

@@ -1759,12 +1759,12 @@ __global__ __launch_bounds__(BLOCK) void dc3_names_update_kernel(const u32 *__re
 // key = (dense group number << 32) | name of the suffix `depth` symbols further on
 __global__ __launch_bounds__(BLOCK) void dc3_double_keys_kernel(const u32 *__restrict__ name_of,
                                                                 const u32 *__restrict__ elems,
-                                                                const u32 *__restrict__ group, u32 m, u32 depth,
+                                                                const u32 *__restrict__ group, u32 m, u32 depth, int name_bits,
                                                                 u64 *__restrict__ keys, u32 *__restrict__ vals)
 {
     const u32 j = blockIdx.x * BLOCK + threadIdx.x;
     if (j >= m) return;
-    keys[j] = ((u64)group[j] << 32) | (u64)name_of[elems[j] + depth];
+    keys[j] = ((u64)group[j] << name_bits) | (u64)name_of[elems[j] + depth];      // (a name is a rank: bit_width(n) bits, not 32 -- a pass less)
     vals[j] = elems[j];                 // (the suffix itself travels with its key: no look-up after the sort)
 }
 
@@ -2176,7 +2176,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             const bool fuse_cls = ctx.knobs.lds_rounds && ctx.knobs.fused_classify && !doubling && !endgame && !long_repeats;
             u32 round_left = m;                         // what the in-LDS round left to the global sort
             auto sort_round = [&](bool names, int w2, const KeyNeqWindowIn<u64> &f) {
-                const int kbits = names ? 32 : w2 * bt;
+                const int kbits = names ? w2 : w2 * bt;     // (names: w2 = the bits of a name)
                 u32 *lcp_r = names ? (u32 *)nullptr : lcp_out;
                 u32 m_left = m;
                 if (ctx.knobs.lds_rounds) {
@@ -2216,7 +2216,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 }
                 const u32 gl = ceil_div_u32(m_left, BLOCK);
                 if (names)
-                    LAUNCH(ctx, dc3_double_keys_kernel, gl, (const u32 *)name_of, elems_s, (const u32 *)group, m_left, depth,
+                    LAUNCH(ctx, dc3_double_keys_kernel, gl, (const u32 *)name_of, elems_s, (const u32 *)group, m_left, depth, w2,
                            rb.keys[0], rb.vals[0]);
                 else
                     LAUNCH(ctx, dc3_refine_keys_kernel, gl, s8, elems_s, (const u32 *)group, m_left, n0, depth, w2, bt, term_first,
@@ -2224,10 +2224,10 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 const int rr = radix_sort_pairs<u64>(ctx, rb, m_left, gb + kbits);
                 LAUNCH(ctx, dc3_refine_writeback_kernel, gl, (const u64 *)rb.keys[rr], (const u32 *)rb.vals[rr], (const u32 *)slot_c,
                        (const u32 *)ebuf[e_c], m_left, f.rep_t, f.ones, f.highs, sa12, names_g, ebuf[e_out], fbuf[f_dom ^ 1], lcp_r,
-                       depth, w2, bt, full, names ? (const uint8_t *)nullptr : xdep);
+                       depth, names ? 0 : w2, bt, full, names ? (const uint8_t *)nullptr : xdep);
             };
             if (doubling) {
-                sort_round(true, 0, KeyNeqWindowIn<u64>{nullptr, 0, 0, 0});
+                sort_round(true, bit_width_u32(n02 > 1 ? n02 - 1 : 1), KeyNeqWindowIn<u64>{nullptr, 0, 0, 0});
                 // the members' new names: where their (possibly split) group now starts
                 device_scan<ArrIn, true>(ctx, ArrIn{fbuf[f_dom ^ 1]}, m, group);
                 LAUNCH(ctx, dc3_group_starts_kernel, gt, (const u32 *)fbuf[f_dom ^ 1], (const u32 *)group, (const u32 *)slot_c, m,
