@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Wall clock of the `east keyphrases table` CLI as a user runs it -- a fresh process per call -- on D files of S MiB
-(prose-like text) and K keyphrases, with and without the background start of the device.  usage: cli_wall.py [D [S [K]]]"""
+(prose-like text) and K keyphrases.  (Measured with it, round 5: 0.45-0.5 s whatever the collection -- interpreter start,
+numpy, library load and device initialisation; starting the device on a background thread while the files are read changed
+nothing, the files come out of the page cache in milliseconds -- that variant was taken out again.)
+usage: cli_wall.py [D [S [K]]]"""
 import os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "ast-text-analysis_amd")
@@ -22,7 +25,7 @@ with open(os.path.join(tmp, "kp.txt"), "wb") as f:
         st = int(rng.integers(0, len(words) - 3))
         f.write(b" ".join(words[st:st + int(rng.integers(1, 4))]) + b"\n")
 env = dict(os.environ, PYTHONPATH=PKG)
-for label, extra in (("device started in the background", {}), ("EAST_HIP_WARMUP=0", {"EAST_HIP_WARMUP": "0"})):
+for label, extra in (("east keyphrases table", {}),):
     walls = []
     for _ in range(4):
         t0 = time.perf_counter()
