@@ -221,9 +221,6 @@ class HipIndex(object):
         self._lib = load()
         self._h = ctypes.c_void_p()
         self.device = default_device() if device is None else int(device)
-        import threading
-        if threading.current_thread() is not _warm_up_thread:
-            warm_up_wait()
         pooled = _handle_pool.get(self.device)
         if pooled and not reserve_symbols:
             self._h = pooled.pop()               # a recycled handle (reset: behaves like a new one)
@@ -561,39 +558,6 @@ def format_table(scores, kp_order, text_order, kp_names, text_names, kind):
     if n < 0:
         raise exceptions.HipBackendError(reason="table formatter: %d" % n)
     return buf.raw[:n].decode("utf-8", "surrogatepass")
-
-
-_warm_up_thread = None
-
-
-def warm_up_async(device=None):
-    """Start the device in the background: the first HIP call of a process initialises the runtime and the device (a
-    quarter of a second), the first handle creates its streams (milliseconds) and the first copy out of host memory sets up
-    the runtime's staging (5 ms).  `east keyphrases table` calls this before it reads its input files, so that all of it
-    overlaps with the file I/O (ctypes drops the GIL around every call); the handle it made goes to the pool, where the
-    measure's HipIndex() finds it.  Errors are swallowed here -- the real call reports them.  EAST_HIP_WARMUP=0 turns it off."""
-    global _warm_up_thread
-    if _warm_up_thread is not None or os.environ.get("EAST_HIP_WARMUP", "1") == "0":
-        return None
-    import threading
-
-    def run():
-        try:
-            index = HipIndex(device)
-            index.build_texts([b"warm up the copy path", b"and the kernels"])
-            index.close()
-        except Exception:                        # noqa: BLE001 (no device, no library: the real call will say so)
-            pass
-
-    _warm_up_thread = threading.Thread(target=run, name="east-hip-warm-up", daemon=True)
-    _warm_up_thread.start()
-    return _warm_up_thread
-
-
-def warm_up_wait():
-    """Let a warm-up under way finish (HipIndex() would otherwise create a second handle next to the one being warmed)."""
-    if _warm_up_thread is not None and _warm_up_thread.is_alive():
-        _warm_up_thread.join()
 
 
 def pack_queries(queries, keep_spaces=False):

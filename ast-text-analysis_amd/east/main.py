@@ -115,12 +115,6 @@ def _main(opts, args, world, measure_factory):
               '"path/to/texts/dir"')
         return 1
 
-    if world == 1 and os.environ.get("EAST_HIP_FORCE_DIST") != "1" and int(opts.get("-g", "1")) <= 1:
-        # (one process, one device: start the device while the input files are read -- runtime and device initialisation, the
-        # first handle and the first copy cost a quarter of a second that has nothing to wait for)
-        from east import hip_backend
-        hip_backend.warm_up_async()
-
     keyphrases = _read(os.path.abspath(args[2])).decode("utf-8", errors="replace").splitlines()   # main.py:60-64
 
     text_collection_path = os.path.abspath(args[3])                                             # main.py:67-89
