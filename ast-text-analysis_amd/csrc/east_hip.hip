@@ -484,6 +484,7 @@ struct east_hip_index {
     std::vector<hipEvent_t> ring_events;
     std::thread ring_alloc;                 // pins the ring in the background after a first call that went without it
     std::atomic<char *> ring_pending{nullptr};
+    bool narrow_upload = false;             // the last build's host symbols went up as 16-bit words (east_hip_build_info [25])
     bool ring_wanted = false;               // (the call under way would have taken the ring: pin it once the call is over --
                                             // while it runs, the pinning and the call's own copies fight over the runtime's locks)
     // symbols prepared on the device by east_hip_build_texts (own allocation)
@@ -971,6 +972,107 @@ static void check_build_args(i64 n_total, const i64 *doc_offsets, const int32_t 
     }
 }
 
+// ---- host symbols go up as 16-bit words ------------------------------------------------------------------------------
+// east_hip_build hands over 4 bytes per symbol, and the link moves 56 GB/s: 245 MB for the 64 MiB bench document are 4.4 ms
+// before the 1.7 ms build can start (tools/pcie_probe.py: pageable and pinned memory alike).  In the reference's encoding
+// a text symbol is below U+0A00 and everything else a terminator whose number the build never reads, so half the bytes
+// say it all: host threads narrow the symbols into the slots of the pinned ring (0xFFFF = "a terminator"), the slots go
+// up one DMA each, and a kernel behind every DMA widens them again into the staging area the build reads -- the link
+// carries 2 bytes per symbol, narrowing and widening hide under it.  (Tagged streams -- text above U+0A00 -- and small
+// inputs take the plain copy; a handle's first call too, while the ring is pinned in the background.)
+#define TP_RING_SLOTS 3                     // slots of TP_RING_SLOT bytes in a handle's pinned ring (common.h; tp_fill_stream further down)
+#define SYM_NARROW_MIN ((u32)4 << 20)
+#define SYM_TERMINATOR16 0xFFFFu
+static void ring_pin_later(east_hip_index *h);
+__global__ __launch_bounds__(BLOCK) void widen_symbols_kernel(const uint16_t *__restrict__ in, u32 n, u32 *__restrict__ out)
+{
+    const u32 i = (blockIdx.x * BLOCK + threadIdx.x) * 8u;
+    if (i + 8u <= n && ((uintptr_t)(in + i) & 15u) == 0 && ((uintptr_t)(out + i) & 15u) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + i);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+        u32 o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32 x = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            o[k] = x == SYM_TERMINATOR16 ? TEXT_SYMBOLS : x;
+        }
+        reinterpret_cast<uint4 *>(out + i)[0] = uint4{o[0], o[1], o[2], o[3]};
+        reinterpret_cast<uint4 *>(out + i)[1] = uint4{o[4], o[5], o[6], o[7]};
+    } else {
+        for (u32 j = i; j < i + 8u && j < n; j++) { const u32 x = in[j]; out[j] = x == SYM_TERMINATOR16 ? TEXT_SYMBOLS : x; }
+    }
+}
+
+// symbols [0, n) from the host into `staging` (device, n words) through the pinned ring; d_narrow: n + 8 halfwords of device scratch
+static void upload_symbols_narrow(east_hip_index *h, const u32 *sym, u32 n, u32 *staging, uint16_t *d_narrow)
+{
+    const size_t slot_syms = TP_RING_SLOT / 2;
+    const u32 n_slots = ceil_div_u32(n, slot_syms);
+    static const int threads_env = getenv("EAST_HIP_SYMBOL_THREADS") ? atoi(getenv("EAST_HIP_SYMBOL_THREADS")) : 0;     // (experiments)
+    const int n_fill = threads_env > 0 ? std::min(threads_env, 64) : (int)std::min<u32>(6u, std::max<u32>(2u, std::thread::hardware_concurrency() / 2u));
+    // (measured on the 256-thread host of the MI355X box, 61 M symbols: 3 threads 5.8-6.4 ms per call, 4: 5.2-5.5, 6: 4.7-5.6,
+    // 8-24: 4.9-5.9 -- against 6.1 ms with the plain 4-byte copy; the narrowing threads, not the link, set the pace)
+    if (h->ring_events.empty())
+        for (int i = 0; i < TP_RING_SLOTS; i++) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->ring_events.push_back(e);
+        }
+    // (the copy stream must not start before what is still queued on the handle's stream has left the arena alone)
+    HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    HIP_CHECK(hipStreamWaitEvent(h->copy_stream, h->ev0, 0));
+    std::vector<std::atomic<int>> slot_parts(n_slots);
+    for (auto &a : slot_parts) a.store(0, std::memory_order_relaxed);
+    std::atomic<u32> slots_free{TP_RING_SLOTS};
+    std::atomic<int> abort{0};
+    uint16_t *ring = (uint16_t *)h->ring;
+    std::vector<std::thread> fillers;
+    for (int j = 0; j < n_fill; j++)
+        fillers.emplace_back([&, j]() {
+            for (u32 sl = 0; sl < n_slots; sl++) {
+                while (slots_free.load(std::memory_order_acquire) <= sl) {
+                    if (abort.load(std::memory_order_acquire)) return;
+                    std::this_thread::yield();
+                }
+                const size_t a = (size_t)sl * slot_syms, len = std::min<size_t>(slot_syms, (size_t)n - a);
+                const size_t lo = len * (size_t)j / (size_t)n_fill, hi = len * (size_t)(j + 1) / (size_t)n_fill;
+                const u32 *src = sym + a;
+                uint16_t *dst = ring + (size_t)(sl % TP_RING_SLOTS) * slot_syms;
+                for (size_t i = lo; i < hi; i++) dst[i] = src[i] < TEXT_SYMBOLS ? (uint16_t)src[i] : (uint16_t)SYM_TERMINATOR16;
+                slot_parts[sl].fetch_add(1, std::memory_order_release);
+            }
+        });
+    struct Joiner {
+        std::vector<std::thread> &fill;
+        std::atomic<int> &abort;
+        hipStream_t copy;
+        bool ok = false;
+        ~Joiner()
+        {
+            if (!ok) abort.store(1, std::memory_order_release);
+            for (auto &f : fill)
+                if (f.joinable()) f.join();
+            if (!ok) (void)hipStreamSynchronize(copy);
+        }
+    } joiner{fillers, abort, h->copy_stream};
+    for (u32 sl = 0; sl < n_slots; sl++) {
+        while (slot_parts[sl].load(std::memory_order_acquire) < n_fill) std::this_thread::yield();
+        const size_t a = (size_t)sl * slot_syms, len = std::min<size_t>(slot_syms, (size_t)n - a);
+        HIP_CHECK(hipMemcpyAsync(d_narrow + a, ring + (size_t)(sl % TP_RING_SLOTS) * slot_syms, len * 2, hipMemcpyHostToDevice, h->copy_stream));
+        HIP_CHECK(hipEventRecord(h->ring_events[sl % TP_RING_SLOTS], h->copy_stream));
+        hipLaunchKernelGGL(widen_symbols_kernel, dim3(ceil_div_u32(len, BLOCK * 8)), dim3(BLOCK), 0, h->copy_stream, (const uint16_t *)(d_narrow + a),
+                           (u32)len, staging + a);
+        HIP_CHECK(hipGetLastError());
+        if (sl >= 1) {                                   // the slot before is on the device: back to the fill threads
+            HIP_CHECK(hipEventSynchronize(h->ring_events[(sl - 1) % TP_RING_SLOTS]));
+            slots_free.store(sl + TP_RING_SLOTS, std::memory_order_release);
+        }
+    }
+    joiner.ok = true;
+    HIP_CHECK(hipEventRecord(h->ev1, h->copy_stream));   // (ev0 / ev1 are recorded anew by the build behind this)
+    HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev1, 0));
+}
+
 static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i64 n_total, const i64 *doc_offsets,
                          const int32_t *n_strings, int32_t n_docs, bool tagged)
 {
@@ -981,7 +1083,14 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     h->built = false;
     const Knobs kn = knobs_snapshot();                   // (the test knobs of this call, from its sizing run to its last launch)
     const u32 n = (u32)n_total;
-    const size_t staging_bytes = sym_on_host ? ((size_t)n * 4 + 255) & ~(size_t)255 : 0;
+    // (host symbols of the reference encoding go up as 16-bit words where that pays: upload_symbols_narrow)
+    if (h->ring_alloc.joinable() && h->ring_pending.load()) h->ring_alloc.join();
+    if (!h->ring && !h->ring_alloc.joinable() && h->ring_pending.load()) h->ring = h->ring_pending.load();
+    const bool narrow_shape = sym_on_host && !tagged && n >= SYM_NARROW_MIN && getenv("EAST_HIP_NO_SYMBOL_NARROW") == nullptr;
+    const bool narrow = narrow_shape && h->ring != nullptr;
+    if (narrow_shape && !narrow) h->ring_wanted = true;      // (pinned in the background when this call is over)
+    const size_t narrow_bytes = narrow_shape ? (((size_t)n + 8) * 2 + 255) & ~(size_t)255 : 0;    // (also while the ring is still being pinned: the arena is sized once)
+    const size_t staging_bytes = (sym_on_host ? ((size_t)n * 4 + 255) & ~(size_t)255 : 0) + narrow_bytes;
     if (h->plan_n != n || h->plan_docs != (u32)n_docs || h->plan_epoch != kn.plan_epoch || h->plan_tagged != tagged) {     // (the sizing run costs host time: remembered per shape)
         h->plan_bytes = plan_arena_bytes(n, (u32)n_docs, false, tagged, &kn);
         h->plan_tagged = tagged;
@@ -1010,10 +1119,12 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     }
     if (sym_on_host) {   // raw symbols are staged at the top of the arena
         staging = (u32 *)(h->arena.base + (h->arena.cap - (((size_t)n * 4 + 255) & ~(size_t)255)));
-        HIP_CHECK(hipMemcpyAsync(staging, sym, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        if (narrow) upload_symbols_narrow(h, sym, n, staging, (uint16_t *)((char *)staging - narrow_bytes));
+        else HIP_CHECK(hipMemcpyAsync(staging, sym, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
         sym = staging;
     }
     h->stats = Stats();
+    h->narrow_upload = narrow;
     h->arena.high = 0;
     Ctx ctx;
     ctx.knobs = kn;
@@ -1093,6 +1204,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     h->h_doc_off.assign(doc_offsets, doc_offsets + n_docs + 1);
     h->h_n_strings.assign(n_strings, n_strings + n_docs);
     h->built = true;
+    ring_pin_later(h);
 }
 
 // ---------------------------------------------------------------- text prep --
@@ -1168,7 +1280,6 @@ static thread_local std::chrono::steady_clock::time_point g_tp_call_start;     /
 // than TP_RING_MAX_TEXT bytes on average therefore go through TP_RING_SLOTS slots of pinned memory: a few host threads
 // copy the stream -- text bytes and the 0xFF separators -- into a slot, each its share, while the slots before it are on
 // their way to the device (one DMA per slot and chunk, no set-up); the uploader thread alone talks to the runtime.
-#define TP_RING_SLOTS 3
 #define TP_RING_MAX_TEXT ((u64)8 << 20)
 #define TP_RING_FIRST_TEXTS 128u              // a handle's first call pins the ring in line only for this many texts or more
 
@@ -2337,15 +2448,15 @@ void *east_hip_stream(east_hip_handle_t h) { return h ? (void *)h->stream : null
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap)
 {
     if (!h || !out) return EAST_HIP_ERR_INVALID;
-    const int64_t v[25] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
+    const int64_t v[26] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
                            (int64_t)h->arena.cap, (int64_t)h->arena.high, h->stats.radix_passes,
                            h->stats.radix_elems, h->stats.radix_elem_bytes, h->stats.radix_passes_u32,
                            h->stats.radix_elems_u32, h->stats.radix_passes_u64, h->stats.radix_elems_u64,
                            h->stats.levels_resolved, h->stats.merge_elems, h->stats.refine_rounds,
                            h->stats.window_sorted, h->stats.lds_sorted, h->stats.fused_finish, h->stats.first_kept,
-                           h->stats.first_n, h->stats.ht_keys, h->stats.seg_sort};
-    for (int i = 0; i < 25 && i < cap; i++) out[i] = v[i];
-    return 25;
+                           h->stats.first_n, h->stats.ht_keys, h->stats.seg_sort, h->narrow_upload ? 1 : 0};
+    for (int i = 0; i < 26 && i < cap; i++) out[i] = v[i];
+    return 26;
 }
 
 int east_hip_profile_enable(east_hip_handle_t h, int on)

@@ -297,7 +297,9 @@ void *east_hip_stream(east_hip_handle_t h);
  * [20] 1 when the last radix digit and the placement ran as one pass in LDS (the fused finish), [21] suffixes the
  * first placement left in large tie groups, [22] of how many, [23] 1 when the first-level keys held variable-length
  * (order-preserving) code words instead of fixed-width symbol fields (csrc/ht_code.h), [24] 1 when the first-level sort
- * kept every document inside its own range of ranks (the segmented sort, csrc/radix_sort.h: RsSeg).
+ * kept every document inside its own range of ranks (the segmented sort, csrc/radix_sort.h: RsSeg), [25] 1 when
+ * east_hip_build's host symbols went up as 16-bit words through the pinned ring (half the bytes over the link; reference
+ * encoding, 4 Mi symbols or more, from a handle's second call on).
  */
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap);
 

@@ -1371,6 +1371,45 @@ def test_long_repeats_at_four_million_symbols(hip, oracle, request, case):
     assert checked > 0 or case in ("one_symbol", "period3")
 
 
+def test_host_symbols_go_up_as_16_bit_words(hip, oracle, request):
+    """east_hip_build from host symbols of the reference encoding (4 Mi symbols or more): from a handle's second call on --
+    the first one leaves the pinning of the ring to a background thread -- the symbols are narrowed to 16 bits by host
+    threads, go up through the pinned ring and are widened on the device (east_hip.hip: upload_symbols_narrow); text
+    symbols right below U+0A00 and terminators far above it included.  Tables and scores as with the plain copy and as
+    the oracle's."""
+    _only_paths(request, "window_sort", "dc3_only", "window_sort_seg")
+    import time
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(16)
+    docs = [synthetic.word_stream_document(rng, int(sz), want_text=False)[1:] for sz in (3 << 20, 2 << 20, 700000)]
+    docs[1][0][docs[1][0] == 65] = 0x09FF                     # a text symbol right below the terminator base
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])]).astype(np.int64)
+    ms = np.array([d[1] for d in docs], dtype=np.int32)
+    index = hip_backend.HipIndex(reserve_symbols=int(sym.size))           # (a handle of its own: none out of the pool)
+    index.build(sym, off, ms)
+    assert index.info()["narrow_upload"] == 0
+    want = {d: index.tables(d) for d in range(3)}
+    qs, qo = synthetic.keyphrases(rng, sym, 100)
+    table = index.score_table(qs, qo, True)
+    for _ in range(200):                                       # the ring is pinned in the background: a few milliseconds
+        time.sleep(0.01)
+        index.build(sym, off, ms)
+        if index.info()["narrow_upload"]:
+            break
+    assert index.info()["narrow_upload"] == 1
+    for d in range(3):
+        got = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(got[name], want[d][name]), (name, d)
+    assert np.array_equal(index.score_table(qs, qo, True), table)
+    o = oracle.OracleEASA(symbols=docs[1][0], n_strings=docs[1][1])
+    for name in TABLES:
+        assert np.array_equal(want[1][name], getattr(o, name)), name
+    index.build(sym[: off[1]], off[:2], ms[:1])                # smaller than the threshold: the plain copy again
+    assert index.info()["narrow_upload"] == 0
+
+
 def test_c_abi_rejects_inconsistent_input(hip):
     """n_strings that does not match the terminators, or a document without a final terminator,
     is an EAST_HIP_ERR_DOMAIN error (not silent garbage, not an out-of-bounds comparison)."""
