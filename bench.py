@@ -505,13 +505,18 @@ def extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D, 
         res["build_ms_without_guesses"] = min(times)
     # the build from host-resident symbols (east_hip_build: one 4 B/symbol H2D copy in front), wall clock
     walls = []
-    for _ in range(3):
+    for _ in range(6):
         t0 = time.perf_counter()
         index.build(symbols, doc_offsets, n_strings)
         walls.append((time.perf_counter() - t0) * 1e3)
-    res["build_from_host_ms"] = {"wall_ms_min": min(walls), "wall_ms_median": sorted(walls)[1],
-                                 "device_build_ms": index.last_build_ms, "h2d_bytes": int(symbols.size) * 4,
-                                 "note": "pageable host memory; the H2D copy precedes the build on the same stream"}
+    narrow = bool(index.info().get("narrow_upload"))
+    res["build_from_host_ms"] = {"wall_ms_min": min(walls), "wall_ms_median": sorted(walls)[len(walls) // 2], "wall_ms_first_call": walls[0],
+                                 "device_build_ms": index.last_build_ms, "h2d_bytes": int(symbols.size) * (2 if narrow else 4),
+                                 "symbols_as_16_bit_words": narrow,
+                                 "note": "pageable host memory in, index out.  A handle's first call copies 4 B/symbol (the link: 56 GB/s, "
+                                         "tools/pcie_probe.py) and leaves the pinning of the upload ring to a background thread; later "
+                                         "calls narrow the symbols to 16 bits on host threads, send them through the ring and widen "
+                                         "them on the device (east_hip.hip: upload_symbols_narrow)"}
     return res
 
 
