@@ -114,12 +114,11 @@ __global__ __launch_bounds__(BLOCK) void lg_rest_compact_kernel(LgUncovered left
 // One stable pass of the in-LDS radix sort: the elements of active waves (wave w owns the LG_IPT * 64
 // consecutive positions from w * LG_IPT * 64 on, row j = 64 consecutive ones) move to their places by the
 // 8-bit digit at `shift`; on return key[] / val[] hold the new occupants of the thread's positions.
-// (n_waves: the active waves, 0 .. n_waves - 1 -- the others hold nothing and only keep the barriers)
-__device__ __forceinline__ void lg_radix_pass(LgLds &lds, u64 (&key)[LG_IPT], u32 (&val)[LG_IPT], int shift, bool active,
-                                              u32 n_waves)
+// (waves behind the tile's elements hold nothing and only keep the barriers)
+__device__ __forceinline__ void lg_radix_pass(LgLds &lds, u64 (&key)[LG_IPT], u32 (&val)[LG_IPT], int shift, bool active)
 {
     const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    for (u32 i = tid; i < n_waves * 128u; i += LG_THREADS) (&lds.wave_cnt[0][0])[i] = 0;
+    for (u32 i = tid; i < LG_WAVES * 128u; i += LG_THREADS) (&lds.wave_cnt[0][0])[i] = 0;   // (all rows: the sums below run over all of them)
     __syncthreads();
     u32 slot[LG_IPT];
     if (active) {
@@ -149,10 +148,13 @@ __device__ __forceinline__ void lg_radix_pass(LgLds &lds, u64 (&key)[LG_IPT], u3
     u32 tot_lo = 0, tot_hi = 0;
     if (tid < 128u) {
         u32 run = 0;                                    // both halves at once: the sums stay below 2^16
-        for (u32 k = 0; k < n_waves; k++) {
-            const u32 c = lds.wave_cnt[k][tid];
+        u32 c[LG_WAVES];                                // (a fixed trip count: the loads go out back to back -- with the loop
+#pragma unroll                                          // bounded by the active waves every step waited for its own load)
+        for (int k = 0; k < LG_WAVES; k++) c[k] = lds.wave_cnt[k][tid];
+#pragma unroll
+        for (int k = 0; k < LG_WAVES; k++) {
             lds.wave_cnt[k][tid] = run;
-            run += c;
+            run += c[k];
         }
         tot_lo = run & 0xFFFFu;
         tot_hi = run >> 16;
@@ -289,41 +291,57 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
     const int bits = wbits + (n_groups > 1u ? 32 - (int)__builtin_clz(n_groups - 1u) : 0);
     const bool active = w * (LG_IPT * WAVE) < n_act;
     // ---- keys from the text ----
+    // Three steps, each over all of the thread's rows, with no branch in between: the elements (coalesced), then every
+    // gather at once, then the keys -- row by row a thread waited for three dependent loads per row.  (Rows behind the
+    // tile's end read its last element and are overwritten.  Measured: 3 % of the kernel.  The same treatment of the slots
+    // in the write-back below made the kernel 50 % SLOWER on natural-language text, 1.36 -> 2.06 ms -- same registers, same
+    // occupancy, not explained --, so that loop stays row by row.)
     u64 key[LG_IPT];
     u32 val[LG_IPT];
     if (active) {
+        u32 gid[LG_IPT], xd[LG_IPT];
 #pragma unroll
         for (int j = 0; j < LG_IPT; j++) {
             const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
-            key[j] = ~0ull;                             // (padding: behind everything, in every digit)
-            val[j] = 0u;
-            if (local < n_act) {
-                const u32 q = begin_q + local;
-                const u32 e = elems[base + q];
-                const u32 gid = lds.word_prefix[q >> 6] + (u32)__popcll(lds.start_bits[q >> 6] & (((u64)2 << (q & 63u)) - 1ull)) - 1u;
-                u64 k = gid;
-                if (name_of) {
-                    k = (k << wbits) | (u64)name_of[e + depth];
-                } else {
-                    const u32 p = lvl0_pos(e, n0) + depth + (cls.xdep ? (u32)cls.xdep[base + q] : 0u);
-                    u64 lo8, hi8;
-                    __builtin_memcpy(&lo8, s8 + p, 8);
-                    __builtin_memcpy(&hi8, s8 + p + 8, 8);
-                    bool ended = false;
-                    for (int i = 0; i < w2; i++) {
-                        const u32 byte = (u32)((i < 8 ? lo8 >> (8 * i) : hi8 >> (8 * (i - 8))) & 0xFFu);
-                        const u32 x = ended ? 0u : byte;
-                        ended = ended || x == 0xFFu;
-                        k = (k << b) | (u64)(x == 0xFFu ? term_first : x);
-                    }
+            const u32 q = begin_q + (local < n_act ? local : n_act - 1u);
+            val[j] = elems[base + q];
+            xd[j] = cls.xdep ? (u32)cls.xdep[base + q] : 0u;
+            gid[j] = lds.word_prefix[q >> 6] + (u32)__popcll(lds.start_bits[q >> 6] & (((u64)2 << (q & 63u)) - 1ull)) - 1u;
+        }
+        if (name_of) {
+            u32 nm[LG_IPT];
+#pragma unroll
+            for (int j = 0; j < LG_IPT; j++) nm[j] = name_of[val[j] + depth];
+#pragma unroll
+            for (int j = 0; j < LG_IPT; j++) key[j] = ((u64)gid[j] << wbits) | (u64)nm[j];
+        } else {
+            u64 lo8[LG_IPT], hi8[LG_IPT];
+#pragma unroll
+            for (int j = 0; j < LG_IPT; j++) {
+                const u32 p = lvl0_pos(val[j], n0) + depth + xd[j];
+                __builtin_memcpy(&lo8[j], s8 + p, 8);
+                __builtin_memcpy(&hi8[j], s8 + p + 8, 8);
+            }
+#pragma unroll
+            for (int j = 0; j < LG_IPT; j++) {
+                u64 k = gid[j];
+                bool ended = false;
+                for (int i = 0; i < w2; i++) {
+                    const u32 byte = (u32)((i < 8 ? lo8[j] >> (8 * i) : hi8[j] >> (8 * (i - 8))) & 0xFFu);
+                    const u32 x = ended ? 0u : byte;
+                    ended = ended || x == 0xFFu;
+                    k = (k << b) | (u64)(x == 0xFFu ? term_first : x);
                 }
                 key[j] = k;
-                val[j] = e;
             }
         }
+#pragma unroll
+        for (int j = 0; j < LG_IPT; j++) {
+            const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+            if (local >= n_act) { key[j] = ~0ull; val[j] = 0u; }      // (padding: behind everything, in every digit)
+        }
     }
-    const u32 n_waves = (n_act + LG_IPT * WAVE - 1u) / (LG_IPT * WAVE);
-    for (int shift = 0; shift < bits; shift += 8) lg_radix_pass(lds, key, val, shift, active, n_waves);
+    for (int shift = 0; shift < bits; shift += 8) lg_radix_pass(lds, key, val, shift, active);
     // ---- what the round's write-back writes, for the tile ----
     const bool fuse = cls.keep != nullptr && !name_of;  // (uniform over the workgroup)
     if (!active && !fuse) return;
