@@ -1673,13 +1673,23 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_compact_kernel(const u32 *__
     if (!nib) return;
     // (the rank of the first kept position among the kept ones; the others follow)
     u32 k = idx.word_prefix[j0 >> 6] + (u32)__popcll(word & (((u64)1 << (j0 & 63u)) - 1ull));
+    // (what the four positions need is read for all four before any of it is used: one wait instead of one per kept
+    // position -- the lines are the same ones)
+    u32 st4[COMPACT_IPT], el4[COMPACT_IPT], sl4[COMPACT_IPT];
+#pragma unroll
+    for (int e = 0; e < COMPACT_IPT; e++) {
+        const u32 j = j0 + e < m ? j0 + e : j0;
+        st4[e] = starts(j);
+        el4[e] = elem[j];
+        sl4[e] = slot ? slot[j] : j;
+    }
 #pragma unroll
     for (int e = 0; e < COMPACT_IPT; e++) {
         const u32 j = j0 + e;
         if (j >= m || !((nib >> e) & 1u)) continue;
-        const u32 st = starts(j);
-        slot_out[k] = slot ? slot[j] : j;
-        elem_out[k] = elem[j];
+        const u32 st = st4[e];
+        slot_out[k] = sl4[e];
+        elem_out[k] = el4[e];
         group_start[k] = st;
         if (xdep_out) xdep_out[k] = xdep_in ? xdep_in[j] : (uint8_t)0;
         if constexpr (Starts::HAS_KEYS) {
