@@ -97,7 +97,11 @@ int east_hip_reset(east_hip_handle_t h);
  * suffixes with tie refinement, data-parallel DC3 as the fallback -- DESIGN.md 4;
  * either way the tables are bit for bit what easa.py computes.)  east_hip_build_device takes a
  * DEVICE pointer for `symbols` (doc_offsets / n_strings stay host pointers);
- * the buffer is only read.
+ * the buffer is only read.  east_hip_build's copy to the device: symbols of the reference's
+ * encoding fit 16 bits, so from 4 Mi symbols on -- and from a handle's second build on, when its
+ * pinned upload ring exists -- host threads narrow them to 16-bit words into the ring and a kernel
+ * widens them on the device (half the bytes over the link; east_hip_build_info [25]); anything else,
+ * and a symbol that does not fit, takes the plain 4-byte copy.
  */
 /*
  * Which encoding east_hip_build / east_hip_build_device read on this handle (default: the reference's).
