@@ -100,8 +100,9 @@ int east_hip_reset(east_hip_handle_t h);
  * the buffer is only read.  east_hip_build's copy to the device: symbols of the reference's
  * encoding fit 16 bits, so from 4 Mi symbols on -- and from a handle's second build on, when its
  * pinned upload ring exists -- host threads narrow them to 16-bit words into the ring and a kernel
- * widens them on the device (half the bytes over the link; east_hip_build_info [25]); anything else,
- * and a symbol that does not fit, takes the plain 4-byte copy.
+ * widens them on the device (half the bytes over the link; east_hip_build_info [25]) -- a text symbol
+ * is below U+0A00, everything from there on is a terminator, whose number the build never reads --;
+ * tagged streams, small inputs and a handle's first build take the plain 4-byte copy.
  */
 /*
  * Which encoding east_hip_build / east_hip_build_device read on this handle (default: the reference's).
