@@ -175,6 +175,7 @@ struct Knobs {
     bool kg_pairs = getenv("EAST_HIP_NO_KG_PAIRS") == nullptr;          // east_hip_debug_set_score_path
     bool kg_pairs_forced = false;                                       // ... (4)
     bool score_fused = getenv("EAST_HIP_SCORE_UNFUSED") == nullptr;     // ... (1 / 3 / 4)
+    int score_endgame = env_int("EAST_HIP_SCORE_ENDGAME", 1);           // KgTables::endgame (A/B timing; east_hip_debug_set_score_path 5 switches it off)
     size_t score_scratch_bytes = SCORE_SCRATCH_BYTES;                   // east_hip_debug_set_score_scratch
     u64 score_grid_blocks = SCORE_GRID_BLOCKS;                          // east_hip_debug_set_score_grid
     i64 tp_stream = getenv("EAST_HIP_TEXT_STREAM") ? atoll(getenv("EAST_HIP_TEXT_STREAM")) : -1;   // east_hip_debug_set_text_stream

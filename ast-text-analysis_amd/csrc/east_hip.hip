@@ -2060,6 +2060,7 @@ static void score_resident(east_hip_index *h, int normalized, unsigned long long
         kt.up_lds = !up_lds_off && h->kg_up_stride <= KG_UP_LDS_WORDS;
     }
     if (kt.k > 0) kt.finish();
+    kt.endgame = ctx.knobs.score_endgame;
     // whole keyphrases per workgroup, summed in the walk (no per-suffix results unless the caller wants them: then the
     // documents go a stretch at a time, as far as the scratch reaches); otherwise per-suffix results + the reduction kernel
     const bool fused = h->n_blk > 0;
@@ -2662,9 +2663,10 @@ int east_hip_debug_set_score_path(int mode)
     // HBM and a reduction kernel; 2: pair tables, separate reduction; 3: filled table, the sums inside the walk.
     // (takes effect with the next build / the next set of keyphrases)
     knobs_update([&](Knobs &k) {
-        k.kg_pairs = mode == 1 || mode == 2 || mode == 4;
+        k.kg_pairs = mode == 1 || mode == 2 || mode == 4 || mode == 5;
         k.kg_pairs_forced = mode == 4;                  // 4: as 1, the pair tables also for collections of fewer than 16 documents
-        k.score_fused = mode == 1 || mode == 3 || mode == 4;
+        k.score_fused = mode == 1 || mode == 3 || mode == 4 || mode == 5;
+        k.score_endgame = mode == 5 ? 0 : 1;                 // 5: as 1, binary search down to the last suffix (no register endgame)
     });
     return EAST_HIP_OK;
 }

@@ -277,11 +277,13 @@ __global__ __launch_bounds__(BLOCK) void query_map_kernel(const u32 *__restrict_
 // A^2 + 1, ... entries one after the other, copied out of kg3 once it is filled), so that EVERY level's interval is two
 // adjacent entries -- one 8-byte load per level.  (The walk is bound by the number of address-divergent loads a
 // wavefront issues -- every lane another sector --, not by bytes and not by the length of its dependency chain.)
+#define WALK_ENDGAME 4u                    // suffixes a walk holds in registers once its interval is that small (score_walk_suffix)
 #define KG_UP_LDS_WORDS 1024u              // the small upper tables of one document staged in LDS (A + 1 + A^2 + 1 <= 1024: A <= 30)
 struct KgTables {
     const u32 *kg = nullptr, *kg3 = nullptr, *up = nullptr;
     int k = 0, pairs = 0;
     int up_lds = 0;                         // the walk kernel stages the document's `up` tables in LDS (they fit KG_UP_LDS_WORDS)
+    int endgame = 1;                        // intervals of at most WALK_ENDGAME suffixes are finished out of registers (0: binary search to the end)
     u32 A = 0, bins = 0, up_stride = 0;
     // (set by the host, so that no walk divides: the bins of the table the levels 1 .. k3 read -- bins / A with pairs -- and
     // the stride of level i in it, A^(k3 - 1 - i))
@@ -298,19 +300,95 @@ struct KgTables {
 };
 static_assert(KGRAM_KEYS_MAX_K == 4, "KgTables::stride");
 
-__device__ __forceinline__ uint2 load_pair_u32(const u32 *p)       // two adjacent 4-byte entries (4-byte aligned)
+// Two adjacent 4-byte entries (4-byte aligned) as ONE 8-byte load.  (A memcpy of 8 bytes is two 4-byte loads until the
+// backend's vectoriser pairs them again, and it did not where the optimiser had first folded this path and the two-load
+// path beside it into "two loads from two selected addresses": global_load_dword x 2 instead of dwordx2 in every walk --
+// 1.27 against 1.18 ms for the walk of configs[2].  A typed load of an under-aligned 64-bit struct stays one load.)
+struct __attribute__((packed, aligned(4))) U64Align4 { u64 v; };
+struct __attribute__((packed, aligned(8))) U128Align8 { u64 lo, hi; };
+struct __attribute__((packed, aligned(4))) U128Align4 { u32 a, b, c, d; };
+__device__ __forceinline__ uint2 load_pair_u32(const u32 *p)
 {
-    uint2 v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
+    const u64 v = reinterpret_cast<const U64Align4 *>(p)->v;
+    return uint2{(u32)v, (u32)(v >> 32)};
+}
+__device__ __forceinline__ uint4 load_quad_u32(const void *p)      // 16 bytes, 8-byte aligned
+{
+    const U128Align8 v = *reinterpret_cast<const U128Align8 *>(p);
+    return uint4{(u32)v.lo, (u32)(v.lo >> 32), (u32)v.hi, (u32)(v.hi >> 32)};
+}
+
+// The endgame of a walk: an interval of at most WALK_ENDGAME suffixes (behind four table levels a bucket of a 1 MiB
+// document holds 2.4 on average).  A binary search would fetch suffix array entry and symbol of one rank after the other --
+// 3 to 4 probes of two dependent loads each per query symbol; here the interval's entries come with ONE 16-byte load, the
+// text behind every one of them four symbols at a time, side by side, and the walk goes on out of registers: the child
+// interval of a symbol is the run of suffixes that carry it (symbols at a fixed depth are sorted inside an interval),
+// counted.  Same intervals, same sums -- half the vector memory instructions per wavefront, which is what the walk is
+// bound by, and two round trips instead of six to eight.  qsym(t): the query symbol at t.
+// (Measured and not kept: only the members behind the first one fetched -- its position comes with the table entry --, with
+// a load as wide as they are: two instructions where there was one, 1.12 -> 1.17 ms at configs[2].)
+template <class SYM, class Q>
+__device__ __forceinline__ void walk_endgame(const SYM *__restrict__ s, const u32 *__restrict__ sad, u32 nd, u32 root_ann, Q qsym,
+                                             u32 t, u32 end, u32 lo, u32 hi, u32 &depth, u32 &nodes, double &acc, bool have_p,
+                                             u32 p_lo, u32 &probes)
+{
+    const u32 n = hi - lo + 1;
+    u32 p[WALK_ENDGAME];
+    if (n == 1 && have_p) {
+        p[0] = p_lo; p[1] = p[2] = p[3] = 0;
+    } else if (nd >= WALK_ENDGAME) {
+        const u32 base = lo + (WALK_ENDGAME - 1) < nd ? lo : nd - WALK_ENDGAME;     // (the 16 bytes stay inside the document's array)
+        const U128Align4 q4 = *reinterpret_cast<const U128Align4 *>(sad + base);
+        p[0] = q4.a; p[1] = q4.b; p[2] = q4.c; p[3] = q4.d;
+        for (u32 sh = lo - base; sh > 0; sh--) { p[0] = p[1]; p[1] = p[2]; p[2] = p[3]; }
+    } else {
+#pragma unroll
+        for (u32 i = 0; i < WALK_ENDGAME; i++) p[i] = i < n ? sad[lo + i] : 0u;
+    }
+    probes += n;
+    u32 i0 = 0, i1 = n - 1;                               // the members of the interval still in the walk: p[i0 .. i1]
+    u32 word[WALK_ENDGAME], d0 = depth;                   // their symbols at the depths d0 .. d0 + 3 (byte stream) / at d0
+    auto fetch = [&]() {
+#pragma unroll
+        for (u32 i = 0; i < WALK_ENDGAME; i++) {
+            const bool on = i >= i0 && i <= i1;
+            if constexpr (sizeof(SYM) == 1) { u32 x = 0; if (on) __builtin_memcpy(&x, s + p[i] + depth, 4); word[i] = x; }
+            else word[i] = on ? (u32)s[p[i] + depth] : 0u;
+        }
+        d0 = depth;
+    };
+    fetch();
+    for (; t < end; t++) {
+        const u32 c = qsym(t);
+        if (c == Q_NOMATCH) break;
+        if (depth - d0 >= (sizeof(SYM) == 1 ? 4u : 1u)) { fetch(); probes += (i1 - i0 + 2) >> 1; }
+        const u32 shift = sizeof(SYM) == 1 ? 8u * (depth - d0) : 0u;
+        u32 lt = 0, eq = 0;
+#pragma unroll
+        for (u32 i = 0; i < WALK_ENDGAME; i++) {
+            const u32 x = sizeof(SYM) == 1 ? (word[i] >> shift) & 0xFFu : word[i];
+            const bool on = i >= i0 && i <= i1;
+            lt += on && x < c ? 1u : 0u;
+            eq += on && x == c ? 1u : 0u;
+        }
+        if (eq == 0) break;                               // no suffix continues with c
+        i0 += lt; i1 = i0 + eq - 1;
+        const u32 a = lo + lt, b = a + eq - 1;
+        if (b - a < hi - lo) {                            // (score_walk_suffix: enter)
+            const u32 parent = depth == 0 ? root_ann : hi - lo + 1;
+            acc += (double)(b - a + 1) / (double)parent;
+            nodes++;
+        }
+        lo = a; hi = b; depth++;
+    }
 }
 
 // One walk: the keyphrase suffix q_code[t0 .. end) down document d's annotated suffix array (sad / nd / root_ann).
 // SYM = uint8_t: the byte stream (a quarter of the footprint; 0xFF terminators sort above every
 // text code, which is all the binary search needs), SYM = u32: the dense symbol stream.
-template <class SYM>
+template <class SYM, class Q>
 __device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, const u32 *__restrict__ sad, u32 nd, u32 root_ann,
-                                                    const u32 *__restrict__ q_code, u32 t0, u32 end, int normalized,
+                                                    Q q_sym, u32 t0, u32 end, int normalized,
                                                     const KgTables &kt, u32 d, u32 &probes, const u32 *up_lds = nullptr)
 {
     u32 lo = 0, hi = nd - 1, depth = 0, nodes = 0;
@@ -339,7 +417,7 @@ __device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, c
         int L = 0;                                        // query symbols the table levels can take
 #pragma unroll
         for (int i = 0; i < KGRAM_KEYS_MAX_K; i++) {
-            const u32 c = (i < kt.k && t0 + (u32)i < end) ? q_code[t0 + i] : Q_NOMATCH;
+            const u32 c = (i < kt.k && t0 + (u32)i < end) ? q_sym(t0 + (u32)i) : Q_NOMATCH;
             cs[i] = c;
             if (c != Q_NOMATCH && L == i) L = i + 1;
         }
@@ -371,8 +449,7 @@ __device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, c
         const bool last = kt.pairs && L == kt.k;           // (then k3 = k - 1 levels were taken above)
         if (last) {
             g = code * kt.A + cs[kt.k - 1];
-            uint4 ee;                                      // the entry and its successor: one 16-byte load (8-byte aligned)
-            __builtin_memcpy(&ee, row2 + g, 16);
+            const uint4 ee = load_quad_u32(row2 + g);      // the entry and its successor: one 16-byte load (8-byte aligned)
             e0 = uint2{ee.x, ee.y};
             e1 = ee.z;
         }
@@ -399,7 +476,8 @@ __device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, c
         if (ended || depth < (u32)kt.k) t = end;          // the walk ended inside the table levels
     }
     for (; t < end; t++) {
-        const u32 c = q_code[t];
+        if (kt.endgame && hi - lo < WALK_ENDGAME) break;                // few suffixes left: see below
+        const u32 c = q_sym(t);
         if (c == Q_NOMATCH) break;
         u32 a, b;
         if (lo == hi) {
@@ -426,6 +504,8 @@ __device__ __forceinline__ double score_walk_suffix(const SYM *__restrict__ s, c
         }
         enter(a, b);
     }
+    if (kt.endgame && t < end && hi - lo < WALK_ENDGAME)
+        walk_endgame<SYM>(s, sad, nd, root_ann, q_sym, t, end, lo, hi, depth, nodes, acc, have_p, p_lo, probes);
     double r = 0.0;
     if (depth > 0) {
         r = (acc + (double)depth) - (double)nodes;        // easa.py:127
@@ -480,7 +560,8 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
         u32 probes = 0;                 // table reads and binary-search probes of this walk (roofline accounting)
         const u32 seg = doc_off[d];
         const u32 nd = doc_off[d + 1] - seg;
-        r = score_walk_suffix<SYM>(s, sa + seg, nd, nd - n_strings[d], q_code, si, q_end[si], normalized, kt, d, probes, up_lds);
+        r = score_walk_suffix<SYM>(s, sa + seg, nd, nd - n_strings[d], [&](u32 t) { return q_code[t]; }, si, q_end[si], normalized,
+                                   kt, d, probes, up_lds);
         if (suffix_out) suffix_out[(u64)dl * n_q + si] = r;
         if (probe_count) atomicAdd(probe_count, (unsigned long long)probes);   // (counting runs only: east_hip_score_probes)
     }

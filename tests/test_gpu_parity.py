@@ -1864,7 +1864,7 @@ def test_score_walk_grid_is_bounded(hip, oracle):
             assert want[True][k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=True), (d, k)
 
 
-@pytest.mark.parametrize("mode", [1, 0, 2, 3, 4])
+@pytest.mark.parametrize("mode", [1, 0, 2, 3, 4, 5])
 def test_score_path_variants(hip, oracle, mode):
     """The score walk's two choices (east_hip_debug_set_score_path): k-gram tables in the pair layout (last level
     unfilled, 8-byte entries with the suffix position; the level above in a table of its own) or as one filled table,
