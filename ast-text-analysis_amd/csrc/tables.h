@@ -624,13 +624,15 @@ __global__ __launch_bounds__(BLOCK) void ann_stream_kernel(const u32 *__restrict
         if (k0 + 1 >= n) x.y = 0u;
         if (k0 + 2 >= n) x.z = 0u;
         if (k0 + 3 >= n) x.w = 0u;
+        // (the halo is requested before the stretch is staged: one round trip for both)
+        const bool has_halo = threadIdx.x < 2 * ANN_HALO / 4;       // ANN_HALO ranks to the left (first threads) and to the right (the next ones)
+        const bool left = threadIdx.x < ANN_HALO / 4;
+        const u32 q = left ? threadIdx.x : threadIdx.x - ANN_HALO / 4;
+        const i64 g = left ? (i64)tile_base - ANN_HALO + 4 * q : (i64)tile_base + ANN_TILE + 4 * q;
+        uint4 h = {0u, 0u, 0u, 0u};
+        if (has_halo && g >= 0 && g < (i64)((n + PYR_FAN - 1u) & ~(PYR_FAN - 1u))) h = *reinterpret_cast<const uint4 *>(lcp + g);
         *reinterpret_cast<uint4 *>(&tile[ANN_HALO + threadIdx.x * ANN_IPT]) = x;
-        if (threadIdx.x < 2 * ANN_HALO / 4) {   // ANN_HALO ranks to the left (first threads) and to the right (the next ones)
-            const bool left = threadIdx.x < ANN_HALO / 4;
-            const u32 q = left ? threadIdx.x : threadIdx.x - ANN_HALO / 4;
-            const i64 g = left ? (i64)tile_base - ANN_HALO + 4 * q : (i64)tile_base + ANN_TILE + 4 * q;
-            uint4 h = {0u, 0u, 0u, 0u};
-            if (g >= 0 && g < (i64)((n + PYR_FAN - 1u) & ~(PYR_FAN - 1u))) h = *reinterpret_cast<const uint4 *>(lcp + g);
+        if (has_halo) {
             if (g + 0 >= (i64)n) h.x = 0u;
             if (g + 1 >= (i64)n) h.y = 0u;
             if (g + 2 >= (i64)n) h.z = 0u;

@@ -1251,25 +1251,27 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
                 valid |= ok ? 1u << e : 0u;
             }
         }
+        // (every load of the prologue is requested before the first one is used: with the staging of the stretch in between,
+        // the halo loads waited for the stretch's and for each other -- three round trips where one does)
+        key[FIN_IPT] = 0; val[FIN_IPT] = 0;
+        if (tid <= (u32)G) {
+            const u32 jr = c0 + FIN_CHUNK + tid;        // right halo
+            if (jr < m) { key[FIN_IPT] = a.keys[jr]; val[FIN_IPT] = a.vals[jr]; valid |= 16u; }
+        }
+        K key_l = 0;
+        u32 val_l = 0;
+        if (tid < (u32)FIN_LEFT) {                      // left halo (never moved)
+            const u32 jl = base + tid;
+            if (jl < m) { key_l = a.keys[jl]; val_l = a.vals[jl]; }
+        }
         if constexpr (sizeof(K) == 4) *reinterpret_cast<uint4 *>(&kt[i0]) = uint4{(u32)key[0], (u32)key[1], (u32)key[2], (u32)key[3]};
         else {
 #pragma unroll
             for (int e = 0; e < FIN_IPT; e++) kt[i0 + e] = key[e];
         }
         *reinterpret_cast<uint4 *>(&vt[i0]) = uint4{val[0], val[1], val[2], val[3]};
-        key[FIN_IPT] = 0; val[FIN_IPT] = 0;
-        if (tid <= (u32)G) {
-            const u32 jr = c0 + FIN_CHUNK + tid;        // right halo
-            if (jr < m) { key[FIN_IPT] = a.keys[jr]; val[FIN_IPT] = a.vals[jr]; valid |= 16u; }
-            kt[ih] = key[FIN_IPT];
-            vt[ih] = val[FIN_IPT];
-        }
-        if (tid < (u32)FIN_LEFT) {                      // left halo (never moved)
-            const u32 jl = base + tid;
-            const bool okl = jl < m;
-            kt[tid] = okl ? a.keys[jl] : (K)0;
-            vt[tid] = okl ? a.vals[jl] : 0u;
-        }
+        if (tid <= (u32)G) { kt[ih] = key[FIN_IPT]; vt[ih] = val[FIN_IPT]; }
+        if (tid < (u32)FIN_LEFT) { kt[tid] = key_l; vt[tid] = val_l; }
     }
     __syncthreads();
     // ---- bucket starts: the top part differs from the rank before (rank 0 and rank m count as starts) ----
