@@ -772,52 +772,57 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     __shared__ uint8_t dep_tile[HT ? BLOCK * PLACE_IPT : 1];   // whole symbols of the stretch's keys
     __shared__ DocHint kg_hint;                         // (segmented sort) the document of the stretch's first rank
     if (threadIdx.x < BLOCK * PLACE_IPT / 32) keep_bits[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        n_keep = 0; n_work = 0;
-        kg_hint = sr.n_docs ? doc_hint_of_rank(sr.doc_off, sr.n_docs, blockIdx.x * (BLOCK * PLACE_IPT)) : DocHint{0u, 0u, 0u};
-    }
+    if (threadIdx.x == 0) { n_keep = 0; n_work = 0; }
     if constexpr (HT) {
         for (u32 i = threadIdx.x; i < HT_DEC_SIZE; i += BLOCK) dec_lds[i] = f.ht_dec[i];
         if (threadIdx.x < TB_WORDS) term_bits[threadIdx.x] = 0;
     }
-    __syncthreads();
+    // (every load of the prologue is requested in front of the first barrier: behind it -- as this was written until round 5
+    // -- the halo's loads and then the stretch's each waited a round trip of their own, after thread 0's search for the
+    // stretch's document, which now runs while they are in flight)
     const u32 j0 = (blockIdx.x * BLOCK + threadIdx.x) * PLACE_IPT;
     u32 my_keep = 0;                                    // suffixes this thread left to the rounds
-    {   // PLACE_HALO entries to either side of the stretch (threads 0 .. 2*PLACE_HALO-1, one each)
-        const u32 stretch0 = blockIdx.x * (BLOCK * PLACE_IPT);
-        if (threadIdx.x < 2 * PLACE_HALO) {
-            const bool left = threadIdx.x < PLACE_HALO;
-            const u32 q = left ? threadIdx.x : threadIdx.x - PLACE_HALO;
-            const u64 g = left ? (u64)stretch0 + q - PLACE_HALO : (u64)stretch0 + BLOCK * PLACE_IPT + q;    // (wraps below 0: skipped)
-            if ((!left || stretch0 >= PLACE_HALO) && g < (u64)m + 8) {
-                const K hk = f.keys[g];
-                const u32 at = left ? q : PLACE_HALO + BLOCK * PLACE_IPT + q;
-                key_tile[at] = hk;
-                val_tile[at] = vals[g];
-                if constexpr (HT)
-                    if (g < m && f.ht_read(hk, hk, dec_lds).term) atomicOr(&term_bits[at >> 5], 1u << (at & 31u));
-            }
-        }
-    }
+    // PLACE_HALO entries to either side of the stretch (threads 0 .. 2*PLACE_HALO-1, one each)
+    const u32 stretch0 = blockIdx.x * (BLOCK * PLACE_IPT);
+    const bool halo_left = threadIdx.x < PLACE_HALO;
+    const u32 halo_q = halo_left ? threadIdx.x : threadIdx.x - PLACE_HALO;
+    const u64 halo_g = halo_left ? (u64)stretch0 + halo_q - PLACE_HALO : (u64)stretch0 + BLOCK * PLACE_IPT + halo_q;    // (wraps below 0: skipped)
+    const bool has_halo = threadIdx.x < 2 * PLACE_HALO && (!halo_left || stretch0 >= PLACE_HALO) && halo_g < (u64)m + 8;
+    // (unconditional loads -- a lane with nothing to fetch reads entry 0 --: behind a branch the compiler waits for each load
+    // where the branch ends, one round trip per load)
+    const u64 halo_at = has_halo ? halo_g : 0u;
+    const K halo_k = f.keys[halo_at];
+    const u32 halo_v = vals[halo_at];
     K k[PLACE_IPT + 2];
     u32 v[PLACE_IPT];
     u32 work_mask = 0;                                  // bit e: rank j0 + e goes to phase 2
-    if (j0 < m) {
+    {
         // keys j0 .. j0+3 and their elements: 16-byte loads (the arrays carry 8 spare entries behind m: whole groups of 4);
         // the keys to either side (j0-1, j0+4) come out of the staged tile behind the barrier -- variable-length keys read
         // them before it (the walk over the five keys), from the array
-        {
-            K k4[5];
-            fin_load4<K>(f.keys + j0, k4);
+        const u32 jl = j0 < m ? j0 : 0u;
+        K k4[5];
+        fin_load4<K>(f.keys + jl, k4);
 #pragma unroll
-            for (int e = 0; e < PLACE_IPT; e++) k[e + 1] = k4[e];
-            const uint4 q = *reinterpret_cast<const uint4 *>(vals + j0);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        }
+        for (int e = 0; e < PLACE_IPT; e++) k[e + 1] = k4[e];
+        const uint4 q = *reinterpret_cast<const uint4 *>(vals + jl);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
         if constexpr (HT) {
-            k[0] = j0 > 0 ? f.keys[j0 - 1] : (K)0;
-            k[PLACE_IPT + 1] = f.keys[j0 + PLACE_IPT];
+            k[0] = jl > 0 ? f.keys[jl - 1] : (K)0;
+            k[PLACE_IPT + 1] = f.keys[jl + PLACE_IPT];
         }
+    }
+    if (threadIdx.x == 0)
+        kg_hint = sr.n_docs ? doc_hint_of_rank(sr.doc_off, sr.n_docs, blockIdx.x * (BLOCK * PLACE_IPT)) : DocHint{0u, 0u, 0u};
+    __syncthreads();
+    if (has_halo) {
+        const u32 at = halo_left ? halo_q : PLACE_HALO + BLOCK * PLACE_IPT + halo_q;
+        key_tile[at] = halo_k;
+        val_tile[at] = halo_v;
+        if constexpr (HT)
+            if (halo_g < m && f.ht_read(halo_k, halo_k, dec_lds).term) atomicOr(&term_bits[at >> 5], 1u << (at & 31u));
+    }
+    if (j0 < m) {
         const u32 at0 = PLACE_HALO + threadIdx.x * PLACE_IPT;
         if constexpr (sizeof(K) == 4) *reinterpret_cast<uint4 *>(&key_tile[at0]) = uint4{(u32)k[1], (u32)k[2], (u32)k[3], (u32)k[4]};
         else {
