@@ -150,6 +150,10 @@ __global__ __launch_bounds__(RS_HIST_THREADS) void radix_hist_kernel(Src src, u3
                     uint4 q[RS_HIST_BATCH];
 #pragma unroll
                     for (int j = 0; j < RS_HIST_BATCH; j++) __builtin_memcpy(&q[j], p + (size_t)(j0 + j) * WAVE * 16u, 16);
+                    // (nothing moves across this line: without the one-bin test the loop body is one basic block, and the
+                    // scheduler -- after the fewest registers -- put every load next to its four adds, each with a wait of
+                    // its own: one load in flight per wave instead of the batch)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < RS_HIST_BATCH; j++) {
                         if constexpr (sizeof(K) == 8) {

@@ -206,6 +206,15 @@ def roofline_of(prof, info, n, n_docs, steps, traffic):
             entry.update({"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(name)})
         by_kernel.append(entry)
     per_step = {k: round(v[1] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+    # the kernel with the next largest share of the step, as a launch: two kernels may lie within a per cent of each other
+    # (the 64 MiB document: the two pair passes of the radix sort together against the one launch of the fused finish), and
+    # which of them leads can change from run to run -- the line carries both
+    if len(by_kernel) > 1 and by_kernel[1].get("frac") is not None:
+        name2 = by_kernel[1]["kernel"]
+        launches2, ms2 = prof[name2]
+        roofline["next"] = {"kernel": name2, "launches_per_step": launches2 // steps, "avg_launch_ms": ms2 / launches2,
+                            "share_of_kernel_time": ms2 / total_kernel_ms, "achieved": by_kernel[1]["achieved"],
+                            "frac": by_kernel[1]["frac"], "traffic": traffic.get(name2)}
     return roofline, by_kernel, per_step
 
 
