@@ -841,13 +841,15 @@ __global__ __launch_bounds__(BLOCK) void child_stream_kernel(Pyramid P, const u3
         if (k0 + 1 >= n) x.y = 0u;
         if (k0 + 2 >= n) x.z = 0u;
         if (k0 + 3 >= n) x.w = 0u;
+        // (the halo is requested before the stretch is staged: one round trip for both)
+        const bool has_halo = threadIdx.x < 2 * CH_HALO / 4;
+        const bool left = threadIdx.x < CH_HALO / 4;
+        const u32 q = left ? threadIdx.x : threadIdx.x - CH_HALO / 4;
+        const i64 g = left ? (i64)tile_base - CH_HALO + 4 * q : (i64)tile_base + CH_TILE + 4 * q;
+        uint4 h = {0u, 0u, 0u, 0u};
+        if (has_halo && g >= 0 && g < (i64)padded) h = *reinterpret_cast<const uint4 *>(lcp + g);
         *reinterpret_cast<uint4 *>(&tile[CH_HALO + threadIdx.x * CH_IPT]) = x;
-        if (threadIdx.x < 2 * CH_HALO / 4) {
-            const bool left = threadIdx.x < CH_HALO / 4;
-            const u32 q = left ? threadIdx.x : threadIdx.x - CH_HALO / 4;
-            const i64 g = left ? (i64)tile_base - CH_HALO + 4 * q : (i64)tile_base + CH_TILE + 4 * q;
-            uint4 h = {0u, 0u, 0u, 0u};
-            if (g >= 0 && g < (i64)padded) h = *reinterpret_cast<const uint4 *>(lcp + g);
+        if (has_halo) {
             if (g + 0 >= (i64)n) h.x = 0u;
             if (g + 1 >= (i64)n) h.y = 0u;
             if (g + 2 >= (i64)n) h.z = 0u;
