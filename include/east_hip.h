@@ -390,8 +390,9 @@ int east_hip_debug_alphabetic_code(const uint64_t *weights, int32_t n, uint32_t 
  * off the window keys + the per-keyphrase sums inside the walk kernel; 0 = one filled table, per-suffix results in HBM
  * and a reduction kernel (rounds 1-3); 2 = pair tables with the reduction kernel; 3 = filled table with the sums in the
  * walk; 4 = as 1 with the pair tables also for collections of fewer than 16 documents (which by default keep the filled
- * table: the 8-byte marks cost their build more than a few thousand walks get back).  Takes effect at the next build
- * (tables) / the next east_hip_set_keyphrases (sums). */
+ * table: the 8-byte marks cost their build more than a few thousand walks get back); 5 = as 1 with every interval searched
+ * down to its last suffix (without the walk's register endgame, score.h: walk_endgame).  Takes effect at the next build
+ * (tables) / the next east_hip_set_keyphrases (sums) / the next score call (endgame). */
 int east_hip_debug_set_score_path(int mode);
 /* Host-only: bytes of device arena a build of n_total symbols / n_docs documents
  * reserves (worst case over inputs).  Needs no device. */

@@ -104,7 +104,7 @@ def main():
         lib.east_hip_debug_set_window_sort(knob)
         lib.east_hip_debug_set_lds_rounds(int(rng.choice([1, 1, 2, 0])))
         lib.east_hip_debug_set_segmented_sort(int(rng.choice([-1, 1, 1, 0])))     # (1: wherever a shard holds 2 .. 65535 documents)
-        lib.east_hip_debug_set_score_path(int(rng.choice([1, 4, 4, 0, 2, 3])))
+        lib.east_hip_debug_set_score_path(int(rng.choice([1, 4, 4, 0, 2, 3, 5])))
         parts = [to_symbols(sc) for sc in docs]
         sym = np.concatenate(parts)
         off = np.concatenate([[0], np.cumsum([p.size for p in parts])])
