@@ -231,11 +231,25 @@ __global__ __launch_bounds__(LG_THREADS) void refine_lds_sort_kernel(
     const u32 lane = lane_id(), w = wave_id();
     const u32 base = blockIdx.x * LG_CHUNK;
     // ---- the group starts of the window [base, base + LG_CAP) (position m counts as one) ----
-    for (u32 word = w; word < LG_WORDS; word += LG_WAVES) {
-        const u64 p = (u64)base + word * 64u + lane;
-        const bool st = p < m ? gstart[p] != 0u : p == m;
-        const u64 bal = __ballot(st);
-        if (lane == 0) lds.start_bits[word] = bal;
+    // (a wave's five words: all five loads requested before the first ballot -- one round trip instead of five; a lane
+    // behind the domain reads its last entry)
+    {
+        static_assert(LG_WORDS % LG_WAVES == 0, "every wave takes the same number of words");
+        constexpr int PER = LG_WORDS / LG_WAVES;
+        u32 gs[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const u64 p = (u64)base + (w + (u32)i * LG_WAVES) * 64u + lane;
+            gs[i] = gstart[p < m ? p : (u64)m - 1u];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const u32 word = w + (u32)i * LG_WAVES;
+            const u64 p = (u64)base + word * 64u + lane;
+            const bool st = p < m ? gs[i] != 0u : p == m;
+            const u64 bal = __ballot(st);
+            if (lane == 0) lds.start_bits[word] = bal;
+        }
     }
     __syncthreads();
     // ---- wave 0: the tile = from the first start of the chunk to the end of the last group that starts in it ----
