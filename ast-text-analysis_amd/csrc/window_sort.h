@@ -767,14 +767,19 @@ __global__ __launch_bounds__(BLOCK) void lvl0_place_kernel(KeyNeqWindowIn<K> f, 
     __shared__ __attribute__((aligned(16))) u32 val_tile[BLOCK * PLACE_IPT + 2 * PLACE_HALO];  // TileElems
     __shared__ u32 n_keep, n_work;
     constexpr int TB_WORDS = (BLOCK * PLACE_IPT + 2 * PLACE_HALO + 31) / 32 + 1;
-    __shared__ uint16_t dec_lds[HT ? HT_DEC_SIZE : 1];  // the decode table
+    __shared__ __attribute__((aligned(16))) uint16_t dec_lds[HT ? HT_DEC_SIZE : 8];  // the decode table
     __shared__ u32 term_bits[HT ? TB_WORDS : 1];        // by staged index: the key holds a terminator
     __shared__ uint8_t dep_tile[HT ? BLOCK * PLACE_IPT : 1];   // whole symbols of the stretch's keys
     __shared__ DocHint kg_hint;                         // (segmented sort) the document of the stretch's first rank
     if (threadIdx.x < BLOCK * PLACE_IPT / 32) keep_bits[threadIdx.x] = 0;
     if (threadIdx.x == 0) { n_keep = 0; n_work = 0; }
     if constexpr (HT) {
-        for (u32 i = threadIdx.x; i < HT_DEC_SIZE; i += BLOCK) dec_lds[i] = f.ht_dec[i];
+        // (the table's 8 KiB with two 16-byte loads per thread: a loop of 2-byte copies was sixteen loads in four round trips)
+        static_assert(HT_DEC_SIZE == BLOCK * 16, "two 16-byte loads per thread");
+        const uint4 *src = reinterpret_cast<const uint4 *>(f.ht_dec) + threadIdx.x * 2u;
+        const uint4 d0 = src[0], d1 = src[1];
+        uint4 *dst = reinterpret_cast<uint4 *>(dec_lds) + threadIdx.x * 2u;
+        dst[0] = d0; dst[1] = d1;
         if (threadIdx.x < TB_WORDS) term_bits[threadIdx.x] = 0;
     }
     // (every load of the prologue is requested in front of the first barrier: behind it -- as this was written until round 5
@@ -1218,10 +1223,8 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
     __shared__ u32 keep_bits[FIN_WORDS], gs_bits[FIN_WORDS];
     __shared__ u32 n_keep, n_work;
     __shared__ DocHint kg_hint;                         // (segmented sort) the document of the stretch's first rank
-    __shared__ uint8_t dec8[HT ? HT_DEC_SIZE : 1];      // variable-length keys: the decode table (length, terminator bit)
+    __shared__ __attribute__((aligned(16))) uint8_t dec8[HT ? HT_DEC_SIZE : 16];   // variable-length keys: the decode table (length, terminator bit)
     __shared__ uint8_t wdep[HT ? FIN_CHUNK + FIN_G : 1];   // ... the whole symbols of the tied members' keys, by work list index
-    if constexpr (HT)
-        for (u32 i = threadIdx.x; i < HT_DEC_SIZE; i += BLOCK) dec8[i] = (uint8_t)(a.ht_dec[i] & 0xFFu);
     const KeyNeqWindowIn<K> hf{a.keys, a.rep_t, a.ones, a.highs, a.ht_sb, a.ht_wmin, a.ht_dec};
     u32 *comp = next4;                                  // (bucket start, low key bits, staged index) of every pair; next4 is used after the ranking
     const u32 m = a.m;
@@ -1268,6 +1271,15 @@ __global__ __launch_bounds__(BLOCK) void lvl0_finish_kernel(FinishArgs<K> a)
         if (tid < (u32)FIN_LEFT) {                      // left halo (never moved)
             const u32 jl = base + tid;
             if (jl < m) { key_l = a.keys[jl]; val_l = a.vals[jl]; }
+        }
+        if constexpr (HT) {
+            // (the low bytes of the table's 4 096 16-bit entries, a thread's sixteen with two 16-byte loads -- requested with
+            // the pairs; a loop of 2-byte loads at the top of the kernel was four round trips in front of them)
+            static_assert(HT_DEC_SIZE == BLOCK * 16, "two 16-byte loads per thread");
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.ht_dec) + tid * 2u;
+            const uint4 d0 = src[0], d1 = src[1];
+            auto lows = [](u32 x, u32 y) { return (x & 0xFFu) | ((x >> 8) & 0xFF00u) | ((y & 0xFFu) << 16) | ((y << 8) & 0xFF000000u); };
+            *reinterpret_cast<uint4 *>(&dec8[tid * 16u]) = uint4{lows(d0.x, d0.y), lows(d0.z, d0.w), lows(d1.x, d1.y), lows(d1.z, d1.w)};
         }
         if constexpr (sizeof(K) == 4) *reinterpret_cast<uint4 *>(&kt[i0]) = uint4{(u32)key[0], (u32)key[1], (u32)key[2], (u32)key[3]};
         else {
