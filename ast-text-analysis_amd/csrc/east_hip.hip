@@ -207,9 +207,26 @@ __global__ __launch_bounds__(BLOCK) void presence_remap_kernel(const u32 *__rest
                                                                uint8_t *__restrict__ s8)
 {
     __shared__ u32 bits[PRESENT_WORDS];
-    __shared__ uint8_t map8[TEXT_SYMBOLS];
+    __shared__ __attribute__((aligned(16))) uint8_t map8[TEXT_SYMBOLS];
     if (threadIdx.x < PRESENT_WORDS) bits[threadIdx.x] = 0;
-    for (u32 c = threadIdx.x; c < TEXT_SYMBOLS; c += BLOCK) map8[c] = (uint8_t)guess[c];
+    {
+        // (the code map's 2 560 words with 16-byte loads, all of a thread's requested before the first is used -- own
+        // allocation, 256-byte aligned --: a loop of one word per step was ten round trips in front of the first symbol)
+        static_assert(TEXT_SYMBOLS % 4 == 0, "whole 16-byte groups");
+        constexpr u32 GROUPS = TEXT_SYMBOLS / 4, ROUNDS = (GROUPS + BLOCK - 1) / BLOCK;
+        uint4 q[ROUNDS];
+#pragma unroll
+        for (u32 r = 0; r < ROUNDS; r++) {
+            const u32 g = threadIdx.x + r * BLOCK;
+            q[r] = reinterpret_cast<const uint4 *>(guess)[g < GROUPS ? g : 0u];
+        }
+#pragma unroll
+        for (u32 r = 0; r < ROUNDS; r++) {
+            const u32 g = threadIdx.x + r * BLOCK;
+            if (g < GROUPS)
+                reinterpret_cast<u32 *>(map8)[g] = (q[r].x & 0xFFu) | ((q[r].y & 0xFFu) << 8) | ((q[r].z & 0xFFu) << 16) | ((q[r].w & 0xFFu) << 24);
+        }
+    }
     __syncthreads();
     auto code = [&](u32 c) -> u32 {
         if (c >= TEXT_SYMBOLS) return 0xFFu;

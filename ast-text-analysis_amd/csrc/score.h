@@ -545,13 +545,31 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
     if (blk) { kp0 = blk[bi]; kp1 = blk[bi + 1]; s0 = q_off[kp0]; s1 = q_off[kp1]; }
     const u32 si = s0 + threadIdx.x;
     const u32 d = doc_first + dl;
+    // (the thread's first query symbols and the end of its suffix are requested here, with the staging below: behind the
+    // barrier they were two more round trips -- the end, then the symbols -- in front of the first table read)
+    u32 q_pre[KGRAM_KEYS_MAX_K];
+#pragma unroll
+    for (u32 i = 0; i < KGRAM_KEYS_MAX_K; i++) q_pre[i] = q_code[si + i < n_q ? si + i : n_q - 1u];
+    const u32 end_pre = q_end[si < n_q ? si : n_q - 1u];
     // The document's small upper tables (levels 1 .. k - 2 of a pair layout: A + 1, A^2 + 1 entries) come into LDS once per
     // workgroup, coalesced: every walk reads them, and the walk is bound by the number of requests its lanes send to the L2
     // (one per lane and level: each lane another line) -- two levels fewer of them.
     const u32 *up_lds = nullptr;
     if (kt.up_lds) {
         const u32 *src = kt.up + (size_t)d * kt.up_stride;
-        for (u32 i = threadIdx.x; i < kt.up_stride; i += BLOCK) up_stage[i] = src[i];
+        // (all of a thread's words requested before the first is stored: a loop of unknown length is a round trip per step)
+        static_assert(KG_UP_LDS_WORDS % BLOCK == 0, "whole rounds");
+        u32 x[KG_UP_LDS_WORDS / BLOCK];
+#pragma unroll
+        for (u32 r = 0; r < KG_UP_LDS_WORDS / BLOCK; r++) {
+            const u32 i = threadIdx.x + r * BLOCK;
+            x[r] = src[i < kt.up_stride ? i : 0u];
+        }
+#pragma unroll
+        for (u32 r = 0; r < KG_UP_LDS_WORDS / BLOCK; r++) {
+            const u32 i = threadIdx.x + r * BLOCK;
+            if (i < kt.up_stride) up_stage[i] = x[r];
+        }
         __syncthreads();
         up_lds = up_stage;
     }
@@ -560,8 +578,11 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
         u32 probes = 0;                 // table reads and binary-search probes of this walk (roofline accounting)
         const u32 seg = doc_off[d];
         const u32 nd = doc_off[d + 1] - seg;
-        r = score_walk_suffix<SYM>(s, sa + seg, nd, nd - n_strings[d], [&](u32 t) { return q_code[t]; }, si, q_end[si], normalized,
-                                   kt, d, probes, up_lds);
+        auto q_sym = [&](u32 t) -> u32 {
+            const u32 k = t - si;
+            return k == 0 ? q_pre[0] : k == 1 ? q_pre[1] : k == 2 ? q_pre[2] : k == 3 ? q_pre[3] : q_code[t];
+        };
+        r = score_walk_suffix<SYM>(s, sa + seg, nd, nd - n_strings[d], q_sym, si, end_pre, normalized, kt, d, probes, up_lds);
         if (suffix_out) suffix_out[(u64)dl * n_q + si] = r;
         if (probe_count) atomicAdd(probe_count, (unsigned long long)probes);   // (counting runs only: east_hip_score_probes)
     }
