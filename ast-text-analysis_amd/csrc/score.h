@@ -551,6 +551,7 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
 #pragma unroll
     for (u32 i = 0; i < KGRAM_KEYS_MAX_K; i++) q_pre[i] = q_code[si + i < n_q ? si + i : n_q - 1u];
     const u32 end_pre = q_end[si < n_q ? si : n_q - 1u];
+    const u32 seg = doc_off[d], nd = doc_off[d + 1] - seg, root_ann = nd - n_strings[d];   // (uniform; in front of the barrier too)
     // The document's small upper tables (levels 1 .. k - 2 of a pair layout: A + 1, A^2 + 1 entries) come into LDS once per
     // workgroup, coalesced: every walk reads them, and the walk is bound by the number of requests its lanes send to the L2
     // (one per lane and level: each lane another line) -- two levels fewer of them.
@@ -576,13 +577,11 @@ __global__ __launch_bounds__(BLOCK) void score_walk_kernel(
     double r = 0.0;
     if (si < s1) {
         u32 probes = 0;                 // table reads and binary-search probes of this walk (roofline accounting)
-        const u32 seg = doc_off[d];
-        const u32 nd = doc_off[d + 1] - seg;
         auto q_sym = [&](u32 t) -> u32 {
             const u32 k = t - si;
             return k == 0 ? q_pre[0] : k == 1 ? q_pre[1] : k == 2 ? q_pre[2] : k == 3 ? q_pre[3] : q_code[t];
         };
-        r = score_walk_suffix<SYM>(s, sa + seg, nd, nd - n_strings[d], q_sym, si, end_pre, normalized, kt, d, probes, up_lds);
+        r = score_walk_suffix<SYM>(s, sa + seg, nd, root_ann, q_sym, si, end_pre, normalized, kt, d, probes, up_lds);
         if (suffix_out) suffix_out[(u64)dl * n_q + si] = r;
         if (probe_count) atomicAdd(probe_count, (unsigned long long)probes);   // (counting runs only: east_hip_score_probes)
     }
