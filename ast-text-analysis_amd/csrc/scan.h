@@ -22,35 +22,44 @@ __global__ __launch_bounds__(BLOCK) void scan_reduce_kernel(In in, u32 n, u32 *b
 {
     __shared__ u32 lds[WAVES_PER_BLOCK];
     const u32 base = blockIdx.x * SCAN_TILE;
-    u32 sum = 0;
-#pragma unroll 4
+    // (unconditional reads -- an index behind the end reads the last element and counts as 0 --: all sixteen are requested
+    // before the first is added; `if (i < n) sum += in(i)` was a round trip per group of four)
+    u32 sum = 0, x[SCAN_IPT];
+#pragma unroll
     for (int j = 0; j < SCAN_IPT; j++) {
         const u32 i = base + j * BLOCK + threadIdx.x;     // striped: coalesced
-        if (i < n) sum += in(i);
+        x[j] = in(i < n ? i : n - 1u);
     }
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; j++) sum += base + j * BLOCK + threadIdx.x < n ? x[j] : 0u;
     sum = wave_sum(sum);
     if (lane_id() == 0) lds[wave_id()] = sum;
     __syncthreads();
     if (threadIdx.x == 0) block_sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
 }
 
-// four consecutive inputs starting at i (i is a multiple of 4); zeros past n
+// four consecutive inputs starting at i (i is a multiple of 4); zeros past n (n > 0).  The reads are unconditional -- an
+// index behind the end reads the last element --, so that a kernel can request all its rows before it uses the first:
+// behind `i < n ?` every row waited for its own round trip.
 template <class In>
 __device__ __forceinline__ void scan_load4(const In &in, u32 i, u32 n, u32 x[4])
 {
 #pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = (i + k < n) ? in(i + k) : 0u;
+    for (int k = 0; k < 4; k++) {
+        const u32 v = in(i + k < n ? i + k : n - 1u);
+        x[k] = i + k < n ? v : 0u;
+    }
 }
 
+// (arrays come from the 256-byte aligned arena, whose blocks are whole multiples of 256 bytes: the 16-byte group of any
+// valid element lies inside its block, also where it reaches behind n)
 __device__ __forceinline__ void scan_load4(const ArrIn &in, u32 i, u32 n, u32 x[4])
 {
-    if (i + 3 < n) {        // arrays come from the 256-byte aligned arena: 16-byte vector load
-        const uint4 v = *reinterpret_cast<const uint4 *>(in.p + i);
-        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) x[k] = (i + k < n) ? in.p[i + k] : 0u;
-    }
+    const uint4 v = *reinterpret_cast<const uint4 *>(in.p + (i < n ? i : 0u));
+    x[0] = i < n ? v.x : 0u;
+    x[1] = i + 1 < n ? v.y : 0u;
+    x[2] = i + 2 < n ? v.z : 0u;
+    x[3] = i + 3 < n ? v.w : 0u;
 }
 
 // out[i] = (exclusive or inclusive) prefix of in over [0, i], plus the scanned
@@ -70,8 +79,14 @@ __global__ __launch_bounds__(BLOCK) void scan_apply_kernel(In in, u32 n, const u
     __shared__ u32 lds_raw[WAVES_PER_BLOCK];
     u32 raw_base = 0;
     if (raw) {
-        u32 part = 0;
-        for (u32 t = threadIdx.x; t < blockIdx.x; t += BLOCK) part += block_offsets[t];
+        u32 part = 0, bs[SCAN_RAW_TILES / BLOCK];
+#pragma unroll
+        for (u32 j = 0; j < SCAN_RAW_TILES / BLOCK; j++) {
+            const u32 t = threadIdx.x + j * BLOCK;
+            bs[j] = block_offsets[t < blockIdx.x ? t : 0u];
+        }
+#pragma unroll
+        for (u32 j = 0; j < SCAN_RAW_TILES / BLOCK; j++) part += threadIdx.x + j * BLOCK < blockIdx.x ? bs[j] : 0u;
         part = wave_sum(part);
         if (lane_id() == 0) lds_raw[wave_id()] = part;
         __syncthreads();
@@ -82,10 +97,10 @@ __global__ __launch_bounds__(BLOCK) void scan_apply_kernel(In in, u32 n, const u
     u32 v[4][4];
     u32 carry = 0;
 #pragma unroll
+    for (int r = 0; r < 4; r++) scan_load4(in, wave_base + r * 256 + lane * 4, n, v[r]);     // (all four rows requested first)
+#pragma unroll
     for (int r = 0; r < 4; r++) {
-        const u32 i = wave_base + r * 256 + lane * 4;
-        u32 x[4];
-        scan_load4(in, i, n, x);
+        u32 x[4] = {v[r][0], v[r][1], v[r][2], v[r][3]};
         const u32 t = x[0] + x[1] + x[2] + x[3];
         const u32 inc = wave_inclusive_sum(t);
         u32 run = carry + inc - t;
@@ -150,14 +165,17 @@ __global__ __launch_bounds__(BLOCK) void scan_reduce2_kernel(const u32 *__restri
     const u32 base = blockIdx.x * SCAN_TILE;
     if (base >= bound) { if (threadIdx.x == 0) block_sums[blockIdx.x] = uint2{0u, 0u}; return; }
     u32 sa = 0, sb = 0;
+    u32 x[SCAN_IPT / 4][4], y[SCAN_IPT / 4][4];
 #pragma unroll
     for (int j = 0; j < SCAN_IPT / 4; j++) {
         const u32 i = base + (j * BLOCK + threadIdx.x) * 4u;
-        u32 x[4], y[4];
-        scan_load4(ArrIn{a}, i, bound, x);
-        scan_load4(ArrIn{b}, i, bound, y);
-        sa += x[0] + x[1] + x[2] + x[3];
-        sb += y[0] + y[1] + y[2] + y[3];
+        scan_load4(ArrIn{a}, i, bound, x[j]);
+        scan_load4(ArrIn{b}, i, bound, y[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT / 4; j++) {
+        sa += x[j][0] + x[j][1] + x[j][2] + x[j][3];
+        sb += y[j][0] + y[j][1] + y[j][2] + y[j][3];
     }
     sa = wave_sum(sa);
     sb = wave_sum(sb);
@@ -198,9 +216,12 @@ __global__ __launch_bounds__(BLOCK) void scan_apply2_kernel(const u32 *__restric
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const u32 i = wave_base + r * 256 + lane * 4;
-        u32 x[4], y[4];
-        scan_load4(ArrIn{a}, i, bound, x);
-        scan_load4(ArrIn{b}, i, bound, y);
+        scan_load4(ArrIn{a}, i, bound, va[r]);
+        scan_load4(ArrIn{b}, i, bound, vb[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        u32 x[4] = {va[r][0], va[r][1], va[r][2], va[r][3]}, y[4] = {vb[r][0], vb[r][1], vb[r][2], vb[r][3]};
         const u32 ta = x[0] + x[1] + x[2] + x[3], tb = y[0] + y[1] + y[2] + y[3];
         const u32 ia = wave_inclusive_sum(ta), ib = wave_inclusive_sum(tb);
         u32 ra = carry_a + ia - ta, rb = carry_b + ib - tb;
