@@ -379,15 +379,21 @@ __global__ __launch_bounds__(BLOCK) void tp_emit_kernel(const u32 *__restrict__ 
     __shared__ u32 lds4[WAVES_PER_BLOCK];
     if (!cpu) up[threadIdx.x] = up256[threadIdx.x];    // (BLOCK == 256)
     const u32 p = blockIdx.x * BLOCK + threadIdx.x;
-    const u32 c = p < n_cp ? cw[p] : 0u;
+    // (everything that does not depend on the token record is requested here, unconditionally -- a position behind the end reads
+    // the last one --: the code point / byte used to be fetched behind the record, a third round trip)
+    const u32 pc = p < n_cp ? p : n_cp - 1u;
+    const u32 c_raw = cw[pc], c_prev = cw[pc > 0 ? pc - 1u : 0u];
+    const u32 cp_raw = cpu ? cpu[pc] : (u32)bytes[pc];
+    const u32 tok0 = tok_prefix[blockIdx.x];
+    const u32 c = p < n_cp ? c_raw : 0u;
     const bool word = (c & TP_CLASS_WORD) != 0;
-    const bool start = word && !(p > 0 && (cw[p - 1] & TP_CLASS_WORD));
+    const bool start = word && !(p > 0 && (c_prev & TP_CLASS_WORD));
     const u32 before = tp_rank_in_block(start, lds4);   // (its barrier also covers up[])
     if (!word) return;
-    const uint4 rec = tok_rec[tok_prefix[blockIdx.x] + before + (start ? 1u : 0u) - 1u];
+    const uint4 rec = tok_rec[tok0 + before + (start ? 1u : 0u) - 1u];
     if (rec.x == TP_DROPPED) return;                        // token dropped
     const u32 out = rec.x + (p - rec.y);
-    const u32 cp = cpu ? cpu[p] : up[bytes[p]];
+    const u32 cp = cpu ? cp_raw : up[cp_raw];
     if (cp >= TP_TEXT_LIMIT) *high = 1u;                    // kept text at or above U+0A00: the build takes the tagged encoding
     sym[out] = cp;
     if (rec.z && p == rec.w) sym[out + 1u] = rec.z;
