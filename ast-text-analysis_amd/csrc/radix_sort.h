@@ -283,6 +283,11 @@ __global__ __launch_bounds__(BLOCK) void radix_spine_docs_kernel(const u32 *__re
     const u32 g0 = seg.doc_group0[doc], g1 = seg.doc_group0[doc + 1];
     if (g1 - g0 > (u32)RS_SPINE_DOC_GROUPS) return;     // (a large document: the column-parallel kernel)
     const size_t row0 = (size_t)doc * seg.shards * RS_BINS;
+    // (the document's group sums -- at most RS_SPINE_DOC_GROUPS rows -- are requested with its totals, all at once: fetched
+    // four at a time behind the scan of the totals, a document of 30 groups waited for nine round trips)
+    u32 x[RS_SPINE_DOC_GROUPS];
+#pragma unroll
+    for (u32 i = 0; i < RS_SPINE_DOC_GROUPS; i++) x[i] = group_sum[(size_t)(g0 + i < g1 ? g0 + i : 0u) * RS_BINS + threadIdx.x];
     u32 t = 0;
     for (u32 k = 0; k < seg.shards; k++) {
         t += digit_total[row0 + k * RS_BINS + threadIdx.x];
@@ -290,11 +295,10 @@ __global__ __launch_bounds__(BLOCK) void radix_spine_docs_kernel(const u32 *__re
     }
     u32 total;
     u32 run = block_exclusive_sum(t, lds4, total) + seg.doc_off[doc];
-#pragma unroll 4
-    for (u32 g = g0; g < g1; g++) {
-        const u32 v = group_sum[(size_t)g * RS_BINS + threadIdx.x];
-        group_prefix[(size_t)g * RS_BINS + threadIdx.x] = run;
-        run += v;
+#pragma unroll
+    for (u32 i = 0; i < RS_SPINE_DOC_GROUPS; i++) {
+        if (g0 + i < g1) group_prefix[(size_t)(g0 + i) * RS_BINS + threadIdx.x] = run;
+        run += x[i];
     }
 }
 
