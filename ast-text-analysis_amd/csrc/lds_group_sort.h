@@ -54,12 +54,11 @@ struct LgUncovered {
     __device__ __forceinline__ void rest(u32 c, u32 &a0, u32 &a1, u32 &b0, u32 &b1) const
     {
         const u32 lo = c * LG_CHUNK, hi = lo + LG_CHUNK < m ? lo + LG_CHUNK : m;
-        const uint2 own = cover[c];
+        // (the three entries requested at once: a loop that stops at the first chunk with a start was a round trip per step)
+        const uint2 own = cover[c], p1 = cover[c >= 1u ? c - 1u : 0u], p2 = cover[c >= 2u ? c - 2u : 0u];
         u32 reached = lo;                               // how far an earlier tile reaches into this chunk
-        for (u32 k = 1; k <= 2 && k <= c; k++) {
-            const uint2 prev = cover[c - k];
-            if (prev.x != LG_NONE) { reached = prev.y > lo ? prev.y : lo; break; }
-        }
+        if (c >= 1u && p1.x != LG_NONE) reached = p1.y > lo ? p1.y : lo;
+        else if (c >= 2u && p2.x != LG_NONE) reached = p2.y > lo ? p2.y : lo;
         if (reached > hi) reached = hi;
         a0 = reached;
         a1 = own.x != LG_NONE ? own.x : hi;             // (own.x >= reached: a tile ends where a group ends)
