@@ -215,6 +215,10 @@ def roofline_of(prof, info, n, n_docs, steps, traffic):
         roofline["next"] = {"kernel": name2, "launches_per_step": launches2 // steps, "avg_launch_ms": ms2 / launches2,
                             "share_of_kernel_time": ms2 / total_kernel_ms, "achieved": by_kernel[1]["achieved"],
                             "frac": by_kernel[1]["frac"], "traffic": traffic.get(name2)}
+        if ms2 > 0.9 * dom_ms:
+            roofline["note"] = ("%s (%d launch(es) per step) and %s (%d) lie within 10 %% of each other in time per step: which of "
+                                "them `roofline` names can change from run to run; `next` is the other one"
+                                % (dom_name, dom_launches // steps, name2, launches2 // steps))
     return roofline, by_kernel, per_step
 
 
