@@ -2665,6 +2665,17 @@ int east_hip_debug_alphabetic_code(const uint64_t *weights, int32_t n, uint32_t 
     return EAST_HIP_OK;
 }
 
+int east_hip_debug_narrow_symbols(const uint32_t *symbols, int64_t n, uint16_t *out, int vector)
+{
+    // host only: what upload_symbols_narrow's host threads do to a stretch of symbols on its way into the pinned ring
+    // (vector != 0: the AVX2 form where the CPU has it; 0: the plain loop)
+    if (!symbols || !out || n < 0) return EAST_HIP_ERR_INVALID;
+    if (vector) narrow_symbols(symbols, out, (size_t)n);
+    else
+        for (int64_t i = 0; i < n; i++) out[i] = symbols[i] < TEXT_SYMBOLS ? (uint16_t)symbols[i] : (uint16_t)SYM_TERMINATOR16;
+    return vector && g_have_avx2 ? 1 : EAST_HIP_OK;
+}
+
 int east_hip_debug_set_lds_rounds(int enabled)
 {
     // 0: every round through the global sort; 1: the default (in-LDS rounds that also classify the next domain);

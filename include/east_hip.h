@@ -386,6 +386,11 @@ int east_hip_debug_set_text_ring(int mode, int64_t slot_bytes);
  * order) with the given weights -- code[i] = the len[i] bits of symbol i's code word, right-aligned.  EAST_HIP_ERR_DOMAIN
  * if no code with word lengths in [3, 12] exists for them (n < 8, n > 256). */
 int east_hip_debug_alphabetic_code(const uint64_t *weights, int32_t n, uint32_t *code, int32_t *len);
+/* Host only (needs no device): out[i] = symbols[i] below U+0A00 ? symbols[i] : 0xFFFF -- the 16-bit words east_hip_build
+ * sends over the link for host symbols of the reference encoding (every symbol from U+0A00 on is a terminator, whose
+ * number the build never reads).  vector != 0: the form the upload's host threads run (AVX2 with streaming stores where
+ * the CPU has it), 0: the plain loop.  Returns 1 if the vector form ran, 0 if the loop did, < 0 on bad arguments. */
+int east_hip_debug_narrow_symbols(const uint32_t *symbols, int64_t n, uint16_t *out, int vector);
 /* Test knob (process-wide): which form of the score path runs (easa.py:91-139).  1 (default) = pair k-gram tables marked
  * off the window keys + the per-keyphrase sums inside the walk kernel; 0 = one filled table, per-suffix results in HBM
  * and a reduction kernel (rounds 1-3); 2 = pair tables with the reduction kernel; 3 = filled table with the sums in the

@@ -349,3 +349,34 @@ def test_score_table_is_the_dict_of_dicts_and_the_graph_from_the_array_is_the_gr
             slow = applications.keyphrases_graph(kps, texts, 0.4, 0.25, support, _ArrayMeasure(scores))
             monkeypatch.undo()
             assert fast == slow and len(fast["edges"]) > 0, (K, D, support)
+
+
+def test_host_symbols_are_narrowed_to_16_bit_words_as_the_plain_loop_does():
+    """east_hip_build sends host symbols of the reference encoding over the link as 16-bit words (east_hip.hip:
+    upload_symbols_narrow): text below U+0A00 as it is, every terminator as 0xFFFF.  The host threads narrow with AVX2 and
+    streaming stores where the CPU has them -- an alignment prologue, sixteen symbols a step, a tail --: every start
+    alignment and length against numpy and against the library's plain loop (host only, no device)."""
+    import ctypes
+    from east import hip_backend
+    lib = hip_backend.load()
+    rng = np.random.default_rng(16)
+    base = rng.integers(0, 0x0A00, size=5000).astype(np.uint32)
+    special = np.array([0x09FF, 0x0A00, 0x0A01, 0xFFFF, 0x10000, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, 0], dtype=np.uint32)
+    base[rng.integers(0, base.size, size=600)] = rng.choice(special, size=600)
+    vector_ran = set()
+    for start in range(0, 40):
+        for n in (0, 1, 15, 16, 17, 31, 33, 100, 1000, 4096 + start):
+            src = np.ascontiguousarray(base[start:start + n])
+            want = np.where(src < 0x0A00, src, 0xFFFF).astype(np.uint16)
+            for vector in (1, 0):
+                buf = np.full(n + 48, 0xABCD, dtype=np.uint16)              # (guard words to either side)
+                out = buf[16 + (start % 16):16 + (start % 16) + n]          # every 2-byte alignment of the destination
+                rc = lib.east_hip_debug_narrow_symbols(src.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n,
+                                                       out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), vector)
+                assert rc in (0, 1), rc
+                if vector:
+                    vector_ran.add(rc)
+                assert np.array_equal(out, want), (start, n, vector)
+                assert (buf[:16 + (start % 16)] == 0xABCD).all() and (buf[16 + (start % 16) + n:] == 0xABCD).all(), (start, n, vector)
+    assert lib.east_hip_debug_narrow_symbols(None, 4, None, 1) < 0
+    assert vector_ran <= {0, 1}

@@ -90,6 +90,17 @@ for n in (0, 1, 7, 257):
     assert lib.east_hip_debug_alphabetic_code(w.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n,
                                               code.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
                                               ln.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))) != 0
+# the narrowing of host symbols to 16-bit words (the upload's AVX2 form and the plain loop), every alignment and tail
+src_all = rng.integers(0, 0x1400, size=3000).astype(np.uint32)
+for start in range(0, 20):
+    for n in (0, 1, 15, 16, 17, 33, 1000, 2048 + start):
+        src = np.ascontiguousarray(src_all[start:start + n])
+        want = np.where(src < 0x0A00, src, 0xFFFF).astype(np.uint16)
+        for vector in (1, 0):
+            out = np.zeros(n + 3, np.uint16)[start %% 3:start %% 3 + n]
+            assert lib.east_hip_debug_narrow_symbols(src.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n,
+                                                     out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), vector) in (0, 1)
+            assert np.array_equal(out, want), (start, n, vector)
 # the sharding rule of the device groups
 for _ in range(100):
     n, g = int(rng.integers(0, 60)), int(rng.integers(1, 12))
