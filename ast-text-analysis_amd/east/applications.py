@@ -52,6 +52,18 @@ class ScoreTable(Mapping):
     def __len__(self):
         return len(self.keyphrases)
 
+    def to_dict(self):
+        """The reference's own return type: a plain, mutable, JSON-serialisable dict of dicts of Python floats."""
+        titles = self.text_titles
+        return {kp: dict(zip(titles, row)) for kp, row in zip(self.keyphrases, np.asarray(self.scores, dtype=np.float64).tolist())}
+
+
+# Tables below this many scores come back as the reference's plain dict of dicts (json.dumps, item assignment and
+# isinstance(table, dict) work as they do there; 65 536 scores cost about 10 ms to box).  From here on the table is a
+# ScoreTable over the array (to_dict() gives the plain form): at configs[2], 2.56 M scores, the dict costs 0.4 s and the
+# device fills the array in a millisecond.
+ARRAY_TABLE_MIN_SCORES = 1 << 16
+
 
 def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=None,
                      language=consts.Language.ENGLISH):
@@ -60,8 +72,8 @@ def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=Non
     :param keyphrases: raw keyphrase strings (empty ones are skipped, duplicates collapse)
     :param texts: {text name: text}
     :param similarity_measure: defaults to ASTRelevanceMeasure() (easa, normalized)
-    :returns: {raw keyphrase: {text name: score}} (a ScoreTable -- a read-only mapping over the score array -- on the
-              batched path)
+    :returns: {raw keyphrase: {text name: score}} -- a plain dict as in the reference; from ARRAY_TABLE_MIN_SCORES scores
+              on, a ScoreTable (a read-only mapping over the score array that compares equal to that dict; `.to_dict()`)
     """
     similarity_measure = similarity_measure or relevance.ASTRelevanceMeasure()
 
@@ -81,7 +93,8 @@ def keyphrases_table(keyphrases, texts, similarity_measure=None, synonimizer=Non
                       else similarity_measure.relevance_table(prepared))
             # (a mapping over the array: no K x D Python floats.  A rank of a multi-process run that is not the one to
             # print gets a K x 0 array -- east/parallel.py, table_rank --: rows without entries, as zip() made them)
-            return ScoreTable(wanted, text_titles[:scores.shape[1]], scores)
+            table = ScoreTable(wanted, text_titles[:scores.shape[1]], scores)
+            return table if scores.size >= ARRAY_TABLE_MIN_SCORES else table.to_dict()
         return res
 
     i = 0

@@ -478,7 +478,135 @@ def main():
         except OSError:
             pass
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        detail_path = write_detail(out)
+        print(compact_line(out, detail_path), flush=True)
+
+
+LINE_LIMIT = 6144          # the driver keeps an 8 KB tail of stdout and parses its LAST line: that line stays under 6 KB
+
+
+def _r(x, digits=5):
+    """Numbers of the line: `digits` significant digits (the full figures are in bench_detail.json)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _leg_summary(leg):
+    """One line per secondary leg: value, step, build, score, the dominant kernel and its fraction of the HBM peak."""
+    if not isinstance(leg, dict):
+        return None
+    res = _pick(leg, ("value", "ms_per_step", "build_ms", "score_ms", "first_build_ms", "refine_rounds"))
+    roof = leg.get("roofline")
+    rows = leg.get("roofline_by_kernel")
+    if isinstance(roof, dict):
+        res["kernel"], res["frac"] = roof.get("kernel"), roof.get("frac")
+    elif rows:                                           # (the config 5 legs: counter fractions per kernel)
+        res["kernel"], res["frac"] = rows[0].get("kernel"), rows[0].get("pmc_frac")
+    elif isinstance(leg.get("kernels_ms_per_step"), dict) and leg["kernels_ms_per_step"]:
+        res["kernel"] = next(iter(leg["kernels_ms_per_step"]))
+    whole = leg.get("rocprof_hbm_fraction") or (roof or {}).get("rocprof_hbm_fraction")
+    if isinstance(whole, dict):
+        res["build_hbm_frac"] = whole.get("frac")
+    if isinstance(leg.get("roofline_score"), dict):
+        res["score_frac"] = leg["roofline_score"].get("frac")
+    if isinstance(leg.get("from_text"), dict):
+        res["from_text_ms"] = leg["from_text"].get("wall_ms")
+    return res
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line the driver parses (its stdout tail is 8 KB; the round-5 line had grown to 21.7 KB and was not
+    parsed): the contract keys, `roofline`, `cpu_baseline`, the host-resident / first-build / raw-text values and a
+    one-line summary per secondary leg.  Everything else -- per-kernel tables, notes, every repetition -- stays in
+    `bench_detail.json` (write_detail).  Pure function of the assembled dict: tests/test_host_logic.py runs it on canned
+    numbers and bounds its length."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    line["vs_baseline"] = out.get("vs_baseline")
+    line.update(_pick(out, ("dtype", "data", "config", "step_ms_min", "step_ms_median", "step_ms_max", "build_ms", "score_ms",
+                            "keyphrase_scores_per_s")))
+    roof = out.get("roofline") or {}
+    r = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_ms",
+                     "algorithmic_bytes_per_launch", "share_of_kernel_time", "traffic_commit"))
+    if "traffic" not in r:
+        r["traffic"] = None
+    if isinstance(roof.get("next"), dict):
+        r["next"] = _pick(roof["next"], ("kernel", "launches_per_step", "avg_launch_ms", "achieved", "frac", "traffic"))
+    if isinstance(roof.get("rocprof_hbm_fraction"), dict):
+        r["rocprof_hbm_fraction"] = _pick(roof["rocprof_hbm_fraction"], ("GBps", "frac", "kernels"))
+    line["roofline"] = r
+    if isinstance(out.get("roofline_score"), dict):
+        line["roofline_score"] = _pick(out["roofline_score"], ("kernel", "avg_launch_ms", "algorithmic_bytes_per_launch",
+                                                               "achieved", "frac"))
+    cpu = out.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        c = _pick(cpu, ("value", "unit", "cores", "kind", "sample", "keyphrase_scores_per_s"))
+        if isinstance(cpu.get("over_documents"), dict):
+            c["over_documents"] = _pick(cpu["over_documents"], ("value", "cores"))
+        line["cpu_baseline"] = c
+    line.update(_pick(out, ("value_from_host", "value_first_build", "value_from_text", "first_build_ms",
+                            "build_ms_without_guesses", "child_tables_ms", "build_ms_constructor")))
+    host = out.get("build_from_host_ms")
+    if isinstance(host, dict):
+        line["build_from_host_ms"] = _pick(host, ("wall_ms_median", "wall_ms_min", "wall_ms_max", "h2d_bytes", "bytes_per_symbol"))
+    ft = (out.get("from_text") or {})
+    if ft:
+        line["from_text"] = {name: _pick(leg, ("wall_ms", "prep_ms", "build_ms", "chars_per_s")) for name, leg in ft.items()}
+    for name in ("config2", "config5", "config5_prose"):
+        if name in out:
+            line[name] = _leg_summary(out[name])
+    wc = out.get("worst_case")
+    if isinstance(wc, dict):
+        line["worst_case"] = {
+            "cases": [_pick(c, ("n", "symbols", "build_ms", "chars_per_s", "random_text_same_size_build_ms",
+                                "speedup_vs_oracle_one_core")) for c in wc.get("cases", [])],
+            "long_repeats_16Mi_ms": {c["input"]: c["build_ms"] for c in wc.get("long_repeats", [])}}
+    mg = out.get("multi_gpu")
+    if isinstance(mg, dict):
+        line["multi_gpu"] = _pick(mg, ("step_local_ms", "allgather_ms", "local_fraction_of_step", "rccl_world_size", "backend",
+                                       "scaling_efficiency", "scaling_base_value", "in_process"))
+    if detail_path:
+        line["detail"] = os.path.basename(detail_path)
+    line = _r(line)
+    text = json.dumps(line, separators=(",", ":"))
+    # (never reached with the keys above -- about 4 KB --; a future key must not push the line past the driver's tail)
+    for victim in ("worst_case", "from_text", "config5_prose", "config5", "config2", "roofline_score"):
+        if len(text) <= LINE_LIMIT:
+            break
+        line.pop(victim, None)
+        line["dropped_for_length"] = line.get("dropped_for_length", []) + [victim]
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:
+        raise RuntimeError("bench line of %d bytes: the driver reads an 8 KB tail" % len(text))
+    return text
+
+
+def write_detail(out):
+    """Everything the run measured, as one JSON document next to bench.py (and under gpurun_out/ when that directory
+    exists, so that it comes back from the GPU box).  Returns the path written, or None."""
+    written = None
+    for directory in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if directory != ROOT and not os.path.isdir(directory):
+            continue
+        try:
+            with open(os.path.join(directory, "bench_detail.json"), "w") as f:
+                json.dump(out, f, indent=1)
+            written = written or os.path.join(directory, "bench_detail.json")
+        except OSError:
+            pass
+    return written
 
 
 def extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D, d_symbols=None):

@@ -2,6 +2,7 @@
 "no silent fallback" rule.  No compute call needs a GPU here."""
 import ctypes
 import io
+import json
 import os
 import re
 import sys
@@ -338,9 +339,20 @@ def test_score_table_is_the_dict_of_dicts_and_the_graph_from_the_array_is_the_gr
         scores = rng.random((len(uniq), D)) * 0.5
         scores[0] = 0.0                                       # a keyphrase that occurs nowhere
         texts = {"t%d" % i: b"x" for i in range(D)}
+        plain = {k: {t: float(scores[i, j]) for j, t in enumerate(texts)} for i, k in enumerate(uniq)}
+        # the default for a table of this size is the reference's own type: a plain dict of dicts that can be changed
+        # and serialised (applications.py:46-52) ...
+        monkeypatch.undo()
+        small = applications.keyphrases_table(kps, texts, _ArrayMeasure(scores))
+        assert type(small) is dict and all(type(row) is dict for row in small.values()) and small == plain
+        assert json.loads(json.dumps(small)) == plain
+        small[uniq[0]]["t0"] = 2.0
+        small["another"] = {}
+        # ... and from ARRAY_TABLE_MIN_SCORES scores on, a mapping over the array
+        monkeypatch.setattr(applications, "ARRAY_TABLE_MIN_SCORES", 0)
         table = applications.keyphrases_table(kps, texts, _ArrayMeasure(scores))
         assert isinstance(table, applications.ScoreTable)
-        plain = {k: {t: float(scores[i, j]) for j, t in enumerate(texts)} for i, k in enumerate(uniq)}
+        assert type(table.to_dict()) is dict and table.to_dict() == plain and json.loads(json.dumps(table.to_dict())) == plain
         assert table == plain and dict(table) == plain and sorted(table) == sorted(plain)
         assert list(table[uniq[2]].items()) == list(plain[uniq[2]].items())
         for support in (0, 1, 3):
@@ -348,6 +360,7 @@ def test_score_table_is_the_dict_of_dicts_and_the_graph_from_the_array_is_the_gr
             monkeypatch.setattr(applications, "keyphrases_table", lambda *a, **k: plain)
             slow = applications.keyphrases_graph(kps, texts, 0.4, 0.25, support, _ArrayMeasure(scores))
             monkeypatch.undo()
+            monkeypatch.setattr(applications, "ARRAY_TABLE_MIN_SCORES", 0)
             assert fast == slow and len(fast["edges"]) > 0, (K, D, support)
 
 
@@ -380,3 +393,51 @@ def test_host_symbols_are_narrowed_to_16_bit_words_as_the_plain_loop_does():
                 assert (buf[:16 + (start % 16)] == 0xABCD).all() and (buf[16 + (start % 16) + n:] == 0xABCD).all(), (start, n, vector)
     assert lib.east_hip_debug_narrow_symbols(None, 4, None, 1) < 0
     assert vector_ran <= {0, 1}
+
+
+def test_bench_line_stays_under_the_drivers_tail():
+    """bench.py prints ONE line for the driver, whose record keeps an 8 KB tail of stdout: the round-5 line had grown to
+    21.7 KB and BENCH_r05.parsed was null.  compact_line() -- a pure function of the assembled numbers -- is run here on
+    canned numbers (the full round-5 record, which holds every leg and note the bench produces, with a multi_gpu block
+    added): the line must parse, stay under 6 KB, carry the contract keys, `roofline` and `cpu_baseline`, and be
+    shortened rather than overflow when a leg grows."""
+    import copy
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r05_final_bench.json")) as f:
+        canned = json.load(f)
+    canned["multi_gpu"] = {"step_local_ms": 7.5, "allgather_ms": 0.4, "local_fraction_of_step": 0.95, "rccl_world_size": 8,
+                           "backend": "nccl", "scaling_efficiency": None, "note": "x" * 400,
+                           "in_process": {"step_ms": 8.1, "gather": "rccl", "rccl_ranks": 8}}
+    text = bench.compact_line(canned, "/somewhere/bench_detail.json")
+    assert "\n" not in text and len(text) <= bench.LINE_LIMIT == 6144
+    line = json.loads(text)
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+    assert all(k in line for k in contract)
+    assert line["vs_baseline"] is None and "workload" in line["config"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_ms",
+              "algorithmic_bytes_per_launch", "next", "rocprof_hbm_fraction", "traffic_commit"):
+        assert k in line["roofline"], k
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-4
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    for k in ("step_ms_min", "step_ms_median", "step_ms_max", "value_from_host", "value_first_build", "value_from_text"):
+        assert k in line, k
+    for leg in ("config2", "config5", "config5_prose"):
+        assert {"value", "ms_per_step", "build_ms", "score_ms", "kernel"} <= set(line[leg]), leg
+        assert not any(isinstance(v, (dict, list)) for v in line[leg].values())      # one-line summaries: no tables
+    assert [c["n"] for c in line["worst_case"]["cases"]] == [1000, 10000, 100000]
+    assert line["multi_gpu"]["in_process"]["rccl_ranks"] == 8 and "note" not in line["multi_gpu"]
+    assert line["detail"] == "bench_detail.json"
+    # values keep five significant digits of what was measured
+    assert abs(line["value"] / canned["value"] - 1) < 1e-4 and abs(line["ms_per_step"] / canned["ms_per_step"] - 1) < 1e-4
+    # a leg that grows is dropped (and named), the contract keys never are
+    fat = copy.deepcopy(canned)
+    fat["worst_case"]["cases"] = fat["worst_case"]["cases"] * 40
+    short = json.loads(bench.compact_line(fat))
+    assert len(json.dumps(short)) <= 6144 + 200 and "worst_case" in short["dropped_for_length"]
+    assert all(k in short for k in contract)
+    # no leg at all (--no-config2 --no-extras --no-cpu-baseline, or an N > 1 line): still a valid line
+    bare = {k: canned[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                   "scaling", "vs_baseline", "dtype", "data", "config", "roofline")}
+    assert json.loads(bench.compact_line(bare))["roofline"]["kernel"] == canned["roofline"]["kernel"]
