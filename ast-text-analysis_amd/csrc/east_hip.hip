@@ -501,6 +501,7 @@ struct east_hip_index {
     std::vector<hipEvent_t> ring_events;
     std::thread ring_alloc;                 // pins the ring in the background after a first call that went without it
     std::atomic<char *> ring_pending{nullptr};
+    std::atomic<bool> ring_done{false};     // the background thread is through (with or without a ring): it can be joined without waiting
     bool narrow_upload = false;             // the last build's host symbols went up as 16-bit words (east_hip_build_info [25])
     bool ring_wanted = false;               // (the call under way would have taken the ring: pin it once the call is over --
                                             // while it runs, the pinning and the call's own copies fight over the runtime's locks)
@@ -1001,6 +1002,17 @@ static void check_build_args(i64 n_total, const i64 *doc_offsets, const int32_t 
 #define SYM_NARROW_MIN ((u32)4 << 20)
 #define SYM_TERMINATOR16 0xFFFFu
 static void ring_pin_later(east_hip_index *h);
+// The ring a background thread pinned becomes the handle's (or is given back when the handle pinned one itself in the
+// meantime); wait: join the thread even if it is still at work (before an inline allocation, at destruction).
+static void ring_adopt(east_hip_index *h, bool wait)
+{
+    if (h->ring_alloc.joinable() && (wait || h->ring_done.load())) h->ring_alloc.join();
+    if (h->ring_alloc.joinable()) return;
+    char *pending = h->ring_pending.exchange(nullptr);
+    if (!pending) return;
+    if (!h->ring) h->ring = pending;
+    else if (pending != h->ring) (void)hipHostFree(pending);
+}
 __global__ __launch_bounds__(BLOCK) void widen_symbols_kernel(const uint16_t *__restrict__ in, u32 n, u32 *__restrict__ out)
 {
     const u32 i = (blockIdx.x * BLOCK + threadIdx.x) * 8u;
@@ -1136,8 +1148,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     const Knobs kn = knobs_snapshot();                   // (the test knobs of this call, from its sizing run to its last launch)
     const u32 n = (u32)n_total;
     // (host symbols of the reference encoding go up as 16-bit words where that pays: upload_symbols_narrow)
-    if (h->ring_alloc.joinable() && h->ring_pending.load()) h->ring_alloc.join();
-    if (!h->ring && !h->ring_alloc.joinable() && h->ring_pending.load()) h->ring = h->ring_pending.load();
+    ring_adopt(h, false);
     const bool narrow_shape = sym_on_host && !tagged && n >= SYM_NARROW_MIN && getenv("EAST_HIP_NO_SYMBOL_NARROW") == nullptr;
     const bool narrow = narrow_shape && h->ring != nullptr;
     if (narrow_shape && !narrow) h->ring_wanted = true;      // (pinned in the background when this call is over)
@@ -1355,14 +1366,18 @@ static void tp_fill_stream(char *dst, u64 a, u64 b, const uint8_t *const *texts,
 // a first call went without the ring (see prepare_texts_streamed): pin it now that the call is over, in the background
 static void ring_pin_later(east_hip_index *h)
 {
+    ring_adopt(h, false);                  // (a thread that failed to pin is joined here, and the next call may try again)
     if (!h->ring_wanted || h->ring || h->ring_alloc.joinable() || h->ring_pending.load()) return;
     h->ring_wanted = false;
+    h->ring_done.store(false);
     const int dev = h->device;
     std::atomic<char *> *slot = &h->ring_pending;
-    h->ring_alloc = std::thread([dev, slot]() {
+    std::atomic<bool> *done = &h->ring_done;
+    h->ring_alloc = std::thread([dev, slot, done]() {
         void *p = nullptr;
         if (hipSetDevice(dev) == hipSuccess && hipHostMalloc(&p, TP_RING_SLOT * TP_RING_SLOTS, hipHostMallocDefault) == hipSuccess) slot->store((char *)p);
         else (void)hipGetLastError();
+        done->store(true);
     });
 }
 
@@ -1448,8 +1463,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     // takes the ring only where that pays at once (TP_RING_FIRST_TEXTS texts or more) -- otherwise it goes the old way and
     // leaves the pinning to a background thread, for the calls after it (`east keyphrases table` over a few dozen files
     // is one call: 64 texts of 1 MiB, first call 11.4-13 ms with the ring pinned in line, second call 5.9).
-    if (h->ring_alloc.joinable() && (h->ring_pending.load() || ctx.knobs.tp_ring > 0)) h->ring_alloc.join();
-    if (!h->ring && !h->ring_alloc.joinable() && h->ring_pending.load()) h->ring = h->ring_pending.load();
+    ring_adopt(h, ctx.knobs.tp_ring > 0);
     const bool ring_shape = texts && ctx.knobs.tp_ring != 0 && (ctx.knobs.tp_ring > 0 || (D >= 4 && (u64)n_bytes / D < TP_RING_MAX_TEXT));
     const bool use_ring = ring_shape && (h->ring || ctx.knobs.tp_ring > 0 || D >= TP_RING_FIRST_TEXTS);
     if (ring_shape && !use_ring && !h->ring_alloc.joinable() && !h->ring_pending.load()) h->ring_wanted = true;   // (pinned when this call is over: ring_pin_later)
@@ -1461,6 +1475,7 @@ static bool prepare_texts_streamed(east_hip_index *h, Ctx &ctx, const uint8_t *b
     static const int ring_threads_env = getenv("EAST_HIP_RING_THREADS") ? atoi(getenv("EAST_HIP_RING_THREADS")) : 0;     // (experiments)
     const int n_fill = !use_ring ? 0 : ring_threads_env > 0 ? std::min(ring_threads_env, 64)
                                      : (int)std::min<u32>(3u, std::max<u32>(2u, std::thread::hardware_concurrency() / 2u));
+    if (use_ring && !h->ring) ring_adopt(h, true);       // (a background pin under way: its ring, not a second one)
     if (use_ring && h->ring && h->ring_events.empty())
         for (int i = 0; i < TP_RING_SLOTS; i++) {
             hipEvent_t e;
@@ -2231,8 +2246,7 @@ void east_hip_destroy(east_hip_handle_t h)
     if (h->tp_tables) (void)hipFree(h->tp_tables);
     if (h->ht_tab) (void)hipFree(h->ht_tab);
     for (auto e : h->copy_events) (void)hipEventDestroy(e);
-    if (h->ring_alloc.joinable()) h->ring_alloc.join();
-    if (!h->ring && h->ring_pending.load()) h->ring = h->ring_pending.load();
+    ring_adopt(h, true);
     for (auto e : h->ring_events) (void)hipEventDestroy(e);
     if (h->ring) (void)hipHostFree(h->ring);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
