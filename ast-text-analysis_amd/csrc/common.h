@@ -94,6 +94,7 @@ struct Stats {
     i64 fused_finish = 0;       // the last radix digit and the placement ran as one pass in LDS (lvl0_finish_kernel)
     i64 ht_keys = 0;            // the first-level keys held variable-length code words (ht_code.h)
     i64 seg_sort = 0;           // the first-level sort was segmented by document (radix_sort.h: RsSeg)
+    i64 persist_rounds = 0;     // rounds run inside ONE launch by the workgroups that keep their tiles (persist_rounds.h)
 };
 
 // Optional per-kernel timing with HIP events on the handle's own stream (the
@@ -170,6 +171,7 @@ struct Knobs {
     int seg_mode = env_int("EAST_HIP_SEG", -1);                         // east_hip_debug_set_segmented_sort: -1 by size, 0 never, 1 wherever it can be done
     bool lds_rounds = getenv("EAST_HIP_NO_LDS_ROUNDS") == nullptr;      // east_hip_debug_set_lds_rounds
     bool fused_classify = getenv("EAST_HIP_NO_FUSED_CLASSIFY") == nullptr;      // ... (2): the stand-alone classification pass
+    bool persist = getenv("EAST_HIP_NO_PERSIST") == nullptr;            // ... (1 only): small domains finish in one launch (persist_rounds.h)
     size_t rank_bucket_bytes = (size_t)192 << 20;                       // east_hip_debug_set_rank_bucket_bytes
     bool speculate = getenv("EAST_HIP_NO_SPECULATION") == nullptr;      // east_hip_debug_set_speculation
     bool kg_pairs = getenv("EAST_HIP_NO_KG_PAIRS") == nullptr;          // east_hip_debug_set_score_path

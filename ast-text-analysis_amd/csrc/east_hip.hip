@@ -2515,15 +2515,16 @@ void *east_hip_stream(east_hip_handle_t h) { return h ? (void *)h->stream : null
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap)
 {
     if (!h || !out) return EAST_HIP_ERR_INVALID;
-    const int64_t v[26] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
+    const int64_t v[27] = {h->n, h->n_docs, h->m_total, h->sigma_t, h->bits0, h->stats.levels,
                            (int64_t)h->arena.cap, (int64_t)h->arena.high, h->stats.radix_passes,
                            h->stats.radix_elems, h->stats.radix_elem_bytes, h->stats.radix_passes_u32,
                            h->stats.radix_elems_u32, h->stats.radix_passes_u64, h->stats.radix_elems_u64,
                            h->stats.levels_resolved, h->stats.merge_elems, h->stats.refine_rounds,
                            h->stats.window_sorted, h->stats.lds_sorted, h->stats.fused_finish, h->stats.first_kept,
-                           h->stats.first_n, h->stats.ht_keys, h->stats.seg_sort, h->narrow_upload ? 1 : 0};
-    for (int i = 0; i < 26 && i < cap; i++) out[i] = v[i];
-    return 26;
+                           h->stats.first_n, h->stats.ht_keys, h->stats.seg_sort, h->narrow_upload ? 1 : 0,
+                           h->stats.persist_rounds};
+    for (int i = 0; i < 27 && i < cap; i++) out[i] = v[i];
+    return 27;
 }
 
 int east_hip_profile_enable(east_hip_handle_t h, int on)
@@ -2692,11 +2693,13 @@ int east_hip_debug_narrow_symbols(const uint32_t *symbols, int64_t n, uint16_t *
 
 int east_hip_debug_set_lds_rounds(int enabled)
 {
-    // 0: every round through the global sort; 1: the default (in-LDS rounds that also classify the next domain);
-    // 2: in-LDS rounds with the stand-alone classification pass
+    // 0: every round through the global sort; 1: the default (in-LDS rounds that also classify the next domain, small
+    // domains finished by one persistent launch); 2: in-LDS rounds with the stand-alone classification pass, launch by
+    // launch; 3: as 1, launch by launch (no persistent kernel)
     knobs_update([&](Knobs &k) {
         k.lds_rounds = enabled != 0;
         k.fused_classify = enabled != 2 && getenv("EAST_HIP_NO_FUSED_CLASSIFY") == nullptr;
+        k.persist = enabled == 1 && getenv("EAST_HIP_NO_PERSIST") == nullptr;
     });
     return EAST_HIP_OK;
 }

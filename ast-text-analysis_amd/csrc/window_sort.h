@@ -26,6 +26,7 @@ __device__ __forceinline__ u32 dc3_sample_pos(u32 t, u32 n0)
 // or over ALL suffixes (n0 == 0: element t = text position), see window_suffix_sort.
 __device__ __forceinline__ u32 lvl0_pos(u32 t, u32 n0) { return n0 ? dc3_sample_pos(t, n0) : t; }
 #include "lds_group_sort.h"
+#include "persist_rounds.h"
 // (the test knobs of this file live in Ctx::knobs -- common.h: Knobs)
 static const bool g_trace = getenv("EAST_HIP_TRACE") != nullptr;   // per-round progress on stderr
 struct FusedAbort {};           // the fused finish met a repeat too long to order directly: the level is redone with the full sort
@@ -1607,13 +1608,19 @@ struct BitStarts {
 __global__ __launch_bounds__(BLOCK) void lvl0_lcp_text_list_kernel(const uint8_t *__restrict__ s8, const u32 *__restrict__ sa,
                                                                    const u32 *__restrict__ ranks, u32 count,
                                                                    u32 *__restrict__ lcp, u32 *__restrict__ capped,
-                                                                   LcpBudget budget)
+                                                                   LcpBudget budget, bool hinted = false)
 {
+    // hinted (the persistent rounds, persist_rounds.h): lcp[r] holds what the two suffixes are known to share -- the depth
+    // of the round in which they came apart --, and the comparison starts there
     const u32 t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= count) return;
     const u32 r = ranks[t];
     if (r == 0) { lcp[0] = 0; return; }
-    const u32 h = lcp_bytes_capped(s8, sa[r - 1], sa[r], 0u, budget);
+    const u32 h0 = hinted ? lcp[r] : 0u;
+    // (a pair known to share LCP_SOFT_CAP symbols or more goes straight to the finishing pass, whose comparisons run a
+    // wavefront wide: one thread walking 10 000 symbols is 300 dependent round trips -- 0.3 ms that a small build waits for)
+    if (hinted) budget.per_slot = 0;                    // (... and none of them goes deeper than that here)
+    const u32 h = h0 >= LCP_SOFT_CAP ? (LCP_PARTIAL_BIT | h0) : lcp_bytes_capped(s8, sa[r - 1], sa[r], h0, budget);
     if (h & LCP_PARTIAL_BIT) atomicOr(capped, 1u);
     lcp[r] = h;
 }
@@ -1874,6 +1881,33 @@ __global__ __launch_bounds__(BLOCK) void spec_counts_kernel(const u32 *__restric
     }
 }
 
+// The persistent rounds (persist_rounds.h): how many of its workgroups the device holds at once -- the launch never asks
+// for more -- and the lock that keeps two such launches of one process from sharing the chip half resident each.
+static std::mutex g_persist_mutex;
+struct PersistCap { u32 one_per_cu = 0, two_per_cu = 0; };      // workgroups resident at once, by kernel variant (0: not available)
+static PersistCap persist_capacity()
+{
+    static std::mutex mu;
+    static PersistCap cap[64];
+    static bool asked[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PersistCap();
+    std::lock_guard<std::mutex> lock(mu);
+    if (!asked[dev]) {
+        asked[dev] = true;
+        int per1 = 0, per2 = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per1, refine_persist_kernel<4>, LG_THREADS, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per2, refine_persist_kernel<8>, LG_THREADS, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); per1 = per2 = 0; }
+        // (two workgroups of 1 024 threads fill a CU's 32 wave slots; the query is trusted up to that)
+        if (cus > 0 && per1 >= 1) cap[dev].one_per_cu = (u32)cus;
+        if (cus > 0 && per2 >= 2) cap[dev].two_per_cu = 2u * (u32)cus;
+        const char *env = getenv("EAST_HIP_PERSIST_WGS");       // (experiments: a smaller grid)
+        if (env) { cap[dev].one_per_cu = std::min<u32>(cap[dev].one_per_cu, (u32)atoi(env)); cap[dev].two_per_cu = std::min<u32>(cap[dev].two_per_cu, (u32)atoi(env)); }
+    }
+    return cap[dev];
+}
+
 // Level 0 on the byte stream: the window keys are sorted, then one classify pass places everything
 // that is untied or tied in a small group (ordered directly on the text); large groups go through
 // refinement rounds (step 2c).  Returns true when sa12 is final (no name string is ever written);
@@ -2102,7 +2136,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     // (the ranks whose entries have to be computed at the end: the slots of the domain of the round that switched over)
     u32 *lcp_redo = lcp_out ? ar.alloc<u32>((size_t)n02 + 1) : nullptr;
     u32 redo_n = 0;
-    bool redo_pending = false;
+    bool redo_pending = false, redo_hinted = false;
     bool done = false;
     bool lcp_from_rounds = true;                        // the rounds write the LCP entries of what they place (symbol windows)
     if (!ctx.lean) {
@@ -2130,6 +2164,8 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             (void)radix_sort_pairs<u64>(ctx, rb, cap, 8);
         }
         bool doubling = false;
+        PersistCap persist_caps = ctx.knobs.lds_rounds && ctx.knobs.persist && !ctx.dry ? persist_capacity() : PersistCap();
+        u32 persist_cap = std::max(persist_caps.one_per_cu, persist_caps.two_per_cu);
         u32 depth = fused ? (u32)depth0 : (u32)w;        // what the members of a group are known to share
         const u32 *elem = fused ? (const u32 *)sa12 : sorted_vals, *slot = nullptr, *flag = nullptr;
         int e_dom = -1, s_dom = 0, f_dom = 0;           // which of the rotating buffers hold the domain
@@ -2143,7 +2179,12 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             stalled = (round > 0 && m_next > m - m / 32) ? stalled + 1 : 0;
             if (round == REFINE_MAX_ROUNDS || (stalled == 2 && !doubling && !name_of)) break;
             const u32 gm = ceil_div_u32((u64)m + 1, BLOCK);
-            if (name_of && !doubling && round > 0 && m_next > m / 2) {
+            // A domain that fits the chip at one tile per resident workgroup is finished by ONE launch (persist_rounds.h):
+            // prefix doubling with the tiles kept in LDS, a grid barrier per round.  It gives up -- having changed nothing
+            // the rounds below rely on -- when a tie group is longer than a tile takes; the next, smaller domain may fit.
+            const bool try_persist = persist_cap > 0 && name_of && !doubling && m_next <= persist_cap * LG_CHUNK && n02 >= 4u * PR_CTL_WORDS;
+            const bool slow = round > 0 && m_next > m / 2;          // slow shrinking = long repeats
+            if (name_of && !doubling && slow && !try_persist) {
                 // slow shrinking = long repeats: from here on the depth doubles every round (see above)
                 doubling = true;
                 lcp_from_rounds = false;                // (names instead of symbols: the seams' entries are computed at the end)
@@ -2184,6 +2225,71 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             }
             const uint8_t *xdep = have_x ? (const uint8_t *)xbuf[x_dom] : (const uint8_t *)nullptr;
             m = m_next;
+            if (try_persist) {
+                // (the second copy of the names and the control words: the round sort's buffers, idle until a sort runs)
+                u32 *name1 = (u32 *)rb.keys[0], *ctl = rb.vals[0];
+                HIP_CHECK(hipMemsetAsync(ctl, 0, PR_CTL_WORDS * sizeof(u32), ctx.stream));
+                LAUNCH(ctx, persist_names_init_kernel, ceil_div_u32(n02, BLOCK), (const u32 *)sa12,
+                       !slot && !fused ? sorted_vals : (const u32 *)nullptr, (const u64 *)keep, n02, name_of, name1);
+                const PrArgs pa{ebuf[e_c], gstart, slot_c, m, depth, bit_width_u32(n02 > 1 ? n02 - 1 : 1), name_of, name1, sa12,
+                                lcp_redo ? lcp_out : (u32 *)nullptr, ctl};
+                u32 h_ctl[4] = {0, 0, 0, 0};
+                {
+                    std::lock_guard<std::mutex> lock(g_persist_mutex);
+                    const u32 tiles = ceil_div_u32(m, LG_CHUNK);
+                    if (tiles <= persist_caps.one_per_cu) LAUNCH_BLOCK(ctx, refine_persist_kernel<4>, tiles, LG_THREADS, pa);
+                    else LAUNCH_BLOCK(ctx, refine_persist_kernel<8>, tiles, LG_THREADS, pa);
+                    HIP_CHECK(hipMemcpyAsync(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, ctx.stream));
+                    HIP_CHECK(sync_stream(ctx.stream));
+                }
+                if (h_ctl[PR_CTL_ABORT])
+                    east_throw(EAST_HIP_ERR_INTERNAL, h_ctl[PR_CTL_ABORT] == 2 ? "persistent rounds: groups still open after the last round"
+                                                                                : "persistent rounds: a grid barrier timed out");
+                if (g_trace)
+                    fprintf(stderr, "[east_hip]   round %d: persistent launch over a domain of %u at depth %u: %s\n", round, m, depth,
+                            h_ctl[PR_CTL_BAIL] ? "a group too long for a tile, the rounds go on launch by launch" : "done");
+                if (h_ctl[PR_CTL_BAIL] && slow) persist_cap = 0;     // (long groups that do not split: prefix doubling launch by launch)
+#ifdef PR_STAMPS
+                if (g_trace && !h_ctl[PR_CTL_BAIL]) {
+                    std::vector<unsigned long long> st(8 * PR_MAX_ROUNDS);
+                    HIP_CHECK(hipMemcpy(st.data(), ctl + PR_CTL_STAMPS, st.size() * 8, hipMemcpyDeviceToHost));
+                    for (u32 r = 0; r < h_ctl[PR_CTL_ROUNDS]; r++) {
+                        auto d = [&](int x, int y) { return (double)(long long)(st[r * 8 + x] - st[r * 8 + y]) * 0.01; };
+                        fprintf(stderr, "[east_hip]     round %u (block 0): gather+test %.2f us, sort %.2f, bounds %.2f, held loads %.2f, names+stores %.2f, count %.2f, barrier %.2f\n",
+                                r, d(1, 0), d(2, 1), d(5, 2), d(6, 5), d(7, 6), d(3, 7), d(4, 3));
+                    }
+                    const u32 nwg = ceil_div_u32(m, LG_CHUNK);
+                    std::vector<unsigned long long> ab(2 * (size_t)nwg);
+                    HIP_CHECK(hipMemcpy(ab.data(), ctl + PR_CTL_WORDS, ab.size() * 8, hipMemcpyDeviceToHost));
+                    if (h_ctl[PR_CTL_ROUNDS] > 3) {
+                        unsigned long long t0 = ~0ull;
+                        for (u32 b = 0; b < nwg; b++) t0 = std::min(t0, ab[2 * b]);
+                        fprintf(stderr, "[east_hip]     round 3, arrival / departure of every 16th block (us after the first arrival):");
+                        for (u32 b = 0; b < nwg; b += 16) fprintf(stderr, " %u:%.1f/%.1f", b, (ab[2 * b] - t0) * 0.01, (ab[2 * b + 1] - t0) * 0.01);
+                        double mx = 0; u32 who = 0;
+                        for (u32 b = 0; b < nwg; b++) if ((ab[2 * b] - t0) * 0.01 > mx) { mx = (ab[2 * b] - t0) * 0.01; who = b; }
+                        fprintf(stderr, "\n[east_hip]     last arrival: block %u at %.1f us\n", who, mx);
+                    }
+                }
+#endif
+                if (!h_ctl[PR_CTL_BAIL]) {
+                    if (ctx.stats) {
+                        ctx.stats->refine_rounds += h_ctl[PR_CTL_ROUNDS];
+                        ctx.stats->persist_rounds += h_ctl[PR_CTL_ROUNDS];
+                        ctx.stats->lds_sorted += (i64)m * h_ctl[PR_CTL_ROUNDS];
+                    }
+                    // the LCP entries of the domain's ranks: compared on the text once the suffix array stands (below)
+                    if (lcp_redo) {
+                        HIP_CHECK(hipMemcpyAsync(lcp_redo, slot_c, (size_t)m * 4, hipMemcpyDeviceToDevice, ctx.stream));
+                        redo_n = m;
+                        lcp_from_rounds = false;
+                        redo_hinted = true;
+                    }
+                    m_next = 0;
+                    done = true;
+                    break;
+                }
+            }
             bool have_group = false;                    // group[] = inclusive scan of gstart: the groups' numbers
             auto number_groups = [&]() {
                 if (!have_group) device_scan<ArrIn, true>(ctx, ArrIn{gstart}, m, group);
@@ -2322,7 +2428,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         if (ctx.stats) ctx.stats->levels_resolved++;
         if (lcp_out && !lcp_from_rounds && redo_n)      // (prefix doubling: the entries of everything those rounds placed)
             LAUNCH(ctx, lvl0_lcp_text_list_kernel, ceil_div_u32(redo_n, BLOCK), s8, (const u32 *)sa12, (const u32 *)lcp_redo, redo_n,
-                   lcp_out, lcp_capped, ctx.lcp_budget);
+                   lcp_out, lcp_capped, ctx.lcp_budget, redo_hinted);
         return true;
     }
     if (!s12) return false;                            // all-suffix mode: the caller falls back to DC3

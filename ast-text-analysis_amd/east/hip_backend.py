@@ -105,7 +105,7 @@ BUILD_INFO_FIELDS = ("n_total", "n_docs", "n_strings", "sigma_text", "bits_level
                      "arena_high_water", "radix_passes", "radix_elements", "radix_element_bytes",
                      "radix_passes_u32", "radix_elements_u32", "radix_passes_u64", "radix_elements_u64",
                      "dc3_levels_resolved", "merge_elements", "refine_rounds", "window_sorted", "lds_sorted",
-                     "fused_finish", "first_kept", "first_n", "ht_keys", "seg_sort", "narrow_upload")
+                     "fused_finish", "first_kept", "first_n", "ht_keys", "seg_sort", "narrow_upload", "persist_rounds")
 
 _lib = None
 

@@ -359,7 +359,7 @@ int east_hip_debug_set_window_sort(int enabled);
 int east_hip_debug_set_segmented_sort(int mode);
 /* Test knob: 0 = the tie-refinement rounds sort every group with the global radix sort; 1 (default) = groups
  * that fit a workgroup's LDS are sorted there (csrc/lds_group_sort.h), the global sort takes the rest. */
-int east_hip_debug_set_lds_rounds(int enabled);   /* 0 / 1 (default: the in-LDS rounds also classify the next domain) / 2 (in-LDS rounds + the stand-alone classification pass) */
+int east_hip_debug_set_lds_rounds(int enabled);   /* 0 / 1 (default: the in-LDS rounds also classify the next domain; a domain that fits the chip is finished by one persistent launch) / 2 (in-LDS rounds + the stand-alone classification pass, launch by launch) / 3 (as 1 without the persistent launch) */
 /* Test knob: 0 = every build waits for the device's answers (alphabet size, tie groups) as a handle's
  * first build does; 1 (default) = later builds on a handle are queued without waiting, on the strength
  * of what the build before found, and checked by the one read-back at their end. */

@@ -344,7 +344,7 @@ def test_64mib_document_vs_oracle(hip, oracle, request):
 
 @pytest.mark.parametrize("n_docs", [1, 8])
 @pytest.mark.parametrize("n", [1000, 10000, 100000])
-def test_reference_worst_case_collection_vs_oracle(hip, oracle, request, n, n_docs):
+def test_reference_worst_case_collection_vs_oracle(hip, oracle, request, suffix_sort_path, n, n_docs):
     """The input of the reference's own runtime harness (analysis/runtime.py:19-31 on analysis/utils.py:5-9): m = 100
     identical strings of n - 4 letters -- every suffix in a tie group of 100 that only the terminators tell apart, common
     prefixes as long as the string (far beyond the direct-comparison cap at n = 10^5: the blocked-Kasai finish) -- as one
@@ -358,6 +358,10 @@ def test_reference_worst_case_collection_vs_oracle(hip, oracle, request, n, n_do
     off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])]).astype(np.int64)
     index = hip_backend.HipIndex()
     index.build(sym, off, np.array([d[1] for d in docs], dtype=np.int32))
+    if suffix_sort_path == "window_sort" and n * n_docs <= 10000:
+        # (100 K .. 1 M symbols tied in groups of 100: the domain fits the chip, one persistent launch runs every round --
+        # csrc/persist_rounds.h -- instead of ~15 launches per round)
+        assert index.info()["persist_rounds"] >= 5, index.info()
     qs, qo = synthetic.keyphrases(rng, sym, 60)
     tables = {norm: index.score_table(qs, qo, norm) for norm in (True, False)}
     sampled = range(n_docs) if n < 100000 else sorted({0, n_docs - 1})       # (11 s of oracle per document at 10^5)
@@ -710,13 +714,15 @@ def test_small_vocabulary_text_tie_refinement_vs_oracle(hip, oracle, seed):
             assert np.array_equal(t[name], getattr(o, name)), (name, d, index.info())
 
 
-@pytest.mark.parametrize("lds_rounds", [1, 2, 0])
+@pytest.mark.parametrize("lds_rounds", [1, 3, 2, 0])
 @pytest.mark.parametrize("seed", range(4))
 def test_refinement_rounds_in_lds_and_by_the_global_sort(hip, oracle, suffix_sort_path, seed, lds_rounds):
     """The rounds order tie groups that fit a workgroup's LDS there (csrc/lds_group_sort.h) and leave longer ones to
     the global radix sort: word text over small vocabularies gives both kinds in one domain -- groups of a few
     dozen members next to groups of tens of thousands --, single documents and several, with the in-LDS path on
-    (1, the default: the in-LDS round also classifies the next domain; 2: with the stand-alone classification pass) and off.  All six tables bit-exact against the oracle, the LCP entries the rounds write included."""
+    (1, the default: the in-LDS round also classifies the next domain, and a domain that fits the chip is finished by one
+    persistent launch; 3: the same launch by launch; 2: with the stand-alone classification pass) and off.  All six tables
+    bit-exact against the oracle, the LCP entries the rounds write included."""
     from east import hip_backend, synthetic
     lib = hip.load()
     rng = np.random.default_rng(7700 + seed)
@@ -733,6 +739,7 @@ def test_refinement_rounds_in_lds_and_by_the_global_sort(hip, oracle, suffix_sor
         if suffix_sort_path == "window_sort":
             assert info["window_sorted"] == 1 and info["refine_rounds"] >= 1, info
             assert (info["lds_sorted"] > 0) == bool(lds_rounds), info
+            assert lds_rounds == 1 or info["persist_rounds"] == 0, info       # (the persistent launch: the default only)
         if suffix_sort_path.startswith("window_sort_ht"):
             assert info["window_sorted"] == 1 and info["ht_keys"] >= 1, info      # variable-length keys really ran
             assert info["fused_finish"] == int(suffix_sort_path == "window_sort_ht"), info
