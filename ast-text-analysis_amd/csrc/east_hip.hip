@@ -502,7 +502,8 @@ struct east_hip_index {
     std::thread ring_alloc;                 // pins the ring in the background after a first call that went without it
     std::atomic<char *> ring_pending{nullptr};
     std::atomic<bool> ring_done{false};     // the background thread is through (with or without a ring): it can be joined without waiting
-    bool narrow_upload = false;             // the last build's host symbols went up as 16-bit words (east_hip_build_info [25])
+    int narrow_upload = 0;                  // the last build's host symbols went up as 16-bit words (1) / as bytes (2) (east_hip_build_info [25])
+    bool bytes_refused = false;             // a text symbol of 0xFF .. 0x9FF was met on the way up as bytes: this handle's later uploads take 16 bits at once
     bool ring_wanted = false;               // (the call under way would have taken the ring: pin it once the call is over --
                                             // while it runs, the pinning and the call's own copies fight over the runtime's locks)
     // symbols prepared on the device by east_hip_build_texts (own allocation)
@@ -1032,6 +1033,28 @@ __global__ __launch_bounds__(BLOCK) void widen_symbols_kernel(const uint16_t *__
     }
 }
 
+// (bytes: text code points below 0xFF as they are, 0xFF = a terminator)
+__global__ __launch_bounds__(BLOCK) void widen_symbols8_kernel(const uint8_t *__restrict__ in, u32 n, u32 *__restrict__ out)
+{
+    const u32 i = (blockIdx.x * BLOCK + threadIdx.x) * 16u;
+    if (i + 16u <= n && ((uintptr_t)(in + i) & 15u) == 0 && ((uintptr_t)(out + i) & 15u) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(in + i);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            u32 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 x = (w[g] >> (k * 8)) & 0xFFu;
+                o[k] = x == 0xFFu ? TEXT_SYMBOLS : x;
+            }
+            reinterpret_cast<uint4 *>(out + i)[g] = uint4{o[0], o[1], o[2], o[3]};
+        }
+    } else {
+        for (u32 j = i; j < i + 16u && j < n; j++) { const u32 x = in[j]; out[j] = x == 0xFFu ? TEXT_SYMBOLS : x; }
+    }
+}
+
 // symbols [0, n) from the host into `staging` (device, n words) through the pinned ring; d_narrow: n + 8 halfwords of device scratch
 // The narrowing of a stretch of host symbols into the pinned ring.  With AVX2 (looked for at run time): sixteen symbols a
 // step -- unsigned compare by max, saturating pack, the lanes put back in order -- and STREAMING stores: the ring is
@@ -1062,18 +1085,70 @@ static const bool g_have_avx2 = __builtin_cpu_supports("avx2") && getenv("EAST_H
 static void narrow_symbols_avx2(const u32 *, uint16_t *, size_t) {}
 static const bool g_have_avx2 = false;
 #endif
+// ... and to BYTES, for text whose code points all lie below 0xFF (every BASELINE input: A-Z): half the bytes over the link
+// again.  A text symbol the byte cannot hold (0xFF .. 0x9FF) is reported and the upload starts over with 16-bit words.
+#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
+__attribute__((target("avx2"))) static bool narrow_symbols8_avx2(const u32 *src, uint8_t *dst, size_t n)
+{
+    size_t i = 0;
+    bool bad = false;
+    auto one = [&](size_t k) { const u32 c = src[k]; bad |= c >= 0xFFu && c < TEXT_SYMBOLS; dst[k] = c < 0xFFu ? (uint8_t)c : (uint8_t)0xFFu; };
+    for (; i < n && ((uintptr_t)(dst + i) & 31u); i++) one(i);
+    const __m256i first_term = _mm256_set1_epi32((int)TEXT_SYMBOLS), byte_max = _mm256_set1_epi32(0xFF);
+    __m256i wrong = _mm256_setzero_si256();
+    for (; i + 32 <= n; i += 32) {
+        __m256i v[4];
+#pragma GCC unroll 4
+        for (int k = 0; k < 4; k++) {
+            const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 8 * k));
+            const __m256i is_term = _mm256_cmpeq_epi32(_mm256_max_epu32(a, first_term), a);           // a >= TEXT_SYMBOLS (unsigned)
+            const __m256i fits = _mm256_cmpeq_epi32(_mm256_min_epu32(a, byte_max), a);                  // a <= 0xFF
+            // (0xFF itself does not fit either: it is the terminator's byte)
+            wrong = _mm256_or_si256(wrong, _mm256_andnot_si256(is_term, _mm256_or_si256(_mm256_cmpeq_epi32(a, byte_max),
+                                                                                         _mm256_xor_si256(fits, _mm256_set1_epi32(-1)))));
+            v[k] = _mm256_blendv_epi8(a, byte_max, is_term);
+        }
+        // 32-bit -> 16-bit -> 8-bit, the 128-bit lanes put back in order at the end
+        const __m256i p01 = _mm256_packus_epi32(v[0], v[1]), p23 = _mm256_packus_epi32(v[2], v[3]);
+        const __m256i b = _mm256_packus_epi16(p01, p23);
+        const __m256i r = _mm256_permutevar8x32_epi32(b, _mm256_setr_epi32(0, 4, 1, 5, 2, 6, 3, 7));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i), r);
+    }
+    bad |= !_mm256_testz_si256(wrong, wrong);
+    for (; i < n; i++) one(i);
+    _mm_sfence();
+    return !bad;
+}
+#else
+static bool narrow_symbols8_avx2(const u32 *, uint8_t *, size_t) { return false; }
+#endif
+static bool narrow_symbols8(const u32 *src, uint8_t *dst, size_t n)
+{
+    if (g_have_avx2) return narrow_symbols8_avx2(src, dst, n);
+    bool bad = false;
+    for (size_t i = 0; i < n; i++) { const u32 c = src[i]; bad |= c >= 0xFFu && c < TEXT_SYMBOLS; dst[i] = c < 0xFFu ? (uint8_t)c : (uint8_t)0xFFu; }
+    return !bad;
+}
 static void narrow_symbols(const u32 *src, uint16_t *dst, size_t n)
 {
     if (g_have_avx2) { narrow_symbols_avx2(src, dst, n); return; }
     for (size_t i = 0; i < n; i++) dst[i] = src[i] < TEXT_SYMBOLS ? (uint16_t)src[i] : (uint16_t)SYM_TERMINATOR16;
 }
 
-static void upload_symbols_narrow(east_hip_index *h, const u32 *sym, u32 n, u32 *staging, uint16_t *d_narrow)
+// T = uint16_t: every symbol of the reference encoding fits (a terminator = 0xFFFF on the wire); T = uint8_t: text below
+// 0xFF only -- returns false, with nothing left in flight, when a symbol did not fit (the caller starts over with 16 bits).
+template <class T>
+static bool upload_symbols_narrow(east_hip_index *h, const u32 *sym, u32 n, u32 *staging, T *d_narrow)
 {
-    const size_t slot_syms = TP_RING_SLOT / 2;
+    constexpr bool BYTES = sizeof(T) == 1;
+    static const size_t slot_env = getenv("EAST_HIP_SYMBOL_SLOT") ? (size_t)atoll(getenv("EAST_HIP_SYMBOL_SLOT")) : 0;     // (experiments)
+    const size_t slot_bytes = slot_env >= 65536 && slot_env <= TP_RING_SLOT ? slot_env & ~(size_t)255 : TP_RING_SLOT;
+    const size_t slot_syms = slot_bytes / sizeof(T);
     const u32 n_slots = ceil_div_u32(n, slot_syms);
     static const int threads_env = getenv("EAST_HIP_SYMBOL_THREADS") ? atoi(getenv("EAST_HIP_SYMBOL_THREADS")) : 0;     // (experiments)
-    const int n_fill = threads_env > 0 ? std::min(threads_env, 64) : (int)std::min<u32>(6u, std::max<u32>(2u, std::thread::hardware_concurrency() / 2u));
+    // (bytes: the link carries a quarter of the symbols' bytes, the narrowing threads read all of them -- eight, measured below)
+    const int n_fill = threads_env > 0 ? std::min(threads_env, 64)
+                                       : (int)std::min<u32>(BYTES ? 8u : 6u, std::max<u32>(2u, std::thread::hardware_concurrency() / 2u));
     // (measured on the 256-thread host of the MI355X box, 61 M symbols: 3 threads 5.8-6.4 ms per call, 4: 5.2-5.5, 6: 4.7-5.6,
     // 8-24: 4.9-5.9 -- against 6.1 ms with the plain 4-byte copy; the narrowing threads, not the link, set the pace)
     if (h->ring_events.empty())
@@ -1088,8 +1163,8 @@ static void upload_symbols_narrow(east_hip_index *h, const u32 *sym, u32 n, u32 
     std::vector<std::atomic<int>> slot_parts(n_slots);
     for (auto &a : slot_parts) a.store(0, std::memory_order_relaxed);
     std::atomic<u32> slots_free{TP_RING_SLOTS};
-    std::atomic<int> abort{0};
-    uint16_t *ring = (uint16_t *)h->ring;
+    std::atomic<int> abort{0}, misfit{0};
+    T *ring = (T *)h->ring;                                  // (slot k of the ring starts at k * TP_RING_SLOT whatever part of it is used)
     std::vector<std::thread> fillers;
     for (int j = 0; j < n_fill; j++)
         fillers.emplace_back([&, j]() {
@@ -1101,8 +1176,9 @@ static void upload_symbols_narrow(east_hip_index *h, const u32 *sym, u32 n, u32 
                 const size_t a = (size_t)sl * slot_syms, len = std::min<size_t>(slot_syms, (size_t)n - a);
                 const size_t lo = len * (size_t)j / (size_t)n_fill, hi = len * (size_t)(j + 1) / (size_t)n_fill;
                 const u32 *src = sym + a;
-                uint16_t *dst = ring + (size_t)(sl % TP_RING_SLOTS) * slot_syms;
-                narrow_symbols(src + lo, dst + lo, hi - lo);
+                T *dst = ring + (size_t)(sl % TP_RING_SLOTS) * (TP_RING_SLOT / sizeof(T));
+                if constexpr (BYTES) { if (!narrow_symbols8(src + lo, (uint8_t *)dst + lo, hi - lo)) misfit.store(1, std::memory_order_release); }
+                else narrow_symbols(src + lo, (uint16_t *)dst + lo, hi - lo);
                 slot_parts[sl].fetch_add(1, std::memory_order_release);
             }
         });
@@ -1121,11 +1197,16 @@ static void upload_symbols_narrow(east_hip_index *h, const u32 *sym, u32 n, u32 
     } joiner{fillers, abort, h->copy_stream};
     for (u32 sl = 0; sl < n_slots; sl++) {
         while (slot_parts[sl].load(std::memory_order_acquire) < n_fill) std::this_thread::yield();
+        if (misfit.load(std::memory_order_acquire)) return false;      // (the joiner stops the fill threads and drains the copy stream)
         const size_t a = (size_t)sl * slot_syms, len = std::min<size_t>(slot_syms, (size_t)n - a);
-        HIP_CHECK(hipMemcpyAsync(d_narrow + a, ring + (size_t)(sl % TP_RING_SLOTS) * slot_syms, len * 2, hipMemcpyHostToDevice, h->copy_stream));
+        HIP_CHECK(hipMemcpyAsync(d_narrow + a, ring + (size_t)(sl % TP_RING_SLOTS) * (TP_RING_SLOT / sizeof(T)), len * sizeof(T), hipMemcpyHostToDevice, h->copy_stream));
         HIP_CHECK(hipEventRecord(h->ring_events[sl % TP_RING_SLOTS], h->copy_stream));
-        hipLaunchKernelGGL(widen_symbols_kernel, dim3(ceil_div_u32(len, BLOCK * 8)), dim3(BLOCK), 0, h->copy_stream, (const uint16_t *)(d_narrow + a),
-                           (u32)len, staging + a);
+        if constexpr (BYTES)
+            hipLaunchKernelGGL(widen_symbols8_kernel, dim3(ceil_div_u32(len, BLOCK * 16)), dim3(BLOCK), 0, h->copy_stream, (const uint8_t *)(d_narrow + a),
+                               (u32)len, staging + a);
+        else
+            hipLaunchKernelGGL(widen_symbols_kernel, dim3(ceil_div_u32(len, BLOCK * 8)), dim3(BLOCK), 0, h->copy_stream, (const uint16_t *)(d_narrow + a),
+                               (u32)len, staging + a);
         HIP_CHECK(hipGetLastError());
         if (sl >= 1) {                                   // the slot before is on the device: back to the fill threads
             HIP_CHECK(hipEventSynchronize(h->ring_events[(sl - 1) % TP_RING_SLOTS]));
@@ -1135,6 +1216,7 @@ static void upload_symbols_narrow(east_hip_index *h, const u32 *sym, u32 n, u32 
     joiner.ok = true;
     HIP_CHECK(hipEventRecord(h->ev1, h->copy_stream));   // (ev0 / ev1 are recorded anew by the build behind this)
     HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev1, 0));
+    return true;
 }
 
 static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i64 n_total, const i64 *doc_offsets,
@@ -1182,12 +1264,24 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     }
     if (sym_on_host) {   // raw symbols are staged at the top of the arena
         staging = (u32 *)(h->arena.base + (h->arena.cap - (((size_t)n * 4 + 255) & ~(size_t)255)));
-        if (narrow) upload_symbols_narrow(h, sym, n, staging, (uint16_t *)((char *)staging - narrow_bytes));
-        else HIP_CHECK(hipMemcpyAsync(staging, sym, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        int went = 0;
+        if (narrow) {
+            // bytes first where the text may fit them (the first 64 Ki symbols say: word text does, Cyrillic does not); a
+            // symbol that does not fit further on starts the upload over with 16-bit words, for this call and the handle's later ones
+            static const bool no_bytes = getenv("EAST_HIP_NO_SYMBOL_BYTES") != nullptr;
+            bool bytes = !no_bytes && !h->bytes_refused;
+            for (u32 i = 0; bytes && i < std::min<u32>(n, 65536u); i++) bytes = sym[i] < 0xFFu || sym[i] >= TEXT_SYMBOLS;
+            if (bytes && upload_symbols_narrow<uint8_t>(h, sym, n, staging, (uint8_t *)((char *)staging - narrow_bytes))) went = 2;
+            else {
+                if (bytes) h->bytes_refused = true;
+                (void)upload_symbols_narrow<uint16_t>(h, sym, n, staging, (uint16_t *)((char *)staging - narrow_bytes));
+                went = 1;
+            }
+        } else HIP_CHECK(hipMemcpyAsync(staging, sym, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        h->narrow_upload = went;
         sym = staging;
-    }
+    } else h->narrow_upload = 0;
     h->stats = Stats();
-    h->narrow_upload = narrow;
     h->arena.high = 0;
     Ctx ctx;
     ctx.knobs = kn;
@@ -2521,7 +2615,7 @@ int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap)
                            h->stats.radix_elems_u32, h->stats.radix_passes_u64, h->stats.radix_elems_u64,
                            h->stats.levels_resolved, h->stats.merge_elems, h->stats.refine_rounds,
                            h->stats.window_sorted, h->stats.lds_sorted, h->stats.fused_finish, h->stats.first_kept,
-                           h->stats.first_n, h->stats.ht_keys, h->stats.seg_sort, h->narrow_upload ? 1 : 0,
+                           h->stats.first_n, h->stats.ht_keys, h->stats.seg_sort, h->narrow_upload,
                            h->stats.persist_rounds};
     for (int i = 0; i < 27 && i < cap; i++) out[i] = v[i];
     return 27;
@@ -2689,6 +2783,18 @@ int east_hip_debug_narrow_symbols(const uint32_t *symbols, int64_t n, uint16_t *
     else
         for (int64_t i = 0; i < n; i++) out[i] = symbols[i] < TEXT_SYMBOLS ? (uint16_t)symbols[i] : (uint16_t)SYM_TERMINATOR16;
     return vector && g_have_avx2 ? 1 : EAST_HIP_OK;
+}
+
+int east_hip_debug_narrow_symbols8(const uint32_t *symbols, int64_t n, uint8_t *out, int vector)
+{
+    // host only, as above: the narrowing to bytes.  Returns 1 when every symbol fitted (text below 0xFF, terminators from
+    // U+0A00 on), 0 when one did not, + 2 when the AVX2 form ran
+    if (!symbols || !out || n < 0) return EAST_HIP_ERR_INVALID;
+    bool ok = true;
+    if (vector) ok = narrow_symbols8(symbols, out, (size_t)n);
+    else
+        for (int64_t i = 0; i < n; i++) { const u32 c = symbols[i]; ok &= !(c >= 0xFFu && c < TEXT_SYMBOLS); out[i] = c < 0xFFu ? (uint8_t)c : (uint8_t)0xFFu; }
+    return (ok ? 1 : 0) + (vector && g_have_avx2 ? 2 : 0);
 }
 
 int east_hip_debug_set_lds_rounds(int enabled)

@@ -1883,6 +1883,7 @@ __global__ __launch_bounds__(BLOCK) void spec_counts_kernel(const u32 *__restric
 
 // The persistent rounds (persist_rounds.h): how many of its workgroups the device holds at once -- the launch never asks
 // for more -- and the lock that keeps two such launches of one process from sharing the chip half resident each.
+#define PERSIST_SMALL_INPUT ((u32)4 << 20)      // inputs whose names cost next to nothing to initialise (0.1 ms)
 static std::mutex g_persist_mutex;
 struct PersistCap { u32 one_per_cu = 0, two_per_cu = 0; };      // workgroups resident at once, by kernel variant (0: not available)
 static PersistCap persist_capacity()
@@ -2182,7 +2183,11 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // A domain that fits the chip at one tile per resident workgroup is finished by ONE launch (persist_rounds.h):
             // prefix doubling with the tiles kept in LDS, a grid barrier per round.  It gives up -- having changed nothing
             // the rounds below rely on -- when a tie group is longer than a tile takes; the next, smaller domain may fit.
-            const bool try_persist = persist_cap > 0 && name_of && !doubling && m_next <= persist_cap * LG_CHUNK && n02 >= 4u * PR_CTL_WORDS;
+            // (the launch needs the name of every placed suffix first -- a scatter over all n02 ranks, 2.1 ms for the 94 M
+            // symbols of the Zipf stand-in, whose last domain of 0.14 M would save a few dozen launches for it: only where
+            // the domain is a good part of the input, or the input small)
+            const bool try_persist = persist_cap > 0 && name_of && !doubling && m_next <= persist_cap * LG_CHUNK && n02 >= 4u * PR_CTL_WORDS &&
+                                     (n02 <= PERSIST_SMALL_INPUT || n02 / 8u <= m_next);
             const bool slow = round > 0 && m_next > m / 2;          // slow shrinking = long repeats
             if (name_of && !doubling && slow && !try_persist) {
                 // slow shrinking = long repeats: from here on the depth doubles every round (see above)

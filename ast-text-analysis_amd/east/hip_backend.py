@@ -78,6 +78,7 @@ SIGNATURES = {
     "east_hip_debug_alphabetic_code": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int32,
                                                       ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int32)]),
     "east_hip_debug_narrow_symbols": (ctypes.c_int, [_c_u32p, ctypes.c_int64, ctypes.POINTER(ctypes.c_uint16), ctypes.c_int]),
+    "east_hip_debug_narrow_symbols8": (ctypes.c_int, [_c_u32p, ctypes.c_int64, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int]),
     "east_hip_group_create": (ctypes.c_int, [_c_i32p, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
     "east_hip_group_destroy": (None, [ctypes.c_void_p]),
     "east_hip_group_build": (ctypes.c_int, [ctypes.c_void_p, _c_u32p, ctypes.c_int64, _c_i64p, _c_i32p, ctypes.c_int32,

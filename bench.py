@@ -652,15 +652,17 @@ def extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D, 
         t0 = time.perf_counter()
         index.build(symbols, doc_offsets, n_strings)
         walls.append((time.perf_counter() - t0) * 1e3)
-    narrow = bool(index.info().get("narrow_upload"))
+    narrow = int(index.info().get("narrow_upload", 0))
+    per_symbol = {0: 4, 1: 2, 2: 1}[narrow]
     res["build_from_host_ms"] = {"wall_ms_min": min(walls), "wall_ms_median": sorted(walls)[len(walls) // 2], "wall_ms_first_call": walls[0],
-                                 "wall_ms_calls": [round(w, 2) for w in walls],
-                                 "device_build_ms": index.last_build_ms, "h2d_bytes": int(symbols.size) * (2 if narrow else 4),
-                                 "symbols_as_16_bit_words": narrow,
+                                 "wall_ms_max": max(walls[2:]), "wall_ms_calls": [round(w, 2) for w in walls],
+                                 "device_build_ms": index.last_build_ms, "h2d_bytes": int(symbols.size) * per_symbol,
+                                 "bytes_per_symbol": per_symbol,
                                  "note": "pageable host memory in, index out.  A handle's first call copies 4 B/symbol (the link: 56 GB/s, "
                                          "tools/pcie_probe.py) and leaves the pinning of the upload ring to a background thread; later "
-                                         "calls narrow the symbols to 16 bits on host threads, send them through the ring and widen "
-                                         "them on the device (east_hip.hip: upload_symbols_narrow)"}
+                                         "calls narrow the symbols on host threads -- to bytes while all text lies below 0xFF, else to "
+                                         "16-bit words --, send them through the ring and widen them on the device (east_hip.hip: "
+                                         "upload_symbols_narrow); wall_ms_max: the slowest call after the first two"}
     return res
 
 

@@ -101,7 +101,9 @@ int east_hip_reset(east_hip_handle_t h);
  * encoding fit 16 bits, so from 4 Mi symbols on -- and from a handle's second build on, when its
  * pinned upload ring exists -- host threads narrow them to 16-bit words into the ring and a kernel
  * widens them on the device (half the bytes over the link; east_hip_build_info [25]) -- a text symbol
- * is below U+0A00, everything from there on is a terminator, whose number the build never reads --;
+ * is below U+0A00, everything from there on is a terminator, whose number the build never reads --,
+ * and to BYTES (a quarter of the bytes) while every text symbol lies below 0xFF, as in ASCII word text: a
+ * symbol that does not fit starts the upload over with 16-bit words, for that call and the handle's later ones;
  * tagged streams, small inputs and a handle's first build take the plain 4-byte copy.
  */
 /*
@@ -304,7 +306,8 @@ void *east_hip_stream(east_hip_handle_t h);
  * (order-preserving) code words instead of fixed-width symbol fields (csrc/ht_code.h), [24] 1 when the first-level sort
  * kept every document inside its own range of ranks (the segmented sort, csrc/radix_sort.h: RsSeg), [25] 1 when
  * east_hip_build's host symbols went up as 16-bit words through the pinned ring (half the bytes over the link; reference
- * encoding, 4 Mi symbols or more, from a handle's second call on).
+ * encoding, 4 Mi symbols or more, from a handle's second call on), 2 when they went up as bytes (text below 0xFF),
+ * [26] refinement rounds run inside one persistent launch (csrc/persist_rounds.h; they count in [17] too).
  */
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap);
 
@@ -391,6 +394,10 @@ int east_hip_debug_alphabetic_code(const uint64_t *weights, int32_t n, uint32_t 
  * number the build never reads).  vector != 0: the form the upload's host threads run (AVX2 with streaming stores where
  * the CPU has it), 0: the plain loop.  Returns 1 if the vector form ran, 0 if the loop did, < 0 on bad arguments. */
 int east_hip_debug_narrow_symbols(const uint32_t *symbols, int64_t n, uint16_t *out, int vector);
+/* The same for the BYTES east_hip_build sends when the text's code points all lie below 0xFF (0xFF on the wire = a
+ * terminator): out[i] = symbols[i] < 0xFF ? symbols[i] : 0xFF.  Returns (1 if every symbol fitted -- text below 0xFF,
+ * terminators from U+0A00 on --, else 0) + (2 if the AVX2 form ran); < 0 on bad arguments. */
+int east_hip_debug_narrow_symbols8(const uint32_t *symbols, int64_t n, uint8_t *out, int vector);
 /* Test knob (process-wide): which form of the score path runs (easa.py:91-139).  1 (default) = pair k-gram tables marked
  * off the window keys + the per-keyphrase sums inside the walk kernel; 0 = one filled table, per-suffix results in HBM
  * and a reduction kernel (rounds 1-3); 2 = pair tables with the reduction kernel; 3 = filled table with the sums in the

@@ -1417,6 +1417,58 @@ def test_host_symbols_go_up_as_16_bit_words(hip, oracle, request):
     assert index.info()["narrow_upload"] == 0
 
 
+def test_host_symbols_go_up_as_bytes_when_the_text_fits_them(hip, oracle, request):
+    """Text whose code points all lie below 0xFF -- the word streams of every BASELINE config -- goes up as BYTES (a
+    quarter of the ABI's four bytes per symbol; east_hip.hip: upload_symbols_narrow<uint8_t>, build_info[25] == 2): same
+    tables and scores as the plain copy and as the oracle's.  A text symbol a byte cannot hold, met half-way through the
+    upload (far behind the 64 Ki symbols the call looks at first), starts it over with 16-bit words -- for that call, with
+    the right tables, and for the handle's later calls at once."""
+    _only_paths(request, "window_sort", "dc3_only", "window_sort_seg")
+    import time
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(17)
+    docs = [synthetic.word_stream_document(rng, int(sz), want_text=False)[1:] for sz in (3 << 20, 2 << 20, 900000)]
+    docs[2][0][docs[2][0] == 66] = 0xFE                         # the largest text symbol a byte holds
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])]).astype(np.int64)
+    ms = np.array([d[1] for d in docs], dtype=np.int32)
+    index = hip_backend.HipIndex(reserve_symbols=int(sym.size))
+    index.build(sym, off, ms)
+    assert index.info()["narrow_upload"] == 0
+    want = {d: index.tables(d) for d in range(3)}
+    qs, qo = synthetic.keyphrases(rng, sym, 100)
+    table = index.score_table(qs, qo, True)
+    for _ in range(200):                                       # the ring is pinned in the background: a few milliseconds
+        time.sleep(0.01)
+        index.build(sym, off, ms)
+        if index.info()["narrow_upload"]:
+            break
+    assert index.info()["narrow_upload"] == 2
+    for d in range(3):
+        got = index.tables(d)
+        for name in TABLES:
+            assert np.array_equal(got[name], want[d][name]), (name, d)
+    assert np.array_equal(index.score_table(qs, qo, True), table)
+    o = oracle.OracleEASA(symbols=docs[2][0], n_strings=docs[2][1])
+    for name in TABLES:
+        assert np.array_equal(want[2][name], getattr(o, name)), name
+    # a symbol that does not fit, 4 M symbols into the stream
+    sym2 = sym.copy()
+    hit = np.flatnonzero(sym2[off[1]:off[2]] == 67) + off[1]
+    sym2[hit] = 0x0416
+    index.build(sym2, off, ms)
+    assert index.info()["narrow_upload"] == 1
+    o = oracle.OracleEASA(symbols=sym2[off[1]:off[2]], n_strings=int(ms[1]))
+    got = index.tables(1)
+    for name in TABLES:
+        assert np.array_equal(got[name], getattr(o, name)), name
+    index.build(sym, off, ms)                                  # the handle remembers: 16-bit words at once
+    assert index.info()["narrow_upload"] == 1
+    got = index.tables(0)
+    for name in TABLES:
+        assert np.array_equal(got[name], want[0][name]), name
+
+
 def test_c_abi_rejects_inconsistent_input(hip):
     """n_strings that does not match the terminators, or a document without a final terminator,
     is an EAST_HIP_ERR_DOMAIN error (not silent garbage, not an out-of-bounds comparison)."""

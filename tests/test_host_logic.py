@@ -395,6 +395,44 @@ def test_host_symbols_are_narrowed_to_16_bit_words_as_the_plain_loop_does():
     assert vector_ran <= {0, 1}
 
 
+def test_host_symbols_are_narrowed_to_bytes_when_the_text_fits_them():
+    """Text whose code points all lie below 0xFF (ASCII word text: every BASELINE input) goes over the link as BYTES,
+    0xFF = a terminator (east_hip.hip: upload_symbols_narrow<uint8_t>): the AVX2 form -- an alignment prologue, 32
+    symbols a step through two saturating packs and a lane permutation, a tail -- and the plain loop against numpy on
+    every start alignment and length, and the verdict "a symbol did not fit" (0xFF .. 0x9FF is text a byte cannot hold:
+    the upload then starts over with 16-bit words) wherever such a symbol sits."""
+    import ctypes
+    from east import hip_backend
+    lib = hip_backend.load()
+    rng = np.random.default_rng(8)
+    base = rng.integers(1, 0xFF, size=6000).astype(np.uint32)
+    terms = np.array([0x0A00, 0x0A01, 0xFFFF, 0x10000, 0x7FFFFFFF, 0xFFFFFFFF], dtype=np.uint32)
+    base[rng.integers(0, base.size, size=700)] = rng.choice(terms, size=700)
+    u8p, u32p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32)
+    for start in range(0, 70):
+        for n in (0, 1, 31, 32, 33, 63, 65, 100, 1000, 4096 + start):
+            src = np.ascontiguousarray(base[start:start + n])
+            want = np.where(src < 0xFF, src, 0xFF).astype(np.uint8)
+            for vector in (1, 0):
+                buf = np.full(n + 96, 0xAB, dtype=np.uint8)                 # (guard bytes to either side)
+                out = buf[32 + (start % 32):32 + (start % 32) + n]          # every alignment of the destination
+                rc = lib.east_hip_debug_narrow_symbols8(src.ctypes.data_as(u32p), n, out.ctypes.data_as(u8p), vector)
+                assert rc & 1, (start, n, vector, rc)                       # every symbol fitted
+                assert np.array_equal(out, want), (start, n, vector)
+                assert (buf[:32 + (start % 32)] == 0xAB).all() and (buf[32 + (start % 32) + n:] == 0xAB).all(), (start, n, vector)
+    # a text symbol a byte cannot hold, at every position of a stretch that covers prologue, vector body and tail
+    src = np.ascontiguousarray(base[5:5 + 200])
+    out = np.zeros(200, dtype=np.uint8)
+    for bad in (0xFF, 0x100, 0x410, 0x09FF):
+        for at in range(200):
+            poisoned = src.copy()
+            poisoned[at] = bad
+            for vector in (1, 0):
+                rc = lib.east_hip_debug_narrow_symbols8(poisoned.ctypes.data_as(u32p), 200, out.ctypes.data_as(u8p), vector)
+                assert rc >= 0 and not (rc & 1), (bad, at, vector, rc)
+    assert lib.east_hip_debug_narrow_symbols8(None, 4, None, 1) < 0
+
+
 def test_bench_line_stays_under_the_drivers_tail():
     """bench.py prints ONE line for the driver, whose record keeps an 8 KB tail of stdout: the round-5 line had grown to
     21.7 KB and BENCH_r05.parsed was null.  compact_line() -- a pure function of the assembled numbers -- is run here on

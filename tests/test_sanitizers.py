@@ -101,6 +101,22 @@ for start in range(0, 20):
             assert lib.east_hip_debug_narrow_symbols(src.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n,
                                                      out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), vector) in (0, 1)
             assert np.array_equal(out, want), (start, n, vector)
+# ... and to bytes (text below 0xFF), with the verdict on a symbol that does not fit
+src_all = rng.integers(1, 0xFF, size=3000).astype(np.uint32)
+src_all[rng.integers(0, 3000, size=300)] = 0x0A00 + rng.integers(0, 5000, size=300).astype(np.uint32)
+for start in range(0, 40):
+    for n in (0, 1, 31, 32, 33, 65, 1000, 2048 + start):
+        src = np.ascontiguousarray(src_all[start:start + n])
+        want = np.where(src < 0xFF, src, 0xFF).astype(np.uint8)
+        for vector in (1, 0):
+            out = np.zeros(n + 7, np.uint8)[start %% 7:start %% 7 + n]
+            assert lib.east_hip_debug_narrow_symbols8(src.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n,
+                                                      out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), vector) & 1
+            assert np.array_equal(out, want), (start, n, vector)
+            if n > 40:
+                src[n // 2] = 0x300
+                assert not lib.east_hip_debug_narrow_symbols8(src.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n,
+                                                              out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), vector) & 1
 # the sharding rule of the device groups
 for _ in range(100):
     n, g = int(rng.integers(0, 60)), int(rng.integers(1, 12))

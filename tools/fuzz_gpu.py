@@ -102,7 +102,7 @@ def main():
         # (7 / 9: first-level keys of variable-length code words, with / without the fused finish)
         knob = int(rng.choice([1, 1, 1, 0, 3, 2, 4, 5, 7, 7, 9, 9]))
         lib.east_hip_debug_set_window_sort(knob)
-        lib.east_hip_debug_set_lds_rounds(int(rng.choice([1, 1, 2, 0])))
+        lib.east_hip_debug_set_lds_rounds(int(rng.choice([1, 1, 3, 2, 0])))
         lib.east_hip_debug_set_segmented_sort(int(rng.choice([-1, 1, 1, 0])))     # (1: wherever a shard holds 2 .. 65535 documents)
         lib.east_hip_debug_set_score_path(int(rng.choice([1, 4, 4, 0, 2, 3, 5])))
         parts = [to_symbols(sc) for sc in docs]

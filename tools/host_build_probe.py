@@ -1,13 +1,28 @@
-import os, sys, time
-sys.path.insert(0, os.path.join(os.getcwd(), "ast-text-analysis_amd"))
+#!/usr/bin/env python3
+"""east_hip_build from host-resident symbols (the bench's 64 MiB document): wall clock per call, for a given number of
+narrowing threads (EAST_HIP_SYMBOL_THREADS, read once per process -- run one process per setting).
+    EAST_HIP_SYMBOL_THREADS=12 python tools/host_build_probe.py"""
+import os
+import sys
+import time
+
 import numpy as np
-from east import hip_backend, synthetic
-_, sym, m = synthetic.word_stream_document(np.random.default_rng(20242), 64 << 20, want_text=False)
-n = sym.size
-index = hip_backend.HipIndex(0, reserve_symbols=n)
-off, ms = np.array([0, n], dtype=np.int64), np.array([m], dtype=np.int32)
-index.build(sym, off, ms); time.sleep(0.3)
-ts = []
-for _ in range(24):
-    t0 = time.perf_counter(); index.build(sym, off, ms); ts.append((time.perf_counter() - t0) * 1e3)
-print(os.environ.get("EAST_HIP_SYMBOL_THREADS"), " ".join("%.2f" % t for t in ts), "| median %.2f" % sorted(ts)[len(ts)//2])
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ast-text-analysis_amd"))
+import torch  # noqa: E402,F401
+from east import hip_backend, synthetic  # noqa: E402
+
+_, sym, m = synthetic.word_stream_document(np.random.default_rng(20240 + 2), 64 << 20, want_text=False)
+off, ms = np.array([0, sym.size], dtype=np.int64), np.array([m], dtype=np.int32)
+index = hip_backend.HipIndex(0, reserve_symbols=int(sym.size))
+walls = []
+for i in range(16):
+    t0 = time.perf_counter()
+    index.build(sym, off, ms)
+    walls.append((time.perf_counter() - t0) * 1e3)
+    if i < 3:
+        time.sleep(0.05)
+print("threads %s: bytes/symbol %s, device build %.2f ms, calls %s, median of the last 10: %.2f ms"
+      % (os.environ.get("EAST_HIP_SYMBOL_THREADS", "default"), {0: 4, 1: 2, 2: 1}[index.info()["narrow_upload"]],
+         index.last_build_ms, " ".join("%.2f" % w for w in walls), sorted(walls[-10:])[5]))
