@@ -114,8 +114,9 @@ for start in range(0, 40):
                                                       out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), vector) & 1
             assert np.array_equal(out, want), (start, n, vector)
             if n > 40:
-                src[n // 2] = 0x300
-                assert not lib.east_hip_debug_narrow_symbols8(src.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n,
+                bad = src.copy()
+                bad[n // 2] = 0x300
+                assert not lib.east_hip_debug_narrow_symbols8(bad.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n,
                                                               out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), vector) & 1
 # the sharding rule of the device groups
 for _ in range(100):
