@@ -25,16 +25,23 @@ struct RcclApi {
     nccl_all_gather_fn all_gather = nullptr;
     nccl_group_fn group_start = nullptr, group_end = nullptr;
     nccl_error_string_fn error_string = nullptr;
+    bool overridden = false;    // EAST_HIP_RCCL_LIB names the library (the tests: a stub that records the calls it gets)
     bool load()
     {
         if (lib) return true;
-        // (a copy the process already holds -- torch brings its own -- before the system's)
-        const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
-        for (int pass = 0; pass < 2 && !lib; pass++)
-            for (const char *name : names) {
-                lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
-                if (lib) break;
-            }
+        const char *forced_lib = getenv("EAST_HIP_RCCL_LIB");
+        if (forced_lib && *forced_lib) {
+            lib = dlopen(forced_lib, RTLD_NOW | RTLD_LOCAL);
+            overridden = lib != nullptr;
+        } else {
+            // (a copy the process already holds -- torch brings its own -- before the system's)
+            const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+            for (int pass = 0; pass < 2 && !lib; pass++)
+                for (const char *name : names) {
+                    lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                    if (lib) break;
+                }
+        }
         if (!lib) return false;
         comm_init_all = (nccl_comm_init_all_fn)dlsym(lib, "ncclCommInitAll");
         comm_destroy = (nccl_comm_destroy_fn)dlsym(lib, "ncclCommDestroy");
@@ -167,6 +174,10 @@ static int decide_gather_mode(east_hip_group *g)
         for (size_t b = a + 1; b < g->devices.size(); b++) distinct = distinct && g->devices[a] != g->devices[b];
     int mode = distinct ? 1 : 2;
     if (forced && !strcmp(forced, "copy")) mode = 2;
+    // (RCCL itself refuses a communicator with one device twice; a library named by EAST_HIP_RCCL_LIB -- the stub of the
+    // gpu tier, which moves the blocks with device-to-device copies -- takes logical shards too: the grouped all-gather
+    // with G > 1, its call order, counts and device switches then run on a one-GPU box)
+    if (forced && !strcmp(forced, "rccl") && !distinct && g->rccl.load() && g->rccl.overridden) mode = 1;
     if (mode == 1) {
         bool ok = g->rccl.load();
         if (ok) {
@@ -239,14 +250,29 @@ static void group_allgather(east_hip_group *g, u32 K)
     east_hip_index *h0 = g->shard[0];
     if (mode == 1) {
         // one grouped all-gather: every shard's block to every device, over xGMI between distinct devices
+        // (nothing throws between group start and group end: a group left open would poison the communicator's next call)
         int rc = g->rccl.group_start();
-        for (u32 s = 0; s < G && rc == 0; s++) {
-            HIP_CHECK(hipSetDevice(g->devices[s]));
-            rc = g->rccl.all_gather(g->buf[s].send, g->buf[s].recv, (size_t)K * width, EAST_NCCL_DOUBLE, g->comms[s], g->shard[s]->stream);
+        hipError_t dev_rc = hipSuccess;
+        const bool opened = rc == 0;
+        for (u32 s = 0; s < G && rc == 0 && dev_rc == hipSuccess; s++) {
+            dev_rc = hipSetDevice(g->devices[s]);
+            if (dev_rc == hipSuccess)
+                rc = g->rccl.all_gather(g->buf[s].send, g->buf[s].recv, (size_t)K * width, EAST_NCCL_DOUBLE, g->comms[s], g->shard[s]->stream);
         }
-        const int rc_end = g->rccl.group_end();
-        if (rc == 0) rc = rc_end;
-        if (rc != 0) east_throw(EAST_HIP_ERR_HIP, std::string("ncclAllGather failed: ") + (g->rccl.error_string ? g->rccl.error_string(rc) : "?"));
+        if (opened) {
+            const int rc_end = g->rccl.group_end();
+            if (rc == 0) rc = rc_end;
+        }
+        if (rc != 0 || dev_rc != hipSuccess) {
+            // the other shards' blocks may be in flight: every stream is drained before the error goes up, and the first
+            // shard's device is current again (guarded() then restores the caller's)
+            for (u32 s = 0; s < G; s++)
+                if (hipSetDevice(g->devices[s]) == hipSuccess) (void)hipStreamSynchronize(g->shard[s]->stream);
+            (void)hipSetDevice(g->devices[0]);
+            (void)hipGetLastError();
+            if (dev_rc != hipSuccess) east_throw(EAST_HIP_ERR_HIP, std::string("hipSetDevice inside the grouped all-gather failed: ") + hipGetErrorString(dev_rc));
+            east_throw(EAST_HIP_ERR_HIP, std::string("ncclAllGather failed: ") + (g->rccl.error_string ? g->rccl.error_string(rc) : "?"));
+        }
     } else {
         // every block to the first shard's device, each on its own stream; the first shard's stream waits for all of them
         for (u32 s = 0; s < G; s++) {

@@ -197,6 +197,7 @@ JOIN_FREE_MIN_BYTES = 1 << 20           # ... this many bytes in all go to the d
 JOIN_FREE_RING_BYTES = 8 << 20          # ... and any number of texts from this size on (the streamed preparation: the
 #                                         library copies them into a pinned ring with a few threads; joining 256 MB in
 #                                         Python takes 50 ms, four times what the device needs for the whole index)
+JOIN_FREE_RING_MIN_MEAN = 4096          # ... while a text averages this many bytes
 JOIN_FREE_RING_MAX_TEXTS = 1 << 20
 POOL_HANDLES = 2                        # recycled handles kept per device ...
 POOL_MAX_ARENA_BYTES = 256 << 20        # ... if their device arena is at most this large
@@ -301,8 +302,11 @@ class HipIndex(object):
         tables = (_ptr(cls, ctypes.POINTER(ctypes.c_uint8)), _ptr(upper, _c_u32p), _ptr(word_hi, _c_u32p),
                   _ptr(digit_hi, _c_u32p), _ptr(hi_from, _c_u32p), _ptr(hi_to, _c_u32p), hi_from.size)
         total = sum(len(t) for t in raw)
+        # (... through the pinned ring only while a text averages JOIN_FREE_RING_MIN_MEAN bytes: half a million one-line
+        # texts cost more as a ctypes pointer array than the one b"".join they would save)
         if (len(raw) <= JOIN_FREE_MAX_TEXTS and total >= JOIN_FREE_MIN_BYTES) or \
-                (len(raw) <= JOIN_FREE_RING_MAX_TEXTS and total >= JOIN_FREE_RING_BYTES):
+                (len(raw) <= JOIN_FREE_RING_MAX_TEXTS and total >= JOIN_FREE_RING_BYTES and
+                 total >= JOIN_FREE_RING_MIN_MEAN * len(raw)):
             # a few large texts: uploaded one by one straight out of their bytes objects (joining 64 MiB costs
             # more host time than the device needs for the whole build)
             ptrs = (ctypes.c_char_p * len(raw))(*raw)

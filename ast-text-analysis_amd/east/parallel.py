@@ -113,7 +113,18 @@ class DistributedASTRelevanceMeasure(relevance.ASTRelevanceMeasure):
         if self._on_gpu():
             import torch
             torch.cuda.set_device(self.gpu)          # also for a rank whose shard is empty and never calls the library
-        self.shards = shard_documents([len(t) for t in texts], world)
+        # The ranks must cut the collection at the same documents, and the sizes of texts that are still files come from
+        # every rank's own os.stat (LazyText): a file that changes between two ranks' looks, or an attribute cache that
+        # shows another size, would shift one rank's bounds -- columns assembled with the wrong counts, documents scored
+        # twice or never, no error.  Rank 0's sizes are everybody's.
+        sizes = [len(t) for t in texts]
+        if world > 1:
+            box = [sizes if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            if len(box[0]) != len(sizes):
+                raise ValueError("the ranks were given collections of different lengths (%d here, %d on rank 0)" % (len(sizes), len(box[0])))
+            sizes = box[0]
+        self.shards = shard_documents(sizes, world)
         self.counts = [e - b for b, e in self.shards]
         b, e = self.shards[rank]
         self.local = self._factory()

@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--base-value", type=float, default=float(os.environ.get("EAST_BENCH_BASE_VALUE", "0") or 0),
                     help="N > 1: the same-shape single-GPU value (config2.value of the N = 1 line, chars/s) -- the line "
                          "then carries multi_gpu.scaling_efficiency = value / (N x base)")
+    ap.add_argument("--no-in-process", action="store_true",
+                    help="N > 1: skip the leg that runs the same shards through the in-process device group on rank 0")
     ap.add_argument("--cpu-sample-mib", type=float, default=64.0,
                     help="size of the CPU-baseline document (64 = the bench document itself, about 15 s of one core)")
     args = ap.parse_args()
@@ -466,6 +468,24 @@ def main():
             out["config5_prose"] = config5_prose_leg(hip_backend, synthetic, torch, dev, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, synthetic)
+    if use_dist and not args.no_in_process:
+        # The path `east -g N` takes by default is not the one timed above (one process per GPU, torch.distributed) but the
+        # library's in-process group: one host thread per device, ncclCommInitAll, one grouped ncclAllGather (csrc/multi.h).
+        # Every rank gives its device memory back and waits on a CPU-side (gloo) barrier -- an NCCL barrier would keep a
+        # kernel spinning on the very devices rank 0 is about to use --, rank 0 runs the same shard shapes through
+        # east_hip_group_build + east_hip_score_table_multi on devices 0 .. N-1, then everybody goes on.
+        index.close()
+        del d_symbols, local_block, full_table
+        torch.cuda.empty_cache()
+        ctl = dist.new_group(backend="gloo")
+        dist.barrier(group=ctl)
+        if rank == 0:
+            try:
+                out.setdefault("multi_gpu", {})["in_process"] = in_process_leg(
+                    hip_backend, world, symbols, doc_offsets, n_strings, q_symbols, q_offsets, not args.denormalized, n_bytes)
+            except Exception as e:                         # noqa: BLE001 (the line must still go out: the torch leg stands)
+                out.setdefault("multi_gpu", {})["in_process"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        dist.barrier(group=ctl)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -607,6 +627,39 @@ def write_detail(out):
         except OSError:
             pass
     return written
+
+
+def in_process_leg(hip_backend, world, symbols, doc_offsets, n_strings, q_symbols, q_offsets, normalized, n_bytes, steps=3):
+    """The in-process device group (east_hip_group_build + east_hip_score_table_multi: what `east -g N` runs by default)
+    on devices 0 .. world-1, on `world` copies of rank 0's shard -- the same per-device shapes as the torch leg.  The
+    group's entry points take HOST symbols and return the K x D table on the host: a step here includes the uploads
+    (bytes or 16-bit words through each shard's pinned ring) and the copy of the table, which the torch leg's
+    device-resident steps do not."""
+    sym_all = np.tile(symbols, world)
+    n = int(symbols.size)
+    off_all = np.concatenate([doc_offsets[:-1] + r * n for r in range(world)] + [[world * n]]).astype(np.int64)
+    ms_all = np.tile(n_strings, world)
+    group = hip_backend.HipGroup(list(range(world)))
+    try:
+        group.build(sym_all, off_all, ms_all)              # (arena allocation, the rings' pinning: not timed)
+        table = group.score_table(q_symbols, q_offsets, normalized)
+        time.sleep(0.1)                                    # (the rings are pinned in the background)
+        walls, parts = [], []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            group.build(sym_all, off_all, ms_all)
+            table = group.score_table(q_symbols, q_offsets, normalized)
+            walls.append((time.perf_counter() - t0) * 1e3)
+            parts.append(group.info())
+        best = int(np.argmin(walls))
+        shards = np.diff(group.first_doc).tolist()
+        return {"step_ms": float(np.median(walls)), "step_ms_min": float(min(walls)), "build_ms": parts[best]["build_ms"],
+                "score_ms": parts[best]["score_ms"], "gather_ms": parts[best]["gather_ms"], "gather": parts[best]["gather"],
+                "rccl_ranks": world if parts[best]["gather"] == "rccl" else 0, "shards": shards,
+                "value": world * n_bytes / (float(np.median(walls)) * 1e-3), "from_host": True, "steps": steps,
+                "table_shape": list(table.shape)}
+    finally:
+        group.close()
 
 
 def extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D, d_symbols=None):

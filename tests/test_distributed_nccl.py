@@ -69,6 +69,11 @@ def test_bench_distributed_line_on_one_gpu(tmp_path):
     assert 0 < mg["local_fraction_of_step"] <= 1.05
     # (the line rounds to five significant digits; bench_detail.json keeps the full figures)
     assert abs(mg["scaling_efficiency"] - out["value"] / 1e9) < 1e-3 * mg["scaling_efficiency"] and mg["scaling_base_value"] == 1e9
+    # the path `east -g N` takes by default -- the in-process group, RCCL through ncclCommInitAll -- runs behind the torch
+    # leg on the same shard shapes (here: a group of the one device)
+    ip = mg["in_process"]
+    assert "error" not in ip, ip
+    assert ip["gather"] == "rccl" and ip["rccl_ranks"] == 1 and ip["shards"] == [8] and ip["step_ms"] > 0 and ip["value"] > 0
     assert out["config"]["all_gather_bytes_per_rank"] == 200 * 8 * 8
     assert out["roofline"]["kernel"] and out["roofline"]["peak"] == 8000.0
 

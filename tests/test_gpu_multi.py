@@ -193,3 +193,88 @@ def test_distinct_handles_on_concurrent_threads(hip, oracle):
         assert np.array_equal(alone[k][0], together[k][0]), k
         for name in ("suftab", "lcptab", "anntab"):
             assert np.array_equal(alone[k][1][name], together[k][1][name]), (k, name)
+
+
+def _build_stub_rccl(tmp_path):
+    """tests/stub_rccl.c -> a shared library (gcc; the HIP runtime is the one the process already holds)."""
+    import subprocess
+    from conftest import ROOT
+    out = str(tmp_path / "libstub_rccl.so")
+    cmd = ["gcc", "-shared", "-fPIC", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "stub_rccl.c"),
+           "-o", out, "-L/opt/rocm/lib", "-lamdhip64"]
+    done = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert done.returncode == 0, done.stderr.decode(errors="replace")
+    return out
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_grouped_all_gather_with_several_shards_against_a_stub_rccl(hip, tmp_path, monkeypatch, n_shards):
+    """csrc/multi.h's RCCL branch -- ncclCommInitAll, then per score call ncclGroupStart, one ncclAllGather per shard with
+    hipSetDevice in front of it, ncclGroupEnd, the pack kernel on the first device -- had only ever run with a group of
+    ONE: RCCL refuses a communicator that names a device twice, and the box has one GPU.  Here the library is
+    tests/stub_rccl.c (EAST_HIP_RCCL_LIB; device-to-device copies on the callers' streams, every call logged) and the
+    mode is forced (EAST_HIP_GROUP_GATHER=rccl), so the branch runs with G = 2, 3, 8 logical shards: the table equals the
+    single handle's bit for bit -- padded block maths and pack kernel included --, the communicator is created once over
+    the group's device list, and every score call makes exactly one group of G all-gathers, rank 0 .. G - 1 in order, each
+    of K x widest-shard doubles, each with its own shard's device current."""
+    from east import hip_backend, synthetic
+    lib_path = _build_stub_rccl(tmp_path)
+    log = tmp_path / "calls.log"
+    monkeypatch.setenv("EAST_HIP_RCCL_LIB", lib_path)
+    monkeypatch.setenv("EAST_HIP_GROUP_GATHER", "rccl")
+    monkeypatch.setenv("EAST_STUB_RCCL_LOG", str(log))
+    rng = np.random.default_rng(1200 + n_shards)
+    docs, sym, off, ms = _collection(rng, rng.integers(300, 40000, size=19))      # unequal shards: the blocks are padded
+    K = 120
+    qs, qo = synthetic.keyphrases(rng, sym, K)
+    single = hip_backend.HipIndex()
+    single.build(sym, off, ms)
+    group = hip_backend.HipGroup([0] * n_shards)
+    group.build(sym, off, ms)
+    widths = np.diff(group.first_doc)
+    assert widths.min() < widths.max()                         # (the padding is exercised)
+    for norm in (True, False, True):
+        assert np.array_equal(group.score_table(qs, qo, norm), single.score_table(qs, qo, norm)), norm
+    assert group.info()["gather"] == "rccl"
+    # fewer keyphrases, then more: the buffers are re-used / grown
+    for k2 in (7, 260):
+        qs2, qo2 = synthetic.keyphrases(rng, sym, k2)
+        assert np.array_equal(group.score_table(qs2, qo2, True), single.score_table(qs2, qo2, True)), k2
+    group.close()
+    lines = log.read_text().splitlines()
+    assert lines[0] == "init n=%d devices=%s" % (n_shards, ",".join("0" for _ in range(n_shards)))
+    assert sum(1 for ln in lines if ln.startswith("init")) == 1            # one communicator for the group's lifetime
+    assert sum(1 for ln in lines if ln.startswith("destroy")) == n_shards
+    body = [ln for ln in lines[1:] if not ln.startswith("destroy")]
+    per_call = n_shards + 2
+    assert len(body) == 5 * per_call, len(body)
+    for c, k in enumerate((K, K, K, 7, 260)):
+        call = body[c * per_call:(c + 1) * per_call]
+        assert call[0] == "group_start" and call[-1] == "group_end calls=%d rc=0" % n_shards, call
+        for r in range(n_shards):
+            assert call[1 + r] == ("allgather rank=%d count=%d dtype=8 device_at_call=0 comm_device=0 grouped=1"
+                                   % (r, k * int(widths.max()))), (c, r, call[1 + r])
+
+
+def test_grouped_all_gather_reports_a_failing_library(hip, tmp_path, monkeypatch):
+    """An all-gather that fails inside the group (here: the stub is handed a group of three and told, through its log
+    path, nothing -- the failure is a communicator destroyed under it) must come back as a HipBackendError with the
+    group closed again: the next call on a fresh group works."""
+    from east import exceptions, hip_backend, synthetic
+    lib_path = _build_stub_rccl(tmp_path)
+    monkeypatch.setenv("EAST_HIP_RCCL_LIB", lib_path)
+    monkeypatch.setenv("EAST_HIP_GROUP_GATHER", "rccl")
+    monkeypatch.setenv("EAST_STUB_RCCL_FAIL_AT", "1")            # the second all-gather of every group returns an error
+    rng = np.random.default_rng(5)
+    docs, sym, off, ms = _collection(rng, rng.integers(300, 9000, size=9))
+    qs, qo = synthetic.keyphrases(rng, sym, 30)
+    group = hip_backend.HipGroup([0, 0, 0])
+    group.build(sym, off, ms)
+    with pytest.raises(exceptions.HipBackendError) as err:
+        group.score_table(qs, qo, True)
+    assert "ncclAllGather failed" in str(err.value)
+    monkeypatch.delenv("EAST_STUB_RCCL_FAIL_AT")
+    single = hip_backend.HipIndex()
+    single.build(sym, off, ms)
+    assert np.array_equal(group.score_table(qs, qo, True), single.score_table(qs, qo, True))     # the same group, next call
+    group.close()
