@@ -227,6 +227,7 @@ struct Ctx {
     int ht_max_len = 0;
     double ht_mean_len = 0.0;
     int plan_ht = -1, did_ht = 0;           // first-level keys of variable-length code words: plan (as plan_wide) / what was done
+    int plan_persist = -1, did_persist = 0; // the first domain went to the persistent rounds at once (repetitive text: persist_rounds.h)
     int did_seg = 0;                        // the first-level sort kept the documents apart by segments, not by key bits
     std::vector<u32> seg_host;              // ... its tables on the host (the uploads are asynchronous)
     LcpBudget lcp_budget;                   // the build's budget of deep LCP comparisons (LCP_SOFT_CAP)

@@ -457,6 +457,7 @@ struct east_hip_index {
     bool hint_valid = false, hint_no_rounds = false, hint_window = false;
     int plan_wide = -1, plan_fused = -1;   // what the last build's window sort did (wide first window, fused finish): a speculative build does the same
     int plan_ht = -1;                      // ... (first-level keys of variable-length code words)
+    int plan_persist = -1;                 // ... (the first domain went straight to the persistent rounds)
     // the order-preserving variable-length code of the last build that made one (ht_code.h): device tables (own
     // allocation: 256 x u32 enc, 4096 x u16 dec), valid for text with ht_sigma text symbols
     char *ht_tab = nullptr;
@@ -1300,6 +1301,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
         ctx.plan_wide = spec ? h->plan_wide : -1;        // (a build that waits for the alphabet plans from its own sample)
         ctx.plan_fused = spec ? h->plan_fused : -1;
         ctx.plan_ht = spec ? h->plan_ht : -1;
+        ctx.plan_persist = spec ? h->plan_persist : -1;
         try {
             build_impl(h, ctx, sym, n, (u32)n_docs, doc_offsets, n_strings, h->hint_sigma, tagged);
         } catch (const SpecAbort &) {
@@ -1347,6 +1349,7 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     if (ctx.did_wide && h->stats.first_n > 0 && h->stats.first_kept * 50 < h->stats.first_n) h->plan_wide = -1;
     h->plan_fused = h->stats.window_sorted ? ctx.did_fused : -1;
     h->plan_ht = h->stats.window_sorted ? ctx.did_ht : -1;
+    h->plan_persist = h->stats.window_sorted ? ctx.did_persist : -1;
     // (the same for the fused finish: it handed more than a few per cent of the suffixes to the rounds, or the separate
     // placement pass left next to nothing -- another kind of text than the plan was made for: the next build decides anew)
     if (h->stats.first_n > 0 && ((ctx.did_fused && h->stats.first_kept * 20 > h->stats.first_n) ||
@@ -2584,7 +2587,7 @@ int east_hip_reset(east_hip_handle_t h)
         h->sigma_hi = 0;
         h->prof.enabled = false;
         h->prof.only.clear();
-        h->plan_wide = h->plan_fused = h->plan_ht = -1;
+        h->plan_wide = h->plan_fused = h->plan_ht = h->plan_persist = -1;
         h->ht_valid = false;
         h->stats = Stats();
         // a recycled handle keeps its stream and a small arena, not gigabytes of side allocations

@@ -2180,15 +2180,21 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             stalled = (round > 0 && m_next > m - m / 32) ? stalled + 1 : 0;
             if (round == REFINE_MAX_ROUNDS || (stalled == 2 && !doubling && !name_of)) break;
             const u32 gm = ceil_div_u32((u64)m + 1, BLOCK);
-            // A domain that fits the chip at one tile per resident workgroup is finished by ONE launch (persist_rounds.h):
-            // prefix doubling with the tiles kept in LDS, a grid barrier per round.  It gives up -- having changed nothing
-            // the rounds below rely on -- when a tie group is longer than a tile takes; the next, smaller domain may fit.
+            // A domain that fits the chip at one tile per resident workgroup can be finished by ONE launch (persist_rounds.h):
+            // prefix doubling with the tiles kept in LDS, a grid barrier per round.  It is taken where the rounds below would
+            // go over to prefix doubling -- a domain that shrinks slowly: long repeats -- and for the FIRST domain of text
+            // the planning sample calls repetitive (most of 8 192 consecutive suffixes share 8 symbols with three others of
+            // the sample: the reference's worst case, 100 identical strings; a speculative build: as the build before).
+            // Natural language is better off launch by launch: its domains shrink eightfold per round and the endgame orders
+            // what is left directly (measured on 0.25 .. 4 MiB of prose: 0.29-0.89 ms against 0.31-0.98 through doubling).
+            // The launch gives up -- having changed nothing the rounds below rely on -- when a tie group is longer than a tile
+            // takes; a later, smaller domain may fit.
             // (the launch needs the name of every placed suffix first -- a scatter over all n02 ranks, 2.1 ms for the 94 M
-            // symbols of the Zipf stand-in, whose last domain of 0.14 M would save a few dozen launches for it: only where
-            // the domain is a good part of the input, or the input small)
-            const bool try_persist = persist_cap > 0 && name_of && !doubling && m_next <= persist_cap * LG_CHUNK && n02 >= 4u * PR_CTL_WORDS &&
-                                     (n02 <= PERSIST_SMALL_INPUT || n02 / 8u <= m_next);
+            // symbols of the Zipf stand-in: only where the domain is a good part of the input, or the input small)
             const bool slow = round > 0 && m_next > m / 2;          // slow shrinking = long repeats
+            const bool repetitive = ctx.sample_n ? ctx.sample_dup4[8] * 2u > ctx.sample_n : ctx.plan_persist == 1;
+            const bool try_persist = persist_cap > 0 && name_of && !doubling && m_next <= persist_cap * LG_CHUNK && n02 >= 4u * PR_CTL_WORDS &&
+                                     (n02 <= PERSIST_SMALL_INPUT || n02 / 8u <= m_next) && (round == 0 ? repetitive : slow);
             if (name_of && !doubling && slow && !try_persist) {
                 // slow shrinking = long repeats: from here on the depth doubles every round (see above)
                 doubling = true;
@@ -2290,6 +2296,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                         lcp_from_rounds = false;
                         redo_hinted = true;
                     }
+                    if (round == 0 && n0 == 0) ctx.did_persist = 1;
                     m_next = 0;
                     done = true;
                     break;
