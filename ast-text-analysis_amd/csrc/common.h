@@ -172,6 +172,7 @@ struct Knobs {
     bool lds_rounds = getenv("EAST_HIP_NO_LDS_ROUNDS") == nullptr;      // east_hip_debug_set_lds_rounds
     bool fused_classify = getenv("EAST_HIP_NO_FUSED_CLASSIFY") == nullptr;      // ... (2): the stand-alone classification pass
     bool persist = getenv("EAST_HIP_NO_PERSIST") == nullptr;            // ... (1 only): small domains finish in one launch (persist_rounds.h)
+    bool persist_large = getenv("EAST_HIP_NO_PERSIST_LARGE") == nullptr;    // ... and large ones, several tiles per workgroup (A/B timing)
     size_t rank_bucket_bytes = (size_t)192 << 20;                       // east_hip_debug_set_rank_bucket_bytes
     bool speculate = getenv("EAST_HIP_NO_SPECULATION") == nullptr;      // east_hip_debug_set_speculation
     bool kg_pairs = getenv("EAST_HIP_NO_KG_PAIRS") == nullptr;          // east_hip_debug_set_score_path
@@ -356,6 +357,13 @@ __device__ __forceinline__ u32 lcp_bytes_capped(const uint8_t *__restrict__ s8, 
             if (step < 8u) return h;
         }
     }
+}
+
+// One flag word for a whole launch ("some comparison was cut short"): on repetitive text nearly every thread raises it, and
+// ten million atomics on one word took 1.7 ms of a 10 ms build -- a thread looks first (the lanes of a wavefront share the request).
+__device__ __forceinline__ void raise_flag(u32 *flag)
+{
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(flag, 1u);
 }
 
 // Inclusive prefix sum across the 64 lanes of a wavefront.

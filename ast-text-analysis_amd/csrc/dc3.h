@@ -575,7 +575,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_merge_lcp_tile_kernel(const uint4 *
                 const u32 pa = l_pos[sa_] & 0x7FFFFFFFu;
                 const u32 h = dc3_window_lcp(((u64)l_hi[sa_] << 32) | l_lo[sa_], ((u64)l_hi[sb] << 32) | l_lo[sb],
                                              s8, pa, pb, budget);
-                if (h & LCP_PARTIAL_BIT) atomicOr(capped, 1u);
+                if (h & LCP_PARTIAL_BIT) raise_flag(capped);
                 lcp_out[k0 + o] = h;
             }
         }
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(BLOCK) void dc3_lcp_heads_kernel(const uint8_t *__r
     __builtin_memcpy(&wa, s8 + pa, 8);
     __builtin_memcpy(&wb, s8 + pb, 8);
     const u32 h = dc3_window_lcp(wa, wb, s8, pa, pb, budget);
-    if (h & LCP_PARTIAL_BIT) atomicOr(capped, 1u);
+    if (h & LCP_PARTIAL_BIT) raise_flag(capped);
     lcp[r] = h;
 }
 

@@ -382,3 +382,318 @@ __global__ __launch_bounds__(LG_THREADS, MIN_WAVES) void refine_persist_kernel(P
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl[PR_CTL_ROUNDS] = round + 1u;
 }
+
+// ================================================================================================================
+// The same rounds for a domain of ANY size: a workgroup walks several tiles per round, and a tile's state -- its
+// elements (permuted in place), the group bounds -- lives in global memory between rounds instead of in LDS.  (The
+// reference's worst case at n = 10^5 is a domain of 10 M: 4 883 tiles; launch by launch its 15 rounds cost 13 ms.)
+// What changes against refine_persist_kernel:
+//   * a round is two phases with a grid barrier behind each.  SORT: every tile reads the names it needs and, where a
+//     group splits, sorts, writes its elements back, the suffix array, the LCP hints and the new group bounds.  NAMES:
+//     the tiles that changed publish the new names.  One copy of the names is enough: nobody writes a name while
+//     anybody may read one.
+//   * the group bounds are double-buffered (a round reads one copy of the flags and writes the other): a tile finds its
+//     range from the flags -- the groups that start in its chunk --, and the range of its right neighbour begins where a
+//     group of its own may have just split; with one copy a neighbour could read that new bound while the elements behind
+//     it are still being written.  The ranges of a round partition the domain, so the copy a round writes is complete.
+//   * a tile's range may move from round to round (a bound that appears inside chunk c + 1 hands the rest of tile c's
+//     last group to tile c + 1); the NAMES phase works on the range its SORT phase had (range[]).
+struct Pr2Args {
+    u32 *elems;                             // the compacted domain's suffixes (permuted in place)
+    const u32 *slots;                       // its slots
+    u32 *flags0, *flags1;                   // group start flags: the copy even rounds read (the compaction's) / odd rounds read
+    u32 m, depth;
+    int name_bits;
+    u32 *name;                              // names by text position (every placed suffix initialised)
+    u32 *order_g, *lcp_hint, *ctl;
+    uint2 *range;                           // per tile: first position (relative to the chunk) and length, as the SORT phase saw them
+    u32 *changed;                           // per tile: its groups split in this round's SORT phase
+    u32 n_tiles;
+};
+
+// The tile of chunk `base / LG_CHUNK` under `gstart`: the groups that start in the chunk (as refine_lds_sort_kernel takes
+// them).  All threads call; leaves chunk-relative start bits in lds.start_bits.
+// (lane / w: the thread's position, made opaque by the caller once per tile -- PR2_POSITION --: what follows from it would
+// otherwise be computed in front of the loops over rounds and tiles and kept there, hundreds of bytes of scratch per lane)
+#define PR2_POSITION                              \
+    u32 tid_r = threadIdx.x;                      \
+    asm volatile("" : "+v"(tid_r));               \
+    const u32 lane = tid_r & 63u, w = tid_r >> 6
+__device__ __forceinline__ void pr2_tile_bounds(LgLds &lds, const u32 *__restrict__ gstart, u32 m, u32 base, u32 lane, u32 w, u32 &begin_q,
+                                                u32 &n_act, bool &too_long)
+{
+    __syncthreads();                                    // (the tile before is done with lds)
+    {
+        constexpr int PER = LG_WORDS / LG_WAVES;
+        u32 gs[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const u64 p = (u64)base + (w + (u32)i * LG_WAVES) * 64u + lane;
+            gs[i] = gstart[p < m ? p : (u64)m - 1u];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const u32 word = w + (u32)i * LG_WAVES;
+            const u64 p = (u64)base + word * 64u + lane;
+            const bool st = p < m ? gs[i] != 0u : p == m;
+            const u64 bal = __ballot(st);
+            if (lane == 0) lds.start_bits[word] = bal;
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        const u64 wv = lane < LG_CHUNK / 64 ? lds.start_bits[lane] : 0ull;
+        const u64 nzb = __ballot(wv != 0ull);
+        u32 bq = LG_NONE, eq = LG_NONE;
+        bool tl = false;
+        if (nzb) {
+            const u32 fl = (u32)__ffsll((unsigned long long)nzb) - 1u, ll = 63u - (u32)__builtin_clzll(nzb);
+            bq = fl * 64u + (u32)__builtin_ctzll(lds.start_bits[fl]);
+            const u32 last_q = ll * 64u + 63u - (u32)__builtin_clzll(lds.start_bits[ll]);
+            const u32 wi = ll + lane;
+            u64 x = wi < LG_WORDS ? lds.start_bits[wi] : 0ull;
+            if (lane == 0) x &= ~(((u64)2 << (last_q & 63u)) - 1ull);
+            const u64 nb = __ballot(x != 0ull);
+            u32 next_q = LG_NONE;
+            if (nb) {
+                const u32 l2 = (u32)__ffsll((unsigned long long)nb) - 1u;
+                const u64 xw = ((u64)__shfl((u32)(x >> 32), l2, WAVE) << 32) | __shfl((u32)x, l2, WAVE);
+                next_q = (ll + l2) * 64u + (u32)__builtin_ctzll(xw);
+            }
+            const bool sentinel = (u64)base + last_q == (u64)m;
+            tl = !sentinel && (next_q == LG_NONE || next_q - last_q > LG_MAX_GROUP);
+            eq = sentinel || tl ? last_q : next_q;
+            if (bq == last_q && sentinel) bq = LG_NONE;
+        }
+        if (lane == 0) {
+            lds.hdr[0] = bq;
+            lds.hdr[1] = (bq == LG_NONE ? 0u : eq - bq) | (tl ? 0x80000000u : 0u);
+        }
+    }
+    __syncthreads();
+    begin_q = lds.hdr[0];
+    n_act = lds.hdr[1] & 0x7FFFFFFFu;
+    too_long = (lds.hdr[1] >> 31) != 0u;
+}
+
+// The tile's elements, slots and group bounds (tile coordinates, all ones behind the tile) for the thread's positions;
+// returns the number of the tile's elements that sit in groups of two or more.
+__device__ __forceinline__ u32 pr2_tile_load(LgLds &lds, u32 *wg_count, const u32 *__restrict__ flags, const u32 *__restrict__ elems,
+                                             const u32 *__restrict__ slots, u32 base, u32 lane, u32 w, u32 begin_q, u32 n_act,
+                                             u32 (&val)[LG_IPT], u32 (&slot_of)[LG_IPT])
+{
+    __syncthreads();                                    // (the chunk-relative bits / the tile before: done with)
+#pragma unroll
+    for (int j = 0; j < LG_IPT; j++) {
+        const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+        const bool in = local < n_act;
+        const u64 r = (u64)base + begin_q + (in ? local : 0u);
+        val[j] = in ? elems[r] : 0u;
+        slot_of[j] = in ? slots[r] : 0u;
+        const u32 st = in ? flags[r] : 1u;
+        const u64 bal = __ballot(st != 0u);
+        if (lane == 0) lds.start_bits[w * LG_IPT + j] = bal;
+    }
+    if (threadIdx.x == 0) { lds.start_bits[LG_WORDS] = ~0ull; *wg_count = 0; }
+    __syncthreads();
+    u32 open_cnt = 0;
+#pragma unroll
+    for (int j = 0; j < LG_IPT; j++) {
+        const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+        if (local >= n_act) continue;
+        const bool single = ((lds.start_bits[local >> 6] >> (local & 63u)) & 1ull) && ((lds.start_bits[(local + 1u) >> 6] >> ((local + 1u) & 63u)) & 1ull);
+        open_cnt += single ? 0u : 1u;
+    }
+    open_cnt = wave_sum(open_cnt);
+    if (lane == 0 && open_cnt) atomicAdd(wg_count, open_cnt);
+    syncthreads_after_lds_atomics();
+    return *wg_count;
+}
+
+// (one workgroup per CU: two of them share a CU's SIMDs without gaining on each other -- measured with the resident form --,
+// and at 128 registers a lane nothing is spilled)
+__global__ __launch_bounds__(LG_THREADS, 4) void refine_persist2_kernel(Pr2Args a)
+{
+    __shared__ LgLds lds;
+    __shared__ u32 bar_flag, wg_count;
+    const u32 m = a.m;
+    u32 barrier_no = 1;
+    // ---- can every group be sorted inside a tile?  (nothing is changed before that is known) ----
+    for (u32 t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        PR2_POSITION;
+        u32 begin_q, n_act;
+        bool too_long;
+        pr2_tile_bounds(lds, a.flags0, m, t * LG_CHUNK, lane, w, begin_q, n_act, too_long);
+        if (too_long && threadIdx.x == 0) __hip_atomic_store(&a.ctl[PR_CTL_BAIL], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!pr_grid_barrier(a.ctl, barrier_no++, &bar_flag)) return;
+    if (__hip_atomic_load(&a.ctl[PR_CTL_BAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    // ---- every member is named by the slot where its group starts; the hints of the first ranks of groups ----
+    for (u32 t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        PR2_POSITION;
+        const u32 base = t * LG_CHUNK;
+        u32 begin_q, n_act, val[LG_IPT], slot_of[LG_IPT];
+        bool too_long;
+        pr2_tile_bounds(lds, a.flags0, m, base, lane, w, begin_q, n_act, too_long);
+        if (n_act == 0) continue;
+        (void)pr2_tile_load(lds, &wg_count, a.flags0, a.elems, a.slots, base, lane, w, begin_q, n_act, val, slot_of);
+#pragma unroll
+        for (int j = 0; j < LG_IPT; j++) {
+            const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+            if (local >= n_act) continue;
+            const u32 nm = slot_of[j] - (local - pr_group_start(lds.start_bits, local));
+            pr_store(&a.name[val[j]], nm);
+            a.order_g[slot_of[j]] = val[j];                 // (a tile that never changes again has its suffixes in place)
+            if (a.lcp_hint && nm == slot_of[j]) a.lcp_hint[nm] = 0u;
+        }
+    }
+    if (!pr_grid_barrier(a.ctl, barrier_no++, &bar_flag)) return;
+
+    u32 depth = a.depth, round = 0;
+    for (;; round++) {
+        const u32 *f_cur = (round & 1u) ? a.flags1 : a.flags0;
+        u32 *f_next = (round & 1u) ? a.flags0 : a.flags1;
+        u32 my_open = 0;
+        // ---- SORT: every tile of this workgroup ----
+        for (u32 t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+            PR2_POSITION;
+            const u32 base = t * LG_CHUNK;
+            u32 begin_q, n_act, val[LG_IPT], slot_of[LG_IPT];
+            bool too_long;
+            pr2_tile_bounds(lds, f_cur, m, base, lane, w, begin_q, n_act, too_long);
+            if (threadIdx.x == 0) { a.range[t] = uint2{begin_q, n_act}; a.changed[t] = 0u; }
+            if (n_act == 0) continue;
+            const bool active = w * (LG_IPT * WAVE) < n_act;
+            const u32 tile_open = pr2_tile_load(lds, &wg_count, f_cur, a.elems, a.slots, base, lane, w, begin_q, n_act, val, slot_of);
+            bool changed = false;
+            u32 nm[LG_IPT];
+            if (tile_open) {
+                u32 differs = 0;
+#pragma unroll
+                for (int j = 0; j < LG_IPT; j++) {
+                    const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+                    const u32 q = local < n_act ? local : n_act - 1u;
+                    const bool single = ((lds.start_bits[q >> 6] >> (q & 63u)) & 1ull) && ((lds.start_bits[(q + 1u) >> 6] >> ((q + 1u) & 63u)) & 1ull);
+                    nm[j] = single || local >= n_act ? 0u : pr_load(&a.name[val[j] + depth]);
+                }
+#pragma unroll
+                for (int j = 0; j < LG_IPT; j++) {
+                    const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+                    if (local < n_act) lds.vals[local] = nm[j];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < LG_IPT; j++) {
+                    const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+                    if (local < n_act) differs |= nm[j] ^ lds.vals[pr_group_start(lds.start_bits, local)];
+                }
+                changed = __syncthreads_or(differs != 0u) != 0;
+            }
+            if (!changed) {
+                // nothing moves: the bounds are copied into the other copy of the flags
+#pragma unroll
+                for (int j = 0; j < LG_IPT; j++) {
+                    const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+                    if (local < n_act) f_next[(u64)base + begin_q + local] = (u32)((lds.start_bits[local >> 6] >> (local & 63u)) & 1ull);
+                }
+                my_open += tile_open;
+                continue;
+            }
+            // ---- number the tile's groups, sort by (group, name) ----
+            if (w == 0) {
+                u32 run = 0;
+                for (u32 k = 0; k < LG_WORDS; k += WAVE) {
+                    const u32 word = k + lane;
+                    u64 x = word < LG_WORDS ? lds.start_bits[word] : 0ull;
+                    if (word * 64u >= n_act) x = 0ull;
+                    else if (n_act - word * 64u < 64u) x &= ((u64)1 << (n_act - word * 64u)) - 1ull;
+                    const u32 c = (u32)__popcll(x);
+                    const u32 inc = wave_inclusive_sum(c);
+                    if (word < LG_WORDS) lds.word_prefix[word] = run + inc - c;
+                    run += __shfl(inc, 63, WAVE);
+                }
+                if (lane == 0) lds.hdr[0] = run;
+            }
+            __syncthreads();
+            const u32 n_groups = lds.hdr[0];
+            const int bits = a.name_bits + (n_groups > 1u ? 32 - (int)__builtin_clz(n_groups - 1u) : 0);
+            u64 key[LG_IPT];
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < LG_IPT; j++) {
+                    const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+                    const u32 q = local < n_act ? local : n_act - 1u;
+                    const u32 gid = lds.word_prefix[q >> 6] + (u32)__popcll(lds.start_bits[q >> 6] & (((u64)2 << (q & 63u)) - 1ull)) - 1u;
+                    key[j] = local < n_act ? ((u64)gid << a.name_bits) | (u64)nm[j] : ~0ull;
+                    if (local >= n_act) val[j] = 0u;
+                }
+            }
+            for (int shift = 0; shift < bits; shift += 8) lg_radix_pass(lds, key, val, shift, active);
+            // ---- the new bounds (into the other copy of the flags), the elements back, the suffix array, the hints ----
+#pragma unroll
+            for (int j = 0; j < LG_IPT; j++) {
+                const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+                const bool st = !active || local >= n_act || local == 0u || key[j] != lds.keys[local - 1u];
+                const bool was = (lds.start_bits[w * LG_IPT + j] >> lane) & 1ull;
+                if (local < n_act) {
+                    const u64 r = (u64)base + begin_q + local;
+                    f_next[r] = st ? 1u : 0u;
+                    a.elems[r] = val[j];
+                    a.order_g[slot_of[j]] = val[j];
+                    if (a.lcp_hint && st && !was) a.lcp_hint[slot_of[j]] = depth;
+                }
+                const u64 bal = __ballot(st);
+                if (lane == 0) lds.start_bits[w * LG_IPT + j] = bal;
+            }
+            if (threadIdx.x == 0) { a.changed[t] = 1u; wg_count = 0; }
+            __syncthreads();
+            u32 open_cnt = 0;
+#pragma unroll
+            for (int j = 0; j < LG_IPT; j++) {
+                const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+                if (local >= n_act) continue;
+                const bool single = ((lds.start_bits[local >> 6] >> (local & 63u)) & 1ull) && ((lds.start_bits[(local + 1u) >> 6] >> ((local + 1u) & 63u)) & 1ull);
+                open_cnt += single ? 0u : 1u;
+            }
+            open_cnt = wave_sum(open_cnt);
+            if (lane == 0 && open_cnt) atomicAdd(&wg_count, open_cnt);
+            syncthreads_after_lds_atomics();
+            my_open += wg_count;
+        }
+        if (threadIdx.x == 0 && my_open)
+            __hip_atomic_fetch_add(&a.ctl[PR_CTL_OPEN + round], my_open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!pr_grid_barrier(a.ctl, barrier_no++, &bar_flag)) return;
+        const u32 all_open = __hip_atomic_load(&a.ctl[PR_CTL_OPEN + round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- NAMES: the tiles that changed publish the new names (the last round's are of no use to anybody) ----
+        if (all_open) {
+            for (u32 t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+                if (!a.changed[t]) continue;                // (this workgroup's own write: uniform)
+                PR2_POSITION;
+                const u32 base = t * LG_CHUNK;
+                const uint2 rg = a.range[t];
+                u32 val[LG_IPT], slot_of[LG_IPT], held[LG_IPT];
+                (void)pr2_tile_load(lds, &wg_count, f_next, a.elems, a.slots, base, lane, w, rg.x, rg.y, val, slot_of);
+#pragma unroll
+                for (int j = 0; j < LG_IPT; j++) {
+                    const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+                    held[j] = pr_load(&a.name[local < rg.y ? val[j] : 0u]);
+                }
+#pragma unroll
+                for (int j = 0; j < LG_IPT; j++) {
+                    const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
+                    if (local >= rg.y) continue;
+                    const u32 name = slot_of[j] - (local - pr_group_start(lds.start_bits, local));
+                    if (held[j] != name) pr_store(&a.name[val[j]], name);
+                }
+            }
+        }
+        if (!pr_grid_barrier(a.ctl, barrier_no++, &bar_flag)) return;
+        if (all_open == 0u) break;
+        if (round + 1u == PR_MAX_ROUNDS) {
+            if (threadIdx.x == 0) __hip_atomic_store(&a.ctl[PR_CTL_ABORT], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        depth *= 2u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl[PR_CTL_ROUNDS] = round + 1u;
+}

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(BLOCK) void lcp_kernel(const u32 *__restrict__ s,
         if (h >= LCP_DIRECT_CAP) { cut = true; break; }
     }
     // (the first rank of every document is reset to 0 by lcp_doc_starts_kernel)
-    if (cut) { h |= LCP_PARTIAL_BIT; atomicOr(capped, 1u); }
+    if (cut) { h |= LCP_PARTIAL_BIT; raise_flag(capped); }
     lcp[r] = h;
 }
 
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(BLOCK) void lcp8_kernel(const uint8_t *__restrict__
     }
     if (h == 8u) h = lcp_bytes_capped(s8, i, j, 8u, budget);         // (most ranks end inside the first windows)
     // (the first rank of every document is reset to 0 by lcp_doc_starts_kernel)
-    if (h & LCP_PARTIAL_BIT) atomicOr(capped, 1u);
+    if (h & LCP_PARTIAL_BIT) raise_flag(capped);
     lcp[r] = h;
 }
 

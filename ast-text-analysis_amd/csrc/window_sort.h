@@ -1621,7 +1621,7 @@ __global__ __launch_bounds__(BLOCK) void lvl0_lcp_text_list_kernel(const uint8_t
     // wavefront wide: one thread walking 10 000 symbols is 300 dependent round trips -- 0.3 ms that a small build waits for)
     if (hinted) budget.per_slot = 0;                    // (... and none of them goes deeper than that here)
     const u32 h = h0 >= LCP_SOFT_CAP ? (LCP_PARTIAL_BIT | h0) : lcp_bytes_capped(s8, sa[r - 1], sa[r], h0, budget);
-    if (h & LCP_PARTIAL_BIT) atomicOr(capped, 1u);
+    if (h & LCP_PARTIAL_BIT) raise_flag(capped);
     lcp[r] = h;
 }
 
@@ -1885,7 +1885,7 @@ __global__ __launch_bounds__(BLOCK) void spec_counts_kernel(const u32 *__restric
 // for more -- and the lock that keeps two such launches of one process from sharing the chip half resident each.
 #define PERSIST_SMALL_INPUT ((u32)4 << 20)      // inputs whose names cost next to nothing to initialise (0.1 ms)
 static std::mutex g_persist_mutex;
-struct PersistCap { u32 one_per_cu = 0, two_per_cu = 0; };      // workgroups resident at once, by kernel variant (0: not available)
+struct PersistCap { u32 one_per_cu = 0, two_per_cu = 0, large = 0; };      // workgroups resident at once, by kernel variant (0: not available)
 static PersistCap persist_capacity()
 {
     static std::mutex mu;
@@ -1896,15 +1896,17 @@ static PersistCap persist_capacity()
     std::lock_guard<std::mutex> lock(mu);
     if (!asked[dev]) {
         asked[dev] = true;
-        int per1 = 0, per2 = 0, cus = 0;
+        int per1 = 0, per2 = 0, per3 = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per1, refine_persist_kernel<4>, LG_THREADS, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per2, refine_persist_kernel<8>, LG_THREADS, 0) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); per1 = per2 = 0; }
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per3, refine_persist2_kernel, LG_THREADS, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); per1 = per2 = per3 = 0; }
         // (two workgroups of 1 024 threads fill a CU's 32 wave slots; the query is trusted up to that)
         if (cus > 0 && per1 >= 1) cap[dev].one_per_cu = (u32)cus;
         if (cus > 0 && per2 >= 2) cap[dev].two_per_cu = 2u * (u32)cus;
+        if (cus > 0 && per3 >= 1) cap[dev].large = (u32)cus;
         const char *env = getenv("EAST_HIP_PERSIST_WGS");       // (experiments: a smaller grid)
-        if (env) { cap[dev].one_per_cu = std::min<u32>(cap[dev].one_per_cu, (u32)atoi(env)); cap[dev].two_per_cu = std::min<u32>(cap[dev].two_per_cu, (u32)atoi(env)); }
+        if (env) { cap[dev].one_per_cu = std::min<u32>(cap[dev].one_per_cu, (u32)atoi(env)); cap[dev].two_per_cu = std::min<u32>(cap[dev].two_per_cu, (u32)atoi(env)); cap[dev].large = std::min<u32>(cap[dev].large, (u32)atoi(env)); }
     }
     return cap[dev];
 }
@@ -2193,7 +2195,10 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // symbols of the Zipf stand-in: only where the domain is a good part of the input, or the input small)
             const bool slow = round > 0 && m_next > m / 2;          // slow shrinking = long repeats
             const bool repetitive = ctx.sample_n ? ctx.sample_dup4[8] * 2u > ctx.sample_n : ctx.plan_persist == 1;
-            const bool try_persist = persist_cap > 0 && name_of && !doubling && m_next <= persist_cap * LG_CHUNK && n02 >= 4u * PR_CTL_WORDS &&
+            // (a domain of more tiles than the device holds workgroups: the same rounds with the tiles' state in global
+            // memory, several tiles per workgroup -- refine_persist2_kernel)
+            const bool try_persist = persist_cap > 0 && name_of && !doubling && n02 >= 4u * PR_CTL_WORDS &&
+                                     (m_next <= persist_cap * LG_CHUNK || (persist_caps.large > 0 && ctx.knobs.persist_large)) &&
                                      (n02 <= PERSIST_SMALL_INPUT || n02 / 8u <= m_next) && (round == 0 ? repetitive : slow);
             if (name_of && !doubling && slow && !try_persist) {
                 // slow shrinking = long repeats: from here on the depth doubles every round (see above)
@@ -2242,14 +2247,19 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 HIP_CHECK(hipMemsetAsync(ctl, 0, PR_CTL_WORDS * sizeof(u32), ctx.stream));
                 LAUNCH(ctx, persist_names_init_kernel, ceil_div_u32(n02, BLOCK), (const u32 *)sa12,
                        !slot && !fused ? sorted_vals : (const u32 *)nullptr, (const u64 *)keep, n02, name_of, name1);
-                const PrArgs pa{ebuf[e_c], gstart, slot_c, m, depth, bit_width_u32(n02 > 1 ? n02 - 1 : 1), name_of, name1, sa12,
-                                lcp_redo ? lcp_out : (u32 *)nullptr, ctl};
+                const int name_bits = bit_width_u32(n02 > 1 ? n02 - 1 : 1);
+                const PrArgs pa{ebuf[e_c], gstart, slot_c, m, depth, name_bits, name_of, name1, sa12, lcp_redo ? lcp_out : (u32 *)nullptr, ctl};
+                const u32 tiles = ceil_div_u32(m, LG_CHUNK);
+                // (the large form: the second copy of the group bounds, the tiles' ranges and "changed" flags in buffers of the
+                // launch-by-launch rounds that are idle here)
+                const Pr2Args pa2{ebuf[e_c], slot_c, gstart, full_idx, m, depth, name_bits, name_of, sa12, lcp_redo ? lcp_out : (u32 *)nullptr,
+                                  ctl, cover, rest_cnt, tiles};
                 u32 h_ctl[4] = {0, 0, 0, 0};
                 {
                     std::lock_guard<std::mutex> lock(g_persist_mutex);
-                    const u32 tiles = ceil_div_u32(m, LG_CHUNK);
                     if (tiles <= persist_caps.one_per_cu) LAUNCH_BLOCK(ctx, refine_persist_kernel<4>, tiles, LG_THREADS, pa);
-                    else LAUNCH_BLOCK(ctx, refine_persist_kernel<8>, tiles, LG_THREADS, pa);
+                    else if (tiles <= persist_caps.two_per_cu) LAUNCH_BLOCK(ctx, refine_persist_kernel<8>, tiles, LG_THREADS, pa);
+                    else LAUNCH_BLOCK(ctx, refine_persist2_kernel, std::min(tiles, persist_caps.large), LG_THREADS, pa2);
                     HIP_CHECK(hipMemcpyAsync(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, ctx.stream));
                     HIP_CHECK(sync_stream(ctx.stream));
                 }
