@@ -617,13 +617,16 @@ def write_detail(out):
     """Everything the run measured, as one JSON document next to bench.py (and under gpurun_out/ when that directory
     exists, so that it comes back from the GPU box).  Returns the path written, or None."""
     written = None
-    for directory in (ROOT, os.path.join(ROOT, "gpurun_out")):
-        if directory != ROOT and not os.path.isdir(directory):
-            continue
+    paths = [os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    if os.environ.get("EAST_BENCH_DETAIL"):                 # (the profiling scripts keep one per run: tools/profile_*.sh)
+        paths.append(os.environ["EAST_BENCH_DETAIL"])
+    for path in paths:
         try:
-            with open(os.path.join(directory, "bench_detail.json"), "w") as f:
+            with open(path, "w") as f:
                 json.dump(out, f, indent=1)
-            written = written or os.path.join(directory, "bench_detail.json")
+            written = written or path
         except OSError:
             pass
     return written

@@ -8,8 +8,12 @@ OUT=gpurun_out/config2
 rm -rf "$OUT"; mkdir -p "$OUT"
 echo "${EAST_COMMIT:-unknown}" > $OUT/commit.txt     # (the tree the passes are taken on: gpurun -- "EAST_COMMIT=$(git rev-parse --short HEAD) tools/...")
 ARGS="--docs 256 --doc-mib 1 --keyphrases 10000 --no-cpu-baseline --no-config2 --no-extras"
+export EAST_BENCH_DETAIL=$OUT/bench_detail.json
 timeout 300 python3 bench.py $ARGS 2>/dev/null | tail -1 > $OUT/bench.json
+unset EAST_BENCH_DETAIL
+export EAST_BENCH_DETAIL=$OUT/bench_profiled_detail.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS --steps 5 --warmup 2 > $OUT/bench_profiled.json 2>/dev/null
+unset EAST_BENCH_DETAIL
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS --steps 2 --warmup 1 > $OUT/fetch.json 2> $OUT/fetch.err
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 bench.py $ARGS --steps 2 --warmup 1 > $OUT/write.json 2> $OUT/write.err
 python3 - <<'PY'

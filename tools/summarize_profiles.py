@@ -82,11 +82,15 @@ def agg(pattern, counter):
 
 stats = newest(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(DST, tag + "_kernel_stats.csv"))
-shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, tag + "_bench.json"))
-shutil.copy(os.path.join(SRC, "bench_profiled.json"), os.path.join(DST, tag + "_bench_profiled.json"))
+# (round 6: bench.py prints a line of under 6 KB for the driver; everything else -- the per-kernel tables the recomputation below
+# works on -- is in bench_detail.json, of which the profiling scripts keep one per run)
+for kind in ("bench", "bench_profiled"):
+    shutil.copy(os.path.join(SRC, kind + ".json"), os.path.join(DST, tag + "_" + kind + ".json"))
+    if os.path.exists(os.path.join(SRC, kind + "_detail.json")):
+        shutil.copy(os.path.join(SRC, kind + "_detail.json"), os.path.join(DST, tag + "_" + kind + "_detail.json"))
 fetch = agg(os.path.join(SRC, "fetch", "*", "*_counter_collection.csv"), "FETCH_SIZE")
 write = agg(os.path.join(SRC, "write", "*", "*_counter_collection.csv"), "WRITE_SIZE")
-bench = json.load(open(os.path.join(SRC, "bench.json")))
+bench = json.loads(open(os.path.join(SRC, "bench.json")).read().strip().splitlines()[-1])
 n = bench["config"]["symbols_per_gpu"]
 traffic = {}
 with open(os.path.join(DST, tag + "_pmc_per_kernel.csv"), "w") as f:
@@ -118,7 +122,9 @@ json.dump(out, open(os.path.join(DST, TRAFFIC), "w"), indent=1, sort_keys=True)
 # traffic.json that was committed before it started)
 for name in (tag + "_bench.json", tag + "_bench_profiled.json"):
     path = os.path.join(DST, name)
-    line = json.load(open(path))
+    detail_path = path[:-len(".json")] + "_detail.json"
+    has_detail = os.path.exists(detail_path)
+    line = json.load(open(detail_path)) if has_detail else json.loads(open(path).read().strip().splitlines()[-1])
     line["roofline"]["traffic"] = out.get(line["roofline"]["kernel"])
     for e in line.get("roofline_by_kernel", []):
         if "traffic" in e or e["kernel"] in out:
@@ -138,8 +144,16 @@ for name in (tag + "_bench.json", tag + "_bench_profiled.json"):
             n_cov = sum(1 for k in ms if k.startswith(bench.BUILD_KERNEL_PREFIXES) and k in out and k in launches)
             line["roofline"]["rocprof_hbm_fraction"].update({"GBps": num / den / 1e9, "frac": num / den / 1e9 / bench.HBM_PEAK_GBS,
                                                              "kernels": n_cov, "share_of_build_kernel_time": den * 1e3 / build_ms})
-    with open(path, "w") as f:
-        f.write(json.dumps(line) + "\n")
+    if has_detail:                                       # the full record, and the driver's line made from it again
+        sys.path.insert(0, ROOT)
+        import bench as bench_module
+        with open(detail_path, "w") as f:
+            json.dump(line, f, indent=1)
+        with open(path, "w") as f:
+            f.write(bench_module.compact_line(line, detail_path) + "\n")
+    else:
+        with open(path, "w") as f:
+            f.write(json.dumps(line) + "\n")
 for k, expect in (("remap_kernel", 8.0 * n), ("remap_bytes_kernel", 4.0 * n), ("presence_kernel", 4.0 * n),
                   ("presence_remap_kernel", 4.0 * n)):
     if k in fetch and expect:
