@@ -173,6 +173,8 @@ struct Knobs {
     bool fused_classify = getenv("EAST_HIP_NO_FUSED_CLASSIFY") == nullptr;      // ... (2): the stand-alone classification pass
     bool persist = getenv("EAST_HIP_NO_PERSIST") == nullptr;            // ... (1 only): small domains finish in one launch (persist_rounds.h)
     bool persist_large = getenv("EAST_HIP_NO_PERSIST_LARGE") == nullptr;    // ... and large ones, several tiles per workgroup (A/B timing)
+    bool persist_force_large = getenv("EAST_HIP_PERSIST_FORCE_LARGE") != nullptr;   // east_hip_debug_set_persist: the large form on any domain
+    int persist_max_wgs = env_int("EAST_HIP_PERSIST_WGS", 0);          // ... with at most this many workgroups (0: what the device holds)
     size_t rank_bucket_bytes = (size_t)192 << 20;                       // east_hip_debug_set_rank_bucket_bytes
     bool speculate = getenv("EAST_HIP_NO_SPECULATION") == nullptr;      // east_hip_debug_set_speculation
     bool kg_pairs = getenv("EAST_HIP_NO_KG_PAIRS") == nullptr;          // east_hip_debug_set_score_path

@@ -2813,6 +2813,18 @@ int east_hip_debug_set_lds_rounds(int enabled)
     return EAST_HIP_OK;
 }
 
+int east_hip_debug_set_persist(int force_large, int max_workgroups)
+{
+    // the persistent rounds (persist_rounds.h): force_large != 0 -- the large form (tiles' state in global memory, several
+    // tiles per workgroup) also where the resident form would do; max_workgroups > 0 -- a grid of at most that many
+    // workgroups (0: what the device holds).  (0, 0) = the default.
+    knobs_update([&](Knobs &k) {
+        k.persist_force_large = force_large != 0;
+        k.persist_max_wgs = max_workgroups > 0 ? max_workgroups : 0;
+    });
+    return EAST_HIP_OK;
+}
+
 int east_hip_debug_set_score_scratch(int64_t bytes)
 {
     knobs_update([&](Knobs &k) { k.score_scratch_bytes = bytes > 0 ? (size_t)bytes : SCORE_SCRATCH_BYTES; });

@@ -2,28 +2,28 @@
 //
 // A round of window_sort.h is ~15 launches and two read-backs however few suffixes are left: the reference's own
 // benchmark collection (analysis/utils.py:5-9, 100 identical strings) at n = 1000 -- 100 K symbols -- spent 4.4 ms in
-// 124 launches, slower than one CPU core.  When the open domain fits the chip at one tile per resident workgroup
-// (PR_MAX_WGS tiles of LG_CHUNK positions: 1 M elements) and no tie group is longer than a tile takes
-// (LG_MAX_GROUP), every workgroup keeps its tile -- elements, group bounds, the slots they will fill -- in LDS and
-// registers and runs prefix doubling (Manber-Myers / Larsson-Sadakane, as the doubling rounds of window_sort.h) to the
-// end:  a round = gather the NAME of the suffix `depth` symbols further on (a name = the slot where a suffix's tie
-// group starts, its own slot once it is placed), sort the tile in LDS by (group, name) with the wave64 multisplit
-// passes of lds_group_sort.h, read the new group bounds off the sorted keys, publish the new names, ONE grid barrier.
-// Names are double-buffered (a round reads one copy and writes the other: no workgroup can see a name of the round
-// under way), so a round costs its sort plus one barrier instead of fifteen kernel boundaries and two host
+// 124 launches, slower than one CPU core.  When the open domain has no more tiles than the device has CUs (one tile of
+// LG_CHUNK positions per workgroup: 512 K elements; beyond that the large form at the end of this file) and no tie group
+// is longer than a tile takes (LG_MAX_GROUP), every workgroup keeps its tile -- elements, group bounds, the slots they
+// will fill -- in LDS and registers and runs prefix doubling (Manber-Myers / Larsson-Sadakane, as the doubling rounds of
+// window_sort.h) to the end:  a round = gather the NAME of the suffix `depth` symbols further on (a name = the slot where
+// a suffix's tie group starts, its own slot once it is placed), sort the tile in LDS by (group, name) with the wave64
+// multisplit passes of lds_group_sort.h, read the new group bounds off the sorted keys, publish the new names, ONE grid
+// barrier.  Names are double-buffered (a round reads one copy and writes the other: no workgroup can see a name of the
+// round under way), so a round costs its sort plus one barrier instead of fifteen kernel boundaries and two host
 // synchronisations.  The depth doubles per round: log2(longest repeat / first depth) rounds.
 //
-// The grid barrier: one monotonic counter -- every storing wave drains its stores, workgroup barrier, lane 0 adds (agent
-// scope) and polls with relaxed agent-scope loads, s_sleep between polls, workgroup barrier.  The names, the only data
-// handed from workgroup to workgroup, are stored write-through and read past the L1 (pr_store / pr_load below), which is
-// what MI355X_MICROARCH.md lists as a valid hand-off without agent-scope fences.  Every spin is bounded: a barrier that
-// does not complete raises the abort flag and the host reports an internal error instead of hanging the device.  The
-// host launches at most the number of workgroups the occupancy query admits at once and holds a lock from the launch to
-// the read-back, so that two such kernels of one process never share the chip half resident each.
+// The grid barrier: one monotonic counter -- every storing wave drains its stores, workgroup barrier, lane 0 releases
+// (agent scope), adds and polls with relaxed agent-scope loads, s_sleep between polls, acquires, workgroup barrier.  What
+// is handed from workgroup to workgroup is stored write-through and read past the L1 (pr_store / pr_load below: few
+// dirty lines for the release to write back).  Every spin is bounded: a barrier that does not complete raises the abort
+// flag and the host reports an internal error instead of hanging the device.  The host launches at most the number of
+// workgroups the occupancy query admits at once and holds a lock from the launch to the read-back, so that two such
+// kernels of one process never share the chip half resident each.
 //
-// LCP entries: none are written here -- the host lists the slots of the domain and lvl0_lcp_text_list_kernel compares
-// the neighbours on the text once the suffix array is final (budgeted, with the irreducible-LCP finishing pass behind
-// it), exactly as it does for the doubling rounds of the multi-launch path.
+// LCP entries: the kernels write, per rank, what the two neighbours are KNOWN to share (the depth of the round in which
+// they came apart); the host lists the slots of the domain and lvl0_lcp_text_list_kernel finishes the entries on the text
+// once the suffix array stands (short ones directly, long ones through the irreducible-LCP finishing pass).
 #pragma once
 #include "lds_group_sort.h"
 
@@ -40,6 +40,9 @@
 #else
 #define PR_CTL_WORDS (PR_CTL_OPEN + PR_MAX_ROUNDS)
 #define PR_STAMP(k) do { } while (0)
+#endif
+#ifndef PR_FENCE_MODE
+#define PR_FENCE_MODE 3                     // 1: lane 0 acquires behind the barrier, 2: lane 0 releases in front of it, 3: both (0 / 1 / 2: diagnostic builds)
 #endif
 #define PR_SPIN_LIMIT (1u << 20)            // polls of a microsecond or two each before a barrier gives up (far beyond any round)
 
@@ -68,11 +71,15 @@ __global__ __launch_bounds__(BLOCK) void persist_names_init_kernel(const u32 *__
     name1[e] = i;
 }
 
-// The names are the only data workgroups hand to each other inside the launch.  They are stored write-through and read
-// past the vector L1 (agent-scope relaxed atomics = `global_store / global_load ... sc1` on gfx950: MI355X_MICROARCH.md,
-// "Valid forms" -- sc1 on both sides, every storing wave drained before its workgroup signals), so the barrier needs no
-// agent-scope release / acquire: with them every arrival wrote the XCD's L2 back and every departure invalidated the CU's
-// L1, and a workgroup that shared its CU with one sitting in the barrier took 40 us over an 8 us round (measured).
+// What workgroups hand to each other inside the launch (the names; in the large form also elements and group bounds near
+// a tile's ends) is stored write-through and read past the vector L1 (agent-scope relaxed atomics = `global_store /
+// global_load ... sc1` on gfx950), AND lane 0 of every workgroup releases in front of the barrier and acquires behind
+// it (MI355X_MICROARCH.md, "Valid forms").  Both were measured to be needed: with plain stores and loads every arrival's
+// release wrote a 1 M-name round's worth of dirty lines back (a workgroup sharing its CU with one sitting in the barrier
+// took 40 us over an 8 us round); with `sc1` / `sc0 sc1` accesses and NO fences the large form left the groups at tile
+// boundaries unsorted -- a workgroup re-reads the group bounds around its tile's ends every round, and got the flags of
+// two rounds ago although a workgroup on another XCD had stored to them since; one workgroup alone was always right,
+// acquire alone was not enough, release + acquire by lane 0 is (a few dirty lines: the release is cheap now).
 __device__ __forceinline__ void pr_store(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u32 pr_load(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -82,6 +89,10 @@ __device__ __forceinline__ bool pr_grid_barrier(u32 *ctl, u32 index, u32 *lds_fl
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its (write-through) stores are done
     __syncthreads();
     if (threadIdx.x == 0) {
+#if PR_FENCE_MODE & 2
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __hip_atomic_fetch_add(&ctl[PR_CTL_BARRIER], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const u32 target = gridDim.x * index;
         u32 spins = 0, ok = 1;
@@ -94,6 +105,10 @@ __device__ __forceinline__ bool pr_grid_barrier(u32 *ctl, u32 index, u32 *lds_fl
                 break;
             }
         }
+#if PR_FENCE_MODE & 1
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         *lds_flag = ok;
     }
     __syncthreads();
@@ -109,8 +124,10 @@ __device__ __forceinline__ u32 pr_group_start(const u64 *bits, u32 local)
     return wi * 64u + 63u - (u32)__builtin_clzll(x);
 }
 
-// MIN_WAVES = 8: two workgroups per CU (64 registers a lane, a few spilled); 4: one per CU with registers to spare -- the
-// host takes that one whenever the domain has no more tiles than the device has CUs.
+// MIN_WAVES = 4: one workgroup per CU, 116 registers a lane, nothing spilled -- what the host launches, for domains of at
+// most as many tiles as the device has CUs (more tiles: the large form below).  (8: two per CU at 64 registers with a few
+// spills; two workgroups share a CU's SIMDs without gaining on each other, and with the barrier's fences the form lost to
+// the large one: no longer launched.)
 template <int MIN_WAVES>
 __global__ __launch_bounds__(LG_THREADS, MIN_WAVES) void refine_persist_kernel(PrArgs a)
 {
@@ -429,7 +446,7 @@ __device__ __forceinline__ void pr2_tile_bounds(LgLds &lds, const u32 *__restric
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             const u64 p = (u64)base + (w + (u32)i * LG_WAVES) * 64u + lane;
-            gs[i] = gstart[p < m ? p : (u64)m - 1u];
+            gs[i] = pr_load(&gstart[p < m ? p : (u64)m - 1u]);
         }
 #pragma unroll
         for (int i = 0; i < PER; i++) {
@@ -488,9 +505,9 @@ __device__ __forceinline__ u32 pr2_tile_load(LgLds &lds, u32 *wg_count, const u3
         const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
         const bool in = local < n_act;
         const u64 r = (u64)base + begin_q + (in ? local : 0u);
-        val[j] = in ? elems[r] : 0u;
+        val[j] = in ? pr_load(&elems[r]) : 0u;
         slot_of[j] = in ? slots[r] : 0u;
-        const u32 st = in ? flags[r] : 1u;
+        const u32 st = in ? pr_load(&flags[r]) : 1u;
         const u64 bal = __ballot(st != 0u);
         if (lane == 0) lds.start_bits[w * LG_IPT + j] = bal;
     }
@@ -561,7 +578,9 @@ __global__ __launch_bounds__(LG_THREADS, 4) void refine_persist2_kernel(Pr2Args 
             u32 begin_q, n_act, val[LG_IPT], slot_of[LG_IPT];
             bool too_long;
             pr2_tile_bounds(lds, f_cur, m, base, lane, w, begin_q, n_act, too_long);
-            if (threadIdx.x == 0) { a.range[t] = uint2{begin_q, n_act}; a.changed[t] = 0u; }
+            // (this workgroup's own notes -- but read rounds later through an L1 that may still hold the line of a round before:
+            // written through and read past it like everything else a round leaves behind)
+            if (threadIdx.x == 0) { pr_store(&a.range[t].x, begin_q); pr_store(&a.range[t].y, n_act); pr_store(&a.changed[t], 0u); }
             if (n_act == 0) continue;
             const bool active = w * (LG_IPT * WAVE) < n_act;
             const u32 tile_open = pr2_tile_load(lds, &wg_count, f_cur, a.elems, a.slots, base, lane, w, begin_q, n_act, val, slot_of);
@@ -594,7 +613,7 @@ __global__ __launch_bounds__(LG_THREADS, 4) void refine_persist2_kernel(Pr2Args 
 #pragma unroll
                 for (int j = 0; j < LG_IPT; j++) {
                     const u32 local = w * (LG_IPT * WAVE) + j * WAVE + lane;
-                    if (local < n_act) f_next[(u64)base + begin_q + local] = (u32)((lds.start_bits[local >> 6] >> (local & 63u)) & 1ull);
+                    if (local < n_act) pr_store(&f_next[(u64)base + begin_q + local], (u32)((lds.start_bits[local >> 6] >> (local & 63u)) & 1ull));
                 }
                 my_open += tile_open;
                 continue;
@@ -637,15 +656,15 @@ __global__ __launch_bounds__(LG_THREADS, 4) void refine_persist2_kernel(Pr2Args 
                 const bool was = (lds.start_bits[w * LG_IPT + j] >> lane) & 1ull;
                 if (local < n_act) {
                     const u64 r = (u64)base + begin_q + local;
-                    f_next[r] = st ? 1u : 0u;
-                    a.elems[r] = val[j];
+                    pr_store(&f_next[r], st ? 1u : 0u);
+                    pr_store(&a.elems[r], val[j]);
                     a.order_g[slot_of[j]] = val[j];
                     if (a.lcp_hint && st && !was) a.lcp_hint[slot_of[j]] = depth;
                 }
                 const u64 bal = __ballot(st);
                 if (lane == 0) lds.start_bits[w * LG_IPT + j] = bal;
             }
-            if (threadIdx.x == 0) { a.changed[t] = 1u; wg_count = 0; }
+            if (threadIdx.x == 0) { pr_store(&a.changed[t], 1u); wg_count = 0; }
             __syncthreads();
             u32 open_cnt = 0;
 #pragma unroll
@@ -667,10 +686,10 @@ __global__ __launch_bounds__(LG_THREADS, 4) void refine_persist2_kernel(Pr2Args 
         // ---- NAMES: the tiles that changed publish the new names (the last round's are of no use to anybody) ----
         if (all_open) {
             for (u32 t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-                if (!a.changed[t]) continue;                // (this workgroup's own write: uniform)
+                if (!pr_load(&a.changed[t])) continue;      // (this workgroup's own write: uniform)
                 PR2_POSITION;
                 const u32 base = t * LG_CHUNK;
-                const uint2 rg = a.range[t];
+                const uint2 rg = uint2{pr_load(&a.range[t].x), pr_load(&a.range[t].y)};
                 u32 val[LG_IPT], slot_of[LG_IPT], held[LG_IPT];
                 (void)pr2_tile_load(lds, &wg_count, f_next, a.elems, a.slots, base, lane, w, rg.x, rg.y, val, slot_of);
 #pragma unroll

@@ -1885,7 +1885,7 @@ __global__ __launch_bounds__(BLOCK) void spec_counts_kernel(const u32 *__restric
 // for more -- and the lock that keeps two such launches of one process from sharing the chip half resident each.
 #define PERSIST_SMALL_INPUT ((u32)4 << 20)      // inputs whose names cost next to nothing to initialise (0.1 ms)
 static std::mutex g_persist_mutex;
-struct PersistCap { u32 one_per_cu = 0, two_per_cu = 0, large = 0; };      // workgroups resident at once, by kernel variant (0: not available)
+struct PersistCap { u32 one_per_cu = 0, large = 0; };      // workgroups resident at once: the resident form / the large form (0: not available)
 static PersistCap persist_capacity()
 {
     static std::mutex mu;
@@ -1896,17 +1896,13 @@ static PersistCap persist_capacity()
     std::lock_guard<std::mutex> lock(mu);
     if (!asked[dev]) {
         asked[dev] = true;
-        int per1 = 0, per2 = 0, per3 = 0, cus = 0;
+        int per1 = 0, per3 = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per1, refine_persist_kernel<4>, LG_THREADS, 0) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per2, refine_persist_kernel<8>, LG_THREADS, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per3, refine_persist2_kernel, LG_THREADS, 0) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); per1 = per2 = per3 = 0; }
-        // (two workgroups of 1 024 threads fill a CU's 32 wave slots; the query is trusted up to that)
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); per1 = per3 = 0; }
+        // (one workgroup of 1 024 threads per CU: see the launch below)
         if (cus > 0 && per1 >= 1) cap[dev].one_per_cu = (u32)cus;
-        if (cus > 0 && per2 >= 2) cap[dev].two_per_cu = 2u * (u32)cus;
         if (cus > 0 && per3 >= 1) cap[dev].large = (u32)cus;
-        const char *env = getenv("EAST_HIP_PERSIST_WGS");       // (experiments: a smaller grid)
-        if (env) { cap[dev].one_per_cu = std::min<u32>(cap[dev].one_per_cu, (u32)atoi(env)); cap[dev].two_per_cu = std::min<u32>(cap[dev].two_per_cu, (u32)atoi(env)); cap[dev].large = std::min<u32>(cap[dev].large, (u32)atoi(env)); }
     }
     return cap[dev];
 }
@@ -2168,7 +2164,12 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
         }
         bool doubling = false;
         PersistCap persist_caps = ctx.knobs.lds_rounds && ctx.knobs.persist && !ctx.dry ? persist_capacity() : PersistCap();
-        u32 persist_cap = std::max(persist_caps.one_per_cu, persist_caps.two_per_cu);
+        if (ctx.knobs.persist_max_wgs > 0) {             // (tests / experiments: a smaller grid -- several tiles per workgroup on small inputs)
+            const u32 cap_wgs = (u32)ctx.knobs.persist_max_wgs;
+            persist_caps.one_per_cu = std::min(persist_caps.one_per_cu, cap_wgs);
+            persist_caps.large = std::min(persist_caps.large, cap_wgs);
+        }
+        u32 persist_cap = persist_caps.one_per_cu;
         u32 depth = fused ? (u32)depth0 : (u32)w;        // what the members of a group are known to share
         const u32 *elem = fused ? (const u32 *)sa12 : sorted_vals, *slot = nullptr, *flag = nullptr;
         int e_dom = -1, s_dom = 0, f_dom = 0;           // which of the rotating buffers hold the domain
@@ -2257,8 +2258,11 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 u32 h_ctl[4] = {0, 0, 0, 0};
                 {
                     std::lock_guard<std::mutex> lock(g_persist_mutex);
-                    if (tiles <= persist_caps.one_per_cu) LAUNCH_BLOCK(ctx, refine_persist_kernel<4>, tiles, LG_THREADS, pa);
-                    else if (tiles <= persist_caps.two_per_cu) LAUNCH_BLOCK(ctx, refine_persist_kernel<8>, tiles, LG_THREADS, pa);
+                    const bool force_large = ctx.knobs.persist_force_large && persist_caps.large > 0;      // (tests: the large form on small domains)
+                    if (tiles <= persist_caps.one_per_cu && !force_large) LAUNCH_BLOCK(ctx, refine_persist_kernel<4>, tiles, LG_THREADS, pa);
+                    // (between one and two tiles per CU the resident form at two workgroups per CU -- 64 registers, spills, and
+                    // with the barrier's fences 1.07 ms for the 488 tiles of the worst case at n = 10^4 -- loses to the large
+                    // form at one workgroup per CU, 0.8 ms: it is not used)
                     else LAUNCH_BLOCK(ctx, refine_persist2_kernel, std::min(tiles, persist_caps.large), LG_THREADS, pa2);
                     HIP_CHECK(hipMemcpyAsync(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, ctx.stream));
                     HIP_CHECK(sync_stream(ctx.stream));

@@ -68,6 +68,7 @@ SIGNATURES = {
     "east_hip_debug_set_rank_bucket_bytes": (ctypes.c_int, [ctypes.c_int64]),
     "east_hip_debug_set_window_sort": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_debug_set_lds_rounds": (ctypes.c_int, [ctypes.c_int]),
+    "east_hip_debug_set_persist": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "east_hip_debug_set_segmented_sort": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_debug_set_speculation": (ctypes.c_int, [ctypes.c_int]),
     "east_hip_debug_set_score_scratch": (ctypes.c_int, [ctypes.c_int64]),

@@ -362,6 +362,7 @@ int east_hip_debug_set_window_sort(int enabled);
 int east_hip_debug_set_segmented_sort(int mode);
 /* Test knob: 0 = the tie-refinement rounds sort every group with the global radix sort; 1 (default) = groups
  * that fit a workgroup's LDS are sorted there (csrc/lds_group_sort.h), the global sort takes the rest. */
+int east_hip_debug_set_persist(int force_large, int max_workgroups);   /* the persistent rounds: (1, n) = the large form (several tiles per workgroup, state in global memory) on every domain, at most n workgroups (0: what the device holds); (0, 0) = default */
 int east_hip_debug_set_lds_rounds(int enabled);   /* 0 / 1 (default: the in-LDS rounds also classify the next domain; a domain that fits the chip is finished by one persistent launch) / 2 (in-LDS rounds + the stand-alone classification pass, launch by launch) / 3 (as 1 without the persistent launch) */
 /* Test knob: 0 = every build waits for the device's answers (alphabet size, tie groups) as a handle's
  * first build does; 1 (default) = later builds on a handle are queued without waiting, on the strength

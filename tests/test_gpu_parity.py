@@ -391,6 +391,49 @@ def test_reference_worst_case_collection_vs_oracle(hip, oracle, request, suffix_
             assert tables[True][k, d] == o.score_symbols(qs[qo[k]:qo[k + 1]], True, fast=False), (d, k)
 
 
+@pytest.mark.parametrize("max_wgs", [3, 25, 0])
+@pytest.mark.parametrize("case", ["identical_strings", "copies_in_two_documents", "binary_text"])
+def test_persistent_rounds_large_form_on_small_domains(hip, oracle, request, case, max_wgs):
+    """The large form of the persistent rounds (csrc/persist_rounds.h: refine_persist2_kernel -- a workgroup walks several
+    tiles per round, the tiles' state in global memory, ranges that move from round to round) is what a 10 M-symbol
+    domain takes; east_hip_debug_set_persist(1, n) runs it on small repetitive collections with 3 / 25 / all workgroups,
+    i.e. with dozens of tiles, a few, one per workgroup: the hand-off of a tile's tail to its right neighbour (found
+    unsorted at tile boundaries while the barrier had no release / acquire), groups of 2 .. 100 equal suffixes, two
+    documents.  All six tables array_equal to the oracle."""
+    _only_paths(request, "window_sort", "window_sort_unfused")
+    from east import hip_backend, synthetic
+    from east.asts import utils as ast_utils
+    lib = hip.load()
+    rng = np.random.default_rng(31 + len(case))
+    if case == "identical_strings":
+        parts = [synthetic.worst_case_collection(rng, 100, 1500)[0]]
+        ms = [100]
+    elif case == "copies_in_two_documents":
+        blob = "".join(rng.choice(list("AB"), size=20000))
+        docs = [[blob, blob, "C" + blob], [blob[::-1], blob[::-1]]]
+        parts = [ast_utils.strings_to_symbols(sc) for sc in docs]
+        ms = [3, 2]
+    else:
+        text = "".join(rng.choice(list("AB"), size=150000))
+        parts = [ast_utils.strings_to_symbols([text[:90000], text[30000:]])]
+        ms = [2]
+    sym = np.concatenate(parts)
+    off = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.int64)
+    assert lib.east_hip_debug_set_persist(1, max_wgs) == 0
+    try:
+        index = hip_backend.HipIndex()
+        index.build(sym, off, np.array(ms, dtype=np.int32))
+        info = index.info()
+        assert info["persist_rounds"] >= 3, info
+        for d in range(len(parts)):
+            o = oracle.OracleEASA(symbols=parts[d], n_strings=ms[d])
+            t = index.tables(d)
+            for name in TABLES:
+                assert np.array_equal(t[name], getattr(o, name)), (name, d, case, max_wgs, info)
+    finally:
+        assert lib.east_hip_debug_set_persist(0, 0) == 0
+
+
 def test_sixteen_copies_of_a_passage_in_one_string(hip, oracle, request):
     """`get_ast([one string])` on a 1 MiB passage written 16 times in a row (16.8 M symbols, no terminator in between):
     common prefixes of up to 15 MiB, tie groups nested 16 deep.  SA, LCP and annotation array_equal to the oracle."""
