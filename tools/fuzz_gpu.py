@@ -103,6 +103,8 @@ def main():
         knob = int(rng.choice([1, 1, 1, 0, 3, 2, 4, 5, 7, 7, 9, 9]))
         lib.east_hip_debug_set_window_sort(knob)
         lib.east_hip_debug_set_lds_rounds(int(rng.choice([1, 1, 3, 2, 0])))
+        # (the persistent rounds: the form by size, or the large form forced, on a grid of what the device holds / 3 / 40 workgroups)
+        lib.east_hip_debug_set_persist(int(rng.choice([0, 0, 1])), int(rng.choice([0, 0, 3, 40])))
         lib.east_hip_debug_set_segmented_sort(int(rng.choice([-1, 1, 1, 0])))     # (1: wherever a shard holds 2 .. 65535 documents)
         lib.east_hip_debug_set_score_path(int(rng.choice([1, 4, 4, 0, 2, 3, 5])))
         parts = [to_symbols(sc) for sc in docs]
@@ -128,7 +130,7 @@ def main():
             index.build(dev_sym, off, np.array([len(sc) for sc in docs], dtype=np.int32))
             info = index.info()
             key = (knob, info["window_sorted"], min(info["dc3_levels"], 3), min(info["refine_rounds"], 3), int(lifted),
-                   info["fused_finish"], info["ht_keys"], info["seg_sort"])
+                   info["fused_finish"], info["ht_keys"], info["seg_sort"], int(info["persist_rounds"] > 0))
             paths[key] = paths.get(key, 0) + 1
             queries = []
             for sc in docs[:2]:
@@ -162,10 +164,11 @@ def main():
         cases += 1
     lib.east_hip_debug_set_window_sort(1)
     lib.east_hip_debug_set_lds_rounds(1)
+    lib.east_hip_debug_set_persist(0, 0)
     lib.east_hip_debug_set_segmented_sort(-1)
     lib.east_hip_debug_set_score_path(1)
     print("fuzz ok: %d collections, %d documents, %d symbols checked; paths (knob, window_sorted, dc3_levels, rounds, lifted, fused, "
-          "variable-length keys, segmented sort):"
+          "variable-length keys, segmented sort, persistent rounds):"
           % (cases, docs_checked, symbols))
     for k in sorted(paths):
         print("   ", k, paths[k])
