@@ -221,6 +221,7 @@ struct Ctx {
     // l symbols with at least 1 / 3 others of the sample.  sample_n == 0: no sample (speculative build: the plan of
     // the build before is taken instead -- plan_wide / plan_fused).
     u32 sample_n = 0, sample_dup2[9] = {0}, sample_dup4[9] = {0};
+    u32 rep_n = 0, rep_dup = 0;             // "is the text repetitive?": of rep_n sample suffixes, rep_dup share 8 symbols with three others (also from samples too small to plan from)
     int plan_wide = -1, plan_fused = -1;    // -1 = decide from the sample / the estimates; 0 / 1 = as the build before did
     int did_wide = 0, did_fused = 0;        // out: what the all-suffix window sort did (the next speculative build's plan)
     // An order-preserving variable-length code for the text's symbols is at hand (ht_code.h; ht_max_len > 0): the device

@@ -714,14 +714,20 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
         LAUNCH(ctx, codemap_kernel, 1, (const u32 *)present, ctx.spec ? spec_sigma : 0xFFFFFFFFu, h->code_map, flags, h->guess,
                (int)fused);
         ctx.sample_n = 0;
-        if (!ctx.dry && !ctx.spec && !tagged && n >= 4 * SAMPLE_N) {
+        ctx.rep_n = ctx.rep_dup = 0;
+        bool sample_plans = false;                          // the sample is large enough to plan the window and the fused finish from
+        if (!ctx.dry && !ctx.spec && !tagged && n >= 1024u) {
             // the planning sample: the middle of the longest document (read back together with the alphabet)
             u32 dl = 0;
             for (u32 d = 1; d < n_docs; d++)
                 if (off32[d + 1] - off32[d] > off32[dl + 1] - off32[dl]) dl = d;
             const u32 len = off32[dl + 1] - off32[dl], cnt = std::min<u32>(SAMPLE_N, len);
-            // (many short documents: a sample of a few dozen suffixes decides nothing -- no sample, the uniform estimates)
-            if (cnt >= SAMPLE_N / 4)
+            // (many short documents: a sample of a few dozen suffixes decides nothing -- no sample, the uniform estimates.
+            // A small input's sample -- 512 suffixes or more -- only answers "is this text repetitive?": the reference's
+            // worst-case collection at n = 300, 30 K symbols, took 3.7 ms through the endgame's direct ordering of its
+            // groups of 100 and takes 0.6 through the persistent rounds, window_sort.h)
+            sample_plans = n >= 4 * SAMPLE_N && cnt >= SAMPLE_N / 4;
+            if (cnt >= 512u)
                 LAUNCH_BLOCK(ctx, sample_prefix_kernel, SAMPLE_MAX_L, SAMPLE_THREADS, d_sym, n, off32[dl] + (len - cnt) / 2, cnt,
                              flags + FLAG_SAMPLE);
         }
@@ -744,6 +750,9 @@ static void build_impl(east_hip_index *h, Ctx &ctx, const u32 *d_sym, u32 n, u32
                     ctx.sample_dup2[l] = hf[FLAG_SAMPLE + 2 * (l - 1)];
                     ctx.sample_dup4[l] = hf[FLAG_SAMPLE + 2 * (l - 1) + 1];
                 }
+                ctx.rep_n = ctx.sample_n;
+                ctx.rep_dup = ctx.sample_dup4[SAMPLE_MAX_L];
+                if (!sample_plans) ctx.sample_n = 0;          // (too small to plan from)
                 if (g_trace && ctx.sample_n) {
                     fprintf(stderr, "[east_hip] sample of %u suffixes, shared prefixes (>= 2 / >= 4 of the sample) by length:", ctx.sample_n);
                     for (int l = 1; l <= SAMPLE_MAX_L; l++) fprintf(stderr, " %d: %u/%u", l, ctx.sample_dup2[l], ctx.sample_dup4[l]);

@@ -2016,7 +2016,12 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
     // ---- the whole sorted input as the first domain --------------------------------------
     // (a small input is better off with the direct ordering of much larger groups than with a round of ~50 launches)
     KgMark km;                                          // k-gram bucket starts ride along with the first placement pass
-    const bool small_input = n02 <= REFINE_SMALL_INPUT;
+    // (repetitive text -- the sample says, or the build before did -- is not ordered directly however small it is: its tie
+    // groups agree for hundreds of symbols, and every member would compare itself with every other to the end; the
+    // persistent rounds take it, persist_rounds.h)
+    const bool repetitive_text = n0 == 0 && !ctx.dry && ctx.knobs.lds_rounds && ctx.knobs.persist && n02 >= 4u * PR_CTL_WORDS &&
+                                 (ctx.rep_n ? ctx.rep_dup * 2u > ctx.rep_n : ctx.plan_persist == 1);
+    const bool small_input = n02 <= REFINE_SMALL_INPUT && !repetitive_text;
     if (kg_mark) kg_mark->k = kg_mark->kg && n0 == 0 && !ctx.dry && !small_input && !ht ? kg_mark->k : 0;   // (variable-length keys: the score side builds its tables itself)
     if (kg_mark && kg_mark->k > 0) {
         km = *kg_mark;
@@ -2195,7 +2200,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // (the launch needs the name of every placed suffix first -- a scatter over all n02 ranks, 2.1 ms for the 94 M
             // symbols of the Zipf stand-in: only where the domain is a good part of the input, or the input small)
             const bool slow = round > 0 && m_next > m / 2;          // slow shrinking = long repeats
-            const bool repetitive = ctx.sample_n ? ctx.sample_dup4[8] * 2u > ctx.sample_n : ctx.plan_persist == 1;
+            const bool repetitive = repetitive_text;
             // (a domain of more tiles than the device holds workgroups: the same rounds with the tiles' state in global
             // memory, several tiles per workgroup -- refine_persist2_kernel)
             const bool try_persist = persist_cap > 0 && name_of && !doubling && n02 >= 4u * PR_CTL_WORDS &&
@@ -2333,7 +2338,7 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // usual limits, no groups with long repeats known)
             // (once groups with long repeats are known to exist the direct ordering of large groups only burns time: every
             // member of such a group compares REFINE_ENDGAME_LEN symbols with every other before it gives up)
-            const bool endgame = m <= REFINE_ENDGAME_DOMAIN && !long_repeats;
+            const bool endgame = m <= REFINE_ENDGAME_DOMAIN && !long_repeats && !repetitive_text;
             const bool fuse_cls = ctx.knobs.lds_rounds && ctx.knobs.fused_classify && !doubling && !endgame && !long_repeats;
             u32 round_left = m;                         // what the in-LDS round left to the global sort
             auto sort_round = [&](bool names, int w2, const KeyNeqWindowIn<u64> &f) {

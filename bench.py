@@ -820,7 +820,7 @@ def worst_case_leg(hip_backend, synthetic, torch, dev, local_rank, with_oracle):
     oracle's time on the same input."""
     res = {"workload": "analysis/utils.py worst_case_strings_collection(m=100, n): 100 identical strings of n-4 letters, "
                        "one document (AST.get_ast), symbols resident in HBM", "cases": []}
-    for n in (1000, 10000, 100000):
+    for n in (100, 1000, 10000, 100000):
         rng = np.random.default_rng(20240 + 6)
         sym, m = synthetic.worst_case_collection(rng, 100, n)
         off, ms = np.array([0, sym.size], dtype=np.int64), np.array([m], dtype=np.int32)

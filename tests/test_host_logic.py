@@ -464,7 +464,7 @@ def test_bench_line_stays_under_the_drivers_tail():
     for leg in ("config2", "config5", "config5_prose"):
         assert {"value", "ms_per_step", "build_ms", "score_ms", "kernel"} <= set(line[leg]), leg
         assert not any(isinstance(v, (dict, list)) for v in line[leg].values())      # one-line summaries: no tables
-    assert [c["n"] for c in line["worst_case"]["cases"]] == [1000, 10000, 100000]
+    assert [c["n"] for c in line["worst_case"]["cases"]] == [1000, 10000, 100000]      # (the canned record is round 5's: three sizes)
     assert line["multi_gpu"]["in_process"]["rccl_ranks"] == 8 and "note" not in line["multi_gpu"]
     assert line["detail"] == "bench_detail.json"
     # values keep five significant digits of what was measured
