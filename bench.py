@@ -474,18 +474,24 @@ def main():
         # Every rank gives its device memory back and waits on a CPU-side (gloo) barrier -- an NCCL barrier would keep a
         # kernel spinning on the very devices rank 0 is about to use --, rank 0 runs the same shard shapes through
         # east_hip_group_build + east_hip_score_table_multi on devices 0 .. N-1, then everybody goes on.
+        # The leg runs in a CHILD process of rank 0 under a time limit (this code path has never seen two GPUs: a
+        # communicator that hangs must not take the torch leg's numbers with it), and the waits around it are bounded.
+        import datetime
         index.close()
         del d_symbols, local_block, full_table
         torch.cuda.empty_cache()
-        ctl = dist.new_group(backend="gloo")
-        dist.barrier(group=ctl)
+        leg = None
+        try:
+            ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=900))
+            dist.monitored_barrier(group=ctl, timeout=datetime.timedelta(seconds=300))
+            if rank == 0:
+                leg = in_process_child(args, world, D, doc_mib, K)
+            dist.monitored_barrier(group=ctl, timeout=datetime.timedelta(seconds=900))
+        except Exception as e:                             # noqa: BLE001 (the line must still go out: the torch leg stands)
+            if rank == 0 and leg is None:
+                leg = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if rank == 0:
-            try:
-                out.setdefault("multi_gpu", {})["in_process"] = in_process_leg(
-                    hip_backend, world, symbols, doc_offsets, n_strings, q_symbols, q_offsets, not args.denormalized, n_bytes)
-            except Exception as e:                         # noqa: BLE001 (the line must still go out: the torch leg stands)
-                out.setdefault("multi_gpu", {})["in_process"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        dist.barrier(group=ctl)
+            out.setdefault("multi_gpu", {})["in_process"] = leg
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -630,6 +636,49 @@ def write_detail(out):
         except OSError:
             pass
     return written
+
+
+def in_process_child(args, world, D, doc_mib, K, limit_s=600):
+    """Rank 0: the in-process leg in a child process (fresh interpreter, no torch, no process group), under a time limit.
+    Returns the leg's record or {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--in-process-child", str(world), "--docs", str(D), "--doc-mib", repr(doc_mib),
+           "--keyphrases", str(K), "--mode", args.mode, "--corpus", args.corpus] + (["--denormalized"] if args.denormalized else [])
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "TORCHELASTIC_RUN_ID", "EAST_HIP_DEVICE")}      # (device masks of the whole job, if any, stay)
+    try:
+        done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "the in-process leg did not finish within %d s" % limit_s}
+    lines = [ln for ln in done.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if done.returncode != 0 or not lines:
+        return {"error": "child exit code %d: %s" % (done.returncode, done.stderr.decode(errors="replace")[-300:])}
+    return json.loads(lines[-1])
+
+
+def in_process_child_main(argv):
+    """`bench.py --in-process-child N --docs D --doc-mib M --keyphrases K ...`: what in_process_child() starts.  Makes rank
+    0's shard again (same seeds as main()), runs in_process_leg, prints its record as one JSON line."""
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--in-process-child", type=int, required=True)
+    ap.add_argument("--docs", type=int, required=True)
+    ap.add_argument("--doc-mib", type=float, required=True)
+    ap.add_argument("--keyphrases", type=int, required=True)
+    ap.add_argument("--mode", default="text")
+    ap.add_argument("--corpus", default="words")
+    ap.add_argument("--duplicate-docs", type=int, default=0)
+    ap.add_argument("--denormalized", action="store_true")
+    args = ap.parse_args(argv)
+    from east import hip_backend, synthetic
+    world, D, K = args.in_process_child, args.docs, args.keyphrases
+    doc_bytes = int(args.doc_mib * (1 << 20))
+    rng = np.random.default_rng(20240 + 2)                  # (rank 0's seed)
+    symbols, doc_offsets, n_strings, _ = make_corpus(args, synthetic, rng, D, doc_bytes)
+    q_symbols, q_offsets = synthetic.keyphrases(rng, symbols, K)
+    leg = in_process_leg(hip_backend, world, symbols, doc_offsets, n_strings, q_symbols, q_offsets, not args.denormalized, doc_bytes * D)
+    sys.stdout.flush()
+    print(json.dumps(leg), flush=True)
 
 
 def in_process_leg(hip_backend, world, symbols, doc_offsets, n_strings, q_symbols, q_offsets, normalized, n_bytes, steps=3):
@@ -1099,4 +1148,7 @@ def cpu_baseline(args, synthetic):
 
 
 if __name__ == "__main__":
-    main()
+    if "--in-process-child" in sys.argv[1:]:
+        in_process_child_main(sys.argv[1:])
+    else:
+        main()
