@@ -405,6 +405,10 @@ __global__ __launch_bounds__(LG_THREADS, MIN_WAVES) void refine_persist_kernel(P
 // elements (permuted in place), the group bounds -- lives in global memory between rounds instead of in LDS.  (The
 // reference's worst case at n = 10^5 is a domain of 10 M: 4 883 tiles; launch by launch its 15 rounds cost 13 ms.)
 // What changes against refine_persist_kernel:
+//   * (measured and not kept: ONE barrier per round with double-buffered names -- a tile brings the other copy up to date
+//     for its current range when it, or one of the two tiles to its left, changed a round ago --: correct, and no faster,
+//     1.07 against 1.05 ms at n = 10^4, 7.1 against 6.8 at n = 10^5: the extra reads of the owed names cost what the barrier
+//     saved.)
 //   * a round is two phases with a grid barrier behind each.  SORT: every tile reads the names it needs and, where a
 //     group splits, sorts, writes its elements back, the suffix array, the LCP hints and the new group bounds.  NAMES:
 //     the tiles that changed publish the new names.  One copy of the names is enough: nobody writes a name while

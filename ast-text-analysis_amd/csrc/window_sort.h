@@ -2205,7 +2205,10 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             // memory, several tiles per workgroup -- refine_persist2_kernel)
             const bool try_persist = persist_cap > 0 && name_of && !doubling && n02 >= 4u * PR_CTL_WORDS &&
                                      (m_next <= persist_cap * LG_CHUNK || (persist_caps.large > 0 && ctx.knobs.persist_large)) &&
-                                     (n02 <= PERSIST_SMALL_INPUT || n02 / 8u <= m_next) && (round == 0 ? repetitive : slow);
+                                     (n02 <= PERSIST_SMALL_INPUT || n02 / 8u <= m_next) &&
+                                     // (... or whose first window -- wide enough to tell random suffixes apart -- left nineteen of
+                                     // twenty suffixes tied: copies further apart than the sample is long)
+                                     (round == 0 ? repetitive || m_next >= n02 - n02 / 20u : slow);
             if (name_of && !doubling && slow && !try_persist) {
                 // slow shrinking = long repeats: from here on the depth doubles every round (see above)
                 doubling = true;
