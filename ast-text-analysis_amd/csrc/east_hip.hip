@@ -2328,8 +2328,16 @@ int east_hip_create(int device, int64_t reserve_symbols, east_hip_handle_t *out)
             void *g = nullptr;
             HIP_CHECK(hipMalloc(&g, (TEXT_SYMBOLS + PRESENT_WORDS) * sizeof(u32)));
             h->guess = (u32 *)g;
-            if (reserve_symbols > 0)
-                ensure_arena(h, plan_arena_bytes((u32)reserve_symbols, 1) + (((size_t)reserve_symbols * 4 + 255) & ~(size_t)255));
+            if (reserve_symbols > 0) {
+                // (a handle made for builds large enough to go up narrowed -- upload_symbols_narrow -- reserves the narrow
+                // staging too and has its upload ring pinned in the background NOW: its first east_hip_build then already
+                // sends bytes or 16-bit words -- 3.5 instead of 6.9 ms for the 64 MiB document -- instead of finding the
+                // arena a few MB short and the ring not there yet)
+                const bool narrow_size = (u64)reserve_symbols >= SYM_NARROW_MIN && getenv("EAST_HIP_NO_SYMBOL_NARROW") == nullptr;
+                const size_t narrow_bytes = narrow_size ? (((size_t)reserve_symbols + 8) * 2 + 255) & ~(size_t)255 : 0;
+                ensure_arena(h, plan_arena_bytes((u32)reserve_symbols, 1) + (((size_t)reserve_symbols * 4 + 255) & ~(size_t)255) + narrow_bytes);
+                if (narrow_size) { h->ring_wanted = true; ring_pin_later(h); }
+            }
         } catch (...) {
             east_hip_destroy(h);
             throw;

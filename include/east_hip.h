@@ -98,8 +98,9 @@ int east_hip_reset(east_hip_handle_t h);
  * either way the tables are bit for bit what easa.py computes.)  east_hip_build_device takes a
  * DEVICE pointer for `symbols` (doc_offsets / n_strings stay host pointers);
  * the buffer is only read.  east_hip_build's copy to the device: symbols of the reference's
- * encoding fit 16 bits, so from 4 Mi symbols on -- and from a handle's second build on, when its
- * pinned upload ring exists -- host threads narrow them to 16-bit words into the ring and a kernel
+ * encoding fit 16 bits, so from 4 Mi symbols on -- once the handle's pinned upload ring exists: a handle
+ * created with reserve_symbols of that size has it pinned in the background from its creation on, any other
+ * from its second build on -- host threads narrow them to 16-bit words into the ring and a kernel
  * widens them on the device (half the bytes over the link; east_hip_build_info [25]) -- a text symbol
  * is below U+0A00, everything from there on is a terminator, whose number the build never reads --,
  * and to BYTES (a quarter of the bytes) while every text symbol lies below 0xFF, as in ASCII word text: a
