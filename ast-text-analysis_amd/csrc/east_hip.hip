@@ -1242,8 +1242,18 @@ static void build_common(east_hip_index *h, const u32 *sym, bool sym_on_host, i6
     // (host symbols of the reference encoding go up as 16-bit words where that pays: upload_symbols_narrow)
     ring_adopt(h, false);
     const bool narrow_shape = sym_on_host && !tagged && n >= SYM_NARROW_MIN && getenv("EAST_HIP_NO_SYMBOL_NARROW") == nullptr;
+    if (narrow_shape && !h->ring) {
+        // The first host-resident build of this size pins the ring in line (3-5 ms, once per handle) and goes up narrowed
+        // already: until round 6 it took the plain copy, left the pinning to a background thread, and the call behind it
+        // -- arriving while that thread was still at work -- took the plain copy again (6.9, 6.7, then 3.5 ms a call).
+        ring_adopt(h, true);                                // (a background pin under way: its ring)
+        if (!h->ring) {
+            void *p = nullptr;
+            if (hipHostMalloc(&p, TP_RING_SLOT * TP_RING_SLOTS, hipHostMallocDefault) == hipSuccess) h->ring = (char *)p;
+            else (void)hipGetLastError();                    // (no ring: the plain copy)
+        }
+    }
     const bool narrow = narrow_shape && h->ring != nullptr;
-    if (narrow_shape && !narrow) h->ring_wanted = true;      // (pinned in the background when this call is over)
     const size_t narrow_bytes = narrow_shape ? (((size_t)n + 8) * 2 + 255) & ~(size_t)255 : 0;    // (also while the ring is still being pinned: the arena is sized once)
     const size_t staging_bytes = (sym_on_host ? ((size_t)n * 4 + 255) & ~(size_t)255 : 0) + narrow_bytes;
     if (h->plan_n != n || h->plan_docs != (u32)n_docs || h->plan_epoch != kn.plan_epoch || h->plan_tagged != tagged) {     // (the sizing run costs host time: remembered per shape)
@@ -2330,13 +2340,13 @@ int east_hip_create(int device, int64_t reserve_symbols, east_hip_handle_t *out)
             h->guess = (u32 *)g;
             if (reserve_symbols > 0) {
                 // (a handle made for builds large enough to go up narrowed -- upload_symbols_narrow -- reserves the narrow
-                // staging too and has its upload ring pinned in the background NOW: its first east_hip_build then already
-                // sends bytes or 16-bit words -- 3.5 instead of 6.9 ms for the 64 MiB document -- instead of finding the
-                // arena a few MB short and the ring not there yet)
+                // staging too: its first east_hip_build does not find the arena a few MB short and grow it.  The upload ring is
+                // NOT pinned here: with it in place a fresh handle's first device-resident build measured 3 % slower -- 1.93
+                // against 1.86 ms wall for the 64 MiB document, with the ring pinned in the background 3.2 --; the first
+                // host-resident build of that size pins it, build_common)
                 const bool narrow_size = (u64)reserve_symbols >= SYM_NARROW_MIN && getenv("EAST_HIP_NO_SYMBOL_NARROW") == nullptr;
                 const size_t narrow_bytes = narrow_size ? (((size_t)reserve_symbols + 8) * 2 + 255) & ~(size_t)255 : 0;
                 ensure_arena(h, plan_arena_bytes((u32)reserve_symbols, 1) + (((size_t)reserve_symbols * 4 + 255) & ~(size_t)255) + narrow_bytes);
-                if (narrow_size) { h->ring_wanted = true; ring_pin_later(h); }
             }
         } catch (...) {
             east_hip_destroy(h);

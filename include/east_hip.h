@@ -98,14 +98,13 @@ int east_hip_reset(east_hip_handle_t h);
  * either way the tables are bit for bit what easa.py computes.)  east_hip_build_device takes a
  * DEVICE pointer for `symbols` (doc_offsets / n_strings stay host pointers);
  * the buffer is only read.  east_hip_build's copy to the device: symbols of the reference's
- * encoding fit 16 bits, so from 4 Mi symbols on -- once the handle's pinned upload ring exists: a handle
- * created with reserve_symbols of that size has it pinned in the background from its creation on, any other
- * from its second build on -- host threads narrow them to 16-bit words into the ring and a kernel
+ * encoding fit 16 bits, so from 4 Mi symbols on -- the handle's first such call pins a 24 MiB upload
+ * ring, once -- host threads narrow them to 16-bit words into the ring and a kernel
  * widens them on the device (half the bytes over the link; east_hip_build_info [25]) -- a text symbol
  * is below U+0A00, everything from there on is a terminator, whose number the build never reads --,
  * and to BYTES (a quarter of the bytes) while every text symbol lies below 0xFF, as in ASCII word text: a
  * symbol that does not fit starts the upload over with 16-bit words, for that call and the handle's later ones;
- * tagged streams, small inputs and a handle's first build take the plain 4-byte copy.
+ * tagged streams and small inputs take the plain 4-byte copy.
  */
 /*
  * Which encoding east_hip_build / east_hip_build_device read on this handle (default: the reference's).
@@ -307,7 +306,7 @@ void *east_hip_stream(east_hip_handle_t h);
  * (order-preserving) code words instead of fixed-width symbol fields (csrc/ht_code.h), [24] 1 when the first-level sort
  * kept every document inside its own range of ranks (the segmented sort, csrc/radix_sort.h: RsSeg), [25] 1 when
  * east_hip_build's host symbols went up as 16-bit words through the pinned ring (half the bytes over the link; reference
- * encoding, 4 Mi symbols or more, from a handle's second call on), 2 when they went up as bytes (text below 0xFF),
+ * encoding, 4 Mi symbols or more), 2 when they went up as bytes (text below 0xFF),
  * [26] refinement rounds run inside one persistent launch (csrc/persist_rounds.h; they count in [17] too).
  */
 int east_hip_build_info(east_hip_handle_t h, int64_t *out, int32_t cap);
