@@ -750,8 +750,7 @@ def extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D, 
         lib.east_hip_debug_set_speculation(1)
         res["build_ms_without_guesses"] = min(times)
     # the build from host-resident symbols (east_hip_build: one 4 B/symbol H2D copy in front), wall clock
-    # (twelve calls: the first goes up as 4-byte words and the one or two behind it may meet the background thread that pins
-    # the ring -- with six calls those were half of the sample and the median jumped between 4.7 and 7 ms from run to run)
+    # (twelve calls: the first one pins the upload ring)
     walls = []
     for _ in range(12):
         t0 = time.perf_counter()
@@ -763,11 +762,11 @@ def extras(index, prof, args, symbols, doc_offsets, n_strings, q_offsets, K, D, 
                                  "wall_ms_max": max(walls[2:]), "wall_ms_calls": [round(w, 2) for w in walls],
                                  "device_build_ms": index.last_build_ms, "h2d_bytes": int(symbols.size) * per_symbol,
                                  "bytes_per_symbol": per_symbol,
-                                 "note": "pageable host memory in, index out.  A handle's first call copies 4 B/symbol (the link: 56 GB/s, "
-                                         "tools/pcie_probe.py) and leaves the pinning of the upload ring to a background thread; later "
-                                         "calls narrow the symbols on host threads -- to bytes while all text lies below 0xFF, else to "
-                                         "16-bit words --, send them through the ring and widen them on the device (east_hip.hip: "
-                                         "upload_symbols_narrow); wall_ms_max: the slowest call after the first two"}
+                                 "note": "pageable host memory in, index out.  Host threads narrow the symbols -- to bytes while all "
+                                         "text lies below 0xFF, else to 16-bit words --, send them through a pinned ring (pinned by the "
+                                         "handle's first such call, in line) and a kernel widens them on the device (east_hip.hip: "
+                                         "upload_symbols_narrow; the link: 56 GB/s, tools/pcie_probe.py); wall_ms_max: the slowest call "
+                                         "after the first two"}
     return res
 
 
