@@ -1648,7 +1648,9 @@ __global__ __launch_bounds__(BLOCK) void dc3_refine_classify_kernel(const u32 *_
     const bool mine = !only_rest || LgUncovered{only_rest, m}(j);       // (a group lies wholly inside or outside the tiles)
     const bool tied = mine && j < m && ((j > 0 && !starts(j)) || (j + 1 < m && !starts(j + 1)));
     if (tied && xdep) depth += (u32)xdep[j];            // (the members of a group share it)
-    if (tied) next8[threadIdx.x] = load_u64_unaligned(s8 + lvl0_pos(elem[j], n0) + depth);
+    // (limit 1: nothing is compared -- deep doubling rounds --, so nothing is fetched: the gather was 0.5 ms of a 0.73 ms launch
+    // over 16 M elements)
+    if (tied && limit > 1u) next8[threadIdx.x] = load_u64_unaligned(s8 + lvl0_pos(elem[j], n0) + depth);
     __syncthreads();
     if (tied)
         my_keep = lvl0_place_tied(j, elem, starts, slot, m, s8, n0, depth, order_g, names_g, lcp_g, NoLcp(), fail, limit, max_len,
@@ -2372,6 +2374,9 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
                 int gb = gbits;
                 if (m_left == m) {
                     number_groups();
+                    // (the in-LDS round ran and took nothing: every group is longer than a tile takes -- the same bound on
+                    // their number as below: a run of one letter is ONE group of 16 M, whose number was sorted on 24 bits)
+                    if (ctx.knobs.lds_rounds) gb = std::min(gbits, bit_width_u32(m_left / (LG_MAX_GROUP + 1u) + 1u));
                 } else {
                     // the rest, compacted (elements, group starts, where they came from), its groups numbered -- every
                     // one of them has more than LG_MAX_GROUP members, which bounds their number
@@ -2421,11 +2426,18 @@ static bool dc3_level0_bytes(Ctx &ctx, const uint8_t *s8, u32 n0, u32 n02, int w
             auto classify = [&](int mode, bool rest_only = false) {
                 if (!rest_only || round_left > 0)       // (rest_only: the in-LDS round has classified its own tiles)
                     LAUNCH(ctx, dc3_refine_classify_kernel, gt, elem, FlagArrIn{flag}, slot, m, s8, n0, depth, sa12, names_g, keep,
-                           fail, endgame ? (u32)REFINE_ENDGAME_GROUP : (u32)REFINE_SMALL_GROUP,
+                           // (doubling rounds with long repeats known, once the depth is beyond what a direct comparison may
+                           // look at: the members of a small group would compare REFINE_DOUBLING_LEN symbols, give up, and do it
+                           // again next round -- 19 of the 53 ms of a 16 M-symbol Fibonacci string; the next round's name look-up
+                           // decides them: only what is alone in its group is placed)
+                           fail, doubling && mode != 0 && depth >= REFINE_DOUBLING_LEN ? 1u : endgame ? (u32)REFINE_ENDGAME_GROUP : (u32)REFINE_SMALL_GROUP,
                            // (doubling rounds with long repeats known -- mark + commit, an undecided group simply stays for the
                            // next round, which doubles the depth by one name look-up per member: comparing 2 048 symbols of text
                            // for it first was 60 of the 96 ms of a 16 M-symbol Fibonacci string)
-                           endgame ? (u32)REFINE_ENDGAME_LEN : doubling && mode != 0 ? (u32)REFINE_DOUBLING_LEN : (u32)RESOLVE_MAX_LEN,
+                           // (... and the first attempt of a doubling round is short as well: in a Fibonacci string the members of
+                           // small groups DO differ within 2 048 symbols, and found that out 256 dependent loads at a time, every
+                           // round -- 0.73 ms a launch)
+                           endgame ? (u32)REFINE_ENDGAME_LEN : doubling ? (u32)REFINE_DOUBLING_LEN : (u32)RESOLVE_MAX_LEN,
                            doubling ? name_of : (u32 *)nullptr,
                            LongRepeats{bad, mode}, lcp_out, rest_only ? (const uint2 *)cover : (const uint2 *)nullptr,
                            doubling ? (const uint8_t *)nullptr : xdep);
