@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--base-value", type=float, default=float(os.environ.get("EAST_BENCH_BASE_VALUE", "0") or 0),
                     help="N > 1: the same-shape single-GPU value (config2.value of the N = 1 line, chars/s) -- the line "
                          "then carries multi_gpu.scaling_efficiency = value / (N x base)")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the whole record (what bench_detail.json holds) as the last line instead of the driver's compact "
+                         "one: the A/B scripts under tools/ read per-kernel tables off it")
     ap.add_argument("--no-in-process", action="store_true",
                     help="N > 1: skip the leg that runs the same shards through the in-process device group on rank 0")
     ap.add_argument("--cpu-sample-mib", type=float, default=64.0,
@@ -505,7 +508,7 @@ def main():
             pass
         sys.stdout.flush()
         detail_path = write_detail(out)
-        print(compact_line(out, detail_path), flush=True)
+        print(json.dumps(out) if args.full_line else compact_line(out, detail_path), flush=True)
 
 
 LINE_LIMIT = 6144          # the driver keeps an 8 KB tail of stdout and parses its LAST line: that line stays under 6 KB

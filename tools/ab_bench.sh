@@ -7,7 +7,7 @@ mkdir -p gpurun_out/ab
 for lib in ast-text-analysis_amd/east/_lib/libeast_hip.so build/variants/lib_*.so; do
   [ -f "$lib" ] || continue
   tag=$(basename "$lib" .so)
-  EAST_HIP_LIBRARY="$PWD/$lib" timeout 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > gpurun_out/ab/$tag.json 2> gpurun_out/ab/$tag.err
+  EAST_HIP_LIBRARY="$PWD/$lib" timeout 300 python3 bench.py --full-line --steps 10 --warmup 3 --no-cpu-baseline "$@" > gpurun_out/ab/$tag.json 2> gpurun_out/ab/$tag.err
   python3 - "$tag" <<'PY'
 import json, sys
 tag = sys.argv[1]

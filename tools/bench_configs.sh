@@ -5,7 +5,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/configs.jsonl
 mkdir -p gpurun_out; : > $OUT
-run() { timeout 300 python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 >> $OUT; }
+run() { timeout 300 python3 bench.py --full-line --no-cpu-baseline "$@" 2>/dev/null | tail -1 >> $OUT; }
 run                                                           # configs[1]: 1 x 64 MiB, text mode, 1 000 keyphrases
 run --mode direct                                             # configs[1], get_ast([one 64 Mi string])
 run --docs 256 --doc-mib 1 --keyphrases 10000                 # configs[2]: 256 x 1 MiB, 10 000 keyphrases

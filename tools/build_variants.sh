@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build several copies of libeast_hip.so with different -D flags into build/variants/ (git-ignored, but
 # they travel to the GPU box) for A/B timing:  tools/build_variants.sh "a:-DFOO=1" "b:-DFOO=2"
-# then on the box:  EAST_HIP_LIBRARY=build/variants/lib_a.so python bench.py ...
+# then on the box:  EAST_HIP_LIBRARY=build/variants/lib_a.so python bench.py --full-line ...
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 mkdir -p "$ROOT/build/variants"

@@ -5,7 +5,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 run() {
   local name=$1 lib=$2; shift 2
-  env "$@" EAST_HIP_LIBRARY="$PWD/$lib" timeout 300 python3 bench.py --docs 256 --doc-mib 1 --keyphrases 10000 --no-cpu-baseline --no-config2 --no-extras --steps 5 --warmup 2 2>/dev/null | tail -1 | python3 -c "
+  env "$@" EAST_HIP_LIBRARY="$PWD/$lib" timeout 300 python3 bench.py --full-line --docs 256 --doc-mib 1 --keyphrases 10000 --no-cpu-baseline --no-config2 --no-extras --steps 5 --warmup 2 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$name', 'CONFIG2 build', round(d['build_ms'],3), 'score', round(d['score_ms'],3), 'step', round(d['ms_per_step'],3))

@@ -8,7 +8,7 @@ timeout 1500 python3 -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1
 tail -5 $OUT/pytest.log
 for mode in fused unfused; do
   if [ $mode = unfused ]; then export EAST_HIP_NO_FUSED_FINISH=1; else unset EAST_HIP_NO_FUSED_FINISH; fi
-  timeout 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline ${BENCH_ARGS:---no-config2 --no-extras} > $OUT/bench_$mode.json 2> $OUT/bench_$mode.err
+  timeout 300 python3 bench.py --full-line --steps 10 --warmup 3 --no-cpu-baseline ${BENCH_ARGS:---no-config2 --no-extras} > $OUT/bench_$mode.json 2> $OUT/bench_$mode.err
   python3 - $OUT/bench_$mode.json $mode <<'PY'
 import json, sys
 try:
