@@ -531,8 +531,8 @@ __device__ __forceinline__ u32 pr2_tile_load(LgLds &lds, u32 *wg_count, const u3
     return *wg_count;
 }
 
-// (one workgroup per CU: two of them share a CU's SIMDs without gaining on each other -- measured with the resident form --,
-// and at 128 registers a lane nothing is spilled)
+// (one workgroup per CU: two of them share a CU's SIMDs without gaining on each other, and at 128 registers a lane nothing
+// is spilled -- measured on this kernel too: at two per CU, 64 registers, 2.25 against 1.04 ms at n = 10^4, 11.4 against 6.9 at 10^5)
 __global__ __launch_bounds__(LG_THREADS, 4) void refine_persist2_kernel(Pr2Args a)
 {
     __shared__ LgLds lds;
