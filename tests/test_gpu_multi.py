@@ -278,3 +278,38 @@ def test_grouped_all_gather_reports_a_failing_library(hip, tmp_path, monkeypatch
     single.build(sym, off, ms)
     assert np.array_equal(group.score_table(qs, qo, True), single.score_table(qs, qo, True))     # the same group, next call
     group.close()
+
+
+def test_group_shards_with_repetitive_documents_share_the_chip(hip, oracle):
+    """Every shard's build runs on a host thread of its own, and repetitive documents finish their refinement in a
+    persistent kernel whose workgroups must all be resident at once (csrc/persist_rounds.h): two such launches from two
+    threads must not share the chip half resident each -- the library holds a process-wide lock from the launch to the
+    read-back.  Four logical shards on device 0, every document the reference's worst-case shape (identical strings) or
+    copies of a passage: tables of sampled documents array_equal to the oracle, the score table equal to a single
+    handle's."""
+    from east import hip_backend, synthetic
+    rng = np.random.default_rng(4242)
+    docs = []
+    for i in range(12):
+        if i % 3 == 2:
+            docs.append(synthetic.repeated_passage_document(rng, int(rng.integers(2000, 9000)), int(rng.integers(3, 9))))
+        else:
+            docs.append(synthetic.worst_case_collection(rng, int(rng.choice([20, 100])), int(rng.integers(300, 1500))))
+    sym = np.concatenate([d[0] for d in docs])
+    off = np.concatenate([[0], np.cumsum([d[0].size for d in docs])]).astype(np.int64)
+    ms = np.array([d[1] for d in docs], dtype=np.int32)
+    qs, qo = synthetic.keyphrases(rng, sym, 60)
+    single = hip_backend.HipIndex()
+    single.build(sym, off, ms)
+    group = hip_backend.HipGroup([0, 0, 0, 0])
+    for _ in range(3):                                         # (again and again: the threads meet at the lock in every order)
+        group.build(sym, off, ms)
+        assert sum(shard.info()["persist_rounds"] > 0 for shard in group.shards if shard.n_docs) >= 2
+        assert np.array_equal(group.score_table(qs, qo, True), single.score_table(qs, qo, True))
+    for d in (0, 2, 7, 11):
+        shard, local = group.locate(d)
+        o = oracle.OracleEASA(symbols=docs[d][0], n_strings=docs[d][1])
+        t = shard.tables(local)
+        for name in TABLES:
+            assert np.array_equal(t[name], getattr(o, name)), (name, d)
+    group.close()
